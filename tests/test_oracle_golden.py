@@ -1,0 +1,219 @@
+"""The oracle (oracle/hwer_oracle.py) against golden vectors captured from the unmodified reference
+(tools/capture_goldens.py).  CPU only.  These pin the oracle; the GPU parity tests then compare the
+HIP path with the oracle."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import hwer_oracle as orc
+from conftest import unit_rows_f32
+
+
+def _flav(V32, f):
+    return V32.astype(np.float64) if f == "f64" else V32
+
+
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+@pytest.mark.parametrize("k", [1, 10, 200])
+def test_g1_knn_basic(golden, flav, k):
+    g = golden("g1_knn_basic")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    V = _flav(g["V32"], flav)
+    rows = np.arange(U, U + I)
+    for u in range(U):
+        idx, score, _ = orc.find_closest(V, rows, u, k=k)
+        assert np.array_equal(idx, g[f"idx_{flav}_k{k}"][u])
+        assert score.dtype == V.dtype
+        assert np.array_equal(score, g[f"score_{flav}_k{k}"][u])  # bit-exact
+
+
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_g5_knn_query_distances_and_gcn_scoring(golden, flav):
+    g = golden("g1_knn_basic")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    V = _flav(g["V32"], flav)
+    rows = np.arange(U, U + I)
+    for k in (10, 200):
+        for u in range(0, U, 7):
+            q = orc.average_embedding(V, [u])
+            local, dist = orc.knn_bruteforce(q, V[rows], k)
+            assert np.array_equal(rows[local], g[f"knnq_idx_{flav}_k{k}"][u])
+            assert np.array_equal(dist, g[f"knnq_dist_{flav}_k{k}"][u])  # sklearn's distances, bit-exact
+            # GcnNCF scoring restated from hwer/gcn_ncf.py:379-383 on the reference's own distances
+            idx, score, _ = orc.find_closest(V, rows, u, k=k, scoring="gcn")
+            ref = (-1 * g[f"knnq_dist_{flav}_k{k}"][u] + 2) / 2
+            assert np.array_equal(score, ref) and np.array_equal(idx, g[f"knnq_idx_{flav}_k{k}"][u])
+    # user -> user returns the anchor first, score 1.0
+    idx, score, _ = orc.find_closest(V, np.arange(U), 3, k=5)
+    assert np.array_equal(idx, g[f"u2u_idx_{flav}"]) and np.array_equal(score, g[f"u2u_score_{flav}"])
+    assert idx[0] == 3 and abs(score[0] - 1.0) < 1e-6
+
+
+def test_g2_ml100k_shape(golden):
+    g = golden("g2_knn_ml100k_shape")
+    U, I, d, k = int(g["n_users"]), int(g["n_items"]), int(g["d"]), int(g["k"])
+    V32 = np.concatenate([unit_rows_f32(int(g["seed_users"]), U, d), unit_rows_f32(int(g["seed_items"]), I, d)])
+    assert hashlib.sha256(V32.tobytes()).hexdigest() == str(g["input_sha256"])
+    V = V32.astype(np.float64)
+    rows = np.arange(U, U + I)
+    idx = np.empty((U, k), np.int64)
+    sc = np.empty((U, k), np.float64)
+    for u in range(U):
+        idx[u], sc[u], _ = orc.find_closest(V, rows, u, k=k)
+    assert np.array_equal(idx - U, g["idx"].astype(np.int64))
+    assert hashlib.sha256(idx.tobytes()).hexdigest() == str(g["idx_sha256"])
+    assert hashlib.sha256(sc.tobytes()).hexdigest() == str(g["score_sha256"])
+    assert np.array_equal(sc[g["score_rows"]], g["score_sel"])
+
+
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_g3_posneg(golden, flav):
+    g = golden("g3_posneg")
+    U, I, k = int(g["n_users"]), int(g["n_items"]), int(g["k"])
+    V = _flav(g["V32"], flav)
+    rows = np.arange(U, U + I)
+    for a in range(32):
+        pos = [int(x) for x in g["pos"][a] if x != -2]
+        neg = [int(x) for x in g["neg"][a] if x != -2]
+        q = orc.query_vector(V, a, np.asarray(pos, np.int64), np.asarray(neg, np.int64))
+        assert np.array_equal(q, g[f"q_{flav}"][a])
+        idx, score, _ = orc.find_closest(V, rows, a, np.asarray(pos, np.int64), np.asarray(neg, np.int64), k=k)
+        assert np.array_equal(idx, g[f"idx_{flav}"][a])
+        assert np.array_equal(score, g[f"score_{flav}"][a])
+    # the query is not re-normalised (hwer/recommendation_base.py:170)
+    norms = np.linalg.norm(g["q_f64"], axis=1)
+    assert norms.min() < 0.9
+
+
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_g4_predict(golden, flav):
+    g = golden("g4_predict")
+    V = _flav(g["V32"], flav)
+    r = orc.pair_score(V, g["src"], g["dst"])
+    assert r.dtype == V.dtype
+    assert np.array_equal(r, g[f"score_{flav}"])
+    unk = (g["src"] == -1) | (g["dst"] == -1)
+    assert unk.sum() > 100 and np.all(np.abs(r[unk] - 0.5) < 1e-4)  # unknown nodes score ~0.5
+    # scalar restatement of numpy's summation order
+    E1, E2 = orc.gather_rows(V, g["src"][:64]), orc.gather_rows(V, g["dst"][:64])
+    mine = np.array([orc.pairwise_sum(E1[i] * E2[i]) for i in range(64)], dtype=V.dtype)
+    assert np.array_equal((mine + 1) / 2, r[:64])
+
+
+def test_g6_content_tail(golden):
+    g = golden("g6_content_tail")
+    A, final = orc.content_tail(g["E"], g["src"], g["dst"])
+    assert np.array_equal(A, g["adjacent"])          # diff 0.0
+    assert np.array_equal(final, g["final"])
+    # generalised blend, 2-table alpha=(.5,.5) special case reproduces :85 + :96 exactly
+    b = orc.blend_normalize([g["E"], g["adjacent"]], [None, None], np.array([0.5, 0.5]))
+    assert np.array_equal(b, g["final"])
+    # adjacency: every node lists itself twice, duplicates kept
+    indptr, indices = orc.adjacency_csr(300, g["src"], g["dst"])
+    assert indptr[-1] == 2 * (len(g["src"]) + 300)
+    for n in (0, 17, 299):
+        assert (indices[indptr[n]:indptr[n + 1]] == n).sum() >= 2
+    # retrieval on the fitted vectors
+    rows = np.nonzero(g["node_type_id"] == 1)[0]
+    idx, score, _ = orc.find_closest(g["final"], rows, 0, k=7)
+    assert np.array_equal(idx, g["knn_idx"]) and np.array_equal(score, g["knn_score"])
+
+
+def test_g7_content_fit_tail_consistency(golden):
+    g = golden("g7_content_fit_e2e")
+    final = g["final"]
+    assert final.shape == (18, 6)
+    assert np.allclose(np.linalg.norm(final, axis=1), 1.0, atol=1e-12)
+    idx, score, _ = orc.find_closest(final, np.arange(3, 18), 0, k=3)
+    assert np.array_equal(idx, g["knn_idx"]) and np.array_equal(score, g["knn_score"])
+
+
+def test_g8_unit_audit(golden):
+    g = golden("g8_unit_audit")
+    for name in ("rows", "rows_zero", "rows_nan"):
+        got = np.asarray(orc.unit_length_violations(g[name], axis=1), dtype=np.float64)
+        assert np.array_equal(got, g["viol_" + name], equal_nan=True)
+        got32 = np.asarray(orc.unit_length_violations(g[name].astype(np.float32), axis=1), dtype=np.float64)
+        assert np.array_equal(got32, g["viol32_" + name], equal_nan=True)
+    assert g["viol_rows"][0] == 3        # 1+2e-4, 1-2e-4, 1-1.01e-4
+    assert g["viol_rows_nan"][0] == 3    # a NaN norm passes both comparisons
+    assert np.array_equal(orc.unit_length(g["rows_zero"], axis=1), g["unit_zero"], equal_nan=True)
+    assert np.isnan(g["unit_zero"][5]).all()
+    assert list(g["build_ok"]) == [1, 0, -1]
+
+
+def test_g9_metrics(golden):
+    g = golden("g9_metrics")
+    yt = dict(zip(g["y_true_keys"].tolist(), g["y_true_vals"].tolist()))
+    yp = g["y_pred"].tolist()
+    assert orc.recall(yt, yp) == float(g["recall"])
+    assert orc.ndcg(yt, yp) == float(g["ndcg"])
+    assert orc.binary_ndcg(yt, yp) == float(g["binary_ndcg"])
+    assert orc.binary_ndcg_v2(list(yt), yp) == float(g["binary_ndcg_v2"])
+    assert orc.reciprocal_rank(list(yt), yp) == float(g["reciprocal_rank"])
+    assert orc.recall({}, yp) == float(g["recall_empty"]) == 0.0
+    assert orc.reciprocal_rank([99], yp) == float(g["rr_miss"]) == 0.0
+    assert orc.recall(yt, [3]) == float(g["recall_short"]) == 1.0
+    # full evaluation loop
+    U, I = int(g["ee_n_users"]), int(g["ee_n_items"])
+    V = g["ee_V32"].astype(np.float64)
+    rows = np.arange(U, U + I)
+    train = [(int(u), int(i), float(r)) for u, i, r in g["ee_train"]]
+    valid = [(int(u), int(i), float(r)) for u, i, r in g["ee_valid"]]
+    users = sorted(set(u for u, _, _ in train + valid))
+    preds = {u: orc.find_closest(V, rows, u, k=200)[0].tolist() for u in users}
+    m = orc.retrieval_metrics(preds, train, valid, I_items_seen(train, valid))
+    for key in ("recall@100", "ndcg_b@100", "ndcg_b@10", "recall@10", "diversity"):
+        assert m[key] == pytest.approx(float(g["ee_" + key.replace("@", "_at_")]), rel=0, abs=1e-15), key
+    assert 0.0 <= float(g["ee_ncf_hr"]) <= 1.0
+
+
+def I_items_seen(train, valid):
+    return len(set(i for _, i, _ in train) | set(i for _, i, _ in valid))
+
+
+def test_g10_ties_as_sets(golden):
+    g = golden("g10_ties")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    V = g["V32"].astype(np.float64)
+    rows = np.arange(U, U + I)
+    saw_tie = False
+    for u in range(U):
+        idx, score, _ = orc.find_closest(V, rows, u, k=10)
+        assert np.array_equal(score, g["score"][u])
+        ref = g["idx"][u]
+        if not np.array_equal(idx, ref):
+            saw_tie = True
+        # compare as sets inside equal-score groups
+        for s in np.unique(score):
+            sel = score == s
+            assert set(idx[sel].tolist()) == set(ref[g["score"][u] == s].tolist())
+            # the build's rule inside a group of identical rows: ascending id
+            if sel.sum() > 1:
+                assert list(idx[sel]) == sorted(idx[sel])
+    assert saw_tie  # the KD-tree's tie order is NOT index order
+
+
+def test_g11_errors(golden):
+    g = golden("g11_errors")
+    assert str(g["k_too_large"]).startswith("ValueError:k must be less than or equal to the number of training points")
+    assert str(g["unknown_anchor"]) == "NodeNotFoundException"
+    assert str(g["bad_type"]) == str(g["not_fitted"]) == str(g["dup_nodes"]) == str(g["bad_node_type"]) == "AssertionError"
+    assert str(g["node_eq_int_str"]) == "True"
+    m = orc.OracleRecommender({"user", "item"})
+    users = [orc.Node("user", i) for i in range(4)]
+    items = [orc.Node("item", i) for i in range(20)]
+    m.add_nodes(users + items)
+    V = np.concatenate([unit_rows_f32(1011, 4, 8), unit_rows_f32(2011, 20, 8)]).astype(np.float64)
+    m.build_knn(V)
+    with pytest.raises(ValueError, match="k must be less than or equal"):
+        m.find_closest_neighbours("item", users[0], k=21)
+    with pytest.raises(orc.NodeNotFoundException):
+        m.find_closest_neighbours("item", orc.Node("user", "zz"))
+    with pytest.raises(AssertionError):
+        m.find_closest_neighbours("movie", users[0])
+    with pytest.raises(AssertionError):
+        m.add_nodes([orc.Node("user", 0)])
+    assert orc.Node("item", 5) == orc.Node("item", "5")
+    assert len(m.find_closest_neighbours("item", users[0], k=3)) == 3

@@ -1,0 +1,415 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (imported from /root/reference
+through tools/ref_shims.py).  Runs only in the build container; the fixtures it writes are data
+(inputs + expected outputs) and are the only thing that travels.
+
+    python tools/capture_goldens.py            # rewrites every fixture
+
+Scenarios follow SURVEY.md §8c (G1..G11).  Inputs are synthetic (SURVEY.md §8d recipe): iid N(0,1)
+float32 rows, L2-normalised in float64, cast to float32.  "f64 flavour" = the reference is handed
+those float32 rows upcast to float64 (ContentRecommendation-like dtype); "f32 flavour" = it is handed
+the float32 rows themselves (GcnNCF-like dtype, hwer/gcn_ncf.py:431,447-456).
+"""
+import hashlib
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_shims  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+
+def unit_rows_f32(seed, n, d):
+    x = np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32).astype(np.float64)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class Concrete:
+    """Factory: a concrete subclass of the reference's abstract RecommendationBase."""
+
+    def __init__(self, pkg):
+        rb = pkg.recommendation_base
+
+        class R(rb.RecommendationBase):
+            def fit(self, nodes, edges, node_data, **kw):
+                raise NotImplementedError
+
+        self.cls = R
+        self.rb = rb
+
+
+def make_model(pkg, V, n_users, n_items):
+    c = Concrete(pkg)
+    Node = c.rb.Node
+    users = [Node("user", i) for i in range(n_users)]
+    items = [Node("item", i) for i in range(n_items)]
+    m = c.cls(node_types={"user", "item"}, n_dims=V.shape[1])
+    m.add_nodes(users + items)
+    m.__build_knn__(V)
+    m.fit_done = True
+    return m, users, items
+
+
+def run_knn(m, anchors, k, positive=None, negative=None):
+    """-> (idx (B,k) int64 global ids, scores (B,k))"""
+    idx, sc = [], []
+    for a_i, a in enumerate(anchors):
+        p = positive[a_i] if positive is not None else None
+        n = negative[a_i] if negative is not None else None
+        res = m.find_closest_neighbours("item", a, positive=p, negative=n, k=k)
+        idx.append([m.nodes_to_idx[nd] if nd in m.nodes_to_idx else -1 for nd, _ in res])
+        sc.append([s for _, s in res])
+    return np.asarray(idx, dtype=np.int64), np.asarray(sc)
+
+
+def g1_g5(pkg):
+    U, I, d = 64, 512, 32
+    V32 = np.concatenate([unit_rows_f32(1001, U, d), unit_rows_f32(2001, I, d)])
+    out = dict(V32=V32, n_users=U, n_items=I)
+    for flav, V in (("f64", V32.astype(np.float64)), ("f32", V32)):
+        m, users, items = make_model(pkg, V, U, I)
+        for k in (1, 10, 200):
+            idx, sc = run_knn(m, users, k)
+            out[f"idx_{flav}_k{k}"] = idx.astype(np.int32)
+            out[f"score_{flav}_k{k}"] = sc
+            assert sc.dtype == V.dtype, (sc.dtype, V.dtype)
+        # G5: raw MultiKNN.query distances (hwer/recommendation_base.py:78-83) for the GcnNCF scoring restatement
+        for k in (10, 200):
+            dist, qidx = [], []
+            for u in users:
+                emb = m.get_average_embeddings([u])
+                r = m.knn.query(emb, "item", k=k)
+                qidx.append([m.nodes_to_idx[n] for n, _ in r])
+                dist.append([dd for _, dd in r])
+            out[f"knnq_idx_{flav}_k{k}"] = np.asarray(qidx, dtype=np.int32)
+            out[f"knnq_dist_{flav}_k{k}"] = np.asarray(dist, dtype=np.float64)
+        # user -> user query returns the anchor first with score 1.0
+        res = m.find_closest_neighbours("user", users[3], k=5)
+        out[f"u2u_idx_{flav}"] = np.asarray([m.nodes_to_idx[n] for n, _ in res], dtype=np.int32)
+        out[f"u2u_score_{flav}"] = np.asarray([s for _, s in res])
+    np.savez_compressed(os.path.join(OUT, "g1_knn_basic.npz"), **out)
+
+    # G3 posneg on the same vectors
+    rng = np.random.default_rng(33)
+    Node = pkg.recommendation_base.Node
+    out = dict(V32=V32, n_users=U, n_items=I)
+    for flav, V in (("f64", V32.astype(np.float64)), ("f32", V32)):
+        m, users, items = make_model(pkg, V, U, I)
+        rng = np.random.default_rng(33)
+        anchors, pos, neg, pos_ids, neg_ids = [], [], [], [], []
+        for a in range(32):
+            anchors.append(users[a])
+            npos, nneg = int(rng.integers(0, 4)), int(rng.integers(0, 3))
+            p = [int(x) for x in rng.integers(0, U + I, npos)]
+            n = [int(x) for x in rng.integers(0, U + I, nneg)]
+            # sprinkle unknown nodes (global id -1) into some lists
+            if a % 7 == 3 and npos:
+                p[0] = -1
+            if a % 5 == 2 and nneg:
+                n[-1] = -1
+            pos_ids.append(p)
+            neg_ids.append(n)
+            inv = m.nodes_to_idx.inverse
+            pos.append([inv[x] if x >= 0 else Node("item", "unknown-%d" % a) for x in p])
+            neg.append([inv[x] if x >= 0 else Node("user", "unknown-%d" % a) for x in n])
+        k = 25
+        idx, sc = run_knn(m, anchors, k, pos, neg)
+        qs = []
+        for a, p, n in zip(anchors, pos, neg):
+            lst = [m.get_average_embeddings([a])]
+            if len(p):
+                lst.append(m.get_average_embeddings(p))
+            if len(n):
+                lst.append(-1 * m.get_average_embeddings(n))
+            qs.append(np.average(lst, axis=0))
+        out[f"q_{flav}"] = np.asarray(qs)
+        out[f"idx_{flav}"] = idx.astype(np.int32)
+        out[f"score_{flav}"] = sc
+    maxp = 3
+    out["pos"] = np.asarray([p + [-2] * (maxp - len(p)) for p in pos_ids], dtype=np.int32)  # -2 = padding
+    out["neg"] = np.asarray([n + [-2] * (maxp - len(n)) for n in neg_ids], dtype=np.int32)
+    out["k"] = 25
+    np.savez_compressed(os.path.join(OUT, "g3_posneg.npz"), **out)
+
+    # G4 predict
+    rng = np.random.default_rng(44)
+    P = 10000
+    src = rng.integers(0, U + I, P).astype(np.int32)
+    dst = rng.integers(0, U + I, P).astype(np.int32)
+    src[rng.random(P) < 0.05] = -1
+    dst[rng.random(P) < 0.05] = -1
+    out = dict(V32=V32, src=src, dst=dst)
+    for flav, V in (("f64", V32.astype(np.float64)), ("f32", V32)):
+        m, users, items = make_model(pkg, V, U, I)
+        inv = m.nodes_to_idx.inverse
+        pairs = [(inv[int(s)] if s >= 0 else Node("user", "nope"), inv[int(t)] if t >= 0 else Node("item", "nope"))
+                 for s, t in zip(src, dst)]
+        r = m.predict(pairs)
+        assert r.dtype == V.dtype
+        out[f"score_{flav}"] = r
+    np.savez_compressed(os.path.join(OUT, "g4_predict.npz"), **out)
+
+
+def g2(pkg):
+    U, I, d, k = 943, 1682, 64, 200
+    V32 = np.concatenate([unit_rows_f32(1001 + 99, U, d), unit_rows_f32(2001 + 99, I, d)])  # "seed 100" family
+    m, users, items = make_model(pkg, V32.astype(np.float64), U, I)
+    idx, sc = run_knn(m, users, k)
+    sel = np.r_[0:32, U - 32:U]
+    np.savez_compressed(os.path.join(OUT, "g2_knn_ml100k_shape.npz"),
+                        seed_users=1100, seed_items=2100, n_users=U, n_items=I, d=d, k=k,
+                        input_sha256=sha(V32), idx=(idx - U).astype(np.int16),  # item-local ids fit int16
+                        idx_sha256=sha(idx.astype(np.int64)), score_sha256=sha(sc.astype(np.float64)),
+                        score_rows=sel.astype(np.int32), score_sel=sc[sel])
+
+
+def g6(pkg):
+    """ContentRecommendation.fit with recorders on module globals (reference files untouched)."""
+    cr = pkg.content_recommender
+    rb = pkg.recommendation_base
+    emb = pkg.embed_base
+    Node, Edge = rb.Node, rb.Edge
+    rng = np.random.default_rng(7)
+    types = ["user", "item", "tag"]
+    N = 300
+    nodes = [Node(types[i % 3], i) for i in range(N)]
+    feats = rng.standard_normal((N, 5))
+    node_data = {n: {"f": feats[i]} for i, n in enumerate(nodes)}
+    src = rng.integers(0, N, 2000)
+    dst = rng.integers(0, N, 2000)
+    # make sure every type pair space has edges and add 50 duplicated edges
+    src = np.concatenate([src, src[:50]])
+    dst = np.concatenate([dst, dst[:50]])
+    w = rng.random(len(src))
+    edges = [Edge(nodes[s], nodes[t], float(ww)) for s, t, ww in zip(src, dst, w)]
+    mapper = {t: {"f": emb.IdentityEmbedding(n_dims=5)} for t in types}
+
+    rec_unit = []
+    orig_unit = cr.unit_length
+
+    def rec_unit_length(a, axis=0):
+        r = orig_unit(a, axis=axis)
+        rec_unit.append((np.array(a, copy=True), np.array(r, copy=True)))
+        return r
+
+    rec_vstack = []
+
+    class NpProxy:
+        def __getattr__(self, name):
+            return getattr(np, name)
+
+        def vstack(self, x):
+            r = np.vstack(x)
+            rec_vstack.append(np.array(r, copy=True))
+            return r
+
+    cr.unit_length = rec_unit_length
+    cr.np = NpProxy()
+    try:
+        model = cr.ContentRecommendation(embedding_mapper=mapper, node_types=set(types), n_dims=8)
+        final = model.fit(nodes, edges, node_data)
+    finally:
+        cr.unit_length = orig_unit
+        cr.np = np
+    pca_unit = rec_unit[-2][1]          # :70 output (300, 8)
+    blend_in = rec_unit[-1][0]          # :96 input = (E + A)/2
+    assert np.array_equal(rec_unit[-1][1], final)
+    adjacent = rec_vstack[-1]           # :83
+    cats = sorted(types)
+    ohe = np.zeros((N, 4))
+    for i, n in enumerate(nodes):
+        ohe[i, cats.index(n.node_type)] = 1.0
+    E = np.concatenate([pca_unit, ohe], axis=1)
+    assert np.array_equal((E + adjacent) / 2.0, blend_in)
+    # retrieval on the fitted model
+    res = model.find_closest_neighbours("item", nodes[0], k=7)
+    np.savez_compressed(os.path.join(OUT, "g6_content_tail.npz"), E=E, src=src.astype(np.int32),
+                        dst=dst.astype(np.int32), adjacent=adjacent, blend=blend_in, final=final,
+                        node_type_id=np.asarray([i % 3 for i in range(N)], dtype=np.int32),
+                        knn_idx=np.asarray([model.nodes_to_idx[n] for n, _ in res], dtype=np.int32),
+                        knn_score=np.asarray([s for _, s in res]))
+
+
+def g7(pkg):
+    """hwer/misc/test_content_recommender.py:8-38 scenario with np.random.seed(0)."""
+    import importlib
+    import sklearn
+    cr = pkg.content_recommender
+    rb = pkg.recommendation_base
+    NumericEmbed = importlib.import_module("hwer.embed.NumericEmbed").NumericEmbed
+    Node, Edge = rb.Node, rb.Edge
+    np.random.seed(0)
+    user_ids = ["A", "B", "C"]
+    ipu = 5
+    item_ids = list(map(str, range(ipu * len(user_ids))))
+    user_nodes = [Node("user", i) for i in user_ids]
+    item_nodes = [Node("item", i) for i in item_ids]
+    ia = np.random.normal(size=(ipu, 2))
+    ib = ia + 7
+    ib[:, 1] = ib[:, 1] - 3
+    ic = ia - 3
+    i1_15 = np.concatenate((ia, ib, ic))
+    edges, e_src, e_dst = [], [], []
+    for i, user in enumerate(user_ids):
+        for j in range(i * ipu, (i + 1) * ipu):
+            edges.append(Edge(Node("user", user), Node("item", item_ids[j]), 1))
+            e_src.append(i)
+            e_dst.append(3 + j)
+    mapper = {"item": {"numeric": NumericEmbed(n_dims=8)}}
+    node_data = {node: {"numeric": i1_15[idx]} for idx, node in enumerate(item_nodes)}
+    recsys = cr.ContentRecommendation(embedding_mapper=mapper, n_dims=4, node_types={"user", "item"})
+    final = recsys.fit(user_nodes + item_nodes, edges, node_data)
+    res = recsys.find_closest_neighbours("item", user_nodes[0], k=3)
+    np.savez_compressed(os.path.join(OUT, "g7_content_fit_e2e.npz"), item_features=i1_15,
+                        e_src=np.asarray(e_src, np.int32), e_dst=np.asarray(e_dst, np.int32), final=final,
+                        knn_idx=np.asarray([recsys.nodes_to_idx[n] for n, _ in res], dtype=np.int32),
+                        knn_score=np.asarray([s for _, s in res]), sklearn_version=sklearn.__version__)
+
+
+def g8(pkg):
+    utils = pkg.utils
+    rng = np.random.default_rng(8)
+    base = rng.standard_normal((12, 16))
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    scale = np.array([1, 1 + 5e-5, 1 - 5e-5, 1 + 2e-4, 1 - 2e-4, 1, 1, 1 + 9.9e-5, 1 - 1.01e-4, 1, 1, 1])
+    rows = base * scale[:, None]
+    rows_zero = rows.copy()
+    rows_zero[5] = 0.0
+    rows_nan = rows.copy()
+    rows_nan[6, 3] = np.nan
+    out = dict(rows=rows, rows_zero=rows_zero, rows_nan=rows_nan)
+    for name, a in (("rows", rows), ("rows_zero", rows_zero), ("rows_nan", rows_nan)):
+        out["viol_" + name] = np.asarray(utils.unit_length_violations(a, axis=1), dtype=np.float64)
+        a32 = a.astype(np.float32)
+        out["viol32_" + name] = np.asarray(utils.unit_length_violations(a32, axis=1), dtype=np.float64)
+    with np.errstate(invalid="ignore"):
+        out["unit_zero"] = utils.unit_length(rows_zero, axis=1)
+    # __build_knn__ assert behaviour
+    c = Concrete(pkg)
+
+    def builds(a):
+        m = c.cls(node_types={"x"}, n_dims=16)
+        m.add_nodes([c.rb.Node("x", i) for i in range(len(a))])
+        try:
+            m.__build_knn__(a)
+            return 1
+        except AssertionError:
+            return 0
+        except ValueError:   # sklearn refuses NaN
+            return -1
+    out["build_ok"] = np.asarray([builds(base), builds(rows), builds(rows_nan[[0, 1, 2, 5, 6, 7]])], dtype=np.int32)
+    np.savez_compressed(os.path.join(OUT, "g8_unit_audit.npz"), **out)
+
+
+def g9(pkg):
+    utils, val, rb = pkg.utils, pkg.validation, pkg.recommendation_base
+    y_true = {3: 5.0, 7: 3.0, 9: 4.0, 11: 1.0}
+    y_pred = [7, 1, 3, 4, 11, 20, 9]
+    out = dict(
+        y_true_keys=np.asarray(list(y_true.keys())), y_true_vals=np.asarray(list(y_true.values())),
+        y_pred=np.asarray(y_pred),
+        recall=utils.recall(y_true, y_pred), ndcg=utils.ndcg(y_true, y_pred),
+        binary_ndcg=utils.binary_ndcg(y_true, y_pred), binary_ndcg_v2=utils.binary_ndcg_v2(list(y_true), y_pred),
+        reciprocal_rank=utils.reciprocal_rank(list(y_true), y_pred),
+        recall_empty=utils.recall({}, y_pred), rr_miss=utils.reciprocal_rank([99], y_pred),
+        recall_short=utils.recall(y_true, [3]),
+    )
+    # one full extraction_efficiency run on a planted-neighbour model
+    U, I, d = 60, 400, 32
+    rngp = np.random.default_rng(9)
+    items = unit_rows_f32(2009, I, d).astype(np.float64)
+    liked = rngp.integers(0, I, (U, 12))
+    users = np.stack([items[liked[u]].mean(0) + 0.05 * rngp.standard_normal(d) for u in range(U)])
+    users /= np.linalg.norm(users, axis=1, keepdims=True)
+    V32 = np.concatenate([users, items]).astype(np.float32)
+    m, unodes, inodes = make_model(pkg, V32.astype(np.float64), U, I)
+    train, valid = [], []
+    t_arr, v_arr = [], []
+    for u in range(U):
+        seen = list(dict.fromkeys(int(x) for x in liked[u]))
+        for j, it in enumerate(seen):
+            r = float(1 + (u * 7 + it * 3) % 5)
+            if j < 3:
+                valid.append(rb.Edge(unodes[u], inodes[it], r))
+                v_arr.append((u, U + it, r))
+            else:
+                train.append(rb.Edge(unodes[u], inodes[it], r))
+                t_arr.append((u, U + it, r))
+    random.seed(0)
+    res = val.extraction_efficiency(m, train, valid, val.model_get_topk, "item")
+    mt = res["metrics"]
+    out.update(ee_V32=V32, ee_n_users=U, ee_n_items=I, ee_train=np.asarray(t_arr), ee_valid=np.asarray(v_arr),
+               **{"ee_" + k.replace("@", "_at_"): v for k, v in mt.items() if k != "retrieval_time"})
+    np.savez_compressed(os.path.join(OUT, "g9_metrics.npz"), **out)
+
+
+def g10(pkg):
+    U, I, d = 8, 64, 16
+    V32 = np.concatenate([unit_rows_f32(1010, U, d), unit_rows_f32(2010, I, d)])
+    V32[U + 5] = V32[U + 3]
+    V32[U + 40] = V32[U + 3]
+    V32[U + 9] = V32[U + 8]
+    # make user 0 very close to the duplicated row so that the tie group is inside the top-k
+    V32[0] = V32[U + 3]
+    m, users, items = make_model(pkg, V32.astype(np.float64), U, I)
+    idx, sc = run_knn(m, users, 10)
+    np.savez_compressed(os.path.join(OUT, "g10_ties.npz"), V32=V32, n_users=U, n_items=I, idx=idx.astype(np.int32),
+                        score=sc)
+
+
+def g11(pkg):
+    utils = pkg.utils
+    U, I, d = 4, 20, 8
+    V = np.concatenate([unit_rows_f32(1011, U, d), unit_rows_f32(2011, I, d)]).astype(np.float64)
+    m, users, items = make_model(pkg, V, U, I)
+    Node = pkg.recommendation_base.Node
+    got = {}
+
+    def kind(f):
+        try:
+            f()
+            return "none"
+        except AssertionError:
+            return "AssertionError"
+        except utils.NodeNotFoundException:
+            return "NodeNotFoundException"
+        except ValueError as e:
+            return "ValueError:" + str(e)
+    got["k_too_large"] = kind(lambda: m.find_closest_neighbours("item", users[0], k=I + 1))
+    got["unknown_anchor"] = kind(lambda: m.find_closest_neighbours("item", Node("user", "zz")))
+    got["bad_type"] = kind(lambda: m.find_closest_neighbours("movie", users[0]))
+    m.fit_done = False
+    got["not_fitted"] = kind(lambda: m.find_closest_neighbours("item", users[0], k=3))
+    got["dup_nodes"] = kind(lambda: m.add_nodes([Node("user", 0)]))
+    got["bad_node_type"] = kind(lambda: m.add_nodes([Node("alien", 0)]))
+    got["node_eq_int_str"] = str(Node("item", 5) == Node("item", "5"))
+    np.savez_compressed(os.path.join(OUT, "g11_errors.npz"), **{k: np.asarray(v) for k, v in got.items()})
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    pkg = ref_shims.install()
+    g1_g5(pkg)
+    g2(pkg)
+    g6(pkg)
+    g7(pkg)
+    g8(pkg)
+    g9(pkg)
+    g10(pkg)
+    g11(pkg)
+    for f in sorted(os.listdir(OUT)):
+        print("%-32s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))
+
+
+if __name__ == "__main__":
+    main()
