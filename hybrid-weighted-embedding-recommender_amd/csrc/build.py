@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Build libhwer_hip.so (gfx950) in-tree:  python build.py [--force]
+
+hipcc cross-compiles without a GPU.  The library lands in ../lib/ (git-ignored, but it travels with gpurun).
+-ffp-contract=off: the re-rank / pair-score kernels reproduce numpy's and scikit-learn's summation orders bit
+for bit, which needs products and sums rounded separately; kernels that want an FMA call fmaf() explicitly.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
+LIB = os.path.join(LIBDIR, "libhwer_hip.so")
+SOURCES = ["rowops.hip", "knn_screen.hip", "knn_select.hip"]
+HEADERS = ["hwer_common.h", "knn_internal.h", os.path.join(ROOT, "include", "hwer_hip.h")]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-I" + os.path.join(ROOT, "include"), "-I" + HERE, "-Wno-unused-result"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS + [os.path.abspath(__file__)]:
+        with open(os.path.join(HERE, f) if not os.path.isabs(f) else f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = LIB + ".sha256"
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
+        if verbose and out.strip():
+            print(out)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,35 @@
+// Internal layout shared by the k-NN screen (knn_screen.hip) and select / re-rank (knn_select.hip) stages.
+#pragma once
+#include "hwer_common.h"
+
+namespace hwer {
+
+// Candidate streams.  Every (list, query) owns two append-only streams (one per MFMA lane half) of CAPH packed
+// keys each, living in the caller's workspace:  cand[((list * Bq + q) * 2 + half) * CAPH + pos].
+constexpr int CAPH = 512;            // entries per stream
+constexpr int KPRIME_MAX = 448;      // a compaction retains K' entries, possibly all in ONE stream, and must leave
+                                     // that stream below the trigger (CAPH - 16): K' <= CAPH - 16, rounded to 64
+constexpr int SLACK = 56;            // K' = roundup64(k + SLACK)
+constexpr int K_MAX = KPRIME_MAX - SLACK;
+constexpr int SCREEN_IB = 64;        // item rows staged per tile
+constexpr int MAX_LISTS_DIRECT = 8;  // lists the select kernel can take in one pass (8 * 1024 keys = 64 KB LDS)
+
+struct ScreenPlan {
+    int ng;        // k-groups of 8 columns = ldx / 8
+    int tq;        // query subtiles (of 32) per wave
+    int wq;        // waves along the query dimension (1, 2, 4); wi = 4 / wq waves split the item subtiles
+    int qb;        // queries per workgroup = wq * 32 * tq
+    int n_qblocks;
+    int n_splits;  // item ranges
+    int64_t split_items;  // items per split (multiple of SCREEN_IB)
+    int n_lists;   // n_splits * wi
+    int64_t bq;    // B rounded up to qb (stream addressing)
+    int kprime;
+};
+
+ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k);
+
+int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, hipStream_t stream);
+
+}  // namespace hwer

@@ -1,0 +1,554 @@
+// HBM-bound row kernels of the hwer hot path for gfx950 (wave64): pair scoring, blend + L2-normalise,
+// neighbour mean, fused content tail, unit-norm audit, per-type table packing, query construction.
+// Each is bounded by HBM bandwidth; algorithmic bytes per unit are listed in DESIGN.md §4.
+#include <algorithm>
+
+#include "hwer_common.h"
+
+namespace hwer {
+
+// =====================================================================================================
+// error plumbing
+// =====================================================================================================
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(HWER_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return HWER_OK;
+}
+
+// unknown node (index -1): row 0 clipped to [1e-6, 1e-5]   (hwer/recommendation_base.py:147-150)
+__device__ __forceinline__ float clip_unknown(float v) { return fminf(fmaxf(v, 1e-6f), 1e-5f); }
+
+__device__ __forceinline__ float4 load_row4(const float* V, int64_t ldv, int32_t idx, int c) {
+    const bool unk = idx < 0;
+    const float4 v = *reinterpret_cast<const float4*>(V + int64_t(unk ? 0 : idx) * ldv + 4 * c);
+    if (!unk) return v;
+    return make_float4(clip_unknown(v.x), clip_unknown(v.y), clip_unknown(v.z), clip_unknown(v.w));
+}
+
+__device__ __forceinline__ int pow2ceil(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// =====================================================================================================
+// K1+K2 pair score.  One wave = 8 pairs per step.
+//   load phase : rows are read as float4, coalesced (L lanes per row, 64/L rows per instruction), the element
+//                products are written to an LDS slab [8][stride];
+//   chain phase: 8 lanes per pair replay numpy's pairwise order on the products (np_pairwise).
+// Bytes per pair: 2*4*d (rows) + 8 (ids) + sizeof(T) (out).
+// =====================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict__ V, int d, int d4, int64_t ldv,
+                                                         const int32_t* __restrict__ src,
+                                                         const int32_t* __restrict__ dst, int64_t P,
+                                                         T* __restrict__ out, int stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    T* slab = reinterpret_cast<T*>(smem_raw) + size_t(wave) * 8 * stride;
+
+    const int L = min(64, pow2ceil(d4));  // lanes per row in the load phase
+    const int rows_per_instr = 64 / L;
+    const int sub = lane / L;             // which of the rows_per_instr rows this lane loads
+    const int c0 = lane % L;
+
+    const int64_t n_batches = cdiv64(P, 8);
+    const int64_t wave_global = int64_t(blockIdx.x) * 4 + wave;
+    const int64_t wave_stride = int64_t(gridDim.x) * 4;
+
+    for (int64_t b = wave_global; b < n_batches; b += wave_stride) {
+        const int64_t p0 = b * 8;
+        for (int pb = 0; pb < 8; pb += rows_per_instr) {
+            const int64_t p = p0 + pb + sub;
+            if (p < P) {
+                const int32_t s = src[p], t = dst[p];
+                for (int c = c0; c < d4; c += L) {
+                    const float4 a = load_row4(V, ldv, s, c);
+                    const float4 bb = load_row4(V, ldv, t, c);
+                    T* w = slab + (pb + sub) * stride + 4 * c;
+                    w[0] = T(a.x) * T(bb.x);
+                    w[1] = T(a.y) * T(bb.y);
+                    w[2] = T(a.z) * T(bb.z);
+                    w[3] = T(a.w) * T(bb.w);
+                }
+            }
+        }
+        wave_lds_sync();
+        const int p8 = lane >> 3, k = lane & 7;
+        const T r = np_pairwise<T, kPairwiseDepth>(slab + p8 * stride, d, k);
+        if (k == 0 && p0 + p8 < P) out[p0 + p8] = (r + T(1)) / T(2);
+        wave_lds_sync();
+    }
+}
+
+template <typename T>
+static int launch_pair_score(const float* V, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst,
+                             int64_t P, T* out, void* stream) {
+    if (P == 0) return HWER_OK;
+    if (!V || !src || !dst || !out) return fail(HWER_EINVAL, "pair_score: null pointer");
+    if (N < 1 || d < 1 || d > 1024) return fail(HWER_EINVAL, "pair_score: need N >= 1 and 1 <= d <= 1024 (d=%d)", d);
+    if (ldv % 4 != 0 || ldv < d) return fail(HWER_EINVAL, "pair_score: ldv must be a multiple of 4 and >= d");
+    if ((reinterpret_cast<uintptr_t>(V) & 15) != 0) return fail(HWER_EINVAL, "pair_score: V must be 16-byte aligned");
+    const int d4 = int((d + 3) / 4);
+    int stride = 4 * d4;
+    while (stride % 32 != 8) ++stride;  // chain reads of 4 pairs x 8 chains hit 32 distinct banks
+    const size_t lds = size_t(4) * 8 * stride * sizeof(T);
+    const int64_t n_batches = cdiv64(P, 8);
+    const int grid = int(std::min<int64_t>(cdiv64(n_batches, 4), kMaxStreamBlocks * 2));
+    hipLaunchKernelGGL(pair_score_kernel<T>, dim3(grid), dim3(256), lds, as_stream(stream), V, d, d4, ldv, src, dst,
+                       P, out, stride);
+    return check_launch("pair_score");
+}
+
+// =====================================================================================================
+// row-group helpers: L = pow2 lanes cooperate on one row, each lane owns float4 chunks c = c0, c0+L, ...
+// (at most MAXC chunks per lane: d <= 4*64*MAXC)
+// =====================================================================================================
+constexpr int MAXC = 4;  // d <= 1024
+
+__device__ __forceinline__ float group_sum(float v, int L) {
+    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m, kWave);
+    return v;
+}
+
+struct RowGroup {
+    int L, sub, c0, groups_per_wave;
+    __device__ __forceinline__ RowGroup(int d4) {
+        const int lane = threadIdx.x & 63;
+        L = min(64, pow2ceil(d4));
+        groups_per_wave = 64 / L;
+        sub = lane / L;
+        c0 = lane % L;
+    }
+};
+
+// K9+K10 (+ optional norms): out[r] = unit(sum_t alpha * T_t[idx_t[r]])
+__global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const* __restrict__ tables,
+                                                              int64_t ldt, const int32_t* const* __restrict__ row_idx,
+                                                              const float* __restrict__ alpha, int alpha_per_row,
+                                                              int T, int64_t R, int d4, float* __restrict__ out,
+                                                              int64_t ldo, float* __restrict__ out_norm) {
+    const RowGroup g(d4);
+    const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
+    const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
+    for (int64_t r0 = group_global - g.sub; r0 < R; r0 += group_stride) {  // r0: wave-uniform base row
+        const int64_t r = r0 + g.sub;
+        const bool live = r < R;
+        float4 acc[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            for (int t = 0; t < T; ++t) {
+                const float a = alpha_per_row ? alpha[r * T + t] : alpha[t];
+                const int32_t* ri = row_idx ? row_idx[t] : nullptr;
+                const int64_t row = ri ? int64_t(ri[r]) : r;
+                const float* base = tables[t] + row * ldt;
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = g.c0 + i * g.L;
+                    if (c < d4) {
+                        const float4 v = *reinterpret_cast<const float4*>(base + 4 * c);
+                        acc[i].x = fmaf(a, v.x, acc[i].x);
+                        acc[i].y = fmaf(a, v.y, acc[i].y);
+                        acc[i].z = fmaf(a, v.z, acc[i].z);
+                        acc[i].w = fmaf(a, v.w, acc[i].w);
+                    }
+                }
+            }
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) ss += acc[i].x * acc[i].x + acc[i].y * acc[i].y + acc[i].z * acc[i].z + acc[i].w * acc[i].w;
+        ss = group_sum(ss, g.L);
+        const float nrm = sqrtf(ss);  // no epsilon: a zero row becomes NaN like hwer/utils.py:43-44
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = g.c0 + i * g.L;
+                if (c < d4) {
+                    float4 o = make_float4(acc[i].x / nrm, acc[i].y / nrm, acc[i].z / nrm, acc[i].w / nrm);
+                    *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = o;
+                }
+            }
+            if (out_norm && g.c0 == 0) out_norm[r] = nrm;
+        }
+    }
+}
+
+// K8 and the fused tail.  FUSE = false: out = mean_adj(E);  FUSE = true: out = unit((E + mean_adj(E))/2)
+template <bool FUSE>
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ E, int64_t lde,
+                                                           const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices, int64_t N, int d4,
+                                                           float* __restrict__ out, int64_t ldo) {
+    const RowGroup g(d4);
+    const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
+    const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
+    for (int64_t r0 = group_global - g.sub; r0 < N; r0 += group_stride) {
+        const int64_t r = r0 + g.sub;
+        const bool live = r < N;
+        float4 acc[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float deg = 0.f;
+        if (live) {
+            const int64_t e0 = indptr[r], e1 = indptr[r + 1];
+            deg = float(e1 - e0);
+            for (int64_t e = e0; e < e1; ++e) {  // sequential adds in adjacency order (numpy mean(0))
+                const float* base = E + int64_t(indices[e]) * lde;
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = g.c0 + i * g.L;
+                    if (c < d4) {
+                        const float4 v = *reinterpret_cast<const float4*>(base + 4 * c);
+                        acc[i].x += v.x; acc[i].y += v.y; acc[i].z += v.z; acc[i].w += v.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                acc[i].x /= deg; acc[i].y /= deg; acc[i].z /= deg; acc[i].w /= deg;
+            }
+        }
+        if constexpr (FUSE) {
+            float ss = 0.f;
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = g.c0 + i * g.L;
+                    if (c < d4) {
+                        const float4 v = *reinterpret_cast<const float4*>(E + r * lde + 4 * c);
+                        acc[i].x = (v.x + acc[i].x) * 0.5f; acc[i].y = (v.y + acc[i].y) * 0.5f;
+                        acc[i].z = (v.z + acc[i].z) * 0.5f; acc[i].w = (v.w + acc[i].w) * 0.5f;
+                        ss += acc[i].x * acc[i].x + acc[i].y * acc[i].y + acc[i].z * acc[i].z + acc[i].w * acc[i].w;
+                    }
+                }
+            }
+            ss = group_sum(ss, g.L);
+            const float nrm = sqrtf(ss);
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    acc[i].x /= nrm; acc[i].y /= nrm; acc[i].z /= nrm; acc[i].w /= nrm;
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = g.c0 + i * g.L;
+                if (c < d4) *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = acc[i];
+            }
+        }
+    }
+}
+
+// K11 pass 1: row norms;  pack_rows: gather rows of one node type into the padded table + half norms
+template <bool PACK>
+__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ V, int64_t ldv, int d, int d4,
+                                                       const int64_t* __restrict__ row_ids, int64_t n_rows,
+                                                       float* __restrict__ X, int64_t ldx, int x4,
+                                                       float* __restrict__ out_norm) {
+    const RowGroup g(PACK ? x4 : d4);
+    const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
+    const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
+    for (int64_t r0 = group_global - g.sub; r0 < n_rows; r0 += group_stride) {
+        const int64_t r = r0 + g.sub;
+        const bool live = r < n_rows;
+        float ss = 0.f;
+        if (live) {
+            const int64_t row = row_ids ? row_ids[r] : r;
+            const float* base = V + row * ldv;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = g.c0 + i * g.L;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < d4) {
+                    v = *reinterpret_cast<const float4*>(base + 4 * c);
+                    // columns >= d inside the last chunk are padding of the source table (must be zero there)
+                    if (4 * c + 1 >= d) v.y = 0.f;
+                    if (4 * c + 2 >= d) v.z = 0.f;
+                    if (4 * c + 3 >= d) v.w = 0.f;
+                }
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                if (PACK && c < x4) *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = v;
+            }
+        }
+        ss = group_sum(ss, g.L);
+        if (live && g.c0 == 0) out_norm[r] = PACK ? 0.5f * ss : sqrtf(ss);
+    }
+}
+
+// K11 pass 2: one block, deterministic tree
+__global__ __launch_bounds__(256) void audit_reduce_kernel(const float* __restrict__ norms, int64_t N, float eps,
+                                                           uint64_t* __restrict__ counts,
+                                                           double* __restrict__ absdev_sum) {
+    __shared__ unsigned long long s_pos[256], s_neg[256], s_nan[256];
+    __shared__ double s_dev[256];
+    unsigned long long pos = 0, neg = 0, nan = 0;
+    double dev = 0.0;
+    // thresholds exactly as numpy evaluates `lengths > 1 + epsilon` with a float32 array and python float epsilon:
+    // the comparison is done in float64
+    const double hi = 1.0 + double(eps), lo = 1.0 - double(eps);
+    for (int64_t i = threadIdx.x; i < N; i += 256) {
+        const float n = norms[i];
+        pos += double(n) > hi;
+        neg += double(n) < lo;
+        nan += (n != n);
+        dev += fabs(double(n) - 1.0);
+    }
+    s_pos[threadIdx.x] = pos; s_neg[threadIdx.x] = neg; s_nan[threadIdx.x] = nan; s_dev[threadIdx.x] = dev;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            s_pos[threadIdx.x] += s_pos[threadIdx.x + s];
+            s_neg[threadIdx.x] += s_neg[threadIdx.x + s];
+            s_nan[threadIdx.x] += s_nan[threadIdx.x + s];
+            s_dev[threadIdx.x] += s_dev[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counts[0] = s_pos[0]; counts[1] = s_neg[0]; counts[2] = s_nan[0];
+        absdev_sum[0] = s_dev[0];
+    }
+}
+
+// =====================================================================================================
+// K3+K4 query construction (hwer/recommendation_base.py:153-155,164-170), T = arithmetic type.
+// 8 lanes per query; lane k owns columns j = k, k+8, ...  LDS per query: vec[d], sq[d], q[d] of T.
+// =====================================================================================================
+template <typename T>
+__device__ __forceinline__ T load_elem(const float* V, int64_t ldv, int32_t idx, int j) {
+    if (idx < 0) return T(clip_unknown(V[j]));
+    return T(V[int64_t(idx) * ldv + j]);
+}
+
+// vec <- unit(mean of the listed rows); returns nothing, result in `vec`
+template <typename T>
+__device__ __forceinline__ void unit_mean_rows(const float* V, int64_t ldv, int d, const int32_t* idx, int64_t n,
+                                               int32_t single, T* vec, T* sq, int k) {
+    for (int j = k; j < d; j += 8) {
+        T acc;
+        if (idx == nullptr) {
+            acc = load_elem<T>(V, ldv, single, j);  // mean of one row = row / 1
+        } else {
+            acc = load_elem<T>(V, ldv, idx[0], j);
+            for (int64_t m = 1; m < n; ++m) acc = acc + load_elem<T>(V, ldv, idx[m], j);
+            acc = acc / T(double(n));
+        }
+        vec[j] = acc;
+        sq[j] = acc * acc;
+    }
+    wave_lds_sync();
+    const T nrm = sqrt(np_pairwise<T, kPairwiseDepth>(sq, d, k));
+    wave_lds_sync();
+    for (int j = k; j < d; j += 8) vec[j] = vec[j] / nrm;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void query_mix_kernel(const float* __restrict__ V, int64_t ldv, int d,
+                                                        const int32_t* __restrict__ anchor,
+                                                        const int64_t* __restrict__ pos_ptr,
+                                                        const int32_t* __restrict__ pos_idx,
+                                                        const int64_t* __restrict__ neg_ptr,
+                                                        const int32_t* __restrict__ neg_idx, int64_t B,
+                                                        double* __restrict__ Q64, float* __restrict__ Q32,
+                                                        int64_t ldq32) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g8 = lane >> 3, k = lane & 7;
+    T* base = reinterpret_cast<T*>(smem_raw) + size_t(wave * 8 + g8) * 3 * d;
+    T* vec = base;
+    T* sq = base + d;
+    T* q = base + 2 * d;
+    const int wpb = blockDim.x >> 6;  // waves per block (1 when the LDS slab of 4 waves would not fit)
+    const int64_t q0 = (int64_t(blockIdx.x) * wpb + wave) * 8;
+    const int64_t qstride = int64_t(gridDim.x) * wpb * 8;
+    for (int64_t qb = q0; qb < B; qb += qstride) {  // qb wave-uniform
+        const int64_t b = qb + g8;
+        const bool live = b < B;
+        // every lane of the wave runs the same control flow; dead groups compute on anchor 0 and skip the store
+        const int64_t bb = live ? b : 0;
+        int cnt = 1;
+        unit_mean_rows<T>(V, ldv, d, nullptr, 1, anchor[bb], vec, sq, k);
+        for (int j = k; j < d; j += 8) q[j] = vec[j];
+        const int64_t np_ = pos_ptr ? pos_ptr[bb + 1] - pos_ptr[bb] : 0;
+        const int64_t nn_ = neg_ptr ? neg_ptr[bb + 1] - neg_ptr[bb] : 0;
+        // the two branches below are taken per 8-lane group; wave_lds_sync inside is a wave-level fence only
+        // (no s_barrier), so divergence between groups is legal.
+        if (np_ > 0) {
+            unit_mean_rows<T>(V, ldv, d, pos_idx + pos_ptr[bb], np_, 0, vec, sq, k);
+            for (int j = k; j < d; j += 8) q[j] = q[j] + vec[j];
+            ++cnt;
+        }
+        if (nn_ > 0) {
+            unit_mean_rows<T>(V, ldv, d, neg_idx + neg_ptr[bb], nn_, 0, vec, sq, k);
+            for (int j = k; j < d; j += 8) q[j] = q[j] + (T(-1) * vec[j]);
+            ++cnt;
+        }
+        if (live) {
+            for (int j = k; j < d; j += 8) {
+                const T v = q[j] / T(double(cnt));
+                Q64[b * d + j] = double(v);
+                Q32[b * ldq32 + j] = float(v);
+            }
+            for (int j = d + k; j < ldq32; j += 8) Q32[b * ldq32 + j] = 0.f;
+        }
+        wave_lds_sync();
+    }
+}
+
+}  // namespace hwer
+
+using namespace hwer;
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int hwer_abi_version(void) { return HWER_ABI_VERSION; }
+const char* hwer_last_error(void) { return g_err; }
+
+int hwer_pair_score_f32(const float* V, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst,
+                        int64_t P, float* out, void* stream) {
+    return launch_pair_score<float>(V, N, d, ldv, src, dst, P, out, stream);
+}
+int hwer_pair_score_f64(const float* V, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst,
+                        int64_t P, double* out, void* stream) {
+    return launch_pair_score<double>(V, N, d, ldv, src, dst, P, out, stream);
+}
+
+static int rows_grid(int64_t rows, int d4) {
+    int L = 1;
+    while (L < d4 && L < 64) L <<= 1;
+    const int64_t rows_per_block = 4 * (64 / L);
+    return int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(rows, rows_per_block), kMaxStreamBlocks)));
+}
+
+static int check_table(const char* fn, const void* p, int64_t ld, int d) {
+    if (!p) return fail(HWER_EINVAL, "%s: null pointer", fn);
+    if (d < 1 || d > 4 * 64 * MAXC) return fail(HWER_EINVAL, "%s: need 1 <= d <= %d (d=%d)", fn, 4 * 64 * MAXC, d);
+    if (ld % 4 != 0 || ld < d) return fail(HWER_EINVAL, "%s: row stride must be a multiple of 4 and >= d", fn);
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return fail(HWER_EINVAL, "%s: table must be 16-byte aligned", fn);
+    return HWER_OK;
+}
+
+int hwer_segment_mean_f32(const float* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N,
+                          int d, float* out, int64_t ldo, void* stream) {
+    if (N == 0) return HWER_OK;
+    int rc;
+    if ((rc = check_table("segment_mean(E)", E, lde, d))) return rc;
+    if ((rc = check_table("segment_mean(out)", out, ldo, d))) return rc;
+    if (!indptr || !indices) return fail(HWER_EINVAL, "segment_mean: null CSR");
+    const int d4 = (d + 3) / 4;
+    hipLaunchKernelGGL(segment_mean_kernel<false>, dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), E, lde,
+                       indptr, indices, N, d4, out, ldo);
+    return check_launch("segment_mean");
+}
+
+int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N,
+                          int d, float* out, int64_t ldo, void* stream) {
+    if (N == 0) return HWER_OK;
+    int rc;
+    if ((rc = check_table("content_tail(E)", E, lde, d))) return rc;
+    if ((rc = check_table("content_tail(out)", out, ldo, d))) return rc;
+    if (!indptr || !indices) return fail(HWER_EINVAL, "content_tail: null CSR");
+    const int d4 = (d + 3) / 4;
+    hipLaunchKernelGGL(segment_mean_kernel<true>, dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), E, lde,
+                       indptr, indices, N, d4, out, ldo);
+    return check_launch("content_tail");
+}
+
+int hwer_blend_normalize_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx,
+                             const float* alpha, int alpha_per_row, int T, int64_t R, int d, float* out,
+                             int64_t ldo, float* out_norm, void* stream) {
+    if (R == 0) return HWER_OK;
+    if (!tables || !alpha || T < 1) return fail(HWER_EINVAL, "blend_normalize: null tables/alpha or T < 1");
+    int rc;
+    if ((rc = check_table("blend_normalize(out)", out, ldo, d))) return rc;
+    if (ld_tables % 4 != 0 || ld_tables < d) return fail(HWER_EINVAL, "blend_normalize: ld_tables must be a multiple of 4 and >= d");
+    const int d4 = (d + 3) / 4;
+    hipLaunchKernelGGL(blend_normalize_kernel, dim3(rows_grid(R, d4)), dim3(256), 0, as_stream(stream), tables,
+                       ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm);
+    return check_launch("blend_normalize");
+}
+
+int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps, float* row_norm_ws,
+                        uint64_t* out_counts, double* out_absdev_sum, void* stream) {
+    int rc;
+    if (N < 1) return fail(HWER_EINVAL, "unit_audit: N < 1");
+    if ((rc = check_table("unit_audit", V, ldv, d))) return rc;
+    if (!row_norm_ws || !out_counts || !out_absdev_sum) return fail(HWER_EINVAL, "unit_audit: null output");
+    const int d4 = (d + 3) / 4;
+    hipLaunchKernelGGL(row_norm_kernel<false>, dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
+                       (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws);
+    if ((rc = check_launch("unit_audit(norms)"))) return rc;
+    hipLaunchKernelGGL(audit_reduce_kernel, dim3(1), dim3(256), 0, as_stream(stream), row_norm_ws, N, eps, out_counts,
+                       out_absdev_sum);
+    return check_launch("unit_audit(reduce)");
+}
+
+int hwer_knn_padded_dim(int d) {
+    if (d < 1 || d > 256) return -1;
+    if (d <= 32) return 32;
+    if (d <= 64) return 64;
+    if (d <= 128) return 128;
+    return 256;
+}
+
+int hwer_pack_rows_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids, int64_t n_rows,
+                       float* X, int64_t ldx, float* hnorm, void* stream) {
+    if (n_rows == 0) return HWER_OK;
+    int rc;
+    if ((rc = check_table("pack_rows(V)", V, ldv, d))) return rc;
+    if ((rc = check_table("pack_rows(X)", X, ldx, d))) return rc;
+    if (!hnorm) return fail(HWER_EINVAL, "pack_rows: null hnorm");
+    if (!row_ids && n_rows > N) return fail(HWER_EINVAL, "pack_rows: n_rows > N without row_ids");
+    const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
+    if (x4 > 64 * MAXC) return fail(HWER_EINVAL, "pack_rows: ldx too large");
+    hipLaunchKernelGGL(row_norm_kernel<true>, dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), V, ldv, d,
+                       d4, row_ids, n_rows, X, ldx, x4, hnorm);
+    return check_launch("pack_rows");
+}
+
+int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                   const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, int arith,
+                   double* Q64, float* Q32, int64_t ldq32, void* stream) {
+    if (B == 0) return HWER_OK;
+    if (!V || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "query_mix: null pointer");
+    if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix: bad shape");
+    if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix: ptr without idx");
+    if (arith != 0 && arith != 1) return fail(HWER_EINVAL, "query_mix: arith must be 0 (float64) or 1 (float32)");
+    const size_t per_wave = size_t(8) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));
+    const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, 8 * wpb), kMaxStreamBlocks * 4)));
+    if (arith == 0) {
+        hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), V,
+                           ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32);
+    } else {
+        hipLaunchKernelGGL(query_mix_kernel<float>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), V,
+                           ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32);
+    }
+    return check_launch("query_mix");
+}
+
+}  // extern "C"

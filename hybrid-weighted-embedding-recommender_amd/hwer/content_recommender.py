@@ -1,0 +1,190 @@
+"""ContentRecommendation — drop-in for the reference's hwer/content_recommender.py.
+
+Hot path (device): the tail of __build_content_embeddings__ (reference lines 77-86) and the unit_length of fit
+(line 96) run as ONE fused HIP kernel (hwer_content_tail_f32: CSR neighbour mean -> (E + A)/2 -> L2 normalise),
+or as the general multi-table, per-row alpha blend (blend_tables / hwer_blend_normalize_f32).
+Fit-time table construction (reference lines 24-76: per-type embedders, block-diagonal concat, one-hot node type,
+IncrementalPCA) is not part of the accelerated path and stays on the host with scikit-learn.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Set
+
+import numpy as np
+
+from . import native
+from .logging import getLogger
+from .recommendation_base import Edge, FeatureName, Node, NodeType, RecommendationBase
+
+
+def adjacency_csr(n_nodes: int, src: np.ndarray, dst: np.ndarray):
+    """CSR of the reference's adjacency lists (hwer/content_recommender.py:77-81): the real edges first, then one
+    self loop per node; every (s, t) appends t to adj[s] and s to adj[t] — self loops list the node twice,
+    parallel edges repeat, weights are ignored.  Append order is preserved (stable sort by owner)."""
+    loops = np.arange(n_nodes, dtype=np.int64)
+    s = np.concatenate([np.asarray(src, dtype=np.int64), loops])
+    t = np.concatenate([np.asarray(dst, dtype=np.int64), loops])
+    owner = np.stack([s, t], axis=1).ravel()
+    other = np.stack([t, s], axis=1).ravel()
+    order = np.argsort(owner, kind="stable")
+    indptr = np.zeros(n_nodes + 1, dtype=np.int64)
+    np.cumsum(np.bincount(owner, minlength=n_nodes), out=indptr[1:])
+    return indptr, other[order].astype(np.int32)
+
+
+def _dev_table(t, device, ld):
+    import torch
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32))
+    t = t.to(device=device, dtype=torch.float32)
+    if t.shape[1] == ld and t.is_contiguous():
+        return t
+    out = torch.zeros((t.shape[0], ld), dtype=torch.float32, device=device)
+    out[:, :t.shape[1]] = t
+    return out
+
+
+def content_tail(E, src, dst, device=None, return_device=False):
+    """unit_rows((E + mean_adj(E)) / 2) on the GPU.  E: (N, D) array; src/dst: edge endpoints as row ids."""
+    import torch
+    from .device_index import _require_gpu, roundup
+    lib = native.lib()
+    dev = _require_gpu(device)
+    N, D = E.shape
+    ld = roundup(D, 4)
+    Ed = _dev_table(E, dev, ld)
+    indptr, indices = adjacency_csr(N, src, dst)
+    ip = torch.from_numpy(indptr).to(dev)
+    ix = torch.from_numpy(indices).to(dev)
+    out = torch.zeros((N, ld), dtype=torch.float32, device=dev)
+    native.check(lib.hwer_content_tail_f32(native.ptr(Ed), ld, native.ptr(ip), native.ptr(ix), N, D, native.ptr(out), ld,
+                                           native.stream_ptr()), "content_tail")
+    return out if return_device else out[:, :D].cpu().numpy()
+
+
+def segment_mean(E, indptr, indices, device=None):
+    """A[n] = mean of E rows listed in CSR row n (reference: hwer/content_recommender.py:83)."""
+    import torch
+    from .device_index import _require_gpu, roundup
+    lib = native.lib()
+    dev = _require_gpu(device)
+    N, D = E.shape
+    ld = roundup(D, 4)
+    Ed = _dev_table(E, dev, ld)
+    ip = torch.from_numpy(np.ascontiguousarray(indptr, dtype=np.int64)).to(dev)
+    ix = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(dev)
+    out = torch.zeros((N, ld), dtype=torch.float32, device=dev)
+    native.check(lib.hwer_segment_mean_f32(native.ptr(Ed), ld, native.ptr(ip), native.ptr(ix), N, D, native.ptr(out), ld,
+                                           native.stream_ptr()), "segment_mean")
+    return out[:, :D].cpu().numpy()
+
+
+def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, device=None, return_device=False,
+                 return_norm=False):
+    """out[r] = unit(sum_t alpha[r, t] * tables[t][row_idx[t][r]]) — the weighted blend of content and
+    collaborative tables (north_star; reference special case hwer/content_recommender.py:85 with alpha=(.5,.5)).
+    alpha: (T,) shared weights or (R, T) per-row weights.  row_idx[t]: None (row r) or an int array (R,)."""
+    import torch
+    from .device_index import _require_gpu, roundup
+    lib = native.lib()
+    dev = _require_gpu(device)
+    T = len(tables)
+    D = tables[0].shape[1]
+    ld = roundup(D, 4)
+    tabs = [_dev_table(t, dev, ld) for t in tables]
+    alpha = np.asarray(alpha, dtype=np.float32)
+    per_row = alpha.ndim == 2
+    idx = [None] * T if row_idx is None else [None if r is None else
+                                               torch.from_numpy(np.ascontiguousarray(r, dtype=np.int32)).to(dev) for r in row_idx]
+    R = alpha.shape[0] if per_row else next((len(r) for r in (row_idx or []) if r is not None), tabs[0].shape[0])
+    tab_ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=dev)
+    has_idx = any(i is not None for i in idx)
+    idx_ptrs = torch.tensor([0 if i is None else i.data_ptr() for i in idx], dtype=torch.int64, device=dev) if has_idx else None
+    al = torch.from_numpy(np.ascontiguousarray(alpha)).to(dev)
+    out = torch.zeros((R, ld), dtype=torch.float32, device=dev)
+    norm = torch.empty(R, dtype=torch.float32, device=dev) if return_norm else None
+    native.check(lib.hwer_blend_normalize_f32(native.ptr(tab_ptrs), ld, native.ptr(idx_ptrs), native.ptr(al), 1 if per_row else 0,
+                                              T, R, D, native.ptr(out), ld, native.ptr(norm), native.stream_ptr()),
+                 "blend_normalize")
+    res = out if return_device else out[:, :D].cpu().numpy()
+    return (res, norm if return_device else norm.cpu().numpy()) if return_norm else res
+
+
+class ContentRecommendation(RecommendationBase):
+    def __init__(self, embedding_mapper: Dict[NodeType, Dict[str, object]], node_types: Set[str], n_dims: int = 32):
+        super().__init__(node_types=node_types, n_dims=n_dims)
+        self.embedding_mapper = embedding_mapper
+        self.log = getLogger(type(self).__name__)
+
+    # host, scikit-learn: reference hwer/content_recommender.py:24-76 (not on the accelerated path)
+    def __build_feature_table__(self, nodes: List[Node], node_data, n_dims) -> np.ndarray:
+        from sklearn.decomposition import IncrementalPCA
+        from .utils import unit_length
+        blocks, order = [], []
+        for nt in self.node_types:
+            members = [n for n in nodes if n.node_type == nt]
+            with_data = sum(1 for n in members if n in node_data)
+            assert with_data in (0, len(members))
+            if with_data == 0:
+                block = np.zeros((len(members), 1))
+            else:
+                feats = [node_data[n] for n in members]
+                names = list(feats[0].keys())
+                # like the reference, only the FIRST feature of a node type contributes (its concatenate result is
+                # discarded at hwer/content_recommender.py:47); the other embedders are still fitted
+                block = None
+                for f in names:
+                    emb = self.embedding_mapper[nt][f].fit_transform([x[f] for x in feats])
+                    if block is None:
+                        block = emb
+                block = unit_length(block, axis=1)
+            blocks.append(block)
+            order.extend(members)
+        width = sum(b.shape[1] for b in blocks)
+        table = np.zeros((len(order), width))
+        r = c = 0
+        for b in blocks:  # block diagonal
+            table[r:r + b.shape[0], c:c + b.shape[1]] = b
+            r, c = r + b.shape[0], c + b.shape[1]
+        pos = {n: i for i, n in enumerate(order)}
+        table = table[[pos[n] for n in nodes]]
+        cats = sorted({n.node_type for n in nodes})
+        ohe = np.zeros((len(nodes), len(cats)))
+        ohe[np.arange(len(nodes)), [cats.index(n.node_type) for n in nodes]] = 1.0
+        table = np.concatenate([table, ohe], axis=1)
+        if n_dims is None or np.isinf(n_dims):
+            n_dims = 2 ** int(np.log2(table.shape[1]))
+        table = unit_length(IncrementalPCA(n_components=n_dims, batch_size=2 ** 16).fit_transform(table), axis=1)
+        extra = 2 ** int(np.ceil(np.log2(ohe.shape[1]))) - ohe.shape[1]
+        if extra:
+            ohe = np.concatenate([ohe, np.zeros((ohe.shape[0], extra))], axis=1)
+        return np.concatenate([table, ohe], axis=1)
+
+    def __build_content_embeddings__(self, nodes, edges, node_data, n_dims):
+        """-> unit-norm (N, D) float32 rows: feature table on the host, neighbour blend + normalise on the GPU."""
+        E = self.__build_feature_table__(nodes, node_data, n_dims)
+        get = self.nodes_to_idx.__getitem__
+        src = np.fromiter((get(e.src) for e in edges), dtype=np.int64, count=len(edges))
+        dst = np.fromiter((get(e.dst) for e in edges), dtype=np.int64, count=len(edges))
+        return content_tail(E, src, dst, device=self.device)
+
+    def fit(self, nodes: List[Node], edges: List[Edge], node_data: Dict[Node, Dict[FeatureName, object]], **kwargs):
+        super().fit(nodes, edges, node_data)
+        embeddings = self.__build_content_embeddings__(nodes, edges, node_data, self.n_dims)
+        # the reference returns float64 rows; these are the device's float32 rows widened
+        embeddings = embeddings.astype(np.float64)
+        self.__build_knn__(embeddings)
+        self.fit_done = True
+        return embeddings
+
+    def fit_tables(self, nodes: List[Node], tables: Sequence, alpha, row_idx=None):
+        """Index a weighted blend of precomputed embedding tables (content + collaborative, optionally per-row alpha)."""
+        assert not self.fit_done
+        self.add_nodes(nodes)
+        vec = blend_tables(tables, alpha, row_idx, device=self.device)
+        self.__build_knn__(vec)
+        self.fit_done = True
+        return vec
+
+
+ContentRecommender = ContentRecommendation  # the name BASELINE.json's north_star uses

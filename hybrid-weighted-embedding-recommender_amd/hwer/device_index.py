@@ -1,0 +1,235 @@
+"""Device-resident index of the retrieval hot path (array level, no Node objects).
+
+HBM layout (all float32, row-major):
+  V      (N, ldv)      the `vectors` table, ldv = roundup4(d), zero padded         — pair scoring, anchors, queries
+  X_t    (N_t, ldx)    per node type copy of its rows, ldx = 32/64/128/256         — MFMA screen + re-rank
+  hnorm_t(N_t)         0.5 * ||x||^2                                               — screen key offset
+  rows_t (N_t) int64   local -> global row id (ascending insertion order)          — K6
+Replaces MultiKNN's per-type KDTree copies (reference hwer/recommendation_base.py:64-76).
+
+PyTorch is used for device memory and streams only; every computation is a call into libhwer_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import native
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _require_gpu(device):
+    torch = _torch()
+    if not torch.cuda.is_available():
+        raise native.HwerNativeError("hwer (MI355X build) needs a ROCm GPU: torch.cuda.is_available() is False; "
+                                     "there is no CPU fallback for the retrieval path")
+    return torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+
+
+def roundup(x, m):
+    return (x + m - 1) // m * m
+
+
+class _TypeTable:
+    __slots__ = ("rows", "rows_dev", "X", "hnorm", "hnorm_max", "n", "id_base")
+
+    def __init__(self):
+        self.rows = None
+        self.rows_dev = None
+        self.X = None
+        self.hnorm = None
+        self.hnorm_max = 0.0
+        self.n = 0
+        self.id_base = 0
+
+
+class DeviceIndex:
+    #: queries per launch of the k-NN kernels (bounds the candidate workspace: 16 KiB per query and list)
+    QUERY_CHUNK = 32768
+
+    def __init__(self, vectors, type_rows: Dict[str, np.ndarray], device=None, arith: Optional[int] = None,
+                 audit: bool = True):
+        """vectors: (N, d) float32/float64 numpy array or float32 torch tensor already on the device.
+        type_rows: node type -> ascending int64 array of global row ids of that type.
+        arith: 0 = score / query arithmetic of the reference when its `vectors` are float64 (default for float64
+        input), 1 = float32 (default for float32 input)."""
+        torch = _torch()
+        self.lib = native.lib()
+        self.device = _require_gpu(device)
+        if isinstance(vectors, np.ndarray):
+            if arith is None:
+                arith = 0 if vectors.dtype == np.float64 else 1
+            host = np.ascontiguousarray(vectors, dtype=np.float32)
+            N, d = host.shape
+            src = torch.from_numpy(host).to(self.device)
+        else:
+            if arith is None:
+                arith = 1
+            src = vectors.to(self.device, dtype=torch.float32)
+            N, d = src.shape
+        self.N, self.d, self.arith = int(N), int(d), int(arith)
+        self.ldv = roundup(self.d, 4)
+        if src.shape[1] == self.ldv and src.is_contiguous():
+            self.V = src
+        else:
+            self.V = torch.zeros((self.N, self.ldv), dtype=torch.float32, device=self.device)
+            self.V[:, :self.d] = src
+        self.ldx = self.lib.hwer_knn_padded_dim(self.d)
+        self.audit_result = self.unit_audit() if audit else None
+        self.tables: Dict[str, _TypeTable] = {}
+        for t, rows in type_rows.items():
+            self.add_type(t, rows)
+        self._ws = None
+
+    # ------------------------------------------------------------------------------------------------
+    def unit_audit(self, eps: float = 1e-4):
+        """(violations, mean |len - 1|, positive, negative, nan_rows) — utils.unit_length_violations on device."""
+        torch = _torch()
+        ws = torch.empty(self.N, dtype=torch.float32, device=self.device)
+        counts = torch.zeros(3, dtype=torch.int64, device=self.device)
+        dev = torch.zeros(1, dtype=torch.float64, device=self.device)
+        native.check(self.lib.hwer_unit_audit_f32(native.ptr(self.V), self.N, self.d, self.ldv, eps, native.ptr(ws),
+                                                  native.ptr(counts), native.ptr(dev), native.stream_ptr()), "unit_audit")
+        pos, neg, nan = (int(x) for x in counts.tolist())
+        return pos + neg, float(dev.item()) / self.N, pos, neg, nan
+
+    def add_type(self, node_type: str, rows: np.ndarray):
+        torch = _torch()
+        if self.ldx < 0:
+            raise native.HwerNativeError("k-NN index supports 1 <= d <= 256 (got d=%d)" % self.d)
+        tt = _TypeTable()
+        tt.rows = np.ascontiguousarray(rows, dtype=np.int64)
+        tt.n = len(tt.rows)
+        tt.rows_dev = torch.from_numpy(tt.rows).to(self.device)
+        tt.X = torch.empty((tt.n, self.ldx), dtype=torch.float32, device=self.device)
+        tt.hnorm = torch.empty(tt.n, dtype=torch.float32, device=self.device)
+        native.check(self.lib.hwer_pack_rows_f32(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(tt.rows_dev), tt.n,
+                                                 native.ptr(tt.X), self.ldx, native.ptr(tt.hnorm), native.stream_ptr()),
+                     "pack_rows")
+        tt.hnorm_max = float(tt.hnorm.max().item()) if tt.n else 0.0
+        self.tables[node_type] = tt
+        return tt
+
+    # ------------------------------------------------------------------------------------------------
+    def pair_score(self, src: np.ndarray, dst: np.ndarray, arith: Optional[int] = None) -> np.ndarray:
+        """RecommendationBase.predict on resolved indices (-1 = unknown node)."""
+        torch = _torch()
+        arith = self.arith if arith is None else arith
+        s = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int32)).to(self.device)
+        t = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int32)).to(self.device)
+        P = s.numel()
+        if arith == 0:
+            out = torch.empty(P, dtype=torch.float64, device=self.device)
+            fn = self.lib.hwer_pair_score_f64
+        else:
+            out = torch.empty(P, dtype=torch.float32, device=self.device)
+            fn = self.lib.hwer_pair_score_f32
+        native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(s), native.ptr(t), P, native.ptr(out),
+                        native.stream_ptr()), "pair_score")
+        return out.cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------------
+    def build_queries(self, anchors: np.ndarray, positive: Optional[Sequence[Sequence[int]]] = None,
+                      negative: Optional[Sequence[Sequence[int]]] = None):
+        """-> (Q64 (B, d) float64, Q32 (B, ldx) float32, anchors_dev int32) on the device."""
+        torch = _torch()
+        a = torch.from_numpy(np.ascontiguousarray(anchors, dtype=np.int32)).to(self.device)
+        B = a.numel()
+
+        def csr(lists):
+            if lists is None:
+                return None, None
+            ptrs = np.zeros(B + 1, dtype=np.int64)
+            flat = []
+            for i, l in enumerate(lists):
+                l = [] if l is None else list(l)
+                flat.extend(l)
+                ptrs[i + 1] = len(flat)
+            if not flat:
+                return None, None
+            return (torch.from_numpy(ptrs).to(self.device),
+                    torch.from_numpy(np.asarray(flat, dtype=np.int32)).to(self.device))
+
+        pp, pi = csr(positive)
+        np_, ni = csr(negative)
+        Q64 = torch.empty((B, self.d), dtype=torch.float64, device=self.device)
+        Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=self.device)
+        native.check(self.lib.hwer_query_mix(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(a), native.ptr(pp),
+                                             native.ptr(pi), native.ptr(np_), native.ptr(ni), B, self.arith,
+                                             native.ptr(Q64), native.ptr(Q32), self.ldx, native.stream_ptr()), "query_mix")
+        return Q64, Q32, a
+
+    def _workspace(self, nbytes):
+        torch = _torch()
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def search_queries(self, node_type: str, Q64, Q32, k: int, anchors_dev=None, score_mode: Optional[int] = None,
+                       sort_by_score: bool = True, id_base: Optional[int] = None):
+        """Exact k nearest rows of `node_type` for B query vectors already on the device.
+        -> torch tensors (idx (B,k) int64 global ids, score (B,k) f64, dist2 (B,k) f64, flags (B) int32)."""
+        torch = _torch()
+        tt = self.tables[node_type]
+        B = Q64.shape[0]
+        if k > tt.n:
+            raise ValueError("k must be less than or equal to the number of training points")
+        if score_mode is None:
+            score_mode = self.arith
+        idx = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        score = torch.empty((B, k), dtype=torch.float64, device=self.device)
+        dist2 = torch.empty((B, k), dtype=torch.float64, device=self.device)
+        flags = torch.empty(B, dtype=torch.int32, device=self.device)
+        use_rows = id_base is None
+        for b0 in range(0, B, self.QUERY_CHUNK):
+            b1 = min(B, b0 + self.QUERY_CHUNK)
+            nb = b1 - b0
+            wsb = self.lib.hwer_knn_workspace_bytes(nb, tt.n, self.d, k)
+            if wsb == 0:
+                raise native.HwerNativeError("knn: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" %
+                                             (nb, tt.n, self.d, k, self.lib.hwer_knn_max_k()))
+            ws = self._workspace(wsb)
+            a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
+            native.check(self.lib.hwer_knn_search_f32(
+                native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
+                native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,
+                1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
+                tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]),
+                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), native.stream_ptr()), "knn_search")
+        bad = torch.nonzero(flags == 0).flatten()
+        if bad.numel():
+            self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
+                                 dist2, flags)
+        return idx, score, dist2, flags
+
+    def _exact_fallback(self, tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
+                        dist2, flags):
+        """Queries whose certificate failed (near-ties at the K'-cut, e.g. many duplicate rows): exhaustive float64
+        pass on the device."""
+        qsel = np.ascontiguousarray(bad.cpu().numpy(), dtype=np.int32)
+        wsb = self.lib.hwer_knn_exact_workspace_bytes(tt.n, k)
+        ws = self._workspace(wsb)
+        native.check(self.lib.hwer_knn_exact_f64(
+            native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64), native.ptr(self.V) if score_mode != 2 else None,
+            self.ldv, native.ptr(anchors_dev), qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), k, score_mode,
+            1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
+            native.ptr(idx), native.ptr(score), native.ptr(dist2), native.ptr(flags), native.ptr(ws), ws.numel(),
+            native.stream_ptr()), "knn_exact")
+
+    def search(self, node_type: str, anchors: np.ndarray, k: int = 200, positive=None, negative=None,
+               scoring: str = "base", sort_by_score: bool = True):
+        """Batched find_closest_neighbours on resolved indices.
+        -> numpy (idx (B,k) int64, score (B,k) in the reference's dtype, dist (B,k) float64, flags (B))."""
+        Q64, Q32, a = self.build_queries(anchors, positive, negative)
+        mode = 2 if scoring == "gcn" else self.arith
+        idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score)
+        sc = score.cpu().numpy()
+        if mode == 1:
+            sc = sc.astype(np.float32)  # exact: the kernel widened float32 values
+        return idx.cpu().numpy(), sc, np.sqrt(dist2.cpu().numpy()), flags.cpu().numpy()

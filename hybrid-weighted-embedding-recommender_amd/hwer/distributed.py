@@ -1,0 +1,99 @@
+"""Item catalogue sharded row-wise over the GPUs of one node (one process per GPU, torch.distributed; backend
+"nccl" is RCCL on ROCm).  No reference counterpart — the reference is single process.
+
+Each rank holds rows [lo, hi) of the retrieved type's table and answers every query against its shard with the
+single-GPU kernels (exact local k nearest in (dist2, id) order).  ONE collective — an all-gather of the packed
+local results over xGMI — is followed by a k-way merge kernel on every rank.  Because the local lists and the
+merge use the same total order (dist2 asc, global id asc), the merged result is identical to the 1-GPU result.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row range of `rank`: ceil(n/G) rows per shard, the last ones may be short or empty."""
+    per = (n_rows + world_size - 1) // world_size
+    lo = min(rank * per, n_rows)
+    return lo, min(lo + per, n_rows)
+
+
+def all_gather_results(idx, score, dist2, group=None):
+    """all_gather_into_tensor of the three (B, k) result tensors -> three (G, B, k) tensors.
+    The payload is packed into ONE byte buffer per rank so that a batch costs a single collective."""
+    import torch
+    import torch.distributed as dist
+    G = dist.get_world_size(group)
+    B, k = idx.shape
+    packed = torch.cat([idx.reshape(-1).view(torch.uint8), score.reshape(-1).view(torch.uint8),
+                        dist2.reshape(-1).view(torch.uint8)])
+    out = torch.empty((G, packed.numel()), dtype=torch.uint8, device=packed.device)
+    dist.all_gather_into_tensor(out.view(-1), packed, group=group)
+    n = B * k * 8
+    g_idx = out[:, 0:n].contiguous().view(torch.int64).view(G, B, k)
+    g_score = out[:, n:2 * n].contiguous().view(torch.float64).view(G, B, k)
+    g_dist2 = out[:, 2 * n:3 * n].contiguous().view(torch.float64).view(G, B, k)
+    return g_idx, g_score, g_dist2
+
+
+def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True):
+    """hwer_merge_topk over gathered (G, B, k) tensors -> (idx, score, dist2) (B, k) tensors."""
+    import torch
+    from . import native
+    lib = native.lib()
+    G, B, k = g_idx.shape
+    o_idx = torch.empty((B, k), dtype=torch.int64, device=g_idx.device)
+    o_score = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
+    o_dist2 = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
+    native.check(lib.hwer_merge_topk(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), G, B, k,
+                                     1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
+                                     native.ptr(o_dist2), native.stream_ptr()), "merge_topk")
+    return o_idx, o_score, o_dist2
+
+
+class ShardedSearch:
+    """k-NN over a row-sharded catalogue.
+
+    local_search(Q64, Q32, k_local) -> (idx, score, dist2) (B, k_local) tensors of the LOCAL shard in ascending
+    (dist2, global id) order with GLOBAL ids; merge(g_idx, g_score, g_dist2, sort_by_score) -> merged tensors.
+    Both are injectable so that the collective plumbing is testable on CPU (gloo) without a GPU."""
+
+    def __init__(self, n_rows: int, local_search: Callable, merge: Callable = merge_on_device, group=None,
+                 pad_value: float = float("inf")):
+        import torch.distributed as dist
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_rows = n_rows
+        self.lo, self.hi = shard_bounds(n_rows, self.world, self.rank)
+        self.local_search, self.merge = local_search, merge
+        self.pad_value = pad_value
+
+    def search(self, Q64, Q32, k: int, sort_by_score: bool = True):
+        import torch
+        if k > self.n_rows:
+            raise ValueError("k must be less than or equal to the number of training points")
+        n_local = self.hi - self.lo
+        k_local = min(k, n_local)
+        B = Q64.shape[0]
+        idx = torch.full((B, k), -1, dtype=torch.int64, device=Q64.device)
+        score = torch.zeros((B, k), dtype=torch.float64, device=Q64.device)
+        dist2 = torch.full((B, k), self.pad_value, dtype=torch.float64, device=Q64.device)  # short shards pad with +inf
+        if k_local > 0:
+            li, ls, ld = self.local_search(Q64, Q32, k_local)
+            idx[:, :k_local], score[:, :k_local], dist2[:, :k_local] = li, ls, ld
+        g = all_gather_results(idx, score, dist2, self.group)
+        return self.merge(*g, sort_by_score)
+
+
+def sharded_index_search(index, node_type: str, shard: ShardedSearch, Q64, Q32, k, anchors_dev=None, score_mode=None,
+                         sort_by_score=True):
+    """Convenience: DeviceIndex whose `node_type` table holds only this rank's rows [shard.lo, shard.hi)."""
+    def local(q64, q32, kl):
+        i, s, d2, _ = index.search_queries(node_type, q64, q32, kl, anchors_dev, score_mode, sort_by_score=False,
+                                           id_base=shard.lo)
+        return i, s, d2
+    shard.local_search = local
+    return shard.search(Q64, Q32, k, sort_by_score)

@@ -1,0 +1,83 @@
+"""ctypes binding of libhwer_hip.so (C ABI: include/hwer_hip.h).
+
+The HIP library is the product path.  There is no CPU fallback: `lib()` raises if the shared object is
+missing, and every device entry point raises on a non-zero status.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhwer_hip.so")
+
+HWER_OK, HWER_EINVAL, HWER_ELAUNCH, HWER_EWORKSPACE = 0, -1, -2, -3
+
+_P = c_void_p
+# name -> (restype, argtypes); mirrors include/hwer_hip.h one to one
+PROTOTYPES = {
+    "hwer_abi_version": (c_int, []),
+    "hwer_last_error": (c_char_p, []),
+    "hwer_pair_score_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),
+    "hwer_pair_score_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),
+    "hwer_segment_mean_f32": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P]),
+    "hwer_blend_normalize_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int64, c_int, _P, c_int64, _P, _P]),
+    "hwer_content_tail_f32": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P]),
+    "hwer_unit_audit_f32": (c_int, [_P, c_int64, c_int, c_int64, c_float, _P, _P, _P, _P]),
+    "hwer_knn_padded_dim": (c_int, [c_int]),
+    "hwer_pack_rows_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
+    "hwer_query_mix": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
+    "hwer_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "hwer_knn_max_k": (c_int, []),
+    "hwer_knn_search_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int,
+                                    c_int, _P, c_int64, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "hwer_knn_exact_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "hwer_knn_exact_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int,
+                                   _P, c_int64, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "hwer_merge_topk": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class HwerNativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the library (once).  Raises loudly when it has not been built — no silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HwerNativeError(
+                "libhwer_hip.so not found at %s — build it with "
+                "`python hybrid-weighted-embedding-recommender_amd/csrc/build.py` (or __graft_entry__.build())" % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.hwer_abi_version() != 1:
+            raise HwerNativeError("libhwer_hip.so ABI version %d != 1" % handle.hwer_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc == HWER_OK:
+        return
+    msg = lib().hwer_last_error().decode("utf-8", "replace")
+    if rc == HWER_EINVAL and "k must be less than or equal" in msg:
+        # same exception type and text as scikit-learn's KDTree.query (reference behaviour)
+        raise ValueError("k must be less than or equal to the number of training points")
+    kind = {HWER_EINVAL: "invalid argument", HWER_ELAUNCH: "HIP launch failure", HWER_EWORKSPACE: "workspace"}.get(rc, "error")
+    raise HwerNativeError("%s: %s (%d): %s" % (what or "hwer native call", kind, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

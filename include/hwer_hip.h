@@ -1,0 +1,159 @@
+/*
+ * hwer_hip.h — C ABI of the MI355X (gfx950) retrieval hot path of `hwer`.
+ *
+ * Drop-in boundary.  The reference is pure Python (numpy / scikit-learn) and has no FFI of
+ * its own; these are the entry points a maintainer binds with `ctypes` (INTEGRATION.md shows the stub) to
+ * replace the numpy / KDTree calls cited per function below (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (hipMalloc / torch.Tensor.data_ptr()) unless it says "host";
+ *   - the library never allocates or frees device memory and never synchronises: callers pass output and
+ *     workspace buffers and a `hipStream_t` (as void*; NULL = default stream);
+ *   - tables are row-major float32; `ld*` are row strides in ELEMENTS;
+ *   - return value: HWER_OK (0) or a negative HWER_E* code; `hwer_last_error()` gives the text (thread local).
+ *   - index semantics: `-1` in a node-index array means "unknown node": row 0 clipped element-wise to
+ *     [1e-6, 1e-5] (hwer/recommendation_base.py:147-150).
+ */
+#ifndef HWER_HIP_H
+#define HWER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HWER_OK 0
+#define HWER_EINVAL (-1)     /* bad argument (shape, alignment, unsupported d / k) */
+#define HWER_ELAUNCH (-2)    /* HIP launch / runtime error */
+#define HWER_EWORKSPACE (-3) /* workspace too small */
+
+#define HWER_ABI_VERSION 1
+
+/* library identity / diagnostics */
+int hwer_abi_version(void);
+const char* hwer_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K1+K2  pair scoring — replaces RecommendationBase.predict, hwer/recommendation_base.py:135-144
+ *        (same body hwer/gcn_ncf.py:330-334): out[p] = (sum_j E_src[p,j]*E_dst[p,j] + 1)/2.
+ *   _f32: products and sums in float32 in numpy's pairwise order  -> bit-identical to the reference when
+ *         its `vectors` are float32 (GcnNCF flavour).
+ *   _f64: rows upcast to float64, same order -> bit-identical to the reference run on the float64 upcast.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_pair_score_f32(const float* V, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst,
+                        int64_t P, float* out, void* stream);
+int hwer_pair_score_f64(const float* V, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst,
+                        int64_t P, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K8     neighbour mean — replaces the list-comprehension at hwer/content_recommender.py:83:
+ *        out[n] = mean_{m in indices[indptr[n]:indptr[n+1]]} E[m]  (sequential adds in CSR order, then / deg).
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_segment_mean_f32(const float* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N,
+                          int d, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K9+K10 blend + L2-normalise — generalises hwer/content_recommender.py:85 and :96 (utils.py:43-44):
+ *        out[r] = unit( sum_t alpha[r or 0][t] * tables[t][ row_idx[t] ? row_idx[t][r] : r ] ), no epsilon.
+ *   tables  : device array of T device pointers, each (rows_t, d) with row stride ld_tables (same for all)
+ *   row_idx : device array of T device pointers (entries may be NULL) or NULL
+ *   alpha   : (T) if alpha_per_row == 0 else (R, T)
+ *   out_norm: optional (R) pre-normalisation L2 norms.
+ *   T = 2, tables = (E, A), alpha = (.5, .5) is exactly the reference's (E + A)/2 then unit_length.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_blend_normalize_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx,
+                             const float* alpha, int alpha_per_row, int T, int64_t R, int d, float* out,
+                             int64_t ldo, float* out_norm, void* stream);
+
+/* Fused content tail — hwer/content_recommender.py:77-86 + :96 in one pass:
+ *        out[n] = unit( (E[n] + mean_{m in adj(n)} E[m]) / 2 ).  CSR as hwer_segment_mean_f32. */
+int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N,
+                          int d, float* out, int64_t ldo, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K11    unit-norm audit — replaces utils.unit_length_violations (hwer/utils.py:51-57) as used by
+ *        RecommendationBase.__build_knn__ (hwer/recommendation_base.py:106-107).
+ *   out_counts[0..2] = rows with norm > 1+eps, rows with norm < 1-eps, rows with NaN norm
+ *   out_absdev_sum   = sum_r |norm_r - 1|  (float64; NaN rows propagate like numpy's mean would)
+ *   row_norm_ws      : (N) float workspace (receives every row norm).
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps, float* row_norm_ws,
+                        uint64_t* out_counts, double* out_absdev_sum, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K6/A4  per-type table — replaces MultiKNN.__init__ grouping + `vectors[v]` copy
+ *        (hwer/recommendation_base.py:64-76): X[i] = V[row_ids[i]] zero-padded to ldx columns,
+ *        hnorm[i] = 0.5*||X[i]||^2.  ldx = hwer_knn_padded_dim(d).
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_knn_padded_dim(int d); /* 32, 64, 128 or 256; -1 if d is unsupported (d < 1 or d > 256) */
+int hwer_pack_rows_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids /*nullable*/,
+                       int64_t n_rows, float* X, int64_t ldx, float* hnorm, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K3+K4  query construction — replaces get_average_embeddings + the list average at
+ *        hwer/recommendation_base.py:153-155,164-170, batched over B anchors with ragged pos / neg lists:
+ *        q = mean([unit(V[anchor]), unit(mean V[pos])?, -unit(mean V[neg])?])  (NOT re-normalised),
+ *        numpy's summation orders, in float64 or float32 arithmetic (`arith`).  Writes Q64 (B, d) and its float32 rounding Q32 (B, ldq32) zero-padded.
+ *   pos_ptr / neg_ptr : (B+1) CSR offsets or NULL (no lists); pos_idx / neg_idx may contain -1 (unknown).
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                   const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B,
+                   int arith /* 0: float64 arithmetic (reference with float64 vectors), 1: float32 */,
+                   double* Q64, float* Q32, int64_t ldq32, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * K5-K7  exact k-NN + re-score + sort — replaces MultiKNN.query (KDTree, hwer/recommendation_base.py:78-83)
+ *        and the re-score / sort at :171-173 (variant hwer/gcn_ncf.py:377-386).
+ *
+ *   Stage 1 (screen) : float32 MFMA  key = q.x - 0.5||x||^2 for all (query, item) pairs, streaming
+ *                      threshold filter keeps >= K' = k + slack candidates per query.
+ *   Stage 2 (re-rank): float64 squared distance of each candidate in scikit-learn's exact summation order,
+ *                      sort by (dist2 asc, id asc), keep k; flags[q] = 1 when the float32 screen provably could
+ *                      not have dropped a true top-k item (certificate), else 0 -> call hwer_knn_exact_f64.
+ *   Scores           : score_mode 0: ((a.x)+1)/2 in float64, numpy pairwise order (reference with float64 vectors)
+ *                      score_mode 1: same in float32 (reference with float32 vectors), widened to double
+ *                      score_mode 2: (2 - dist)/2 (GcnNCF without NCF, hwer/gcn_ncf.py:379-383)
+ *   Order            : sort_by_score != 0: stable sort by score desc (the reference's final order);
+ *                      else ascending (dist2, id) (MultiKNN.query order; what the multi-GPU merge consumes).
+ *
+ *   X, hnorm : from hwer_pack_rows_f32 (n_items, ldx) / (n_items)
+ *   Q32      : (B, ldx) zero-padded float32 queries;  Q64 : (B, d) exact queries
+ *   A32, a_idx: anchor rows for score_mode 0/1 (NULL for mode 2): row of query b = A32[a_idx ? a_idx[b] : b], stride lda
+ *              (pass the whole vector table as A32 and the anchors' global ids as a_idx)
+ *   row_ids  : (n_items) local->global id map or NULL (then id = id_base + local)
+ *   hnorm_max: max(hnorm) over the table (enters the float32 error bound of the certificate)
+ *   outputs  : out_idx (B,k) int64, out_score (B,k) double, out_dist2 (B,k) double, out_flags (B) int32
+ * ------------------------------------------------------------------------------------------------- */
+size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k);
+int hwer_knn_max_k(void);
+int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
+                        const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
+                        int score_mode,
+                        int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
+                        double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
+/* Exhaustive float64 k-NN for the (rare) queries whose certificate failed; same outputs / order as above.
+ * `qsel` (nq) lists the query rows to recompute; their output rows are overwritten and flags set to 2. */
+size_t hwer_knn_exact_workspace_bytes(int64_t n_items, int k);
+int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
+                       int64_t lda, const int32_t* a_idx, const int32_t* qsel_host /*host*/, int64_t nq, int k,
+                       int score_mode, int sort_by_score,
+                       const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
+                       double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * X1     multi-GPU merge (no reference counterpart): n_lists per-shard results, each
+ *        (B,k) ascending (dist2, id), gathered as (n_lists, B, k) -> global k nearest, then the same
+ *        optional stable sort by score.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_merge_topk(const int64_t* idx, const double* score, const double* dist2, int n_lists, int64_t B, int k,
+                    int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HWER_HIP_H */

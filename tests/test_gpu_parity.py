@@ -1,0 +1,362 @@
+"""GPU parity tests: the HIP path (through the C ABI / the hwer host API) against the oracle and the golden
+vectors captured from the reference.  Bit-exact for indices, float64 and float32 scores and distances; 1e-6 for the
+float32 blend stage (tolerances written at each assert)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import unit_rows_f32
+from oracle import hwer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hw():
+    import hwer
+    from hwer import native
+    native.lib()
+    return hwer
+
+
+def make_index(V, U, I, arith=None):
+    from hwer.device_index import DeviceIndex
+    return DeviceIndex(V, {"user": np.arange(U, dtype=np.int64), "item": np.arange(U, U + I, dtype=np.int64)}, arith=arith)
+
+
+def _flav(V32, f):
+    return V32.astype(np.float64) if f == "f64" else V32
+
+
+# ------------------------------------------------------------------------------------------------- pair score
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_pair_score_golden_g4(golden, hw, flav):
+    g = golden("g4_predict")
+    V = _flav(g["V32"], flav)
+    ix = make_index(V, 64, 512)
+    r = ix.pair_score(g["src"], g["dst"])
+    assert r.dtype == V.dtype
+    assert np.array_equal(r, g[f"score_{flav}"])  # bit-exact vs the reference
+
+
+@pytest.mark.parametrize("d", [1, 5, 8, 31, 64, 66, 128, 130, 200, 256, 300, 515])
+def test_pair_score_dims_bit_exact(hw, d):
+    rng = np.random.default_rng(d)
+    N, P = 700, 5003
+    V32 = unit_rows_f32(10 + d, N, d)
+    src = rng.integers(-1, N, P).astype(np.int32)
+    dst = rng.integers(-1, N, P).astype(np.int32)
+    from hwer.device_index import DeviceIndex
+    for arith, V in ((0, V32.astype(np.float64)), (1, V32)):
+        ix = DeviceIndex(V, {}, arith=arith) if d > 256 else make_index(V, 100, 600, arith)
+        got = ix.pair_score(src, dst)
+        assert np.array_equal(got, orc.pair_score(V, src, dst)), (d, arith)
+
+
+def test_pair_score_empty(hw):
+    ix = make_index(unit_rows_f32(1, 40, 16), 8, 32)
+    assert ix.pair_score(np.zeros(0, np.int32), np.zeros(0, np.int32)).shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------------- blend stage
+def test_content_tail_golden_g6(golden, hw):
+    from hwer.content_recommender import content_tail, segment_mean, adjacency_csr
+    g = golden("g6_content_tail")
+    E32 = g["E"].astype(np.float32)
+    got = content_tail(E32, g["src"], g["dst"])
+    ref_A, ref = orc.content_tail(E32.astype(np.float64), g["src"], g["dst"])
+    assert np.abs(got - ref).max() <= 1e-6          # stage A tolerance
+    assert np.abs(got - g["final"]).max() <= 1e-6   # and against the reference's own float64 output
+    indptr, indices = adjacency_csr(300, g["src"], g["dst"])
+    oi, ox = orc.adjacency_csr(300, g["src"], g["dst"])
+    assert np.array_equal(indptr, oi) and np.array_equal(indices, ox)
+    A = segment_mean(E32, indptr, indices)
+    assert np.abs(A - ref_A).max() <= 1e-6
+    # float32 oracle of the same sequential order: bit-exact
+    assert np.array_equal(A, orc.segment_mean(E32, indptr, indices))
+
+
+@pytest.mark.parametrize("d,T", [(128, 2), (256, 4), (66, 3), (8, 1)])
+def test_blend_normalize(hw, d, T):
+    from hwer.content_recommender import blend_tables
+    rng = np.random.default_rng(d * T)
+    R = 1500
+    tables = [unit_rows_f32(30 + t, 900 + 50 * t, d) for t in range(T)]
+    idx = [None if t == 0 else rng.integers(0, tables[t].shape[0], R).astype(np.int32) for t in range(T)]
+    tables[0] = unit_rows_f32(29, R, d)
+    alpha = rng.dirichlet(np.ones(T), R).astype(np.float32)
+    alpha[::5, -1] = 0.0  # "cold-start" rows
+    out, norm = blend_tables(tables, alpha, idx, return_norm=True)
+    ref = orc.blend_normalize(tables, idx, alpha)
+    assert np.abs(out - ref).max() <= 1e-6
+    assert np.abs(np.linalg.norm(out.astype(np.float64), axis=1) - 1).max() <= 1e-6
+    # shared alpha, no index: reference special case (E + A)/2
+    E, A = tables[0], unit_rows_f32(77, R, d)
+    out2 = blend_tables([E, A], np.array([0.5, 0.5], np.float32))
+    ref2 = orc.unit_length((E.astype(np.float64) + A) / 2.0, axis=1)
+    assert np.abs(out2 - ref2).max() <= 1e-6
+    # a zero row normalises to NaN (no epsilon), like hwer/utils.py:43-44
+    Z = E.copy(); Z[3] = 0
+    assert np.isnan(blend_tables([Z], np.array([1.0], np.float32))[3]).all()
+
+
+def test_unit_audit_golden_g8(golden, hw):
+    from hwer.device_index import DeviceIndex
+    g = golden("g8_unit_audit")
+    for name in ("rows", "rows_zero", "rows_nan"):
+        ix = DeviceIndex(g[name].astype(np.float32), {}, audit=True)
+        v, mean_dev, pos, neg, nan = ix.audit_result
+        ref = g["viol32_" + name]
+        assert (v, pos, neg) == (int(ref[0]), int(ref[2]), int(ref[3])), name
+        if not np.isnan(ref[1]):
+            assert abs(mean_dev - ref[1]) <= 1e-6
+        assert nan == (1 if name == "rows_nan" else 0)
+
+
+# ------------------------------------------------------------------------------------------------- queries
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_query_mix_golden_g3(golden, hw, flav):
+    g = golden("g3_posneg")
+    V = _flav(g["V32"], flav)
+    ix = make_index(V, 64, 512)
+    pos = [[int(x) for x in row if x != -2] for row in g["pos"]]
+    neg = [[int(x) for x in row if x != -2] for row in g["neg"]]
+    Q64, Q32, _ = ix.build_queries(np.arange(32), pos, neg)
+    assert np.array_equal(Q64.cpu().numpy(), g[f"q_{flav}"].astype(np.float64))  # bit-exact vs the reference
+    assert np.array_equal(Q32.cpu().numpy()[:, :32], g[f"q_{flav}"].astype(np.float32))
+    assert not Q32.cpu().numpy()[:, 32:].any()
+
+
+@pytest.mark.parametrize("d", [5, 66, 128, 200, 256])
+def test_query_mix_dims(hw, d):
+    rng = np.random.default_rng(d)
+    V32 = unit_rows_f32(d, 400, d)
+    for arith, V in ((0, V32.astype(np.float64)), (1, V32)):
+        ix = make_index(V, 100, 300, arith)
+        anchors = rng.integers(0, 100, 50)
+        pos = [list(rng.integers(-1, 400, rng.integers(0, 12))) for _ in range(50)]
+        neg = [list(rng.integers(-1, 400, rng.integers(0, 4))) for _ in range(50)]
+        Q64, _, _ = ix.build_queries(anchors, pos, neg)
+        ref = np.stack([orc.query_vector(V, int(a), np.asarray(p, np.int64), np.asarray(n, np.int64))
+                        for a, p, n in zip(anchors, pos, neg)])
+        assert np.array_equal(Q64.cpu().numpy(), ref.astype(np.float64)), (d, arith)
+
+
+# ------------------------------------------------------------------------------------------------- k-NN
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+@pytest.mark.parametrize("k", [1, 10, 200])
+def test_knn_golden_g1(golden, hw, flav, k):
+    g = golden("g1_knn_basic")
+    V = _flav(g["V32"], flav)
+    ix = make_index(V, 64, 512)
+    idx, score, dist, flags = ix.search("item", np.arange(64), k=k)
+    assert (flags > 0).all()
+    assert np.array_equal(idx, g[f"idx_{flav}_k{k}"])
+    assert score.dtype == V.dtype and np.array_equal(score, g[f"score_{flav}_k{k}"])  # bit-exact scores
+
+
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_knn_query_order_and_gcn_scoring_g5(golden, hw, flav):
+    g = golden("g1_knn_basic")
+    V = _flav(g["V32"], flav)
+    ix = make_index(V, 64, 512)
+    for k in (10, 200):
+        idx, score, dist, _ = ix.search("item", np.arange(64), k=k, scoring="gcn", sort_by_score=False)
+        assert np.array_equal(idx, g[f"knnq_idx_{flav}_k{k}"])
+        assert np.array_equal(dist, g[f"knnq_dist_{flav}_k{k}"])       # scikit-learn's distances, bit-exact
+        assert np.array_equal(score, (-1 * g[f"knnq_dist_{flav}_k{k}"] + 2) / 2)
+    idx, score, _, _ = ix.search("user", np.array([3]), k=5)
+    assert np.array_equal(idx[0], g[f"u2u_idx_{flav}"]) and np.array_equal(score[0], g[f"u2u_score_{flav}"])
+
+
+def test_knn_golden_g2_ml100k_shape(golden, hw):
+    g = golden("g2_knn_ml100k_shape")
+    U, I, d, k = int(g["n_users"]), int(g["n_items"]), int(g["d"]), int(g["k"])
+    V32 = np.concatenate([unit_rows_f32(int(g["seed_users"]), U, d), unit_rows_f32(int(g["seed_items"]), I, d)])
+    ix = make_index(V32.astype(np.float64), U, I)
+    idx, score, _, flags = ix.search("item", np.arange(U), k=k)
+    assert (flags == 1).all()
+    assert np.array_equal(idx - U, g["idx"].astype(np.int64))
+    assert hashlib.sha256(np.ascontiguousarray(idx).tobytes()).hexdigest() == str(g["idx_sha256"])
+    assert hashlib.sha256(np.ascontiguousarray(score).tobytes()).hexdigest() == str(g["score_sha256"])
+
+
+@pytest.mark.parametrize("flav", ["f64", "f32"])
+def test_knn_posneg_golden_g3(golden, hw, flav):
+    g = golden("g3_posneg")
+    V = _flav(g["V32"], flav)
+    ix = make_index(V, 64, 512)
+    pos = [[int(x) for x in row if x != -2] for row in g["pos"]]
+    neg = [[int(x) for x in row if x != -2] for row in g["neg"]]
+    idx, score, _, _ = ix.search("item", np.arange(32), k=int(g["k"]), positive=pos, negative=neg)
+    assert np.array_equal(idx, g[f"idx_{flav}"])
+    assert np.array_equal(score, g[f"score_{flav}"])
+
+
+def test_knn_ties_g10(golden, hw):
+    g = golden("g10_ties")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    ix = make_index(g["V32"].astype(np.float64), U, I)
+    idx, score, _, _ = ix.search("item", np.arange(U), k=10)
+    assert np.array_equal(score, g["score"])
+    for u in range(U):
+        o_idx, _, _ = orc.find_closest(g["V32"].astype(np.float64), np.arange(U, U + I), u, k=10)
+        assert np.array_equal(idx[u], o_idx)  # the build's tie rule == the oracle's (dist asc, id asc)
+        for s in np.unique(score[u]):
+            assert set(idx[u][score[u] == s].tolist()) == set(g["idx"][u][g["score"][u] == s].tolist())
+
+
+@pytest.mark.parametrize("d,N,B,k", [(64, 5000, 300, 200), (128, 9000, 257, 200), (256, 3000, 100, 50), (66, 2500, 70, 33),
+                                     (32, 700, 33, 392), (128, 150, 40, 150), (8, 64, 5, 64)])
+def test_knn_random_vs_oracle(hw, d, N, B, k):
+    U = B
+    V32 = np.concatenate([unit_rows_f32(5 + d, U, d), unit_rows_f32(6 + d, N, d)])
+    rows = np.arange(U, U + N)
+    for arith, V in ((0, V32.astype(np.float64)), (1, V32)):
+        ix = make_index(V, U, N, arith)
+        idx, score, dist, flags = ix.search("item", np.arange(U), k=k)
+        assert (flags > 0).all()
+        for u in range(0, U, max(1, U // 40)):
+            o_idx, o_score, o_dist = orc.find_closest(V, rows, u, k=k)
+            assert np.array_equal(idx[u], o_idx), (d, arith, u)
+            assert np.array_equal(score[u], o_score)
+            assert np.array_equal(dist[u], o_dist)
+        assert (np.diff(score, axis=1) <= 0).all()
+
+
+def test_knn_multi_split_lists(hw):
+    """few queries x many items: the item range is split over many workgroups / lists (reduce path)."""
+    d, N, B, k = 64, 60000, 3, 100
+    V32 = np.concatenate([unit_rows_f32(91, B, d), unit_rows_f32(92, N, d)])
+    V = V32.astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all()
+    for u in range(B):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+
+
+def test_knn_exact_fallback_kernel(hw):
+    """drive hwer_knn_exact_f64 directly and through massive duplication (certificate must fail, fallback must fix it)."""
+    d, N, B, k = 32, 3000, 6, 20
+    X = unit_rows_f32(55, N, d)
+    X[100:900] = X[50]  # 800 identical rows: the K' cut falls inside an exact tie group for queries near row 50
+    V32 = np.concatenate([X[[50, 51, 52, 53, 54, 55]] , X])
+    V = V32.astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert flags[0] == 2, flags          # query 0 == the duplicated row: uncertifiable by the screen -> exhaustive pass
+    for u in range(B):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+
+
+def test_multiknn_query_arbitrary_vector(golden, hw):
+    from hwer import MultiKNN, Node
+    from hwer.recommendation_base import BiMap
+    g = golden("g1_knn_basic")
+    V = g["V32"].astype(np.float64)
+    nodes = [Node("user", i) for i in range(64)] + [Node("item", i) for i in range(512)]
+    m = MultiKNN(BiMap(zip(nodes, range(len(nodes)))), V, leaf_size=128)
+    q = orc.average_embedding(V, [7])
+    res = m.query(q, "item", k=10)
+    assert [m.nodes_to_idx[n] for n, _ in res] == g["knnq_idx_f64_k10"][7].tolist()
+    assert np.array_equal(np.array([dd for _, dd in res]), g["knnq_dist_f64_k10"][7])
+    assert set(m.knn) == {"user", "item"} and m.idxs["item"][0] == 64 and m.idxs["item"].inverse[64] == 0
+
+
+# ------------------------------------------------------------------------------------------------- API level
+def test_api_drop_in_and_errors_g11(golden, hw):
+    from hwer import Node, NodeNotFoundException, VectorIndex
+    g = golden("g1_knn_basic")
+    V = g["V32"].astype(np.float64)
+    users = [Node("user", i) for i in range(64)]
+    items = [Node("item", i) for i in range(512)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=32)
+    with pytest.raises(AssertionError):
+        m.find_closest_neighbours("item", users[0])        # not fitted
+    m.fit(users + items, V)
+    res = m.find_closest_neighbours("item", users[5], k=10)
+    assert [m.nodes_to_idx[n] for n, _ in res] == g["idx_f64_k10"][5].tolist()
+    assert [s for _, s in res] == g["score_f64_k10"][5].tolist()
+    assert m.find_items_for_user(users[5], k=10) == res
+    with pytest.raises(ValueError, match="k must be less than or equal to the number of training points"):
+        m.find_closest_neighbours("item", users[0], k=513)
+    with pytest.raises(NodeNotFoundException):
+        m.find_closest_neighbours("item", Node("user", "zz"))
+    with pytest.raises(AssertionError):
+        m.find_closest_neighbours("movie", users[0])
+    with pytest.raises(AssertionError):
+        m.add_nodes([Node("user", 0)])
+    # predict with unknown nodes (G4 semantics) and get_embeddings
+    p = m.predict([(users[0], items[0]), (Node("user", "nope"), items[1])])
+    assert np.array_equal(p, orc.pair_score(V, np.array([0, -1]), np.array([64, 65])))
+    assert np.array_equal(m.get_embeddings([users[1], Node("x", 1)]), orc.gather_rows(V, np.array([1, -1])))
+    # non-unit vectors are refused like the reference's assert
+    bad = VectorIndex(node_types={"user", "item"}, n_dims=32)
+    with pytest.raises(AssertionError):
+        bad.fit(users + items, V * 1.01)
+
+
+def test_content_recommendation_fit_g7(golden, hw):
+    from hwer import ContentRecommendation, Edge, IdentityEmbedding, Node
+    g = golden("g7_content_fit_e2e")
+    g6 = golden("g6_content_tail")
+    # G6 scenario end to end through the drop-in class (IdentityEmbedding features, 3 node types)
+    rng = np.random.default_rng(7)
+    types = ["user", "item", "tag"]
+    nodes = [Node(types[i % 3], i) for i in range(300)]
+    feats = rng.standard_normal((300, 5))
+    node_data = {n: {"f": feats[i]} for i, n in enumerate(nodes)}
+    edges = [Edge(nodes[s], nodes[t], 1.0) for s, t in zip(g6["src"], g6["dst"])]
+    model = ContentRecommendation({t: {"f": IdentityEmbedding(n_dims=5)} for t in types}, set(types), n_dims=8)
+    final = model.fit(nodes, edges, node_data)
+    assert np.abs(final - g6["final"]).max() <= 1e-6   # float32 device rows vs the reference's float64 rows
+    res = model.find_closest_neighbours("item", nodes[0], k=7)
+    assert [model.nodes_to_idx[n] for n, _ in res] == g6["knn_idx"].tolist()
+    assert np.abs(np.array([s for _, s in res]) - g6["knn_score"]).max() <= 1e-5
+    assert final.shape == (300, 12) and g["final"].shape == (18, 6)
+
+
+def test_extraction_efficiency_g9(golden, hw):
+    import random
+    from hwer import Edge, Node, VectorIndex, validation
+    g = golden("g9_metrics")
+    U, I = int(g["ee_n_users"]), int(g["ee_n_items"])
+    users = [Node("user", i) for i in range(U)]
+    items = [Node("item", i) for i in range(I)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=32)
+    m.fit(users + items, g["ee_V32"].astype(np.float64))
+    allv = users + items
+    train = [Edge(allv[int(u)], allv[int(i)], float(r)) for u, i, r in g["ee_train"]]
+    valid = [Edge(allv[int(u)], allv[int(i)], float(r)) for u, i, r in g["ee_valid"]]
+    random.seed(0)
+    res = validation.extraction_efficiency(m, train, valid, validation.model_get_topk, "item")
+    for key in ("recall@100", "ndcg_b@100", "ndcg_b@10", "recall@10", "diversity"):
+        assert res["metrics"][key] == pytest.approx(float(g["ee_" + key.replace("@", "_at_")]), rel=0, abs=1e-15), key
+    assert 0 <= res["metrics"]["ncf_hr"] <= 1 and res["metrics"]["retrieval_time"] > 0
+
+
+# ------------------------------------------------------------------------------------------------- merge (X1)
+def test_merge_topk_matches_single_shard(hw):
+    import torch
+    from hwer.distributed import merge_on_device, shard_bounds
+    d, N, B, k, G = 64, 4000, 50, 100, 4
+    V32 = np.concatenate([unit_rows_f32(71, B, d), unit_rows_f32(72, N, d)])
+    V = V32.astype(np.float64)
+    full = make_index(V, B, N)
+    Q64, Q32, a = full.build_queries(np.arange(B))
+    ref = full.search_queries("item", Q64, Q32, k, a)
+    parts = []
+    for r in range(G):
+        lo, hi = shard_bounds(N, G, r)
+        from hwer.device_index import DeviceIndex
+        Vr = np.concatenate([V[:B], V[B + lo:B + hi]])
+        ixr = DeviceIndex(Vr, {"user": np.arange(B), "item": np.arange(B, B + hi - lo)}, arith=0)
+        i, s, d2, _ = ixr.search_queries("item", Q64, Q32, k, a, sort_by_score=False, id_base=B + lo)
+        parts.append((i, s, d2))
+    g_idx = torch.stack([p[0] for p in parts]); g_s = torch.stack([p[1] for p in parts]); g_d = torch.stack([p[2] for p in parts])
+    idx, score, dist2 = merge_on_device(g_idx, g_s, g_d, True)
+    assert torch.equal(idx, ref[0]) and torch.equal(score, ref[1]) and torch.equal(dist2, ref[2])
