@@ -31,14 +31,21 @@ int check_launch(const char* what) {
     return HWER_OK;
 }
 
-// unknown node (index -1): row 0 clipped to [1e-6, 1e-5]   (hwer/recommendation_base.py:147-150)
-__device__ __forceinline__ float clip_unknown(float v) { return fminf(fmaxf(v, 1e-6f), 1e-5f); }
+// unknown node (index -1): row 0 clipped to [1e-6, 1e-5]   (hwer/recommendation_base.py:147-150).
+// np.clip works in the dtype of `vectors`: the bounds are the float64 values 1e-6 / 1e-5 for float64 vectors and
+// their float32 roundings for float32 vectors, so the clip happens AFTER the widening to T.
+template <typename T>
+__device__ __forceinline__ T clip_unknown(T v) {
+    const T lo = T(1e-6), hi = T(1e-5);
+    return v < lo ? lo : (v > hi ? hi : v);
+}
 
 __device__ __forceinline__ float4 load_row4(const float* V, int64_t ldv, int32_t idx, int c) {
-    const bool unk = idx < 0;
-    const float4 v = *reinterpret_cast<const float4*>(V + int64_t(unk ? 0 : idx) * ldv + 4 * c);
-    if (!unk) return v;
-    return make_float4(clip_unknown(v.x), clip_unknown(v.y), clip_unknown(v.z), clip_unknown(v.w));
+    return *reinterpret_cast<const float4*>(V + int64_t(idx < 0 ? 0 : idx) * ldv + 4 * c);
+}
+template <typename T>
+__device__ __forceinline__ T widen(float v, bool unknown) {
+    return unknown ? clip_unknown<T>(T(v)) : T(v);
 }
 
 __device__ __forceinline__ int pow2ceil(int x) {
@@ -83,10 +90,11 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
                     const float4 a = load_row4(V, ldv, s, c);
                     const float4 bb = load_row4(V, ldv, t, c);
                     T* w = slab + (pb + sub) * stride + 4 * c;
-                    w[0] = T(a.x) * T(bb.x);
-                    w[1] = T(a.y) * T(bb.y);
-                    w[2] = T(a.z) * T(bb.z);
-                    w[3] = T(a.w) * T(bb.w);
+                    const bool us = s < 0, ut = t < 0;
+                    w[0] = widen<T>(a.x, us) * widen<T>(bb.x, ut);
+                    w[1] = widen<T>(a.y, us) * widen<T>(bb.y, ut);
+                    w[2] = widen<T>(a.z, us) * widen<T>(bb.z, ut);
+                    w[3] = widen<T>(a.w, us) * widen<T>(bb.w, ut);
                 }
             }
         }
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256) void audit_reduce_kernel(const float* __restri
 // =====================================================================================================
 template <typename T>
 __device__ __forceinline__ T load_elem(const float* V, int64_t ldv, int32_t idx, int j) {
-    if (idx < 0) return T(clip_unknown(V[j]));
+    if (idx < 0) return clip_unknown<T>(T(V[j]));
     return T(V[int64_t(idx) * ldv + j]);
 }
 

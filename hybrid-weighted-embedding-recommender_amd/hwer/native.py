@@ -51,6 +51,9 @@ def lib():
             raise HwerNativeError(
                 "libhwer_hip.so not found at %s — build it with "
                 "`python hybrid-weighted-embedding-recommender_amd/csrc/build.py` (or __graft_entry__.build())" % LIB_PATH)
+        # torch first: its wheel bundles the HIP runtime (libamdhip64.so.7) that owns every device pointer we are
+        # handed; loading ours afterwards binds to that already-loaded soname instead of a second runtime.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol

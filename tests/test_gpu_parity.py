@@ -86,11 +86,14 @@ def test_blend_normalize(hw, d, T):
     idx = [None if t == 0 else rng.integers(0, tables[t].shape[0], R).astype(np.int32) for t in range(T)]
     tables[0] = unit_rows_f32(29, R, d)
     alpha = rng.dirichlet(np.ones(T), R).astype(np.float32)
-    alpha[::5, -1] = 0.0  # "cold-start" rows
+    if T > 1:
+        alpha[::5, -1] = 0.0  # "cold-start" rows: the last (collaborative) table gets weight 0
     out, norm = blend_tables(tables, alpha, idx, return_norm=True)
     ref = orc.blend_normalize(tables, idx, alpha)
     assert np.abs(out - ref).max() <= 1e-6
     assert np.abs(np.linalg.norm(out.astype(np.float64), axis=1) - 1).max() <= 1e-6
+    pre = sum(alpha[:, t:t + 1].astype(np.float64) * (tables[t] if idx[t] is None else tables[t][idx[t]]) for t in range(T))
+    assert np.abs(norm - np.linalg.norm(pre, axis=1)).max() <= 1e-6
     # shared alpha, no index: reference special case (E + A)/2
     E, A = tables[0], unit_rows_f32(77, R, d)
     out2 = blend_tables([E, A], np.array([0.5, 0.5], np.float32))
