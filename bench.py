@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Benchmark of the hwer retrieval hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5]
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  blend of the content + collaborative tables with alpha weights -> L2-normalise -> unit-norm audit ->
+  per-type item table (+ half norms) -> query construction for every user -> exact top-K retrieval
+  (float32 MFMA screen + float64 re-rank + re-score + sort), K = 200.
+`value` = user-item pairs scored per second = users * items / step time (whole job, all GPUs).
+
+Default (N = 1): BASELINE.json configs[1] — ML-1M-shaped synthetic, 6040 users x 3706 items, d = 128, two tables,
+alpha = 0.5.  N > 1 (launched by torch.distributed.run, one rank per GPU): the item catalogue is row-sharded, every
+rank holds a shard of the SAME size as the N = 1 catalogue (weak scaling), queries are replicated, and the local
+top-K are exchanged with one RCCL all-gather followed by the merge kernel on every rank.
+
+Prints ONE JSON line (rank 0).  See DESIGN.md §6 for the roofline arithmetic.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "hybrid-weighted-embedding-recommender_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+CONFIGS = {
+    # name: users, items per GPU, d, tables, per-row alpha, queries per step (None = all users), description
+    "c1": dict(U=943, I=1682, d=64, T=2, per_row=False, B=None, name="ML-100K-shaped synthetic (943x1682, d=64)"),
+    "c2": dict(U=6040, I=3706, d=128, T=2, per_row=False, B=None, name="ML-1M-shaped synthetic (6040x3706, d=128, alpha=0.5)"),
+    "c3": dict(U=138493, I=26744, d=128, T=2, per_row=False, B=None, name="ML-20M-shaped synthetic (138493x26744, d=128)"),
+    "c4": dict(U=4096, I=1250000, d=128, T=2, per_row=False, B=None, name="10M-item catalogue shard (4096 queries x 1.25M items/GPU, d=128)"),
+    "c5": dict(U=4096, I=1250000, d=256, T=4, per_row=True, B=None, name="multi-alpha hybrid (3 content + 1 collaborative, per-row alpha, d=256)"),
+}
+K = 200
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+HBM_PEAK_GBS = 8000.0          # same guide: HBM3E 8 TB/s spec
+
+
+def unit_rows(torch, gen, n, d, device):
+    x = torch.randn((n, d), generator=gen, device=device, dtype=torch.float32)
+    return x / x.norm(dim=1, keepdim=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="users in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hwer import native
+    from hwer.device_index import roundup
+    from hwer.distributed import all_gather_results, merge_on_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    lib = native.lib()
+    cfg = CONFIGS[args.config]
+    U, I, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
+    N = U + I                      # rows held by this rank: replicated users + the local item shard
+    ldv = roundup(d, 4)
+    ldx = lib.hwer_knn_padded_dim(d)
+    S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+    P = native.ptr
+
+    # ---------------- synthetic inputs, resident in HBM ------------------------------------------------------
+    gen = torch.Generator(device=dev)
+    tables = []
+    for t in range(T):
+        gen.manual_seed(3000 + 10 * 2 + t)                       # users: identical on every rank
+        users = unit_rows(torch, gen, U, d, dev)
+        gen.manual_seed(100003 * (rank + 1) + 3000 + t)          # items: this rank's shard
+        items = unit_rows(torch, gen, I, d, dev)
+        tables.append(torch.cat([users, items]).contiguous())
+    if cfg["per_row"]:
+        g = torch.Generator(device="cpu").manual_seed(5005)
+        alpha = torch.distributions.Dirichlet(torch.ones(T)).sample((N,)).to(torch.float32)
+        cold = torch.rand(N, generator=g) < 0.2
+        alpha[cold, T - 1] = 0.0
+        alpha = (alpha / alpha.sum(1, keepdim=True)).to(dev).contiguous()
+    else:
+        alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
+    tab_ptrs = torch.tensor([t.data_ptr() for t in tables], dtype=torch.int64, device=dev)
+    item_rows = torch.arange(U, N, dtype=torch.int64, device=dev)
+    anchors = torch.arange(0, U, dtype=torch.int32, device=dev)
+
+    # ---------------- preallocated outputs / workspace ----------------------------------------------------------
+    V = torch.zeros((N, ldv), dtype=torch.float32, device=dev)
+    norm_ws = torch.empty(N, dtype=torch.float32, device=dev)
+    audit_counts = torch.zeros(3, dtype=torch.int64, device=dev)
+    audit_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+    X = torch.empty((I, ldx), dtype=torch.float32, device=dev)
+    hnorm = torch.empty(I, dtype=torch.float32, device=dev)
+    Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
+    Q32 = torch.empty((U, ldx), dtype=torch.float32, device=dev)
+    o_idx = torch.empty((U, K), dtype=torch.int64, device=dev)
+    o_score = torch.empty((U, K), dtype=torch.float64, device=dev)
+    o_dist2 = torch.empty((U, K), dtype=torch.float64, device=dev)
+    o_flags = torch.empty(U, dtype=torch.int32, device=dev)
+    CH = 32768
+    ws_bytes = lib.hwer_knn_workspace_bytes(min(U, CH), I, d, K)
+    assert ws_bytes > 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    # rows passed the 1e-4 unit-norm audit (checked after the timed region) => 0.5||x||^2 <= 0.5 (1 + 1e-4)^2
+    hnorm_max = 0.5 * (1.0 + 1e-4) ** 2
+    id_base = U + rank * I          # global row id of this rank's first item (users first, then shards in rank order)
+    arith = 0                       # float64 score arithmetic (ContentRecommendation flavour)
+
+    def step():
+        native.check(lib.hwer_blend_normalize_f32(P(tab_ptrs), d, None, P(alpha), 1 if cfg["per_row"] else 0, T, N, d,
+                                                  P(V), ldv, None, S()), "blend")
+        native.check(lib.hwer_unit_audit_f32(P(V), N, d, ldv, 1e-4, P(norm_ws), P(audit_counts), P(audit_dev), S()), "audit")
+        native.check(lib.hwer_pack_rows_f32(P(V), N, d, ldv, P(item_rows), I, P(X), ldx, P(hnorm), S()), "pack")
+        native.check(lib.hwer_query_mix(P(V), N, d, ldv, P(anchors), None, None, None, None, U, arith, P(Q64), P(Q32),
+                                        ldx, S()), "query_mix")
+        for b0 in range(0, U, CH):
+            b1 = min(U, b0 + CH)
+            native.check(lib.hwer_knn_search_f32(P(X), P(hnorm), I, d, ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(V), ldv,
+                                                 P(anchors[b0:b1]), b1 - b0, K, arith, 1 if world == 1 else 0, None, id_base,
+                                                 hnorm_max, P(o_idx[b0:b1]), P(o_score[b0:b1]), P(o_dist2[b0:b1]),
+                                                 P(o_flags[b0:b1]), P(ws), ws.numel(), S()), "knn_search")
+        if world > 1:
+            g = all_gather_results(o_idx, o_score, o_dist2)
+            return merge_on_device(*g, True)
+        return o_idx, o_score, o_dist2
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    assert d == ldv, "bench tables are passed with row stride d"
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    lib.hwer_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.hwer_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    tot = ctypes.c_double()
+    cnt = ctypes.c_int64()
+    lib.hwer_profile_read(0, ctypes.byref(tot), ctypes.byref(cnt))
+    screen_ms = tot.value / max(cnt.value, 1)
+    screen_launches_per_step = cnt.value / max(args.steps, 1)
+    lib.hwer_profile_read(1, ctypes.byref(tot), ctypes.byref(cnt))
+    select_ms = tot.value / max(cnt.value, 1)
+
+    # ---------------- post-hoc checks (outside the timed region) ------------------------------------------------
+    pos, neg, nan = audit_counts.tolist()
+    assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
+    n_uncert = int((o_flags == 0).sum().item())
+    assert n_uncert == 0, "%d queries were not certified by the screen (would need the exhaustive pass)" % n_uncert
+    idx_h = res[0].cpu().numpy()
+    score_h = res[1].cpu().numpy()
+    parity_n = 0
+    if world == 1:
+        from oracle import c_oracle
+        Vh = V[:, :d].cpu().numpy()
+        sel = np.unique(np.linspace(0, U - 1, 16).astype(np.int64))
+        V64 = Vh.astype(np.float64)
+        Qh = V64[sel] / np.sqrt(np.stack([(V64[s] * V64[s]).sum() for s in sel]))[:, None]
+        # oracle query = unit(anchor) in numpy's own arithmetic
+        from oracle import hwer_oracle as orc
+        Qh = np.stack([orc.query_vector(V64, int(s)) for s in sel])
+        oi, osc, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=os.cpu_count())
+        assert np.array_equal(idx_h[sel], oi + U), "GPU indices differ from the oracle"
+        assert np.array_equal(score_h[sel], osc), "GPU scores differ from the oracle"
+        parity_n = len(sel)
+
+    total_items = I * world
+    pairs_per_step = float(U) * float(total_items)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = pairs_per_step / (elapsed / args.steps)
+    # dominant kernel: the float32 MFMA screen.  Algorithmic work per launch = 2 * B * N_t * d flops
+    launches = max(1.0, screen_launches_per_step)
+    flops_per_launch = 2.0 * U * I * d / launches
+    achieved = flops_per_launch / (screen_ms * 1e-3) / 1e12 if screen_ms > 0 else 0.0
+    out = {
+        "metric": "user-item pairs/sec scored (blend + L2-normalise + exact top-%d retrieval)" % K,
+        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["name"], "users": U, "items_per_gpu": I, "items_total": total_items, "d": d, "k": K,
+                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": "items row-sharded x%d, all-gather + merge" % world if world > 1 else "none"},
+        "roofline": {"kernel": "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)", "bound": "mfma",
+                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "avg_launch_ms": screen_ms, "launches_per_step": launches},
+        "kernels_ms": {"knn_screen": screen_ms, "knn_select_rerank": select_ms},
+        "recall_latency_ms": ms_per_step, "certified_queries": U - n_uncert, "parity_checked_queries": parity_n,
+    }
+
+    # ---------------- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) -------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+        from oracle import hwer_oracle as orc
+        Vh = V[:, :d].cpu().numpy()
+        V64 = Vh.astype(np.float64)
+        cores = os.cpu_count() or 1
+        n_s = args.cpu_sample or int(min(U, max(64, 6.0e9 * cores / (float(I) * d * 8))))  # ~10-20 s of CPU work
+        sel = np.linspace(0, U - 1, n_s).astype(np.int64)
+        Qh = V64[sel] / np.linalg.norm(V64[sel], axis=1, keepdims=True)
+        c_oracle.find_closest_f64(Vh[U:U + min(I, 2048)], Qh[:8], V64[sel[:8]], min(K, 64), threads=cores)  # warm up the thread pool
+        t1 = time.perf_counter()
+        c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=cores)
+        t_all = time.perf_counter() - t1
+        n_1 = max(8, n_s // (4 * cores))
+        t1 = time.perf_counter()
+        c_oracle.find_closest_f64(Vh[U:], Qh[:n_1], V64[sel[:n_1]], K, threads=1)
+        t_one = time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": n_s * float(I) / t_all, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": "%d of %d users x %d items, exact float64 brute force + re-score + sort (oracle/hwer_oracle.c, OpenMP)" % (n_s, U, I),
+                               "seconds": t_all, "single_thread_value": n_1 * float(I) / t_one}
+        out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -490,6 +490,63 @@ static int set_max_lds(const void* fn, size_t bytes, const char* what) {
 
 using namespace hwer;
 
+// ---- optional per-kernel timing with HIP events recorded on the launch stream (bench.py roofline) -----------
+#include <vector>
+namespace {
+struct ProfSlot {
+    std::vector<hipEvent_t> start, stop;
+    size_t used = 0;
+};
+bool g_prof_on = false;
+ProfSlot g_prof[2];  // 0: knn_screen, 1: knn_select (+ reduce)
+
+struct ProfScope {
+    int which;
+    hipStream_t st;
+    bool on;
+    ProfScope(int w, hipStream_t s) : which(w), st(s), on(g_prof_on) {
+        if (!on) return;
+        ProfSlot& p = g_prof[which];
+        if (p.used == p.start.size()) {
+            hipEvent_t a, b;
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            p.start.push_back(a);
+            p.stop.push_back(b);
+        }
+        hipEventRecord(p.start[p.used], st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        ProfSlot& p = g_prof[which];
+        hipEventRecord(p.stop[p.used], st);
+        ++p.used;
+    }
+};
+}  // namespace
+
+extern "C" int hwer_profile_enable(int on) {
+    g_prof_on = on != 0;
+    return HWER_OK;
+}
+// Sum of the event-bracketed durations since the last read.  Synchronises on the recorded events (call it outside
+// the timed region).
+extern "C" int hwer_profile_read(int which, double* total_ms, int64_t* launches) {
+    if (which < 0 || which > 1 || !total_ms || !launches) return fail(HWER_EINVAL, "profile_read: bad argument");
+    ProfSlot& p = g_prof[which];
+    double sum = 0.0;
+    for (size_t i = 0; i < p.used; ++i) {
+        hipEventSynchronize(p.stop[i]);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
+        sum += ms;
+    }
+    *total_ms = sum;
+    *launches = int64_t(p.used);
+    p.used = 0;
+    return HWER_OK;
+}
+
 // workspace layout: [cand A][cnt A][cand B][cnt B]   (B only when lists must be pre-reduced)
 static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -548,8 +605,13 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     uint64_t* cand = reinterpret_cast<uint64_t*>(ws + w.cand_a);
     int32_t* cnt = reinterpret_cast<int32_t*>(ws + w.cnt_a);
-    int rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, st);
+    int rc;
+    {
+        ProfScope ps(0, st);
+        rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, st);
+    }
     if (rc) return rc;
+    ProfScope ps_select(1, st);
 
     int n_lists = plan.n_lists;
     uint64_t* cand_other = reinterpret_cast<uint64_t*>(ws + w.cand_b);

@@ -34,6 +34,10 @@ extern "C" {
 /* library identity / diagnostics */
 int hwer_abi_version(void);
 const char* hwer_last_error(void);
+/* Optional kernel timing: when enabled, hwer_knn_search_f32 brackets its screen kernel (which = 0) and its select /
+ * re-rank kernels (which = 1) with HIP events recorded on the launch stream.  hwer_profile_read sums and clears. */
+int hwer_profile_enable(int on);
+int hwer_profile_read(int which, double* total_ms, int64_t* launches);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1+K2  pair scoring — replaces RecommendationBase.predict, hwer/recommendation_base.py:135-144

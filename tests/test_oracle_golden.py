@@ -217,3 +217,33 @@ def test_g11_errors(golden):
         m.add_nodes([orc.Node("user", 0)])
     assert orc.Node("item", 5) == orc.Node("item", "5")
     assert len(m.find_closest_neighbours("item", users[0], k=3)) == 3
+
+
+# ---- the C part of the oracle (oracle/hwer_oracle.c) against the numpy oracle and the goldens ---------------------
+def test_c_oracle_matches_golden_and_numpy(golden):
+    from oracle import c_oracle
+    g = golden("g1_knn_basic")
+    U, I = int(g["n_users"]), int(g["n_items"])
+    V32 = g["V32"]
+    V = V32.astype(np.float64)
+    Q = np.stack([orc.query_vector(V, u) for u in range(U)])
+    for k in (1, 10, 200):
+        idx, sc, d2 = c_oracle.find_closest_f64(V32[U:], Q, V[:U], k, threads=2)
+        assert np.array_equal(idx + U, g[f"idx_f64_k{k}"])
+        assert np.array_equal(sc, g[f"score_f64_k{k}"])
+    idx, sc, d2 = c_oracle.find_closest_f64(V32[U:], Q, None, 10, sort_by_score=False)
+    assert np.array_equal(idx + U, g["knnq_idx_f64_k10"]) and np.array_equal(np.sqrt(d2), g["knnq_dist_f64_k10"])
+    g4 = golden("g4_predict")
+    assert np.array_equal(c_oracle.pair_score_f64(g4["V32"], g4["src"], g4["dst"], threads=2), g4["score_f64"])
+    for d in (5, 66, 130, 256, 300):
+        Vd = unit_rows_f32(d, 300, d)
+        rng = np.random.default_rng(d)
+        s, t = rng.integers(-1, 300, 500), rng.integers(-1, 300, 500)
+        assert np.array_equal(c_oracle.pair_score_f64(Vd, s, t), orc.pair_score(Vd.astype(np.float64), s, t))
+        Qd = Vd[:7].astype(np.float64) * 0.9
+        idx, sc, d2 = c_oracle.find_closest_f64(Vd[10:], Qd, Vd[:7].astype(np.float64), 20)
+        for b in range(7):
+            loc, dist = orc.knn_bruteforce(Qd[b], Vd[10:].astype(np.float64), 20)
+            score = ((Vd[:7].astype(np.float64)[b] * Vd[10:].astype(np.float64)[loc]).sum(1) + 1) / 2
+            order = np.argsort(-score, kind="stable")
+            assert np.array_equal(idx[b], loc[order]) and np.array_equal(sc[b], score[order]) and np.array_equal(d2[b], (dist ** 2)[order]) or np.allclose(np.sqrt(d2[b]), dist[order], rtol=0, atol=0)
