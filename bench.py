@@ -111,15 +111,16 @@ def main():
     norm_ws = torch.empty(N, dtype=torch.float32, device=dev)
     audit_counts = torch.zeros(3, dtype=torch.int64, device=dev)
     audit_dev = torch.zeros(1, dtype=torch.float64, device=dev)
-    X = torch.empty((I, ldx), dtype=torch.float32, device=dev)
-    hnorm = torch.empty(I, dtype=torch.float32, device=dev)
+    I_pad = lib.hwer_knn_padded_rows(I)
+    X = torch.empty((I_pad, ldx), dtype=torch.float32, device=dev)
+    hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
     Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
     Q32 = torch.empty((U, ldx), dtype=torch.float32, device=dev)
     o_idx = torch.empty((U, K), dtype=torch.int64, device=dev)
     o_score = torch.empty((U, K), dtype=torch.float64, device=dev)
     o_dist2 = torch.empty((U, K), dtype=torch.float64, device=dev)
     o_flags = torch.empty(U, dtype=torch.int32, device=dev)
-    CH = 32768
+    CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
     ws_bytes = lib.hwer_knn_workspace_bytes(min(U, CH), I, d, K)
     assert ws_bytes > 0
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

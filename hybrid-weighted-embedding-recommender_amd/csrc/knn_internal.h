@@ -11,7 +11,7 @@ constexpr int KPRIME_MAX = 448;      // a compaction retains K' entries, possibl
                                      // that stream below the trigger (CAPH - 16): K' <= CAPH - 16, rounded to 64
 constexpr int SLACK = 56;            // K' = roundup64(k + SLACK)
 constexpr int K_MAX = KPRIME_MAX - SLACK;
-constexpr int SCREEN_IB = 64;        // item rows staged per tile
+constexpr int SCREEN_IB = 32;        // item rows per LDS tile (one 32-row MFMA subtile)
 constexpr int MAX_LISTS_DIRECT = 8;  // lists the select kernel can take in one pass (8 * 1024 keys = 64 KB LDS)
 
 struct ScreenPlan {
@@ -25,9 +25,11 @@ struct ScreenPlan {
     int n_lists;   // n_splits * wi
     int64_t bq;    // B rounded up to qb (stream addressing)
     int kprime;
+    int scaled_first;  // use the sample-scaled first threshold (verified; UNDERFULL lists are flagged)
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k);
+constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, hipStream_t stream);

@@ -16,12 +16,37 @@
 // Bound: fp32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles / SIMD) once a workgroup keeps >= ~50 queries resident;
 // HBM (streaming X once per query block) below that.
 #include <algorithm>
+#include <cstdlib>
 
 #include "knn_internal.h"
 
 namespace hwer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+#ifndef HWER_SCREEN_SLOTS
+#define HWER_SCREEN_SLOTS 0
+#endif
+
+// LDS-DMA (global -> LDS without a register destination) issued through inline asm: hipcc counts a builtin
+// global_load_lds as a pending LDS write and drains vmcnt(0) before the NEXT ds_read, which would serialise the
+// prefetch with the tile that is being computed.  An asm statement is invisible to that bookkeeping; the kernel waits
+// for it explicitly (s_waitcnt vmcnt(0) right before the tile barrier).  M0 carries the wave-uniform LDS byte
+// address and is saved / restored inside the same statement (it is compiler-reserved).
+// scalar 64-bit base (wave-uniform) + 32-bit per-lane byte offset: keeps the per-lane address state to ONE VGPR
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)(p)));
+}
 
 struct ScreenArgs {
     const float* X;
@@ -31,12 +56,15 @@ struct ScreenArgs {
     const float* Q;
     int64_t B;
     uint64_t* cand;
-    int32_t* cand_cnt;
+    int32_t* cand_cnt;   // a count with bit 30 set marks an UNDERFULL list (scaled threshold was too high): recompute exactly
     int n_qblocks;
     int wq;
     int64_t split_items;
     int64_t bq;
     int kprime;
+    int scaled_first;    // 1: first compaction selects the sample-scaled rank (verified afterwards), 0: always K'
+    int debug_nofilter;  // ablation only (HWER_SCREEN_NOFILTER=1): thresholds start at +inf, nothing is appended
+    float debug_tau0;    // ablation only (HWER_SCREEN_TAU0=x): thresholds start at x instead of -inf
 };
 
 __device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t* p) {
@@ -47,29 +75,55 @@ __device__ __forceinline__ uint64_t ld_u64_l2(const uint64_t* p) {
 }
 
 // Exact K'-selection over the two streams (s0: c0 entries, s1: c1 entries) of one query, by the whole wave.
-// Afterwards the streams hold exactly `kprime` entries in total (all keys > T, plus the first few == T), and
-// T (orderable bits of the K'-th largest score) is the new strict threshold.
-__device__ __noinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0, int c1, int kprime, uint32_t* hist,
+// All keys are fetched in ONE batch of loads (16 x 8 B per lane, a single L2 round trip) and stay in registers;
+// the K'-th largest score is found by a 4-pass byte radix select (ballot-free LDS histogram), then both streams
+// are rewritten in place.  Afterwards the streams hold exactly `kprime` entries in total (all keys > T plus the
+// first few == T) and T (orderable bits of the K'-th largest score) is the new strict threshold.
+__device__ __forceinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0, int c1, int kprime, uint32_t* hist,
                                            uint32_t& T_out, int& n0_out, int& n1_out) {
+    constexpr int NCH = CAPH / 64;
     const int lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's appends have reached L2
-    uint32_t sc[2 * CAPH / 64];
+    uint64_t key[2 * NCH];
 #pragma unroll
-    for (int c = 0; c < CAPH / 64; ++c) {
+    for (int c = 0; c < NCH; ++c) {
         const int e = 64 * c + lane;
-        sc[c] = e < c0 ? ld_u32_l2(reinterpret_cast<const uint32_t*>(s0 + e) + 1) : 0u;
-        sc[CAPH / 64 + c] = e < c1 ? ld_u32_l2(reinterpret_cast<const uint32_t*>(s1 + e) + 1) : 0u;
+        key[c] = e < c0 ? ld_u64_l2(s0 + e) : 0ull;
+        key[NCH + c] = e < c1 ? ld_u64_l2(s1 + e) : 0ull;
     }
+    // bytes on which every valid key agrees need no histogram pass (the keys of one query sit in a narrow score
+    // range: sign and most exponent bits are shared, and hammering one LDS bin with 64-lane atomics is slow)
+    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 2 * NCH; ++i) {
+        const uint32_t sv = uint32_t(key[i] >> 32);
+        if (key[i] != 0ull) {
+            all_or |= sv;
+            all_and &= sv;
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        all_or |= __shfl_xor(all_or, off, kWave);
+        all_and &= __shfl_xor(all_and, off, kWave);
+    }
+    const uint32_t differ = all_or ^ all_and;
     uint32_t prefix = 0, mask = 0;
     int want = kprime;
 #pragma unroll 1
     for (int shift = 24; shift >= 0; shift -= 8) {
+        if (((differ >> shift) & 0xFFu) == 0u) {   // wave-uniform
+            prefix |= all_and & (0xFFu << shift);
+            mask |= 0xFFu << shift;
+            continue;
+        }
         *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
         wave_lds_sync();
 #pragma unroll
-        for (int i = 0; i < 2 * CAPH / 64; ++i) {
-            if (sc[i] != 0u && (sc[i] & mask) == prefix) atomicAdd(&hist[(sc[i] >> shift) & 255u], 1u);
+        for (int i = 0; i < 2 * NCH; ++i) {
+            const uint32_t sv = uint32_t(key[i] >> 32);
+            if (key[i] != 0ull && (sv & mask) == prefix) atomicAdd(&hist[(sv >> shift) & 255u], 1u);
         }
         wave_lds_sync();
         const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
@@ -82,23 +136,14 @@ __device__ __noinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0, i
         }
         const uint64_t bal = __ballot(S >= want);
         const int lstar = 63 - __builtin_clzll(bal);  // bal != 0: the streams hold >= kprime valid keys
-        int bstar = 0, want_new = want;
+        int bstar, want_new;
         {
-            int cum = S - s;
-            const uint32_t hh[4] = {h4.x, h4.y, h4.z, h4.w};
-            bool done = false;
-#pragma unroll
-            for (int t = 3; t >= 0; --t) {
-                if (!done) {
-                    if (cum + int(hh[t]) >= want) {
-                        bstar = 4 * lane + t;
-                        want_new = want - cum;
-                        done = true;
-                    } else {
-                        cum += int(hh[t]);
-                    }
-                }
-            }
+            int cum = S - s;  // keys in the bins above this lane's four
+            const int h3 = int(h4.w), h2 = int(h4.z), h1 = int(h4.y);
+            if (cum + h3 >= want) { bstar = 4 * lane + 3; want_new = want - cum; }
+            else if (cum + h3 + h2 >= want) { bstar = 4 * lane + 2; want_new = want - cum - h3; }
+            else if (cum + h3 + h2 + h1 >= want) { bstar = 4 * lane + 1; want_new = want - cum - h3 - h2; }
+            else { bstar = 4 * lane; want_new = want - cum - h3 - h2 - h1; }
         }
         bstar = __shfl(bstar, lstar, kWave);
         want = __shfl(want_new, lstar, kWave);
@@ -107,47 +152,70 @@ __device__ __noinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0, i
     }
     const uint32_t T = prefix;  // exact K'-th largest orderable score; keep `want` of the entries equal to it
     int eq_seen = 0;
-    int n_out[2];
+    int out0 = 0, out1 = 0;
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
-        uint64_t* s = st == 0 ? s0 : s1;
-        const int cn = st == 0 ? c0 : c1;
-        int out = 0;
-        for (int c = 0; 64 * c < cn; ++c) {
-            const int e = 64 * c + lane;
-            const bool valid = e < cn;
-            const uint64_t key = valid ? ld_u64_l2(s + e) : 0ull;
-            const uint32_t sv = uint32_t(key >> 32);
-            const bool gt = valid && sv > T;
-            const bool eq = valid && sv == T;
-            const uint64_t be = __ballot(eq);
-            const int rank = eq_seen + __builtin_popcountll(be & lt_mask);
-            const bool keep = gt || (eq && rank < want);
-            const uint64_t bk = __ballot(keep);
-            if (keep) s[out + __builtin_popcountll(bk & lt_mask)] = key;  // in place: out + .. <= e
-            out += __builtin_popcountll(bk);
-            eq_seen += __builtin_popcountll(be);
+    for (int i = 0; i < 2 * NCH; ++i) {
+        const uint32_t sv = uint32_t(key[i] >> 32);
+        const bool valid = key[i] != 0ull;
+        const bool gt = valid && sv > T;
+        const bool eq = valid && sv == T;
+        const uint64_t be = __ballot(eq);
+        const int rank = eq_seen + __builtin_popcountll(be & lt_mask);
+        const bool keep = gt || (eq && rank < want);
+        const uint64_t bk = __ballot(keep);
+        const int pos = __builtin_popcountll(bk & lt_mask);
+        if (i < NCH) {
+            if (keep) s0[out0 + pos] = key[i];  // every load of this stream happened before the first store
+            out0 += __builtin_popcountll(bk);
+        } else {
+            if (keep) s1[out1 + pos] = key[i];
+            out1 += __builtin_popcountll(bk);
         }
-        n_out[st] = out;
+        eq_seen += __builtin_popcountll(be);
     }
     T_out = T;
-    n0_out = n_out[0];
-    n1_out = n_out[1];
+    n0_out = out0;
+    n1_out = out1;
 }
 
-template <int NG, int TQ, int IB>
-__global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
-    constexpr int RS = NG * 8 + 4;                 // LDS row stride in floats (one 16-B pad chunk: conflict-free b128)
-    constexpr int CHUNKS = IB * NG * 2;            // float4 chunks per tile
-    constexpr int NST = CHUNKS / 256;              // staging float4 per thread
-    constexpr int S = IB / 32;                     // 32-row subtiles per tile
-    static_assert(CHUNKS % 256 == 0, "tile must split evenly over 256 threads");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* xs = reinterpret_cast<float*>(smem_raw);               // [2][IB][RS]
-    float* hn = xs + 2 * IB * RS;                                 // [2][IB]
-    uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);  // [4][256]
+// a step near 0.618 n that is coprime with n: t -> (t * step) mod n is a permutation that scatters consecutive t
+__device__ __forceinline__ int coprime_step(int n) {
+    if (n <= 2) return 1;
+    int s = int(0.6180339887f * float(n)) | 1;
+    for (;; s += 2) {
+        int x = n, y = s % n;
+        while (y) { const int tt = x % y; x = y; y = tt; }
+        if (x == 1) return s % n == 0 ? 1 : s % n;
+    }
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// LDS image of an item tile: IB rows of CH = 2*NG 16-byte chunks, UNPADDED (the LDS-DMA writes 1 KiB per
+// wave-instruction linearly), XOR-swizzled so that the ds_read_b128 of the MFMA A fragments (16 lanes = 16
+// different rows, same logical chunk) hits 16 different 16-byte slots of the 256-byte bank row:
+//   physical chunk = logical chunk ^ swz(row)
+template <int CH>
+__device__ __forceinline__ int swz(int row) {
+    if constexpr (CH >= 16) return row & 15;
+    else return (row >> 1) & (CH - 1);   // CH == 8: two 128-byte rows share a bank row
+}
+
+template <int NG, int TQ>
+__global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
+    constexpr int IB = 32;                         // item rows per tile = one 32-row MFMA subtile
+    constexpr int CH = 2 * NG;                     // 16-byte chunks per row
+    constexpr int TILE_CHUNKS = IB * CH;
+    constexpr int DMA_PER_WAVE = TILE_CHUNKS / 256 > 0 ? TILE_CHUNKS / 256 : 1;   // 1-KiB LDS-DMA pieces per wave and tile
+    constexpr int SL = 4;                          // LDS append slots per lane and query subtile
+    static_assert(TILE_CHUNKS % 64 == 0, "tile must be a whole number of 1-KiB pieces");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* xs = reinterpret_cast<float*>(smem_raw);                         // [2][IB][CH*4]
+    float* hn = xs + 2 * IB * CH * 4;                                       // [2][IB]
+    uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);          // [4][256]
+    float* keypark_all = reinterpret_cast<float*>(hist_all + 4 * 256);      // [4][64][16]: a wave's 16 keys per lane
+    uint64_t* slots_all = reinterpret_cast<uint64_t*>(keypark_all + 4 * 64 * 16);   // [4][TQ][SL][64] append slots
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int wq = a.wq, wi_n = 4 / wq;
     const int wqi = wave % wq, wii = wave / wq;
@@ -155,12 +223,16 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int list = split * wi_n + wii;
     const int64_t qw0 = int64_t(qblock) * (wq * 32 * TQ) + int64_t(wqi) * 32 * TQ;  // wave's first query
     uint32_t* hist = hist_all + wave * 256;
+    float* keypark = keypark_all + wave * (64 * 16);
+    uint64_t* slots = slots_all + wave * (TQ * SL * 64);
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
     float4 qf[TQ][NG];
     float tau[TQ];
-    int cnt[TQ];
-    uint64_t* sbuf[TQ];
+    int cnt[TQ], nloc[TQ];
+    bool first[TQ], scaled[TQ];
+    uint32_t soff[TQ];   // this lane's stream = wg_cand[soff .. soff + CAPH)
+    uint64_t* const wg_cand = a.cand + ((int64_t(list) * a.bq + qw0) * 2) * CAPH;   // wave-uniform base
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
         const int64_t q = qw0 + 32 * b + r;
@@ -168,62 +240,66 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             qf[b][g] = live ? *reinterpret_cast<const float4*>(a.Q + q * a.ldx + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
-        tau[b] = live ? -INFINITY : INFINITY;  // strict '>' filter: dead queries never append
+        tau[b] = (live && !a.debug_nofilter) ? a.debug_tau0 : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
-        sbuf[b] = a.cand + ((int64_t(list) * a.bq + q) * 2 + h) * CAPH;
+        nloc[b] = 0;
+        first[b] = true;
+        scaled[b] = false;
+        soff[b] = (uint32_t(32 * b + r) * 2u + uint32_t(h)) * CAPH;
     }
 
     const int64_t i_begin = int64_t(split) * a.split_items;
     const int64_t i_end = std::min<int64_t>(i_begin + a.split_items, a.n_items);
     const int n_tiles = int((i_end - i_begin + IB - 1) / IB);
 
-    float4 st[NST];
-    float st_h = 0.f;
-    auto tile_load = [&](int t) {
-        const int64_t base = i_begin + int64_t(t) * IB;
+    // LDS-DMA fill of tile t into ring slot (t & 1): every wave issues DMA_PER_WAVE pieces of 64 x 16 B.
+    // Tiles are visited in the order perm(t) = (t * tile_mul) mod n_tiles (tile_mul coprime with n_tiles), so the
+    // first tiles of a stream sample the whole list instead of its head (needed by the scaled first threshold).
+    const int tile_mul = a.scaled_first ? coprime_step(n_tiles) : 1;
+    auto perm = [&](int t) { return int((int64_t(t) * tile_mul) % max(n_tiles, 1)); };
+    // The table is allocated with its row count padded to a multiple of 32 (zero rows whose half norm is +inf, see
+    // hwer_pack_rows_f32), so tile reads never leave the allocation and pad rows can never pass the filter.
+    // Per-lane byte offset of this lane's chunk inside a tile (piece 0); piece i adds i * PIECE_ROWS rows.
+    constexpr int PIECE_ROWS = 64 / CH > 0 ? 64 / CH : 1;        // rows covered by one 1-KiB piece (CH <= 64)
+    static_assert(CH <= 64, "one LDS-DMA piece must hold at least one whole row");
+    const uint32_t row_bytes = uint32_t(a.ldx) * 4u;
+    auto tile_dma = [&](int t) {
+        const int64_t base = i_begin + int64_t(perm(t)) * IB;
+        const uint32_t xb_addr = __builtin_amdgcn_readfirstlane(lds_addr(xs + (t & 1) * IB * CH * 4));
+        const char* tile_ptr = reinterpret_cast<const char*>(a.X + base * a.ldx);    // wave-uniform
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // opaque: the per-piece offsets below are recomputed (a few VALU) rather than hoisted + spilled
 #pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / (2 * NG), c = e % (2 * NG);
-            const int64_t gi = std::min<int64_t>(base + row, a.n_items - 1);
-            st[i] = *reinterpret_cast<const float4*>(a.X + gi * a.ldx + 4 * c);
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {
+            const int piece = wave * DMA_PER_WAVE + i;       // wave-uniform
+            // chunk L = piece * 64 + lane lives at LDS row L / CH, physical position L % CH, and holds the logical chunk
+            // (L % CH) ^ swz(row); PIECE_ROWS is a multiple of the swizzle period or divides it evenly, so the XOR term
+            // is the same lane constant for every piece (rows piece * PIECE_ROWS + lane / CH: PIECE_ROWS in {8,4,2,1},
+            // swz period 16 rows -> the low row bits used by swz come from piece too when PIECE_ROWS < 16).
+            if (piece * 64 < TILE_CHUNKS) {
+                const int row = piece * PIECE_ROWS + ln / CH;
+                const uint32_t off = uint32_t(row) * row_bytes + uint32_t(((ln % CH) ^ swz<CH>(row)) * 16);
+                lds_dma16(tile_ptr, off, xb_addr + uint32_t(piece) * 1024u);
+            }
         }
-        if (tid < IB) {
-            const int64_t gi = base + tid;
-            st_h = gi < i_end ? a.hnorm[gi] : INFINITY;  // +inf half-norm: key = -inf, never passes
-        }
-    };
-    auto tile_store = [&](int buf) {
-        float* xb = xs + buf * IB * RS;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-            const int e = tid + 256 * i;
-            const int row = e / (2 * NG), c = e % (2 * NG);
-            *reinterpret_cast<float4*>(xb + row * RS + 4 * c) = st[i];
-        }
-        if (tid < IB) hn[buf * IB + tid] = st_h;
+        if (wave == 0 && lane < IB)   // half norms of the tile rows: one 4-byte piece, lanes 0..31
+            lds_dma4(a.hnorm + base, uint32_t(lane) * 4u, __builtin_amdgcn_readfirstlane(lds_addr(hn + (t & 1) * IB)));
     };
 
-    if (n_tiles > 0) {
-        tile_load(0);
-        tile_store(0);
-    }
-    __syncthreads();
+    if (n_tiles > 0) tile_dma(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // tile 0 has landed for every wave
+    if (n_tiles > 1) tile_dma(1);
 
     for (int t = 0; t < n_tiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < n_tiles) tile_load(t + 1);
-        const float* xb = xs + buf * IB * RS;
-        const float* hb = hn + buf * IB;
-#pragma unroll 1
-        for (int s = 0; s < S; ++s) {
-            if ((t * S + s) % wi_n != wii) continue;  // wave-uniform: item subtiles are dealt round-robin over wi waves
-            const int64_t i0 = i_begin + int64_t(t) * IB + 32 * s;
-            if (i0 >= i_end) continue;
+        const float* xb = xs + (t & 1) * IB * CH * 4;
+        const float* hb = hn + (t & 1) * IB;
+        const int64_t i0 = i_begin + int64_t(perm(t)) * IB;
+        if (t % wi_n == wii) {   // wave-uniform: tiles are dealt round-robin over the wi waves that share these queries
             f32x16 acc[TQ];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float4 hv = *reinterpret_cast<const float4*>(hb + 32 * s + 8 * rg + 4 * h);
+                const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
                     acc[b][4 * rg + 0] = -hv.x;
@@ -232,10 +308,21 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     acc[b][4 * rg + 3] = -hv.w;
                 }
             }
-            const float* arow = xb + (32 * s + r) * RS + 4 * h;
+            // A fragment of k-group g: logical chunk 2g + h of row r, stored at chunk (2g + h) ^ swz(r).
+            // (2g + h) ^ sw = 2 (g ^ (sw >> 1)) + (h ^ (sw & 1)), and XOR-ing g with a 3-bit value only touches g's low
+            // three bits: the address is lane_base + 32 B * ((g & 7) ^ swh) + 256 B * (g >> 3).  `swh` is made opaque to
+            // the optimiser once per tile so that the 8 XOR terms are recomputed (1 VALU each) instead of being hoisted
+            // out of the tile loop into registers that spill.
+            int sw = swz<CH>(r);
+            asm volatile("" : "+v"(sw));
+            const int swh = (sw >> 1) & (NG >= 8 ? 7 : (NG - 1));
+            const float* abase = xb + r * (CH * 4) + 4 * (h ^ (sw & 1));
+            auto a_ptr = [&](int g) { return abase + 8 * ((g & 7) ^ swh) + 64 * (g >> 3); };
+            float4 av_next = *reinterpret_cast<const float4*>(a_ptr(0));
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                const float4 av = *reinterpret_cast<const float4*>(arow + 8 * g);
+                const float4 av = av_next;
+                if (g + 1 < NG) av_next = *reinterpret_cast<const float4*>(a_ptr(g + 1));   // prefetch under the MFMAs
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, qf[b][g].x, acc[b], 0, 0, 0);
@@ -244,47 +331,110 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qf[b][g].w, acc[b], 0, 0, 0);
                 }
             }
-            // ---- streaming filter: append keys > tau to this lane's stream ------------------------------------
+            // ---- streaming filter ---------------------------------------------------------------------------------
+            // Lane (r, h) holds 16 keys of query r.  Passing keys are rare (K'/n per key), so instead of 16 predicated
+            // append blocks the lane builds a 16-bit pass mask, parks its 16 keys in LDS and pops set bits: the loop runs
+            // max-popcount-over-the-wave times (2-3 in steady state, 16 only during warm-up).
 #pragma unroll
             for (int b = 0; b < TQ; ++b) {
                 float m = acc[b][0];
 #pragma unroll
                 for (int q = 1; q < 16; ++q) m = fmaxf(m, acc[b][q]);
                 if (__any(m > tau[b])) {
-                    const uint32_t item0 = uint32_t(i0) + 4 * h;
+                    uint32_t mask = 0;
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const float v = acc[b][q];
-                        if (v > tau[b]) {
-                            sbuf[b][cnt[b]] = pack_key(v, item0 + (q & 3) + 8 * (q >> 2));
-                            ++cnt[b];
+                    for (int q = 0; q < 16; ++q) mask |= (acc[b][q] > tau[b]) ? (1u << q) : 0u;
+                    const uint32_t item0 = uint32_t(i0) + 4 * h;
+                    float* park = keypark + lane * 16;
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg)
+                        *reinterpret_cast<float4*>(park + 4 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
+                    while (__any(mask != 0u)) {
+                        if (mask != 0u) {
+                            const int q = __builtin_ctz(mask);
+                            mask &= mask - 1u;
+                            const uint64_t key = pack_key(park[q], item0 + (q & 3) + 8 * (q >> 2));
+                            if (nloc[b] < SL) {
+                                slots[(b * SL + nloc[b]) * 64 + lane] = key;   // flushed to HBM after the tile barrier
+                                ++nloc[b];
+                            } else {
+                                wg_cand[soff[b] + uint32_t(cnt[b])] = key;      // warm-up / bursts
+                                ++cnt[b];
+                            }
                         }
                     }
                 }
-                // ---- keep every stream at least 16 slots from its end --------------------------------------
-                uint64_t need = __ballot(cnt[b] > CAPH - 16);
-                while (need != 0ull) {
-                    const int jj = (__builtin_ctzll(need)) & 31;
-                    const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
-                    uint64_t* s0 = a.cand + ((int64_t(list) * a.bq + (qw0 + 32 * b + jj)) * 2) * CAPH;
-                    uint32_t T;
-                    int n0, n1;
-                    compact_query(s0, s0 + CAPH, c0, c1, a.kprime, hist, T, n0, n1);
-                    if (r == jj) {
-                        tau[b] = f32_from_orderable(T);
-                        cnt[b] = h == 0 ? n0 : n1;
-                    }
-                    need &= ~((1ull << jj) | (1ull << (jj + 32)));
-                }
             }
         }
-        if (t + 1 < n_tiles) tile_store(buf ^ 1);
+        // ---- tile boundary ---------------------------------------------------------------------------------------------
+        // Outstanding VMEM here: the DMA of tile t+1 and the previous flush, both issued a whole tile ago (appends of
+        // this tile sit in LDS slots), so this wait is normally free.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TQ; ++b) {
+#pragma unroll
+            for (int sidx = 0; sidx < SL; ++sidx) {
+                if (sidx < nloc[b]) {
+                    wg_cand[soff[b] + uint32_t(cnt[b])] = slots[(b * SL + sidx) * 64 + lane];
+                    ++cnt[b];
+                }
+            }
+            nloc[b] = 0;
+        }
+        if (t + 2 < n_tiles) tile_dma(t + 2);      // refill the ring slot every wave has just finished reading
+#pragma unroll
+        for (int b = 0; b < TQ; ++b) {
+            // ---- keep every stream at least 16 slots from its end ------------------------------------------------
+            uint64_t need = __ballot(cnt[b] > CAPH - 16);
+            while (need != 0ull) {
+                const int jj = (__builtin_ctzll(need)) & 31;
+                const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
+                const int was_first = __shfl(int(first[b]), jj, kWave);
+                uint64_t* s0 = wg_cand + (uint32_t(32 * b + jj) * 2u) * CAPH;
+                // First compaction of a query: its streams hold (nearly) every key of the n items seen so far, a
+                // pseudo-random sample of the list (tiles are visited in a permuted order).  Of the list's K' best,
+                // mu = K' n / N are expected in the sample; selecting rank mu + 4 sqrt(mu) + 4 instead of K' puts the
+                // threshold just below the list's K'-th best key with overwhelming probability, and the end-of-stream
+                // count check (>= K' keys above the threshold, else UNDERFULL) makes the shortcut exact.
+                int rank = a.kprime;
+                if (was_first && a.scaled_first) {
+                    const float mu = float(a.kprime) * float(c0 + c1) * float(wi_n) / float(i_end - i_begin);   // this list sees 1/wi_n of the tiles
+                    const int mrank = int(mu + 4.0f * sqrtf(mu) + 5.0f);
+                    if (2 * mrank < a.kprime) rank = mrank;
+                }
+                uint32_t T;
+                int n0, n1;
+                compact_query(s0, s0 + CAPH, c0, c1, rank, hist, T, n0, n1);
+                if (r == jj) {
+                    tau[b] = f32_from_orderable(T);
+                    cnt[b] = h == 0 ? n0 : n1;
+                    scaled[b] = scaled[b] || (rank != a.kprime);
+                    first[b] = false;
+                }
+                need &= ~((1ull << jj) | (1ull << (jj + 32)));
+            }
+        }
     }
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
+        // final compaction: queries holding more than K' keys keep exactly their K' best
+        const int partner = __shfl_xor(cnt[b], 32, kWave);
+        const int total = cnt[b] + partner;
+        const bool underfull = scaled[b] && total < a.kprime;   // the scaled threshold dropped keys it should not have
+        uint64_t need = __ballot(total > a.kprime) & 0xFFFFFFFFull;
+        while (need != 0ull) {
+            const int jj = __builtin_ctzll(need);
+            const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
+            uint64_t* s0 = wg_cand + (uint32_t(32 * b + jj) * 2u) * CAPH;
+            uint32_t T;
+            int n0, n1;
+            compact_query(s0, s0 + CAPH, c0, c1, a.kprime, hist, T, n0, n1);
+            if (r == jj) cnt[b] = h == 0 ? n0 : n1;
+            need &= ~(1ull << jj);
+        }
         const int64_t q = qw0 + 32 * b + r;
-        a.cand_cnt[(int64_t(list) * a.bq + q) * 2 + h] = cnt[b];
+        a.cand_cnt[(int64_t(list) * a.bq + q) * 2 + h] = cnt[b] | (underfull ? (1 << 30) : 0);
     }
 }
 
@@ -303,49 +453,54 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     p.n_qblocks = int(cdiv64(B, p.qb));
     p.bq = int64_t(p.n_qblocks) * p.qb;
     const int wi = 4 / p.wq;
-    // item splits: aim at >= 2 workgroups per CU-slot (256 CUs x 2 resident), but keep >= 2048 items per list
-    const int64_t target_wgs = 1024;
-    int64_t splits = std::max<int64_t>(1, target_wgs / p.n_qblocks);
-    const int64_t max_splits = std::max<int64_t>(1, n_items / (2048 * wi));
+    // item splits: every split re-pays the selection warm-up (~4 K' appends + a compaction per query), so split
+    // only when the query blocks alone cannot fill the 512 workgroup slots (256 CUs x 2 resident), and keep
+    // >= 4096 items per list.  Callers chunk B to multiples of 512 * qb queries (DeviceIndex.QUERY_CHUNK).
+    const int64_t slots = 512;
+    int64_t splits = std::max<int64_t>(1, slots / p.n_qblocks);
+    if (const char* e = getenv("HWER_SCREEN_SPLITS")) splits = std::max(1, atoi(e));  // tuning / ablation override
+    const int64_t max_splits = std::max<int64_t>(1, n_items / (4096 * wi));
     splits = std::min(splits, max_splits);
-    const int ib = p.ng < 16 ? 64 : 32;
+    const int ib = 32;
     int64_t per = cdiv64(cdiv64(n_items, splits), ib) * ib;
     splits = cdiv64(n_items, per);
     p.n_splits = int(splits);
     p.split_items = per;
     p.n_lists = p.n_splits * wi;
+    p.scaled_first = 1;
     return p;
 }
 
-template <int NG, int TQ, int IB>
+template <int NG, int TQ>
 static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    constexpr int RS = NG * 8 + 4;
-    const size_t lds = size_t(2) * IB * RS * 4 + size_t(2) * IB * 4 + 4 * 256 * 4;
+    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 waves x 64 lanes x 16 keys
+    const size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4 + size_t(4) * TQ * 4 * 64 * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, IB>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     const int grid = plan.n_qblocks * plan.n_splits;
-    hipLaunchKernelGGL((screen_kernel<NG, TQ, IB>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((screen_kernel<NG, TQ>), dim3(grid), dim3(256), lds, stream, a);
     return check_launch("knn_screen");
 }
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, hipStream_t stream) {
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
-                 plan.kprime};
+                 plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? 1 : 0,
+                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY};
     const int key = plan.ng * 10 + plan.tq;
     switch (key) {
-        case 41: return launch_screen_t<4, 1, 64>(plan, a, stream);
-        case 42: return launch_screen_t<4, 2, 64>(plan, a, stream);
-        case 81: return launch_screen_t<8, 1, 64>(plan, a, stream);
-        case 82: return launch_screen_t<8, 2, 64>(plan, a, stream);
-        case 161: return launch_screen_t<16, 1, 32>(plan, a, stream);
-        case 162: return launch_screen_t<16, 2, 32>(plan, a, stream);
-        case 321: return launch_screen_t<32, 1, 32>(plan, a, stream);
+        case 41: return launch_screen_t<4, 1>(plan, a, stream);
+        case 42: return launch_screen_t<4, 2>(plan, a, stream);
+        case 81: return launch_screen_t<8, 1>(plan, a, stream);
+        case 82: return launch_screen_t<8, 2>(plan, a, stream);
+        case 161: return launch_screen_t<16, 1>(plan, a, stream);
+        case 162: return launch_screen_t<16, 2>(plan, a, stream);
+        case 321: return launch_screen_t<32, 1>(plan, a, stream);
         default: return fail(HWER_EINVAL, "knn_screen: unsupported padded dim %d / tq %d", plan.ng * 8, plan.tq);
     }
 }

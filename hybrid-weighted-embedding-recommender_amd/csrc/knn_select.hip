@@ -136,167 +136,340 @@ struct EmitArgs {
     int32_t* out_flags;
 };
 
-// LDS carve used by rerank_emit (bytes): q64[d] | a32 as double[d] | item[NC] | d2[NC] | sc[NC] | ent[NC2]
-__host__ __device__ inline size_t emit_lds_bytes(int d, int nc2) {
-    return size_t(d) * 8 * 2 + size_t(nc2) * (4 + 4 + 8 + 8 + 16);
+// ---------------------------------------------------------------------------------------------------
+// Wave-per-query back end.  One 64-lane wave owns one query from the candidate keys to the output rows; there
+// is no workgroup barrier anywhere (a 256-thread block is just four independent queries).
+// LDS per wave, for a candidate capacity kp (multiple of 64) and kp2 = pow2 >= kp:
+//   a64[d] f64 | q64[d] f64 | t_d2[kp] f64 | t_sc[kp] f64 | cand[kp] u32 | work = max(stage 64 x 20 f32, ent[kp2] 16 B)
+// ---------------------------------------------------------------------------------------------------
+constexpr int RR_CW = 16;            // columns staged per pass
+constexpr int RR_RS = RR_CW + 4;     // LDS row stride in floats (5 x 16 B: odd -> conflict-free ds_read_b128)
+__host__ __device__ inline int pow2ceil_h(int x) { int p = 2; while (p < x) p <<= 1; return p; }
+__host__ __device__ inline size_t wave_work_bytes(int kp) {
+    const size_t st = size_t(64) * RR_RS * 4, en = size_t(pow2ceil_h(kp)) * 16;
+    return st > en ? st : en;
+}
+__host__ __device__ inline size_t wave_lds_bytes(int d, int kp) {
+    return size_t(d) * 16 + size_t(kp) * (8 + 8 + 4) + wave_work_bytes(kp);
 }
 
-// b: query row; c_item[0..n_c): local item ids (any order); cut_key: every item NOT in c_item has screen key <= cut_key
-// (-inf when c_item is exhaustive); e32_scale: factor of the float32 error bound.  flag_value: what to store
-// when certified (1 = screened + certified, 2 = exhaustive).
-__device__ void rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, const uint32_t* c_item_in, int n_c, int nc2,
-                            bool exhaustive, float cut_key, float hnorm_max, int flag_value) {
-    const int d = a.d;
-    double* q64 = reinterpret_cast<double*>(lds);
-    double* a64 = q64 + d;
-    uint32_t* item = reinterpret_cast<uint32_t*>(a64 + d);
-    uint32_t* pad_ = item + nc2;  // keeps the doubles 8-byte aligned
-    double* d2 = reinterpret_cast<double*>(pad_ + nc2);
-    double* sc = d2 + nc2;
-    Ent* ent = reinterpret_cast<Ent*>(sc + nc2);
+__device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
+    // |key32 - (q.x - 0.5||x||^2)| <= E32 for every item: fmaf chain of d+1 terms, float32 rounding of q and of the
+    // half norm.  Generous constant factor; typical errors are ~100x smaller.
+    const double u = 5.9604644775390625e-08;  // 2^-24
+    const double xn = sqrt(2.0 * double(hnorm_max)) * (1.0 + 1e-6);
+    return float((2.0 * d + 16.0) * u * (sqrt(Q2) * xn + double(hnorm_max)) * (1.0 + 1e-6));
+}
 
-    for (int j = threadIdx.x; j < d; j += blockDim.x) {
+// ascending bitonic sort of n2 (power of two) 16-byte entries in wave-private LDS, by ONE wave
+__device__ __forceinline__ void wave_bitonic_asc(Ent* a, int n2) {
+    const int lane = threadIdx.x & 63;
+    for (int size = 2; size <= n2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            wave_lds_sync();
+            for (int t = lane; t < (n2 >> 1); t += 64) {
+                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const Ent x = a[lo], y = a[hi];
+                if (ent_less(y, x) == asc) {
+                    a[lo] = y;
+                    a[hi] = x;
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+}
+
+// Re-rank + emit for ONE query by ONE wave.  cand[0..n_r) (wave-private LDS, part of `lds`): local item ids, n_r >= k.
+//   dist2: scikit-learn euclidean_rdist64 — sequential, (q - x) in float64, mul and add rounded separately
+//   score: numpy pairwise summation of the rounded products (8 chains per <=128-element leaf, then the tail)
+// then: the k smallest (dist2, item), ordered by (score desc, distance rank) [= the reference's stable sort by score
+// of the distance-ordered list] or left in (dist2, item) order when sort_by_score == 0.
+__device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int flag) {
+    const int d = a.d, lane = threadIdx.x & 63;
+    double* a64 = reinterpret_cast<double*>(lds);
+    double* q64 = a64 + d;
+    double* t_d2 = q64 + d;
+    double* t_sc = t_d2 + kp;
+    uint32_t* cand = reinterpret_cast<uint32_t*>(t_sc + kp);
+    unsigned char* work = reinterpret_cast<unsigned char*>(cand + kp);
+    float* stage = reinterpret_cast<float*>(work);
+    Ent* ent = reinterpret_cast<Ent*>(work);
+
+    for (int j = lane; j < d; j += 64) {
         q64[j] = a.Q64[b * d + j];
         a64[j] = a.A32 ? double(a.A32[(a.a_idx ? int64_t(a.a_idx[b]) : b) * a.lda + j]) : 0.0;
     }
-    for (int i = threadIdx.x; i < n_c; i += blockDim.x) item[i] = c_item_in[i];
-    __syncthreads();
+    wave_lds_sync();
+    // numpy pairwise structure for this d (d <= 256: at most two leaves)
+    const bool two = d > 128;
+    int n2 = d / 2;
+    n2 -= n2 & 7;
+    const int gA = two ? n2 / 8 : -1;          // first 8-group of the second leaf
+    const int lim = d - (d & 7);               // elements >= lim form the sequential tail of the last leaf
+    const int n_groups8 = lim / 8;
+    const int mode = a.score_mode;
+    const int n_chunks = (d + RR_CW - 1) / RR_CW;
 
-    for (int i = threadIdx.x; i < n_c; i += blockDim.x) {
-        const float* xr = a.X + int64_t(item[i]) * a.ldx;
-        // scikit-learn euclidean_rdist64: sequential, (q - x) in float64, mul and add rounded separately
+#pragma unroll 1
+    for (int g0 = 0; g0 < n_r; g0 += 64) {   // wave-uniform rounds of 64 candidates
+        const int ci = g0 + lane;
+        const bool live = ci < n_r;
+        const uint32_t it = cand[live ? ci : g0];
         double acc = 0.0;
-        for (int j = 0; j < d; ++j) {
-            const double tmp = __dsub_rn(q64[j], double(xr[j]));
-            acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+        double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, sA = 0.0;
+        float f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0, fA = 0.f;
+        // staging map: 4 lanes x 16 B per row, 16 rows per instruction, 4 instructions per 16-column chunk
+        uint32_t src_item[4];
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4) src_item[i4] = cand[min(g0 + i4 * 16 + (lane >> 2), n_r - 1)];
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (int i4 = 0; i4 < 4; ++i4) {
+                const float4 v = *reinterpret_cast<const float4*>(a.X + int64_t(src_item[i4]) * a.ldx + RR_CW * c + 4 * (lane & 3));
+                *reinterpret_cast<float4*>(stage + (i4 * 16 + (lane >> 2)) * RR_RS + 4 * (lane & 3)) = v;
+            }
+            wave_lds_sync();
+            float xv[RR_CW];
+#pragma unroll
+            for (int t = 0; t < RR_CW / 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
+                xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
+            }
+            wave_lds_sync();
+            const int j0 = RR_CW * c;
+#pragma unroll
+            for (int t = 0; t < RR_CW; ++t) {
+                if (j0 + t < d) {   // uniform
+                    const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
+                    acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                }
+            }
+            if (mode != 2) {
+#pragma unroll
+                for (int gg = 0; gg < RR_CW / 8; ++gg) {
+                    const int g8 = (RR_CW / 8) * c + gg;
+                    if (g8 < n_groups8) {   // uniform
+                        const bool first = g8 == 0 || g8 == gA;
+                        const int jj = 8 * g8;
+                        if (mode == 0) {
+                            const double p0 = __dmul_rn(a64[jj + 0], double(xv[8 * gg + 0])), p1 = __dmul_rn(a64[jj + 1], double(xv[8 * gg + 1]));
+                            const double p2 = __dmul_rn(a64[jj + 2], double(xv[8 * gg + 2])), p3 = __dmul_rn(a64[jj + 3], double(xv[8 * gg + 3]));
+                            const double p4 = __dmul_rn(a64[jj + 4], double(xv[8 * gg + 4])), p5 = __dmul_rn(a64[jj + 5], double(xv[8 * gg + 5]));
+                            const double p6 = __dmul_rn(a64[jj + 6], double(xv[8 * gg + 6])), p7 = __dmul_rn(a64[jj + 7], double(xv[8 * gg + 7]));
+                            if (first) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; r5 = p5; r6 = p6; r7 = p7; }
+                            else { r0 = __dadd_rn(r0, p0); r1 = __dadd_rn(r1, p1); r2 = __dadd_rn(r2, p2); r3 = __dadd_rn(r3, p3);
+                                   r4 = __dadd_rn(r4, p4); r5 = __dadd_rn(r5, p5); r6 = __dadd_rn(r6, p6); r7 = __dadd_rn(r7, p7); }
+                            if (g8 == gA - 1) sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                        } else {
+                            const float p0 = __fmul_rn(float(a64[jj + 0]), xv[8 * gg + 0]), p1 = __fmul_rn(float(a64[jj + 1]), xv[8 * gg + 1]);
+                            const float p2 = __fmul_rn(float(a64[jj + 2]), xv[8 * gg + 2]), p3 = __fmul_rn(float(a64[jj + 3]), xv[8 * gg + 3]);
+                            const float p4 = __fmul_rn(float(a64[jj + 4]), xv[8 * gg + 4]), p5 = __fmul_rn(float(a64[jj + 5]), xv[8 * gg + 5]);
+                            const float p6 = __fmul_rn(float(a64[jj + 6]), xv[8 * gg + 6]), p7 = __fmul_rn(float(a64[jj + 7]), xv[8 * gg + 7]);
+                            if (first) { f0 = p0; f1 = p1; f2 = p2; f3 = p3; f4 = p4; f5 = p5; f6 = p6; f7 = p7; }
+                            else { f0 = __fadd_rn(f0, p0); f1 = __fadd_rn(f1, p1); f2 = __fadd_rn(f2, p2); f3 = __fadd_rn(f3, p3);
+                                   f4 = __fadd_rn(f4, p4); f5 = __fadd_rn(f5, p5); f6 = __fadd_rn(f6, p6); f7 = __fadd_rn(f7, p7); }
+                            if (g8 == gA - 1) fA = ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7));
+                        }
+                    }
+                }
+            }
         }
-        d2[i] = acc;
-        double s = 0.0;
-        if (a.score_mode == 0) {
-            const double dot = np_dot<double, 2>([&](int j) { return a64[j]; }, [&](int j) { return double(xr[j]); }, 0, d);
-            s = (dot + 1.0) / 2.0;
-        } else if (a.score_mode == 1) {
-            const float dot = np_dot<float, 2>([&](int j) { return float(a64[j]); }, [&](int j) { return xr[j]; }, 0, d);
-            s = double((dot + 1.0f) / 2.0f);
+        double sco;
+        const float* xr = a.X + int64_t(it) * a.ldx;
+        if (mode == 0) {
+            double res = n_groups8 > 0 ? ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) : 0.0;
+            for (int j = lim; j < d; ++j) res = __dadd_rn(res, __dmul_rn(a64[j], double(xr[j])));   // <= 7 tail elements
+            if (two) res = sA + res;
+            sco = (res + 1.0) / 2.0;
+        } else if (mode == 1) {
+            float res = n_groups8 > 0 ? ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7)) : 0.f;
+            for (int j = lim; j < d; ++j) res = __fadd_rn(res, __fmul_rn(float(a64[j]), xr[j]));
+            if (two) res = fA + res;
+            sco = double((res + 1.0f) / 2.0f);
         } else {
-            s = (-1.0 * sqrt(acc) + 2.0) / 2.0;  // hwer/gcn_ncf.py:381
+            sco = (-1.0 * sqrt(acc) + 2.0) / 2.0;  // hwer/gcn_ncf.py:381
         }
-        sc[i] = s;
+        if (live) {
+            t_d2[ci] = acc;
+            t_sc[ci] = sco;
+        }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nc2; i += blockDim.x) {
+    wave_lds_sync();
+    // ---- order by (dist2, item): the first k entries are the exact k nearest (MultiKNN.query order) ------------------
+    const int k = a.k;
+    const int nr2 = pow2ceil_h(n_r);
+    for (int i = lane; i < nr2; i += 64) {
         Ent e;
-        if (i < n_c) {
-            e.hi = f64_orderable(d2[i]);
-            e.lo = (uint64_t(item[i]) << 32) | uint64_t(uint32_t(i));
+        if (i < n_r) {
+            e.hi = f64_orderable(t_d2[i]);
+            e.lo = (uint64_t(cand[i]) << 32) | uint64_t(uint32_t(i));
         } else {
             e.hi = ~0ull;
             e.lo = ~0ull;
         }
         ent[i] = e;
     }
-    bitonic_asc_ent(ent, nc2);  // (dist2 asc, item asc)
-
-    const int k = a.k;  // k <= n_c guaranteed by the host
-    // ---- certificate -------------------------------------------------------------------------------------
-    int flag = flag_value;
-    if (!exhaustive) {
-        double Q2 = 0.0;
-        for (int j = 0; j < d; ++j) Q2 += q64[j] * q64[j];
-        const double Dk = d2[uint32_t(ent[k - 1].lo)];
-        const double u = 5.9604644775390625e-08;  // 2^-24
-        const double xn = sqrt(2.0 * double(hnorm_max)) * (1.0 + 1e-6);
-        const double E32 = (2.0 * d + 16.0) * u * (sqrt(Q2) * xn + double(hnorm_max));
-        const double bound = Q2 - 2.0 * double(cut_key) - 2.0 * E32 - 1e-12 * (1.0 + Q2);
-        flag = (Dk < bound) ? flag_value : 0;
-    }
-    // ---- final order ---------------------------------------------------------------------------------------
-    const int k2 = pow2ceil_i(k);
-    __syncthreads();
+    wave_bitonic_asc(ent, nr2);
     if (a.sort_by_score) {
-        // stable sort by score desc == ascending (~orderable(score), rank in the dist order)
-        auto make = [&](int i) {
+        // stable sort by score desc == ascending (~orderable(score), rank in the distance order)
+        const int k2 = pow2ceil_h(k);
+        Ent mine[8];   // k2 <= 512: at most 8 per lane, statically indexed below
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int i = lane + 64 * m;
             Ent e;
+            e.hi = ~0ull;
+            e.lo = ~0ull;
             if (i < k) {
                 const uint32_t slot = uint32_t(ent[i].lo);
-                e.hi = ~f64_orderable(sc[slot]);
+                e.hi = ~f64_orderable(t_sc[slot]);
                 e.lo = (uint64_t(uint32_t(i)) << 32) | uint64_t(slot);
-            } else {
-                e.hi = ~0ull;
-                e.lo = ~0ull;
             }
-            return e;
-        };
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;  // k2 <= 512, 256 threads
-        Ent e0{}, e1{};
-        if (i0 < k2) e0 = make(i0);
-        if (i1 < k2) e1 = make(i1);
-        __syncthreads();
-        if (i0 < k2) ent[i0] = e0;
-        if (i1 < k2) ent[i1] = e1;
-        bitonic_asc_ent(ent, k2);
+            mine[m] = e;
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int i = lane + 64 * m;
+            if (i < k2) ent[i] = mine[m];
+        }
+        wave_bitonic_asc(ent, k2);
     }
-    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    for (int i = lane; i < k; i += 64) {
         const uint32_t slot = uint32_t(ent[i].lo);
-        const uint32_t it = item[slot];
+        const uint32_t it = cand[slot];
         a.out_idx[b * k + i] = a.row_ids ? a.row_ids[it] : a.id_base + int64_t(it);
-        a.out_score[b * k + i] = sc[slot];
-        a.out_dist2[b * k + i] = d2[slot];
+        a.out_score[b * k + i] = t_sc[slot];
+        a.out_dist2[b * k + i] = t_d2[slot];
     }
-    if (threadIdx.x == 0) a.out_flags[b] = flag;
+    if (lane == 0) a.out_flags[b] = flag;
 }
 
 // ---------------------------------------------------------------------------------------------------
-// select: gather the candidate streams of one query, keep the K' best screen keys, re-rank
+constexpr int RR_MAXR = (KPRIME_MAX + 63) / 64;   // candidate keys per lane (7)
+// select: one wave per query.  Input: ONE candidate list per query (<= K' keys, unsorted, split over the two lane
+// streams).  Finds the k-th largest screen key by an in-register radix select, derives the re-rank set and the
+// exactness certificate from the float32 error bound, then re-ranks.
 // ---------------------------------------------------------------------------------------------------
 struct SelectArgs {
     const uint64_t* cand;
     const int32_t* cand_cnt;
-    int n_lists;
     int64_t bq;
+    int64_t B;
     int kprime;
-    int m2max;  // power of two >= n_lists * 2 * CAPH
     float hnorm_max;
     EmitArgs emit;
 };
 
 __global__ __launch_bounds__(256) void select_rerank_kernel(const SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    int* s_off = reinterpret_cast<int*>(smem_raw);  // [2 * MAX_LISTS_DIRECT + 1] in the first 128 bytes
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);
-    const int64_t b = blockIdx.x;
-    const int n_streams = a.n_lists * 2;
-    if (threadIdx.x == 0) {
-        int off = 0;
-        for (int s = 0; s < n_streams; ++s) {
-            const int list = s >> 1, half = s & 1;
-            s_off[s] = off;
-            off += a.cand_cnt[(int64_t(list) * a.bq + b) * 2 + half];
-        }
-        s_off[n_streams] = off;
-    }
-    __syncthreads();
-    const int M = s_off[n_streams];
-    const int m2 = pow2ceil_i(max(M, 2));
-    for (int s = 0; s < n_streams; ++s) {
-        const int list = s >> 1, half = s & 1;
-        const uint64_t* src = a.cand + ((int64_t(list) * a.bq + b) * 2 + half) * CAPH;
-        const int n = s_off[s + 1] - s_off[s];
-        for (int i = threadIdx.x; i < n; i += blockDim.x) keys[s_off[s] + i] = src[i];
-    }
-    for (int i = M + threadIdx.x; i < m2; i += blockDim.x) keys[i] = 0ull;
-    bitonic_desc_u64(keys, m2);  // (screen key desc, item asc)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = int64_t(blockIdx.x) * 4 + wave;
+    if (b >= a.B) return;   // no workgroup barrier below
+    const int d = a.emit.d, k = a.emit.k;
+    const int kp = a.kprime;                                           // candidate capacity (multiple of 64)
+    unsigned char* lds = smem_raw + size_t(wave) * (wave_lds_bytes(d, kp) + 1024);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds);                 // 256 bins
+    unsigned char* lds_emit = lds + 1024;
+    uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(d) * 16 + size_t(kp) * 16);   // = `cand` of wave_rerank_emit
 
-    const int n_c = min(M, a.kprime);
-    const bool exhaustive = M < a.kprime;  // no stream ever compacted -> nothing was dropped
-    const float cut = exhaustive ? -INFINITY : key_score(keys[n_c - 1]);
-    // candidate ids move behind the key array's live prefix
-    const int nc2 = pow2ceil_i(max(n_c, 2));
-    unsigned char* tail = smem_raw + 128 + size_t(a.m2max) * 8;
-    uint32_t* c_item = reinterpret_cast<uint32_t*>(tail);
-    for (int i = threadIdx.x; i < n_c; i += blockDim.x) c_item[i] = key_item(keys[i]);
-    __syncthreads();
-    rerank_emit(a.emit, b, tail + size_t(KPRIME_MAX) * 4, c_item, n_c, nc2, exhaustive, cut, a.hnorm_max, 1);
+    const int c0r = a.cand_cnt[b * 2], c1r = a.cand_cnt[b * 2 + 1];
+    const bool underfull = ((c0r | c1r) & CNT_UNDERFULL) != 0;
+    const int c0 = c0r & ~CNT_UNDERFULL, c1 = c1r & ~CNT_UNDERFULL;
+    const int M = c0 + c1;                                             // <= K' (final compaction of the screen)
+    const uint64_t* s0 = a.cand + (b * 2) * CAPH;
+    const uint64_t* s1 = s0 + CAPH;
+    uint64_t key[RR_MAXR];
+#pragma unroll
+    for (int i = 0; i < RR_MAXR; ++i) {
+        const int e = 64 * i + lane;
+        key[i] = e < c0 ? s0[e] : (e - c0 < c1 ? s1[e - c0] : 0ull);
+    }
+    // ---- k-th largest screen key: byte radix select over the score words ---------------------------------------------
+    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < RR_MAXR; ++i) {
+        if (key[i] != 0ull) {
+            all_or |= uint32_t(key[i] >> 32);
+            all_and &= uint32_t(key[i] >> 32);
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        all_or |= __shfl_xor(all_or, off, kWave);
+        all_and &= __shfl_xor(all_and, off, kWave);
+    }
+    const uint32_t differ = all_or ^ all_and;
+    uint32_t prefix = 0, mask = 0;
+    int want = k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (((differ >> shift) & 0xFFu) == 0u) {
+            prefix |= all_and & (0xFFu << shift);
+            mask |= 0xFFu << shift;
+            continue;
+        }
+        *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+#pragma unroll
+        for (int i = 0; i < RR_MAXR; ++i) {
+            const uint32_t sv = uint32_t(key[i] >> 32);
+            if (key[i] != 0ull && (sv & mask) == prefix) atomicAdd(&hist[(sv >> shift) & 255u], 1u);
+        }
+        wave_lds_sync();
+        const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
+        const int sN = int(h4.x + h4.y + h4.z + h4.w);
+        int S = sN;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_down(S, off, kWave);
+            if (lane + off < 64) S += t;
+        }
+        const uint64_t bal = __ballot(S >= want);
+        const int lstar = 63 - __builtin_clzll(bal);
+        int bstar, want_new;
+        {
+            const int cum = S - sN;
+            const int h3 = int(h4.w), h2 = int(h4.z), h1 = int(h4.y);
+            if (cum + h3 >= want) { bstar = 4 * lane + 3; want_new = want - cum; }
+            else if (cum + h3 + h2 >= want) { bstar = 4 * lane + 2; want_new = want - cum - h3; }
+            else if (cum + h3 + h2 + h1 >= want) { bstar = 4 * lane + 1; want_new = want - cum - h3 - h2; }
+            else { bstar = 4 * lane; want_new = want - cum - h3 - h2 - h1; }
+        }
+        bstar = __shfl(bstar, lstar, kWave);
+        want = __shfl(want_new, lstar, kWave);
+        prefix |= uint32_t(bstar) << shift;
+        mask |= 0xFFu << shift;
+    }
+    const float t_k = f32_from_orderable(prefix);   // k-th largest screen key
+    // ---- re-rank set + certificate (float32 only) ------------------------------------------------------------------
+    // Every item has |key32 - key| <= E32.  An item can belong to the true top-k only if key32 >= t_k - 2 E32: those
+    // candidates form the re-rank set.  Items that never became candidates have key32 <= min candidate key; if some
+    // candidate already falls below t_k - 2 E32 (n_r < M), none of them can enter the top-k: provably exact.
+    double Q2 = 0.0;
+    {
+        const double* q = a.emit.Q64 + b * d;
+        for (int j = lane; j < d; j += 64) Q2 += q[j] * q[j];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
+    }
+    const float thr = t_k - 2.0f * e32_bound(d, Q2, a.hnorm_max);
+    int n_r = 0;
+#pragma unroll
+    for (int i = 0; i < RR_MAXR; ++i) {
+        const bool in = key[i] != 0ull && key_score(key[i]) >= thr;
+        const uint64_t bal = __ballot(in);
+        if (in) cand_item[n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = key_item(key[i]);
+        n_r += __builtin_popcountll(bal);
+    }
+    wave_lds_sync();
+    const bool exhaustive = M < a.kprime && !underfull;   // no stream ever compacted: the candidates are ALL the items
+    const int flag = (!underfull && (exhaustive || n_r < M)) ? 1 : 0;
+    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, flag);
 }
 
 // pre-reduction when a query has more than MAX_LISTS_DIRECT lists: groups of 8 lists -> one list of K' keys
@@ -320,12 +493,15 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
     const int nl = min(MAX_LISTS_DIRECT, a.n_lists_in - l0);
     const int n_streams = nl * 2;
     if (threadIdx.x == 0) {
-        int off = 0;
+        int off = 0, under = 0;
         for (int s = 0; s < n_streams; ++s) {
             s_off[s] = off;
-            off += a.cnt_in[(int64_t(l0 + (s >> 1)) * a.bq + b) * 2 + (s & 1)];
+            const int c = a.cnt_in[(int64_t(l0 + (s >> 1)) * a.bq + b) * 2 + (s & 1)];
+            under |= c & CNT_UNDERFULL;
+            off += c & ~CNT_UNDERFULL;
         }
         s_off[n_streams] = off;
+        s_off[25] = under;
     }
     __syncthreads();
     const int M = s_off[n_streams];
@@ -341,7 +517,7 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
     uint64_t* dst = a.cand_out + ((int64_t(group) * a.bq + b) * 2) * CAPH;  // streams 0 and 1 are contiguous
     for (int i = threadIdx.x; i < n_c; i += blockDim.x) dst[i] = keys[i];
     if (threadIdx.x == 0) {
-        a.cnt_out[(int64_t(group) * a.bq + b) * 2 + 0] = min(n_c, CAPH);
+        a.cnt_out[(int64_t(group) * a.bq + b) * 2 + 0] = min(n_c, CAPH) | s_off[25];
         a.cnt_out[(int64_t(group) * a.bq + b) * 2 + 1] = max(n_c - CAPH, 0);
     }
 }
@@ -391,17 +567,17 @@ __global__ __launch_bounds__(256) void exact_chunk_select_kernel(const Ent* __re
     for (int i = threadIdx.x; i < keep; i += blockDim.x) out[int64_t(blockIdx.x) * keep + i] = ent[i];
 }
 
-__global__ __launch_bounds__(256) void exact_emit_kernel(const Ent* __restrict__ sel, int n_sel, int64_t b,
-                                                         const EmitArgs a) {
+__global__ __launch_bounds__(64) void exact_emit_kernel(const Ent* __restrict__ sel, int n_sel, int64_t b,
+                                                        const EmitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint32_t* c_item = reinterpret_cast<uint32_t*>(smem_raw);
+    const int kp = ((a.k + 63) / 64) * 64;
+    uint32_t* c_item = reinterpret_cast<uint32_t*>(smem_raw + size_t(a.d) * 16 + size_t(kp) * 16);   // `cand` of wave_rerank_emit
     int n_c = 0;
-    for (int i = 0; i < n_sel; ++i) n_c += (sel[i].lo != ~0ull);  // padding entries sort last; count is tiny work
+    for (int i = 0; i < n_sel; ++i) n_c += (sel[i].lo != ~0ull);  // padding entries sort last
     n_c = min(n_c, a.k);
-    for (int i = threadIdx.x; i < n_c; i += blockDim.x) c_item[i] = uint32_t(sel[i].lo);
-    __syncthreads();
-    const int nc2 = pow2ceil_i(max(n_c, 2));
-    rerank_emit(a, b, smem_raw + size_t(K_MAX + 8) * 4, c_item, n_c, nc2, true, -INFINITY, 0.f, 2);
+    for (int i = threadIdx.x; i < n_c; i += 64) c_item[i] = uint32_t(sel[i].lo);
+    wave_lds_sync();
+    wave_rerank_emit(a, b, smem_raw, kp, n_c, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -560,7 +736,7 @@ static WsLayout ws_layout(const ScreenPlan& p) {
     off += align256(size_t(p.n_lists) * p.bq * 2 * CAPH * 8);
     w.cnt_a = off;
     off += align256(size_t(p.n_lists) * p.bq * 2 * 4);
-    int groups = p.n_lists > MAX_LISTS_DIRECT ? int(cdiv64(p.n_lists, MAX_LISTS_DIRECT)) : 0;
+    int groups = p.n_lists > 1 ? int(cdiv64(p.n_lists, MAX_LISTS_DIRECT)) : 0;
     w.cand_b = off;
     off += align256(size_t(groups) * p.bq * 2 * CAPH * 8);
     w.cnt_b = off;
@@ -616,10 +792,10 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     int n_lists = plan.n_lists;
     uint64_t* cand_other = reinterpret_cast<uint64_t*>(ws + w.cand_b);
     int32_t* cnt_other = reinterpret_cast<int32_t*>(ws + w.cnt_b);
-    while (n_lists > MAX_LISTS_DIRECT) {
+    while (n_lists > 1) {   // item splits / shared-query waves: merge the lists of a query into one list of K' keys
         const int groups = int(cdiv64(n_lists, MAX_LISTS_DIRECT));
         ReduceArgs ra{cand, cnt, n_lists, cand_other, cnt_other, plan.bq, plan.kprime};
-        const size_t lds = 128 + size_t(MAX_LISTS_DIRECT) * 2 * CAPH * 8;
+        const size_t lds = 128 + size_t(MAX_LISTS_DIRECT) * 512 * 8;  // 8 lists x K' <= 8 x 448 keys -> 4096 slots
         if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_kernel), lds, "knn_reduce"))) return rc;
         hipLaunchKernelGGL(reduce_lists_kernel, dim3(unsigned(B), unsigned(groups)), dim3(256), lds, st, ra);
         if ((rc = check_launch("knn_reduce"))) return rc;
@@ -630,18 +806,15 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     SelectArgs sa{};
     sa.cand = cand;
     sa.cand_cnt = cnt;
-    sa.n_lists = n_lists;
     sa.bq = plan.bq;
+    sa.B = B;
     sa.kprime = plan.kprime;
-    int m2 = 2;
-    while (m2 < n_lists * 2 * CAPH) m2 <<= 1;
-    sa.m2max = m2;
     sa.hnorm_max = hnorm_max;
     sa.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags};
-    const size_t lds = 128 + size_t(m2) * 8 + size_t(KPRIME_MAX) * 4 + emit_lds_bytes(d, 512);
+    const size_t lds = size_t(4) * (wave_lds_bytes(d, plan.kprime) + 1024);
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel), lds, "knn_select"))) return rc;
-    hipLaunchKernelGGL(select_rerank_kernel, dim3(unsigned(B)), dim3(256), lds, st, sa);
+    hipLaunchKernelGGL(select_rerank_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, sa);
     return check_launch("knn_select");
 }
 
@@ -694,8 +867,8 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
         } while (n > keep);
         EmitArgs ea{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, row_ids, id_base, k,
                     out_idx, out_score, out_dist2, out_flags};
-        const size_t lds = size_t(K_MAX + 8) * 4 + emit_lds_bytes(d, 512);
-        hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(256), lds, st, in, int(n), b, ea);
+        const size_t lds = wave_lds_bytes(d, ((k + 63) / 64) * 64);
+        hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(64), lds, st, in, int(n), b, ea);
         if ((rc = check_launch("knn_exact(emit)"))) return rc;
     }
     return HWER_OK;

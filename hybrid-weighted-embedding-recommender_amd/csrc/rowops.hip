@@ -277,10 +277,19 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
     const RowGroup g(PACK ? x4 : d4);
     const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
-    for (int64_t r0 = group_global - g.sub; r0 < n_rows; r0 += group_stride) {
+    const int64_t n_out = PACK ? ((n_rows + 31) / 32) * 32 : n_rows;   // PACK: pad rows (zeros, half norm +inf)
+    for (int64_t r0 = group_global - g.sub; r0 < n_out; r0 += group_stride) {
         const int64_t r = r0 + g.sub;
         const bool live = r < n_rows;
         float ss = 0.f;
+        if (PACK && !live && r < n_out) {
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = g.c0 + i * g.L;
+                if (c < x4) *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (g.c0 == 0) out_norm[r] = INFINITY;
+        }
         if (live) {
             const int64_t row = row_ids ? row_ids[r] : r;
             const float* base = V + row * ldv;
@@ -514,6 +523,8 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
                        out_absdev_sum);
     return check_launch("unit_audit(reduce)");
 }
+
+int64_t hwer_knn_padded_rows(int64_t n_rows) { return ((n_rows + 31) / 32) * 32; }
 
 int hwer_knn_padded_dim(int d) {
     if (d < 1 || d > 256) return -1;

@@ -50,8 +50,9 @@ class _TypeTable:
 
 
 class DeviceIndex:
-    #: queries per launch of the k-NN kernels (bounds the candidate workspace: 16 KiB per query and list)
-    QUERY_CHUNK = 32768
+    #: queries per launch of the k-NN kernels = 512 workgroup slots (256 CUs x 2) x 256 queries: one full round of
+    #: workgroups without item splits; also bounds the candidate workspace (8 KiB per query and list)
+    QUERY_CHUNK = 131072
 
     def __init__(self, vectors, type_rows: Dict[str, np.ndarray], device=None, arith: Optional[int] = None,
                  audit: bool = True):
@@ -107,12 +108,13 @@ class DeviceIndex:
         tt.rows = np.ascontiguousarray(rows, dtype=np.int64)
         tt.n = len(tt.rows)
         tt.rows_dev = torch.from_numpy(tt.rows).to(self.device)
-        tt.X = torch.empty((tt.n, self.ldx), dtype=torch.float32, device=self.device)
-        tt.hnorm = torch.empty(tt.n, dtype=torch.float32, device=self.device)
+        n_pad = self.lib.hwer_knn_padded_rows(tt.n)   # whole 32-row tiles: pad rows are zero with a +inf half norm
+        tt.X = torch.empty((n_pad, self.ldx), dtype=torch.float32, device=self.device)
+        tt.hnorm = torch.empty(n_pad, dtype=torch.float32, device=self.device)
         native.check(self.lib.hwer_pack_rows_f32(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(tt.rows_dev), tt.n,
                                                  native.ptr(tt.X), self.ldx, native.ptr(tt.hnorm), native.stream_ptr()),
                      "pack_rows")
-        tt.hnorm_max = float(tt.hnorm.max().item()) if tt.n else 0.0
+        tt.hnorm_max = float(tt.hnorm[:tt.n].max().item()) if tt.n else 0.0
         self.tables[node_type] = tt
         return tt
 

@@ -89,9 +89,13 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
 /* ---------------------------------------------------------------------------------------------------
  * K6/A4  per-type table — replaces MultiKNN.__init__ grouping + `vectors[v]` copy
  *        (hwer/recommendation_base.py:64-76): X[i] = V[row_ids[i]] zero-padded to ldx columns,
- *        hnorm[i] = 0.5*||X[i]||^2.  ldx = hwer_knn_padded_dim(d).
+ *        hnorm[i] = 0.5*||X[i]||^2.  ldx = hwer_knn_padded_dim(d); X / hnorm hold hwer_knn_padded_rows(n_rows) rows.
  * ------------------------------------------------------------------------------------------------- */
 int hwer_knn_padded_dim(int d); /* 32, 64, 128 or 256; -1 if d is unsupported (d < 1 or d > 256) */
+/* Rows the caller must ALLOCATE for X and hnorm: n_rows rounded up to a multiple of 32.  hwer_pack_rows_f32 fills
+ * the pad rows with zeros and a +inf half norm, so that the screen kernel reads whole 32-row tiles without bounds
+ * checks and pad rows can never be selected. */
+int64_t hwer_knn_padded_rows(int64_t n_rows);
 int hwer_pack_rows_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids /*nullable*/,
                        int64_t n_rows, float* X, int64_t ldx, float* hnorm, void* stream);
 
@@ -122,7 +126,7 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
  *   Order            : sort_by_score != 0: stable sort by score desc (the reference's final order);
  *                      else ascending (dist2, id) (MultiKNN.query order; what the multi-GPU merge consumes).
  *
- *   X, hnorm : from hwer_pack_rows_f32 (n_items, ldx) / (n_items)
+ *   X, hnorm : from hwer_pack_rows_f32, allocated with hwer_knn_padded_rows(n_items) rows
  *   Q32      : (B, ldx) zero-padded float32 queries;  Q64 : (B, d) exact queries
  *   A32, a_idx: anchor rows for score_mode 0/1 (NULL for mode 2): row of query b = A32[a_idx ? a_idx[b] : b], stride lda
  *              (pass the whole vector table as A32 and the anchors' global ids as a_idx)
