@@ -12,6 +12,7 @@ constexpr int KPRIME_MAX = 448;      // a compaction retains K' entries, possibl
 constexpr int SLACK = 56;            // K' = roundup64(k + SLACK)
 constexpr int K_MAX = KPRIME_MAX - SLACK;
 constexpr int SCREEN_IB = 32;        // item rows per LDS tile (one 32-row MFMA subtile)
+constexpr int DENSE_MAX_ITEMS = 8192; // catalogues up to this size take the dense path
 constexpr int MAX_LISTS_DIRECT = 8;  // lists the select kernel can take in one pass (8 * 1024 keys = 64 KB LDS)
 
 struct ScreenPlan {
@@ -26,12 +27,14 @@ struct ScreenPlan {
     int64_t bq;    // B rounded up to qb (stream addressing)
     int kprime;
     int scaled_first;  // use the sample-scaled first threshold (verified; UNDERFULL lists are flagged)
+    int dense;         // small catalogue: write every key to a (B, ld_dense) float matrix, select from it
+    int64_t ld_dense;
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k);
 constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
-                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, hipStream_t stream);
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, hipStream_t stream);
 
 }  // namespace hwer

@@ -55,6 +55,8 @@ struct ScreenArgs {
     int64_t ldx;
     const float* Q;
     int64_t B;
+    float* dense;        // DENSE mode: every key is written to dense[q * ld_dense + item] instead of being filtered
+    int64_t ld_dense;
     uint64_t* cand;
     int32_t* cand_cnt;   // a count with bit 30 set marks an UNDERFULL list (scaled threshold was too high): recompute exactly
     int n_qblocks;
@@ -199,7 +201,7 @@ __device__ __forceinline__ int swz(int row) {
     else return (row >> 1) & (CH - 1);   // CH == 8: two 128-byte rows share a bank row
 }
 
-template <int NG, int TQ>
+template <int NG, int TQ, bool DENSE>
 __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     constexpr int IB = 32;                         // item rows per tile = one 32-row MFMA subtile
     constexpr int CH = 2 * NG;                     // 16-byte chunks per row
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // LDS-DMA fill of tile t into ring slot (t & 1): every wave issues DMA_PER_WAVE pieces of 64 x 16 B.
     // Tiles are visited in the order perm(t) = (t * tile_mul) mod n_tiles (tile_mul coprime with n_tiles), so the
     // first tiles of a stream sample the whole list instead of its head (needed by the scaled first threshold).
-    const int tile_mul = a.scaled_first ? coprime_step(n_tiles) : 1;
+    const int tile_mul = (!DENSE && a.scaled_first) ? coprime_step(n_tiles) : 1;
     auto perm = [&](int t) { return int((int64_t(t) * tile_mul) % max(n_tiles, 1)); };
     // The table is allocated with its row count padded to a multiple of 32 (zero rows whose half norm is +inf, see
     // hwer_pack_rows_f32), so tile reads never leave the allocation and pad rows can never pass the filter.
@@ -331,6 +333,19 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qf[b][g].w, acc[b], 0, 0, 0);
                 }
             }
+            if constexpr (DENSE) {
+                // small catalogues: keep every key (lane (r, h): query r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store)
+#pragma unroll
+                for (int b = 0; b < TQ; ++b) {
+                    const int64_t q = qw0 + 32 * b + r;
+                    if (q < a.B) {
+                        float* row = a.dense + q * a.ld_dense + i0 + 4 * h;
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg)
+                            *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
+                    }
+                }
+            } else {
             // ---- streaming filter ---------------------------------------------------------------------------------
             // Lane (r, h) holds 16 keys of query r.  Passing keys are rare (K'/n per key), so instead of 16 predicated
             // append blocks the lane builds a 16-bit pass mask, parks its 16 keys in LDS and pops set bits: the loop runs
@@ -365,12 +380,17 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     }
                 }
             }
+            }   // !DENSE
         }
         // ---- tile boundary ---------------------------------------------------------------------------------------------
         // Outstanding VMEM here: the DMA of tile t+1 and the previous flush, both issued a whole tile ago (appends of
         // this tile sit in LDS slots), so this wait is normally free.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (DENSE) {
+            if (t + 2 < n_tiles) tile_dma(t + 2);
+            continue;
+        }
 #pragma unroll
         for (int b = 0; b < TQ; ++b) {
 #pragma unroll
@@ -416,6 +436,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
         }
     }
+    if constexpr (DENSE) return;
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
         // final compaction: queries holding more than K' keys keep exactly their K' best
@@ -468,28 +489,44 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     p.split_items = per;
     p.n_lists = p.n_splits * wi;
     p.scaled_first = 1;
+    // Small catalogues: materialise every key (8 B of HBM traffic per pair) instead of streaming selection, whose
+    // warm-up (~4 K' appends + a compaction per query and list) dominates when N is only a few K'.
+    p.dense = n_items <= DENSE_MAX_ITEMS && !getenv("HWER_NO_DENSE");
+    if (p.dense) {
+        const int64_t n_tiles = cdiv64(n_items, 32);
+        int64_t sp = std::min<int64_t>(n_tiles, std::max<int64_t>(1, cdiv64(768, p.n_qblocks)));
+        int64_t per_d = cdiv64(n_tiles, sp) * 32;
+        p.n_splits = int(cdiv64(n_items, per_d));
+        p.split_items = per_d;
+        p.n_lists = 0;
+        p.ld_dense = n_tiles * 32;
+    }
     return p;
 }
 
-template <int NG, int TQ>
-static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
+template <int NG, int TQ, bool DENSE>
+static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 waves x 64 lanes x 16 keys
     const size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4 + size_t(4) * TQ * 4 * 64 * 8;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, DENSE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done = true;
     }
     const int grid = plan.n_qblocks * plan.n_splits;
-    hipLaunchKernelGGL((screen_kernel<NG, TQ>), dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((screen_kernel<NG, TQ, DENSE>), dim3(grid), dim3(256), lds, stream, a);
     return check_launch("knn_screen");
+}
+template <int NG, int TQ>
+static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
+    return plan.dense ? launch_screen_t2<NG, TQ, true>(plan, a, stream) : launch_screen_t2<NG, TQ, false>(plan, a, stream);
 }
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
-                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, hipStream_t stream) {
-    ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, hipStream_t stream) {
+    ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? 1 : 0,
                  getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY};
     const int key = plan.ng * 10 + plan.tq;

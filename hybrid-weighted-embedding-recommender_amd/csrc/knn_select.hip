@@ -221,16 +221,29 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         double acc = 0.0;
         double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, sA = 0.0;
         float f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0, fA = 0.f;
-        // staging map: 4 lanes x 16 B per row, 16 rows per instruction, 4 instructions per 16-column chunk
-        uint32_t src_item[4];
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) src_item[i4] = cand[min(g0 + i4 * 16 + (lane >> 2), n_r - 1)];
+        // staging map: 4 lanes x 16 B per row, 16 rows per instruction, 4 instructions per 16-column chunk.
+        // (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop in scratch)
+        const int srow = lane >> 2, scol = 4 * (lane & 3);
+        const float* src0 = a.X + int64_t(cand[min(g0 + 0 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src1 = a.X + int64_t(cand[min(g0 + 16 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src2 = a.X + int64_t(cand[min(g0 + 32 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src3 = a.X + int64_t(cand[min(g0 + 48 + srow, n_r - 1)]) * a.ldx + scol;
+        float* dst = stage + srow * RR_RS + scol;
+        // software pipeline: the gathers of chunk c + 1 are in flight while chunk c is reduced in float64
+        float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
+        float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.X + int64_t(src_item[i4]) * a.ldx + RR_CW * c + 4 * (lane & 3));
-                *reinterpret_cast<float4*>(stage + (i4 * 16 + (lane >> 2)) * RR_RS + 4 * (lane & 3)) = v;
+            *reinterpret_cast<float4*>(dst) = pre0;
+            *reinterpret_cast<float4*>(dst + 16 * RR_RS) = pre1;
+            *reinterpret_cast<float4*>(dst + 32 * RR_RS) = pre2;
+            *reinterpret_cast<float4*>(dst + 48 * RR_RS) = pre3;
+            if (c + 1 < n_chunks) {
+                const int o = RR_CW * (c + 1);
+                pre0 = *reinterpret_cast<const float4*>(src0 + o);
+                pre1 = *reinterpret_cast<const float4*>(src1 + o);
+                pre2 = *reinterpret_cast<const float4*>(src2 + o);
+                pre3 = *reinterpret_cast<const float4*>(src3 + o);
             }
             wave_lds_sync();
             float xv[RR_CW];
@@ -241,11 +254,19 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
             }
             wave_lds_sync();
             const int j0 = RR_CW * c;
+            if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
 #pragma unroll
-            for (int t = 0; t < RR_CW; ++t) {
-                if (j0 + t < d) {   // uniform
+                for (int t = 0; t < RR_CW; ++t) {
                     const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
                     acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < RR_CW; ++t) {
+                    if (j0 + t < d) {   // uniform
+                        const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
+                        acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                    }
                 }
             }
             if (mode != 2) {
@@ -365,7 +386,7 @@ struct SelectArgs {
     EmitArgs emit;
 };
 
-__global__ __launch_bounds__(256) void select_rerank_kernel(const SelectArgs a) {
+__global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = int64_t(blockIdx.x) * 4 + wave;
@@ -470,6 +491,123 @@ __global__ __launch_bounds__(256) void select_rerank_kernel(const SelectArgs a) 
     const bool exhaustive = M < a.kprime && !underfull;   // no stream ever compacted: the candidates are ALL the items
     const int flag = (!underfull && (exhaustive || n_r < M)) ? 1 : 0;
     wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, flag);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// dense select (small catalogues): one wave per query reads its row of fp32 keys (written by the DENSE screen),
+// radix-selects the k-th largest, collects the re-rank set and re-ranks.  Every item is a candidate, so the result is
+// exact by construction unless the re-rank set overflows its capacity (massive ties) -> flag 0.
+// ---------------------------------------------------------------------------------------------------
+struct DenseSelectArgs {
+    const float* keys;   // (B, ld)
+    int64_t ld;          // multiple of 32; entries >= n_items hold -inf (pad rows have a +inf half norm)
+    int64_t B;
+    int kp;              // re-rank capacity (multiple of 64)
+    float hnorm_max;
+    EmitArgs emit;
+};
+
+__global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = int64_t(blockIdx.x) * 4 + wave;
+    if (b >= a.B) return;   // no workgroup barrier below
+    const int d = a.emit.d, k = a.emit.k, kp = a.kp;
+    unsigned char* lds = smem_raw + size_t(wave) * (wave_lds_bytes(d, kp) + 1024);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(lds);
+    unsigned char* lds_emit = lds + 1024;
+    uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(d) * 16 + size_t(kp) * 16);
+    const float4* row = reinterpret_cast<const float4*>(a.keys + b * a.ld);
+    const int n4 = int(a.ld / 4);
+
+    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
+    for (int i = lane; i < n4; i += 64) {
+        const float4 v = row[i];
+        const uint32_t o0 = f32_orderable(v.x), o1 = f32_orderable(v.y), o2 = f32_orderable(v.z), o3 = f32_orderable(v.w);
+        all_or |= o0 | o1 | o2 | o3;
+        all_and &= o0 & o1 & o2 & o3;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        all_or |= __shfl_xor(all_or, off, kWave);
+        all_and &= __shfl_xor(all_and, off, kWave);
+    }
+    const uint32_t differ = all_or ^ all_and;
+    uint32_t prefix = 0, mask = 0;
+    int want = k;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (((differ >> shift) & 0xFFu) == 0u) {
+            prefix |= all_and & (0xFFu << shift);
+            mask |= 0xFFu << shift;
+            continue;
+        }
+        *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
+        wave_lds_sync();
+        for (int i = lane; i < n4; i += 64) {
+            const float4 v = row[i];
+            const uint32_t o[4] = {f32_orderable(v.x), f32_orderable(v.y), f32_orderable(v.z), f32_orderable(v.w)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if ((o[c] & mask) == prefix) atomicAdd(&hist[(o[c] >> shift) & 255u], 1u);
+        }
+        wave_lds_sync();
+        const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
+        const int sN = int(h4.x + h4.y + h4.z + h4.w);
+        int S = sN;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_down(S, off, kWave);
+            if (lane + off < 64) S += t;
+        }
+        const uint64_t bal = __ballot(S >= want);
+        const int lstar = 63 - __builtin_clzll(bal);
+        int bstar, want_new;
+        {
+            const int cum = S - sN;
+            const int h3 = int(h4.w), h2 = int(h4.z), h1 = int(h4.y);
+            if (cum + h3 >= want) { bstar = 4 * lane + 3; want_new = want - cum; }
+            else if (cum + h3 + h2 >= want) { bstar = 4 * lane + 2; want_new = want - cum - h3; }
+            else if (cum + h3 + h2 + h1 >= want) { bstar = 4 * lane + 1; want_new = want - cum - h3 - h2; }
+            else { bstar = 4 * lane; want_new = want - cum - h3 - h2 - h1; }
+        }
+        bstar = __shfl(bstar, lstar, kWave);
+        want = __shfl(want_new, lstar, kWave);
+        prefix |= uint32_t(bstar) << shift;
+        mask |= 0xFFu << shift;
+    }
+    const float t_k = f32_from_orderable(prefix);   // k-th largest key
+    double Q2 = 0.0;
+    {
+        const double* q = a.emit.Q64 + b * d;
+        for (int j = lane; j < d; j += 64) Q2 += q[j] * q[j];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
+    }
+    const float thr = t_k - 2.0f * e32_bound(d, Q2, a.hnorm_max);
+    int n_r = 0;
+    bool overflow = false;
+    for (int i0 = 0; i0 < n4; i0 += 64) {   // wave-uniform trip count
+        const int i = i0 + lane;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (i < n4) v = row[i];
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool in = vv[c] >= thr;
+            const uint64_t bal = __ballot(in);
+            const int pos = n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+            if (in && pos < kp) cand_item[pos] = uint32_t(4 * i + c);
+            n_r += __builtin_popcountll(bal);
+        }
+    }
+    if (n_r > kp) {   // more near-ties than the re-rank capacity: not certifiable here
+        overflow = true;
+        n_r = kp;
+    }
+    wave_lds_sync();
+    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, overflow ? 0 : 1);
 }
 
 // pre-reduction when a query has more than MAX_LISTS_DIRECT lists: groups of 8 lists -> one list of K' keys
@@ -729,9 +867,13 @@ static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 struct WsLayout {
     size_t cand_a, cnt_a, cand_b, cnt_b, total;
 };
-static WsLayout ws_layout(const ScreenPlan& p) {
+static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     WsLayout w{};
     size_t off = 0;
+    if (p.dense) {   // one (B, ld_dense) float matrix of keys
+        w.total = align256(size_t(B) * size_t(p.ld_dense) * 4);
+        return w;
+    }
     w.cand_a = off;
     off += align256(size_t(p.n_lists) * p.bq * 2 * CAPH * 8);
     w.cnt_a = off;
@@ -752,7 +894,7 @@ int hwer_knn_max_k(void) { return K_MAX; }
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) {
     const int ldx = hwer_knn_padded_dim(d);
     if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
-    return ws_layout(make_screen_plan(B, n_items, ldx, k)).total;
+    return ws_layout(make_screen_plan(B, n_items, ldx, k), B).total;
 }
 
 int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
@@ -775,7 +917,7 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         (reinterpret_cast<uintptr_t>(workspace) & 255))
         return fail(HWER_EINVAL, "knn_search: X/Q32 must be 16-byte and workspace 256-byte aligned");
     const ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);
-    const WsLayout w = ws_layout(plan);
+    const WsLayout w = ws_layout(plan, B);
     if (workspace_bytes < w.total) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, w.total);
     hipStream_t st = as_stream(stream);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
@@ -784,10 +926,24 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     int rc;
     {
         ProfScope ps(0, st);
-        rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, st);
+        rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, reinterpret_cast<float*>(ws), st);
     }
     if (rc) return rc;
     ProfScope ps_select(1, st);
+    if (plan.dense) {
+        DenseSelectArgs da{};
+        da.keys = reinterpret_cast<const float*>(ws);
+        da.ld = plan.ld_dense;
+        da.B = B;
+        da.kp = plan.kprime;
+        da.hnorm_max = hnorm_max;
+        da.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, row_ids, id_base, k,
+                           out_idx, out_score, out_dist2, out_flags};
+        const size_t lds = size_t(4) * (wave_lds_bytes(d, plan.kprime) + 1024);
+        if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel), lds, "knn_select_dense"))) return rc;
+        hipLaunchKernelGGL(select_dense_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+        return check_launch("knn_select_dense");
+    }
 
     int n_lists = plan.n_lists;
     uint64_t* cand_other = reinterpret_cast<uint64_t*>(ws + w.cand_b);

@@ -12,6 +12,15 @@ from oracle import hwer_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["auto", "streaming"])
+def knn_path(request, monkeypatch):
+    """Small catalogues take the dense path by default; "streaming" forces the MFMA screen + streaming top-K' filter
+    (the large-catalogue path) onto the same inputs so that both are held to the same goldens."""
+    if request.param == "streaming":
+        monkeypatch.setenv("HWER_NO_DENSE", "1")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def hw():
     import hwer
@@ -149,7 +158,7 @@ def test_query_mix_dims(hw, d):
 # ------------------------------------------------------------------------------------------------- k-NN
 @pytest.mark.parametrize("flav", ["f64", "f32"])
 @pytest.mark.parametrize("k", [1, 10, 200])
-def test_knn_golden_g1(golden, hw, flav, k):
+def test_knn_golden_g1(golden, hw, knn_path, flav, k):
     g = golden("g1_knn_basic")
     V = _flav(g["V32"], flav)
     ix = make_index(V, 64, 512)
@@ -160,7 +169,7 @@ def test_knn_golden_g1(golden, hw, flav, k):
 
 
 @pytest.mark.parametrize("flav", ["f64", "f32"])
-def test_knn_query_order_and_gcn_scoring_g5(golden, hw, flav):
+def test_knn_query_order_and_gcn_scoring_g5(golden, hw, knn_path, flav):
     g = golden("g1_knn_basic")
     V = _flav(g["V32"], flav)
     ix = make_index(V, 64, 512)
@@ -173,7 +182,7 @@ def test_knn_query_order_and_gcn_scoring_g5(golden, hw, flav):
     assert np.array_equal(idx[0], g[f"u2u_idx_{flav}"]) and np.array_equal(score[0], g[f"u2u_score_{flav}"])
 
 
-def test_knn_golden_g2_ml100k_shape(golden, hw):
+def test_knn_golden_g2_ml100k_shape(golden, hw, knn_path):
     g = golden("g2_knn_ml100k_shape")
     U, I, d, k = int(g["n_users"]), int(g["n_items"]), int(g["d"]), int(g["k"])
     V32 = np.concatenate([unit_rows_f32(int(g["seed_users"]), U, d), unit_rows_f32(int(g["seed_items"]), I, d)])
@@ -186,7 +195,7 @@ def test_knn_golden_g2_ml100k_shape(golden, hw):
 
 
 @pytest.mark.parametrize("flav", ["f64", "f32"])
-def test_knn_posneg_golden_g3(golden, hw, flav):
+def test_knn_posneg_golden_g3(golden, hw, knn_path, flav):
     g = golden("g3_posneg")
     V = _flav(g["V32"], flav)
     ix = make_index(V, 64, 512)
@@ -197,7 +206,7 @@ def test_knn_posneg_golden_g3(golden, hw, flav):
     assert np.array_equal(score, g[f"score_{flav}"])
 
 
-def test_knn_ties_g10(golden, hw):
+def test_knn_ties_g10(golden, hw, knn_path):
     g = golden("g10_ties")
     U, I = int(g["n_users"]), int(g["n_items"])
     ix = make_index(g["V32"].astype(np.float64), U, I)
@@ -212,7 +221,7 @@ def test_knn_ties_g10(golden, hw):
 
 @pytest.mark.parametrize("d,N,B,k", [(64, 5000, 300, 200), (128, 9000, 257, 200), (256, 3000, 100, 50), (66, 2500, 70, 33),
                                      (32, 700, 33, 392), (128, 150, 40, 150), (8, 64, 5, 64)])
-def test_knn_random_vs_oracle(hw, d, N, B, k):
+def test_knn_random_vs_oracle(hw, knn_path, d, N, B, k):
     U = B
     V32 = np.concatenate([unit_rows_f32(5 + d, U, d), unit_rows_f32(6 + d, N, d)])
     rows = np.arange(U, U + N)
@@ -241,7 +250,7 @@ def test_knn_multi_split_lists(hw):
         assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
 
 
-def test_knn_exact_fallback_kernel(hw):
+def test_knn_exact_fallback_kernel(hw, knn_path):
     """drive hwer_knn_exact_f64 directly and through massive duplication (certificate must fail, fallback must fix it)."""
     d, N, B, k = 32, 3000, 6, 20
     X = unit_rows_f32(55, N, d)
