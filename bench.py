@@ -70,11 +70,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    backend = os.environ.get("HWER_BENCH_BACKEND", "nccl")     # "gloo" only to exercise the N > 1 code path on a 1-GPU box
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     lib = native.lib()
     cfg = CONFIGS[args.config]
@@ -160,6 +166,7 @@ def main():
     ws_exact = torch.empty(lib.hwer_knn_exact_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -176,7 +183,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.hwer_profile_enable(0)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     tot = ctypes.c_double()

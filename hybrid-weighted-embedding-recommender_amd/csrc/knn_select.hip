@@ -465,8 +465,10 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
         want = __shfl(want_new, lstar, kWave);
         prefix |= uint32_t(bstar) << shift;
         mask |= 0xFFu << shift;
+        const int inbin = int(hist[bstar]);
+        if ((k - want) + inbin <= k + 12) break;   // early exit: the bin's lower edge is a good enough threshold
     }
-    const float t_k = f32_from_orderable(prefix);   // k-th largest screen key
+    const float t_k = f32_from_orderable(prefix);   // <= k-th largest screen key, within one nearly empty radix bin
     // ---- re-rank set + certificate (float32 only) ------------------------------------------------------------------
     // Every item has |key32 - key| <= E32.  An item can belong to the true top-k only if key32 >= t_k - 2 E32: those
     // candidates form the re-rank set.  Items that never became candidates have key32 <= min candidate key; if some
@@ -576,8 +578,12 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
         want = __shfl(want_new, lstar, kWave);
         prefix |= uint32_t(bstar) << shift;
         mask |= 0xFFu << shift;
+        // early exit: the k-th key lies in this bin; if the bin is nearly empty its LOWER EDGE (remaining bits zero) is
+        // as good a threshold as the exact key - the re-rank set grows by at most the bin's population
+        const int inbin = int(hist[bstar]);
+        if ((k - want) + inbin <= k + 12) break;
     }
-    const float t_k = f32_from_orderable(prefix);   // k-th largest key
+    const float t_k = f32_from_orderable(prefix);   // <= k-th largest key, within one (nearly empty) radix bin of it
     double Q2 = 0.0;
     {
         const double* q = a.emit.Q64 + b * d;

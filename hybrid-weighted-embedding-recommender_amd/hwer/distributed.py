@@ -29,8 +29,14 @@ def all_gather_results(idx, score, dist2, group=None):
     B, k = idx.shape
     packed = torch.cat([idx.reshape(-1).view(torch.uint8), score.reshape(-1).view(torch.uint8),
                         dist2.reshape(-1).view(torch.uint8)])
-    out = torch.empty((G, packed.numel()), dtype=torch.uint8, device=packed.device)
-    dist.all_gather_into_tensor(out.view(-1), packed, group=group)
+    if packed.is_cuda and dist.get_backend(group) != "nccl":
+        # test harness only (e.g. two ranks sharing one GPU over gloo): stage the payload through host memory
+        host = torch.empty((G, packed.numel()), dtype=torch.uint8)
+        dist.all_gather_into_tensor(host.view(-1), packed.cpu(), group=group)
+        out = host.to(packed.device)
+    else:
+        out = torch.empty((G, packed.numel()), dtype=torch.uint8, device=packed.device)
+        dist.all_gather_into_tensor(out.view(-1), packed, group=group)
     n = B * k * 8
     g_idx = out[:, 0:n].contiguous().view(torch.int64).view(G, B, k)
     g_score = out[:, n:2 * n].contiguous().view(torch.float64).view(G, B, k)

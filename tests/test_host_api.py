@@ -1,0 +1,88 @@
+"""Host-side logic that needs no GPU: node registry, CSR adjacency, metrics, the C ABI surface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import hwer_oracle as orc
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    from hwer import native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "hwer_hip.h")).read()
+    declared = set(re.findall(r"\b(hwer_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    lib = native.lib()          # raises if the .so is missing: there is no fallback
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in native.PROTOTYPES, "native.py has no prototype for %s" % name
+    assert set(native.PROTOTYPES) == declared
+    assert lib.hwer_abi_version() == 1
+    assert lib.hwer_knn_padded_dim(66) == 128 and lib.hwer_knn_padded_dim(257) == -1 and lib.hwer_knn_padded_dim(1) == 32
+    assert lib.hwer_knn_padded_rows(33) == 64 and lib.hwer_knn_max_k() >= 200
+    assert lib.hwer_knn_workspace_bytes(6040, 3706, 128, 200) > 0      # dense plan
+    assert lib.hwer_knn_workspace_bytes(4096, 1_250_000, 128, 200) > 0  # streaming plan with item splits
+    assert lib.hwer_knn_workspace_bytes(10, 100, 128, 100000) == 0      # k beyond the supported maximum
+
+
+def test_product_path_fails_loudly_without_library(monkeypatch):
+    from hwer import native
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", "/nonexistent/libhwer_hip.so")
+    with pytest.raises(native.HwerNativeError, match="not found"):
+        native.lib()
+
+
+def test_no_gpu_means_error_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hwer import native
+    from hwer.device_index import DeviceIndex
+    with pytest.raises(native.HwerNativeError, match="no CPU fallback"):
+        DeviceIndex(np.eye(4, dtype=np.float32), {"x": np.arange(4)})
+
+
+def test_node_edge_registry_semantics():
+    from hwer import Edge, Node, VectorIndex
+    from hwer.recommendation_base import BiMap
+    assert Node("item", 5) == Node("item", "5") and hash(Node("item", 5)) == hash(Node("item", "5"))
+    assert Node("item", 5) != Node("user", 5) and repr(Node("a", 1)) == "('a', '1')"
+    e = Edge(Node("u", 1), Node("i", 2), 0.5)
+    assert list(e) == [Node("u", 1), Node("i", 2), 0.5] and e == Edge(Node("u", "1"), Node("i", 2), 0.5)
+    m = VectorIndex(node_types={"u", "i"}, n_dims=4)
+    m.add_nodes([Node("u", 0), Node("i", 0)]).add_nodes([Node("i", 1)])
+    assert m.nodes_to_idx[Node("i", 1)] == 2 and m.nodes_to_idx.inverse[1] == Node("i", 0)
+    with pytest.raises(AssertionError):
+        m.add_nodes([Node("i", 1)])
+    with pytest.raises(AssertionError):
+        m.add_nodes([Node("x", 1)])
+    b = BiMap([("a", 1)]); b.update({"b": 2})
+    assert b.inverse[2] == "b" and 1 in b.inverse and len(b.inverse) == 2
+
+
+def test_adjacency_csr_matches_oracle():
+    from hwer.content_recommender import adjacency_csr
+    rng = np.random.default_rng(0)
+    src, dst = rng.integers(0, 50, 400), rng.integers(0, 50, 400)
+    a, b = adjacency_csr(50, src, dst)
+    oa, ob = orc.adjacency_csr(50, src, dst)
+    assert np.array_equal(a, oa) and np.array_equal(b, ob)
+
+
+def test_metrics_match_oracle(golden):
+    from hwer import utils
+    g = golden("g9_metrics")
+    yt = dict(zip(g["y_true_keys"].tolist(), g["y_true_vals"].tolist()))
+    yp = g["y_pred"].tolist()
+    assert utils.recall(yt, yp) == float(g["recall"]) and utils.ndcg(yt, yp) == float(g["ndcg"])
+    assert utils.binary_ndcg(yt, yp) == float(g["binary_ndcg"]) and utils.binary_ndcg_v2(list(yt), yp) == float(g["binary_ndcg_v2"])
+    assert utils.reciprocal_rank(list(yt), yp) == float(g["reciprocal_rank"])
+    assert utils.recall({}, yp) == 0.0 and utils.reciprocal_rank([99], yp) == 0.0
+    g8 = golden("g8_unit_audit")
+    got = np.asarray(utils.unit_length_violations(g8["rows"], axis=1), dtype=np.float64)
+    assert np.array_equal(got, g8["viol_rows"])
+    assert np.array_equal(utils.unit_length(g8["rows_zero"], axis=1), g8["unit_zero"], equal_nan=True)
