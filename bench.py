@@ -114,7 +114,7 @@ def main():
 
     # ---------------- preallocated outputs / workspace ----------------------------------------------------------
     V = torch.zeros((N, ldv), dtype=torch.float32, device=dev)
-    norm_ws = torch.empty(N, dtype=torch.float32, device=dev)
+    norm_ws = torch.empty(lib.hwer_unit_audit_ws_floats(N), dtype=torch.float32, device=dev)
     audit_counts = torch.zeros(3, dtype=torch.int64, device=dev)
     audit_dev = torch.zeros(1, dtype=torch.float64, device=dev)
     I_pad = lib.hwer_knn_padded_rows(I)
@@ -150,8 +150,9 @@ def main():
                                                  P(o_flags[b0:b1]), P(ws), ws.numel(), S()), "knn_search")
         # queries the screen could not certify (rare: near-ties at the cut, or a sample-scaled threshold that was too
         # tight) are recomputed by the exhaustive float64 pass INSIDE the step: the step always returns exact results
-        bad = torch.nonzero(o_flags == 0).flatten()
-        if bad.numel():
+        native.check(lib.hwer_knn_count_uncertified(P(o_flags), U, P(n_bad), S()), "count_uncertified")
+        if int(n_bad.item()):
+            bad = torch.nonzero(o_flags == 0).flatten()
             fallback_count[0] += int(bad.numel())
             qsel = np.ascontiguousarray(bad.cpu().numpy(), dtype=np.int32)
             native.check(lib.hwer_knn_exact_f64(P(X), I, d, ldx, P(Q64), P(V), ldv, P(anchors), qsel.ctypes.data_as(ctypes.c_void_p),
@@ -163,6 +164,7 @@ def main():
         return o_idx, o_score, o_dist2
 
     fallback_count = [0]
+    n_bad = torch.zeros(1, dtype=torch.int32, device=dev)
     ws_exact = torch.empty(lib.hwer_knn_exact_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
 
     def barrier():

@@ -320,46 +320,62 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         }
     }
     wave_lds_sync();
-    // ---- order by (dist2, item): the first k entries are the exact k nearest (MultiKNN.query order) ------------------
+    // ---- membership: drop the n_r - k largest (dist2, item) (n_r - k is tiny: the re-rank set is k + a few) -------------
     const int k = a.k;
+    for (int drop = n_r - k; drop > 0; --drop) {
+        uint64_t bh = 0, bl = 0;   // arg-max of (dist2, item) over live entries; dist2 >= 0 so orderable(dist2) > 0
+        for (int i = lane; i < n_r; i += 64) {
+            if (cand[i] != 0xFFFFFFFFu) {
+                const uint64_t h2 = f64_orderable(t_d2[i]), ll = (uint64_t(cand[i]) << 32) | uint32_t(i);
+                if (bh < h2 || (bh == h2 && bl < ll)) { bh = h2; bl = ll; }
+            }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t oh = __shfl_xor(bh, off, kWave), ol = __shfl_xor(bl, off, kWave);
+            if (bh < oh || (bh == oh && bl < ol)) { bh = oh; bl = ol; }
+        }
+        if (lane == 0) cand[uint32_t(bl)] = 0xFFFFFFFFu;   // low word of bl = slot
+        wave_lds_sync();
+    }
+    // ---- ONE sort gives the output order: (score desc, dist2 asc, item asc) = the reference's stable sort by score of
+    // the distance-ordered list; or (dist2, item) when sort_by_score == 0.  Entry: hi = primary key, lo = slot; equal
+    // primaries are resolved by looking (dist2, item) up in LDS (rare).
     const int nr2 = pow2ceil_h(n_r);
     for (int i = lane; i < nr2; i += 64) {
         Ent e;
-        if (i < n_r) {
-            e.hi = f64_orderable(t_d2[i]);
-            e.lo = (uint64_t(cand[i]) << 32) | uint64_t(uint32_t(i));
-        } else {
-            e.hi = ~0ull;
-            e.lo = ~0ull;
+        e.hi = ~0ull;
+        e.lo = ~0ull;
+        if (i < n_r && cand[i] != 0xFFFFFFFFu) {
+            e.hi = a.sort_by_score ? ~f64_orderable(t_sc[i]) : f64_orderable(t_d2[i]);
+            e.lo = uint64_t(uint32_t(i));
         }
         ent[i] = e;
     }
-    wave_bitonic_asc(ent, nr2);
-    if (a.sort_by_score) {
-        // stable sort by score desc == ascending (~orderable(score), rank in the distance order)
-        const int k2 = pow2ceil_h(k);
-        Ent mine[8];   // k2 <= 512: at most 8 per lane, statically indexed below
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int i = lane + 64 * m;
-            Ent e;
-            e.hi = ~0ull;
-            e.lo = ~0ull;
-            if (i < k) {
-                const uint32_t slot = uint32_t(ent[i].lo);
-                e.hi = ~f64_orderable(t_sc[slot]);
-                e.lo = (uint64_t(uint32_t(i)) << 32) | uint64_t(slot);
+    auto less = [&](const Ent& x, const Ent& y) {
+        if (x.hi != y.hi) return x.hi < y.hi;
+        if (x.lo == y.lo) return false;
+        if (x.lo == ~0ull || y.lo == ~0ull) return x.lo < y.lo;   // padding last
+        const uint64_t dx = f64_orderable(t_d2[uint32_t(x.lo)]), dy = f64_orderable(t_d2[uint32_t(y.lo)]);
+        if (dx != dy) return dx < dy;
+        return cand[uint32_t(x.lo)] < cand[uint32_t(y.lo)];
+    };
+    for (int size = 2; size <= nr2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            wave_lds_sync();
+            for (int t = lane; t < (nr2 >> 1); t += 64) {
+                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                const int hi = lo + stride;
+                const bool asc = (lo & size) == 0;
+                const Ent x = ent[lo], y = ent[hi];
+                if (less(y, x) == asc) {
+                    ent[lo] = y;
+                    ent[hi] = x;
+                }
             }
-            mine[m] = e;
         }
-        wave_lds_sync();
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int i = lane + 64 * m;
-            if (i < k2) ent[i] = mine[m];
-        }
-        wave_bitonic_asc(ent, k2);
     }
+    wave_lds_sync();
     for (int i = lane; i < k; i += 64) {
         const uint32_t slot = uint32_t(ent[i].lo);
         const uint32_t it = cand[slot];

@@ -313,38 +313,47 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
     }
 }
 
-// K11 pass 2: one block, deterministic tree
+// K11 pass 2: AUDIT_BLOCKS blocks write partials, the last block to finish (ticket) combines them in block order:
+// deterministic, one launch.  `scratch` = AUDIT_BLOCKS * 4 doubles + 1 ticket word (zeroed by the previous call).
+constexpr int AUDIT_BLOCKS = 64;
 __global__ __launch_bounds__(256) void audit_reduce_kernel(const float* __restrict__ norms, int64_t N, float eps,
-                                                           uint64_t* __restrict__ counts,
-                                                           double* __restrict__ absdev_sum) {
-    __shared__ unsigned long long s_pos[256], s_neg[256], s_nan[256];
-    __shared__ double s_dev[256];
-    unsigned long long pos = 0, neg = 0, nan = 0;
-    double dev = 0.0;
-    // thresholds exactly as numpy evaluates `lengths > 1 + epsilon` with a float32 array and python float epsilon:
+                                                           uint64_t* __restrict__ counts, double* __restrict__ absdev_sum,
+                                                           double* __restrict__ partial, unsigned int* __restrict__ ticket) {
+    __shared__ double s_v[4][256];
+    __shared__ bool s_last;
+    double pos = 0, neg = 0, nan = 0, dev = 0.0;
+    // thresholds exactly as numpy evaluates `lengths > 1 + epsilon` with a float32 array and a python float epsilon:
     // the comparison is done in float64
     const double hi = 1.0 + double(eps), lo = 1.0 - double(eps);
-    for (int64_t i = threadIdx.x; i < N; i += 256) {
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < N; i += int64_t(gridDim.x) * 256) {
         const float n = norms[i];
         pos += double(n) > hi;
         neg += double(n) < lo;
         nan += (n != n);
         dev += fabs(double(n) - 1.0);
     }
-    s_pos[threadIdx.x] = pos; s_neg[threadIdx.x] = neg; s_nan[threadIdx.x] = nan; s_dev[threadIdx.x] = dev;
+    s_v[0][threadIdx.x] = pos; s_v[1][threadIdx.x] = neg; s_v[2][threadIdx.x] = nan; s_v[3][threadIdx.x] = dev;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if (threadIdx.x < s) {
-            s_pos[threadIdx.x] += s_pos[threadIdx.x + s];
-            s_neg[threadIdx.x] += s_neg[threadIdx.x + s];
-            s_nan[threadIdx.x] += s_nan[threadIdx.x + s];
-            s_dev[threadIdx.x] += s_dev[threadIdx.x + s];
-        }
+        if (threadIdx.x < s)
+            for (int c = 0; c < 4; ++c) s_v[c][threadIdx.x] += s_v[c][threadIdx.x + s];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        counts[0] = s_pos[0]; counts[1] = s_neg[0]; counts[2] = s_nan[0];
-        absdev_sum[0] = s_dev[0];
+        for (int c = 0; c < 4; ++c) __hip_atomic_store(&partial[blockIdx.x * 4 + c], s_v[c][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        double tot[4] = {0, 0, 0, 0};
+        for (unsigned int bI = 0; bI < gridDim.x; ++bI)
+            for (int c = 0; c < 4; ++c) tot[c] += __hip_atomic_load(&partial[bI * 4 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        counts[0] = uint64_t(tot[0]); counts[1] = uint64_t(tot[1]); counts[2] = uint64_t(tot[2]);
+        absdev_sum[0] = tot[3];
     }
 }
 
@@ -509,6 +518,28 @@ int hwer_blend_normalize_f32(const float* const* tables, int64_t ld_tables, cons
     return check_launch("blend_normalize");
 }
 
+int64_t hwer_unit_audit_ws_floats(int64_t N) { return ((N + 3) / 4) * 4 + (AUDIT_BLOCKS * 4 * 2) + 8; }
+
+// number of queries whose flag is 0 (uncertified) -> out[0]; lets the host decide on the exhaustive pass with one
+// 4-byte read instead of a device-wide nonzero()
+__global__ __launch_bounds__(256) void count_zero_flags_kernel(const int32_t* __restrict__ flags, int64_t B, int32_t* __restrict__ out) {
+    __shared__ int s[256];
+    int c = 0;
+    for (int64_t i = threadIdx.x; i < B; i += 256) c += flags[i] == 0;
+    s[threadIdx.x] = c;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+int hwer_knn_count_uncertified(const int32_t* flags, int64_t B, int32_t* out_count, void* stream) {
+    if (!flags || !out_count || B < 0) return fail(HWER_EINVAL, "count_uncertified: bad argument");
+    hipLaunchKernelGGL(count_zero_flags_kernel, dim3(1), dim3(256), 0, as_stream(stream), flags, B, out_count);
+    return check_launch("count_uncertified");
+}
+
 int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps, float* row_norm_ws,
                         uint64_t* out_counts, double* out_absdev_sum, void* stream) {
     int rc;
@@ -519,8 +550,14 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
     hipLaunchKernelGGL(row_norm_kernel<false>, dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
                        (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws);
     if ((rc = check_launch("unit_audit(norms)"))) return rc;
-    hipLaunchKernelGGL(audit_reduce_kernel, dim3(1), dim3(256), 0, as_stream(stream), row_norm_ws, N, eps, out_counts,
-                       out_absdev_sum);
+    // partials + ticket live behind the N row norms (callers size row_norm_ws with hwer_unit_audit_ws_floats(N))
+    double* partial = reinterpret_cast<double*>(row_norm_ws + ((N + 3) / 4) * 4);
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(partial + AUDIT_BLOCKS * 4);
+    // zero the arrival ticket on every call (a memset node on the stream: the workspace may be freshly allocated)
+    if (hipMemsetAsync(ticket, 0, 16, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "unit_audit: memset failed");
+    const int blocks = int(std::max<int64_t>(1, std::min<int64_t>(AUDIT_BLOCKS, cdiv64(N, 1024))));
+    hipLaunchKernelGGL(audit_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), row_norm_ws, N, eps, out_counts,
+                       out_absdev_sum, partial, ticket);
     return check_launch("unit_audit(reduce)");
 }
 

@@ -92,7 +92,7 @@ class DeviceIndex:
     def unit_audit(self, eps: float = 1e-4):
         """(violations, mean |len - 1|, positive, negative, nan_rows) — utils.unit_length_violations on device."""
         torch = _torch()
-        ws = torch.empty(self.N, dtype=torch.float32, device=self.device)
+        ws = torch.empty(self.lib.hwer_unit_audit_ws_floats(self.N), dtype=torch.float32, device=self.device)
         counts = torch.zeros(3, dtype=torch.int64, device=self.device)
         dev = torch.zeros(1, dtype=torch.float64, device=self.device)
         native.check(self.lib.hwer_unit_audit_f32(native.ptr(self.V), self.N, self.d, self.ldv, eps, native.ptr(ws),
@@ -204,8 +204,10 @@ class DeviceIndex:
                 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
                 tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]),
                 native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), native.stream_ptr()), "knn_search")
-        bad = torch.nonzero(flags == 0).flatten()
-        if bad.numel():
+        n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+        native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr()), "count_uncertified")
+        if int(n_bad.item()):
+            bad = torch.nonzero(flags == 0).flatten()
             self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
                                  dist2, flags)
         return idx, score, dist2, flags

@@ -81,8 +81,9 @@ int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, co
  *        RecommendationBase.__build_knn__ (hwer/recommendation_base.py:106-107).
  *   out_counts[0..2] = rows with norm > 1+eps, rows with norm < 1-eps, rows with NaN norm
  *   out_absdev_sum   = sum_r |norm_r - 1|  (float64; NaN rows propagate like numpy's mean would)
- *   row_norm_ws      : (N) float workspace (receives every row norm).
+ *   row_norm_ws      : float workspace of hwer_unit_audit_ws_floats(N) elements (receives every row norm, then partials).
  * ------------------------------------------------------------------------------------------------- */
+int64_t hwer_unit_audit_ws_floats(int64_t N);
 int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps, float* row_norm_ws,
                         uint64_t* out_counts, double* out_absdev_sum, void* stream);
 
@@ -142,6 +143,10 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
                         int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
                         double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                         size_t workspace_bytes, void* stream);
+
+/* out_count[0] = number of queries with flags == 0 (device int32): one 4-byte read tells the host whether the
+ * exhaustive pass is needed. */
+int hwer_knn_count_uncertified(const int32_t* flags, int64_t B, int32_t* out_count, void* stream);
 
 /* Exhaustive float64 k-NN for the (rare) queries whose certificate failed; same outputs / order as above.
  * `qsel` (nq) lists the query rows to recompute; their output rows are overwritten and flags set to 2. */
