@@ -81,6 +81,48 @@ __device__ __forceinline__ T np_pairwise(const T* p, int n, int k) {
 }
 constexpr int kPairwiseDepth = 3;  // d <= 1024
 
+// ---- wave-level selection by float bisection ---------------------------------------------------------------------
+// v[0..NV) per lane (entries that do not exist hold -inf).  Finds `lo` with rank <= count(v >= lo) <= rank + slack
+// whenever the data allows it (stops early when the interval is exhausted by ties: then count(>= lo) may be larger and
+// the caller trims the keys equal to lo).  Conflict-free: ballot counting (v_cmp + s_bcnt1) per register, no LDS.
+// Precondition: at least `rank` finite entries.
+template <int NV>
+__device__ __forceinline__ int wave_count_ge(const float (&v)[NV], float t) {
+    // one v_cmp (-> SGPR pair) + s_bcnt1 + s_add per register: scalar counting, no cross-lane traffic
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) c += __builtin_popcountll(__ballot(v[i] >= t));
+    return c;
+}
+template <int NV>
+__device__ __forceinline__ float wave_bisect_rank(const float (&v)[NV], int rank, int slack, int& count_ge_lo) {
+    float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        vmax = fmaxf(vmax, v[i]);
+        if (v[i] > -INFINITY) vmin = fminf(vmin, v[i]);
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
+        vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
+    }
+    float lo = vmin, hi = vmax;   // invariant: count(>= lo) >= rank
+    int c_lo = wave_count_ge<NV>(v, lo);
+    for (int iter = 0; iter < 64 && c_lo > rank + slack; ++iter) {
+        const float mid = 0.5f * lo + 0.5f * hi;
+        if (!(mid > lo) || !(mid < hi)) {   // hi is the next float above lo (or equal): try hi itself, then stop
+            const int c = wave_count_ge<NV>(v, hi);
+            if (c >= rank) { lo = hi; c_lo = c; }
+            break;
+        }
+        const int c = wave_count_ge<NV>(v, mid);
+        if (c >= rank) { lo = mid; c_lo = c; } else { hi = mid; }
+    }
+    count_ge_lo = c_lo;
+    return lo;
+}
+
 // make LDS traffic of one wave visible to its own lanes (no cross-wave sync)
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);                         // [2][IB][CH*4]
     float* hn = xs + 2 * IB * CH * 4;                                       // [2][IB]
-    uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);          // [4][256]
+    uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);          // [4][256] radix histograms of the compaction
     float* keypark_all = reinterpret_cast<float*>(hist_all + 4 * 256);      // [4][64][16]: a wave's 16 keys per lane
     uint64_t* slots_all = reinterpret_cast<uint64_t*>(keypark_all + 4 * 64 * 16);   // [4][TQ][SL][64] append slots
 
@@ -336,14 +336,14 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             if constexpr (DENSE) {
                 // small catalogues: keep every key (lane (r, h): query r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store)
 #pragma unroll
+                // The key matrix has bq >= B rows, so every lane stores unconditionally: exactly 4 * TQ store
+                // instructions per wave and tile, which the counted wait at the tile boundary relies on.
                 for (int b = 0; b < TQ; ++b) {
                     const int64_t q = qw0 + 32 * b + r;
-                    if (q < a.B) {
-                        float* row = a.dense + q * a.ld_dense + i0 + 4 * h;
+                    float* row = a.dense + q * a.ld_dense + i0 + 4 * h;
 #pragma unroll
-                        for (int rg = 0; rg < 4; ++rg)
-                            *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
-                    }
+                    for (int rg = 0; rg < 4; ++rg)
+                        *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
                 }
             } else {
             // ---- streaming filter ---------------------------------------------------------------------------------
@@ -352,13 +352,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // max-popcount-over-the-wave times (2-3 in steady state, 16 only during warm-up).
 #pragma unroll
             for (int b = 0; b < TQ; ++b) {
-                float m = acc[b][0];
+                // pass mask, 2 VALU per key: tau - key is negative exactly when key > tau (strict), and a funnel shift
+                // (v_alignbit) pushes that sign bit into the mask.  Bit (15 - q) <-> accumulator register q.
+                uint32_t mask = 0;
 #pragma unroll
-                for (int q = 1; q < 16; ++q) m = fmaxf(m, acc[b][q]);
-                if (__any(m > tau[b])) {
-                    uint32_t mask = 0;
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) mask |= (acc[b][q] > tau[b]) ? (1u << q) : 0u;
+                for (int q = 0; q < 16; ++q)
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(tau[b] - acc[b][q]), 31);
+                if (__any(mask != 0u)) {
                     const uint32_t item0 = uint32_t(i0) + 4 * h;
                     float* park = keypark + lane * 16;
 #pragma unroll
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                         *reinterpret_cast<float4*>(park + 4 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
                     while (__any(mask != 0u)) {
                         if (mask != 0u) {
-                            const int q = __builtin_ctz(mask);
+                            const int q = 15 - __builtin_ctz(mask);
                             mask &= mask - 1u;
                             const uint64_t key = pack_key(park[q], item0 + (q & 3) + 8 * (q >> 2));
                             if (nloc[b] < SL) {
@@ -385,7 +385,14 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         // ---- tile boundary ---------------------------------------------------------------------------------------------
         // Outstanding VMEM here: the DMA of tile t+1 and the previous flush, both issued a whole tile ago (appends of
         // this tile sit in LDS slots), so this wait is normally free.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (DENSE) {
+            // the 4 * TQ key stores of this tile are YOUNGER than the DMA of tile t+1 (vmcnt retires in issue order):
+            // wait for everything but them, so the DMA has landed while the stores stay in flight
+            if (t % wi_n == wii) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if constexpr (DENSE) {
             if (t + 2 < n_tiles) tile_dma(t + 2);
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             uint64_t* s0 = wg_cand + (uint32_t(32 * b + jj) * 2u) * CAPH;
             uint32_t T;
             int n0, n1;
-            compact_query(s0, s0 + CAPH, c0, c1, a.kprime, hist, T, n0, n1);
+            compact_query(s0, s0 + CAPH, c0, c1, a.kprime, hist, T, n0, n1);   // exact: a list hands over <= K' keys
             if (r == jj) cnt[b] = h == 0 ? n0 : n1;
             need &= ~(1ull << jj);
         }
@@ -494,7 +501,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     p.dense = n_items <= DENSE_MAX_ITEMS && !getenv("HWER_NO_DENSE");
     if (p.dense) {
         const int64_t n_tiles = cdiv64(n_items, 32);
-        int64_t sp = std::min<int64_t>(n_tiles, std::max<int64_t>(1, cdiv64(768, p.n_qblocks)));
+        // one full round of workgroups: 256 CUs x 2 resident = 512 slots
+        int64_t sp = std::min<int64_t>(n_tiles, std::max<int64_t>(1, 512 / p.n_qblocks));
         int64_t per_d = cdiv64(n_tiles, sp) * 32;
         p.n_splits = int(cdiv64(n_items, per_d));
         p.split_items = per_d;
@@ -506,7 +514,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
 
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 waves x 64 lanes x 16 keys
+    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 waves x 64 lanes x 16 keys | append slots
     const size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4 + size_t(4) * TQ * 4 * 64 * 8;
     static bool attr_done = false;
     if (!attr_done) {

@@ -6,6 +6,7 @@
 //   dist2 : scikit-learn `euclidean_rdist64`  -> sequential  d += (q_j - x_j)^2, separate mul and add roundings
 //   score : numpy `(a * b).sum(1)`             -> pairwise summation of the rounded products
 #include <algorithm>
+#include <cstdlib>
 
 #include "knn_internal.h"
 
@@ -127,6 +128,7 @@ struct EmitArgs {
     const int32_t* a_idx;  // nullable: anchor row of query b is A32[a_idx[b]] (else A32[b])
     int score_mode;
     int sort_by_score;
+    int debug_skip;   // ablation only (HWER_SELECT_SKIP bits: 1 = no re-rank rounds, 2 = no sort, 4 = no selection passes)
     const int64_t* row_ids;
     int64_t id_base;
     int k;
@@ -214,7 +216,7 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
     const int n_chunks = (d + RR_CW - 1) / RR_CW;
 
 #pragma unroll 1
-    for (int g0 = 0; g0 < n_r; g0 += 64) {   // wave-uniform rounds of 64 candidates
+    for (int g0 = 0; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += 64) {   // wave-uniform rounds of 64 candidates
         const int ci = g0 + lane;
         const bool live = ci < n_r;
         const uint32_t it = cand[live ? ci : g0];
@@ -360,7 +362,7 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         if (dx != dy) return dx < dy;
         return cand[uint32_t(x.lo)] < cand[uint32_t(y.lo)];
     };
-    for (int size = 2; size <= nr2; size <<= 1) {
+    for (int size = 2; size <= ((a.debug_skip & 2) ? 0 : nr2); size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             wave_lds_sync();
             for (int t = lane; t < (nr2 >> 1); t += 64) {
@@ -387,7 +389,7 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
 }
 
 // ---------------------------------------------------------------------------------------------------
-constexpr int RR_MAXR = (KPRIME_MAX + 63) / 64;   // candidate keys per lane (7)
+constexpr int RR_MAXR = (KPRIME_MAX + 63) / 64;   // candidate keys per lane (7): a list holds at most K' keys
 // select: one wave per query.  Input: ONE candidate list per query (<= K' keys, unsorted, split over the two lane
 // streams).  Finds the k-th largest screen key by an in-register radix select, derives the re-rank set and the
 // exactness certificate from the float32 error bound, then re-ranks.
@@ -398,6 +400,7 @@ struct SelectArgs {
     int64_t bq;
     int64_t B;
     int kprime;
+    int kcap;     // LDS capacity of the re-rank tables (= K')
     float hnorm_max;
     EmitArgs emit;
 };
@@ -408,10 +411,8 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
     const int64_t b = int64_t(blockIdx.x) * 4 + wave;
     if (b >= a.B) return;   // no workgroup barrier below
     const int d = a.emit.d, k = a.emit.k;
-    const int kp = a.kprime;                                           // candidate capacity (multiple of 64)
-    unsigned char* lds = smem_raw + size_t(wave) * (wave_lds_bytes(d, kp) + 1024);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds);                 // 256 bins
-    unsigned char* lds_emit = lds + 1024;
+    const int kp = a.kcap;                                             // candidate capacity (multiple of 64)
+    unsigned char* lds_emit = smem_raw + size_t(wave) * wave_lds_bytes(d, kp);
     uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(d) * 16 + size_t(kp) * 16);   // = `cand` of wave_rerank_emit
 
     const int c0r = a.cand_cnt[b * 2], c1r = a.cand_cnt[b * 2 + 1];
@@ -426,65 +427,12 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
         const int e = 64 * i + lane;
         key[i] = e < c0 ? s0[e] : (e - c0 < c1 ? s1[e - c0] : 0ull);
     }
-    // ---- k-th largest screen key: byte radix select over the score words ---------------------------------------------
-    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
+    // ---- (approximately) the k-th largest screen key: float bisection on the register-resident scores -------------------
+    float sv[RR_MAXR];
 #pragma unroll
-    for (int i = 0; i < RR_MAXR; ++i) {
-        if (key[i] != 0ull) {
-            all_or |= uint32_t(key[i] >> 32);
-            all_and &= uint32_t(key[i] >> 32);
-        }
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        all_or |= __shfl_xor(all_or, off, kWave);
-        all_and &= __shfl_xor(all_and, off, kWave);
-    }
-    const uint32_t differ = all_or ^ all_and;
-    uint32_t prefix = 0, mask = 0;
-    int want = k;
-#pragma unroll 1
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (((differ >> shift) & 0xFFu) == 0u) {
-            prefix |= all_and & (0xFFu << shift);
-            mask |= 0xFFu << shift;
-            continue;
-        }
-        *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < RR_MAXR; ++i) {
-            const uint32_t sv = uint32_t(key[i] >> 32);
-            if (key[i] != 0ull && (sv & mask) == prefix) atomicAdd(&hist[(sv >> shift) & 255u], 1u);
-        }
-        wave_lds_sync();
-        const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
-        const int sN = int(h4.x + h4.y + h4.z + h4.w);
-        int S = sN;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_down(S, off, kWave);
-            if (lane + off < 64) S += t;
-        }
-        const uint64_t bal = __ballot(S >= want);
-        const int lstar = 63 - __builtin_clzll(bal);
-        int bstar, want_new;
-        {
-            const int cum = S - sN;
-            const int h3 = int(h4.w), h2 = int(h4.z), h1 = int(h4.y);
-            if (cum + h3 >= want) { bstar = 4 * lane + 3; want_new = want - cum; }
-            else if (cum + h3 + h2 >= want) { bstar = 4 * lane + 2; want_new = want - cum - h3; }
-            else if (cum + h3 + h2 + h1 >= want) { bstar = 4 * lane + 1; want_new = want - cum - h3 - h2; }
-            else { bstar = 4 * lane; want_new = want - cum - h3 - h2 - h1; }
-        }
-        bstar = __shfl(bstar, lstar, kWave);
-        want = __shfl(want_new, lstar, kWave);
-        prefix |= uint32_t(bstar) << shift;
-        mask |= 0xFFu << shift;
-        const int inbin = int(hist[bstar]);
-        if ((k - want) + inbin <= k + 12) break;   // early exit: the bin's lower edge is a good enough threshold
-    }
-    const float t_k = f32_from_orderable(prefix);   // <= k-th largest screen key, within one nearly empty radix bin
+    for (int i = 0; i < RR_MAXR; ++i) sv[i] = key[i] != 0ull ? key_score(key[i]) : -INFINITY;
+    int c_ge;
+    const float t_k = wave_bisect_rank<RR_MAXR>(sv, k, 12, c_ge);   // <= k-th largest key, <= 12 extra keys above it
     // ---- re-rank set + certificate (float32 only) ------------------------------------------------------------------
     // Every item has |key32 - key| <= E32.  An item can belong to the true top-k only if key32 >= t_k - 2 E32: those
     // candidates form the re-rank set.  Items that never became candidates have key32 <= min candidate key; if some
@@ -500,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
     int n_r = 0;
 #pragma unroll
     for (int i = 0; i < RR_MAXR; ++i) {
-        const bool in = key[i] != 0ull && key_score(key[i]) >= thr;
+        const bool in = sv[i] >= thr;
         const uint64_t bal = __ballot(in);
         if (in) cand_item[n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = key_item(key[i]);
         n_r += __builtin_popcountll(bal);
@@ -526,80 +474,67 @@ struct DenseSelectArgs {
     EmitArgs emit;
 };
 
+template <int MAXV>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys
 __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = int64_t(blockIdx.x) * 4 + wave;
     if (b >= a.B) return;   // no workgroup barrier below
     const int d = a.emit.d, k = a.emit.k, kp = a.kp;
-    unsigned char* lds = smem_raw + size_t(wave) * (wave_lds_bytes(d, kp) + 1024);
-    uint32_t* hist = reinterpret_cast<uint32_t*>(lds);
-    unsigned char* lds_emit = lds + 1024;
+    unsigned char* lds_emit = smem_raw + size_t(wave) * wave_lds_bytes(d, kp);
     uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(d) * 16 + size_t(kp) * 16);
     const float4* row = reinterpret_cast<const float4*>(a.keys + b * a.ld);
     const int n4 = int(a.ld / 4);
-
-    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
-    for (int i = lane; i < n4; i += 64) {
-        const float4 v = row[i];
-        const uint32_t o0 = f32_orderable(v.x), o1 = f32_orderable(v.y), o2 = f32_orderable(v.z), o3 = f32_orderable(v.w);
-        all_or |= o0 | o1 | o2 | o3;
-        all_and &= o0 & o1 & o2 & o3;
+    // The lane's slice of the key row lives in registers (rows up to 256 * MAXV keys): every load is in flight at once,
+    // and the k-th key is bracketed by a float BISECTION on those registers (per-lane counting + one wave reduction per
+    // step).  A byte-radix histogram in LDS is the wrong tool here: thousands of keys share their top bytes, so every
+    // LDS atomic would serialise 64 lanes on one bin.
+    float kv[MAXV][4];   // slices beyond the row hold -inf (below every real key; pad items are -inf too)
+#pragma unroll
+    for (int m = 0; m < MAXV; ++m) {
+        const int i = lane + 64 * m;
+        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        if (i < n4) v = row[i];
+        kv[m][0] = v.x; kv[m][1] = v.y; kv[m][2] = v.z; kv[m][3] = v.w;
+    }
+    const int n_m = (n4 + 63) / 64;   // live slices (wave-uniform)
+    float vmax = -INFINITY, vmin = INFINITY;
+#pragma unroll
+    for (int m = 0; m < MAXV; ++m) {
+        if (m < n_m) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                vmax = fmaxf(vmax, kv[m][c]);
+                if (kv[m][c] > -INFINITY) vmin = fminf(vmin, kv[m][c]);
+            }
+        }
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
-        all_or |= __shfl_xor(all_or, off, kWave);
-        all_and &= __shfl_xor(all_and, off, kWave);
+        vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
+        vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
-    const uint32_t differ = all_or ^ all_and;
-    uint32_t prefix = 0, mask = 0;
-    int want = k;
-#pragma unroll 1
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (((differ >> shift) & 0xFFu) == 0u) {
-            prefix |= all_and & (0xFFu << shift);
-            mask |= 0xFFu << shift;
-            continue;
-        }
-        *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-        for (int i = lane; i < n4; i += 64) {
-            const float4 v = row[i];
-            const uint32_t o[4] = {f32_orderable(v.x), f32_orderable(v.y), f32_orderable(v.z), f32_orderable(v.w)};
+    auto count_ge = [&](float t) {
+        int c = 0;   // ballot counting: v_cmp -> s_bcnt1 -> s_add, no cross-lane traffic
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if ((o[c] & mask) == prefix) atomicAdd(&hist[(o[c] >> shift) & 255u], 1u);
-        }
-        wave_lds_sync();
-        const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
-        const int sN = int(h4.x + h4.y + h4.z + h4.w);
-        int S = sN;
+        for (int m = 0; m < MAXV; ++m) {
+            if (m < n_m) {
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_down(S, off, kWave);
-            if (lane + off < 64) S += t;
+                for (int cc = 0; cc < 4; ++cc) c += __builtin_popcountll(__ballot(kv[m][cc] >= t));
+            }
         }
-        const uint64_t bal = __ballot(S >= want);
-        const int lstar = 63 - __builtin_clzll(bal);
-        int bstar, want_new;
-        {
-            const int cum = S - sN;
-            const int h3 = int(h4.w), h2 = int(h4.z), h1 = int(h4.y);
-            if (cum + h3 >= want) { bstar = 4 * lane + 3; want_new = want - cum; }
-            else if (cum + h3 + h2 >= want) { bstar = 4 * lane + 2; want_new = want - cum - h3; }
-            else if (cum + h3 + h2 + h1 >= want) { bstar = 4 * lane + 1; want_new = want - cum - h3 - h2; }
-            else { bstar = 4 * lane; want_new = want - cum - h3 - h2 - h1; }
-        }
-        bstar = __shfl(bstar, lstar, kWave);
-        want = __shfl(want_new, lstar, kWave);
-        prefix |= uint32_t(bstar) << shift;
-        mask |= 0xFFu << shift;
-        // early exit: the k-th key lies in this bin; if the bin is nearly empty its LOWER EDGE (remaining bits zero) is
-        // as good a threshold as the exact key - the re-rank set grows by at most the bin's population
-        const int inbin = int(hist[bstar]);
-        if ((k - want) + inbin <= k + 12) break;
+        return c;
+    };
+    // invariant: count(>= lo) >= k (every finite key is >= vmin and there are >= k of them), count(>= hi) < k or hi > vmax
+    float lo = vmin, hi = vmax;
+    int c_lo = count_ge(lo);
+    for (int iter = 0; iter < 64 && c_lo > k + 12; ++iter) {
+        const float mid = 0.5f * lo + 0.5f * hi;
+        if (!(mid > lo) || !(mid < hi)) break;   // interval exhausted (ties at the cut): keep lo
+        const int c = count_ge(mid);
+        if (c >= k) { lo = mid; c_lo = c; } else { hi = mid; }
     }
-    const float t_k = f32_from_orderable(prefix);   // <= k-th largest key, within one (nearly empty) radix bin of it
+    const float t_k = lo;   // <= k-th largest key, with at most c_lo - k extra keys above it
     double Q2 = 0.0;
     {
         const double* q = a.emit.Q64 + b * d;
@@ -610,18 +545,17 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
     const float thr = t_k - 2.0f * e32_bound(d, Q2, a.hnorm_max);
     int n_r = 0;
     bool overflow = false;
-    for (int i0 = 0; i0 < n4; i0 += 64) {   // wave-uniform trip count
-        const int i = i0 + lane;
-        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (i < n4) v = row[i];
-        const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool in = vv[c] >= thr;
-            const uint64_t bal = __ballot(in);
-            const int pos = n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-            if (in && pos < kp) cand_item[pos] = uint32_t(4 * i + c);
-            n_r += __builtin_popcountll(bal);
+    for (int m = 0; m < MAXV; ++m) {
+        if (m < n_m) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool in = kv[m][c] >= thr;
+                const uint64_t bal = __ballot(in);
+                const int pos = n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+                if (in && pos < kp) cand_item[pos] = uint32_t(4 * (lane + 64 * m) + c);
+                n_r += __builtin_popcountll(bal);
+            }
         }
     }
     if (n_r > kp) {   // more near-ties than the re-rank capacity: not certifiable here
@@ -893,7 +827,7 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     WsLayout w{};
     size_t off = 0;
     if (p.dense) {   // one (B, ld_dense) float matrix of keys
-        w.total = align256(size_t(B) * size_t(p.ld_dense) * 4);
+        w.total = align256(size_t(p.bq) * size_t(p.ld_dense) * 4);   // bq >= B rows: the screen stores unconditionally
         return w;
     }
     w.cand_a = off;
@@ -959,11 +893,17 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         da.B = B;
         da.kp = plan.kprime;
         da.hnorm_max = hnorm_max;
-        da.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, row_ids, id_base, k,
+        da.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                            out_idx, out_score, out_dist2, out_flags};
-        const size_t lds = size_t(4) * (wave_lds_bytes(d, plan.kprime) + 1024);
-        if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel), lds, "knn_select_dense"))) return rc;
-        hipLaunchKernelGGL(select_dense_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+        const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
+        if (plan.ld_dense <= 256 * 16) {
+            if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<16>), lds, "knn_select_dense"))) return rc;
+            hipLaunchKernelGGL(select_dense_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+        } else {
+            static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
+            if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<32>), lds, "knn_select_dense"))) return rc;
+            hipLaunchKernelGGL(select_dense_kernel<32>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+        }
         return check_launch("knn_select_dense");
     }
 
@@ -987,10 +927,11 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     sa.bq = plan.bq;
     sa.B = B;
     sa.kprime = plan.kprime;
+    sa.kcap = plan.kprime;   // the screen's final compaction is exact: a list holds at most K' keys
     sa.hnorm_max = hnorm_max;
-    sa.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, row_ids, id_base, k,
+    sa.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags};
-    const size_t lds = size_t(4) * (wave_lds_bytes(d, plan.kprime) + 1024);
+    const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel), lds, "knn_select"))) return rc;
     hipLaunchKernelGGL(select_rerank_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, sa);
     return check_launch("knn_select");
@@ -1043,7 +984,7 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
             n = chunks * keep;
             std::swap(in, out);
         } while (n > keep);
-        EmitArgs ea{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, row_ids, id_base, k,
+        EmitArgs ea{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
                     out_idx, out_score, out_dist2, out_flags};
         const size_t lds = wave_lds_bytes(d, ((k + 63) / 64) * 64);
         hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(64), lds, st, in, int(n), b, ea);
