@@ -115,8 +115,9 @@ def main():
     # ---------------- preallocated outputs / workspace ----------------------------------------------------------
     V = torch.zeros((N, ldv), dtype=torch.float32, device=dev)
     norm_ws = torch.empty(lib.hwer_unit_audit_ws_floats(N), dtype=torch.float32, device=dev)
-    audit_counts = torch.zeros(3, dtype=torch.int64, device=dev)
-    audit_dev = torch.zeros(1, dtype=torch.float64, device=dev)
+    audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)      # counts[4] | sum |norm-1| (f64) | pad: one 48-byte memset
+    audit_counts = audit_buf[:4]
+    audit_dev = audit_buf[4:5].view(torch.float64)
     I_pad = lib.hwer_knn_padded_rows(I)
     X = torch.empty((I_pad, ldx), dtype=torch.float32, device=dev)
     hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
@@ -136,9 +137,9 @@ def main():
     arith = 0                       # float64 score arithmetic (ContentRecommendation flavour)
 
     def step():
-        native.check(lib.hwer_blend_normalize_f32(P(tab_ptrs), d, None, P(alpha), 1 if cfg["per_row"] else 0, T, N, d,
-                                                  P(V), ldv, None, S()), "blend")
-        native.check(lib.hwer_unit_audit_f32(P(V), N, d, ldv, 1e-4, P(norm_ws), P(audit_counts), P(audit_dev), S()), "audit")
+        # blend + L2-normalise with the unit-norm audit of the output rows fused into the same pass
+        native.check(lib.hwer_blend_normalize_audit_f32(P(tab_ptrs), d, None, P(alpha), 1 if cfg["per_row"] else 0, T, N, d,
+                                                        P(V), ldv, 1e-4, P(audit_counts), P(audit_dev), S()), "blend+audit")
         native.check(lib.hwer_pack_rows_f32(P(V), N, d, ldv, P(item_rows), I, P(X), ldx, P(hnorm), S()), "pack")
         native.check(lib.hwer_query_mix(P(V), N, d, ldv, P(anchors), None, None, None, None, U, arith, P(Q64), P(Q32),
                                         ldx, S()), "query_mix")
@@ -151,7 +152,7 @@ def main():
         # queries the screen could not certify (rare: near-ties at the cut, or a sample-scaled threshold that was too
         # tight) are recomputed by the exhaustive float64 pass INSIDE the step: the step always returns exact results
         native.check(lib.hwer_knn_count_uncertified(P(o_flags), U, P(n_bad), S()), "count_uncertified")
-        if int(n_bad.item()):
+        if (not os.environ.get("HWER_BENCH_NOSYNC")) and int(n_bad.item()):   # NOSYNC: diagnosis only (breaks exactness)
             bad = torch.nonzero(o_flags == 0).flatten()
             fallback_count[0] += int(bad.numel())
             qsel = np.ascontiguousarray(bad.cpu().numpy(), dtype=np.int32)
@@ -197,7 +198,7 @@ def main():
     select_ms = tot.value / max(cnt.value, 1)
 
     # ---------------- post-hoc checks (outside the timed region) ------------------------------------------------
-    pos, neg, nan = audit_counts.tolist()
+    pos, neg, nan = audit_counts.tolist()[:3]
     assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
     n_uncert = int((o_flags == 0).sum().item())
     assert n_uncert == 0, "%d queries left without an exact result" % n_uncert
@@ -227,6 +228,15 @@ def main():
     launches = max(1.0, screen_launches_per_step)
     flops_per_launch = 2.0 * U * I * d / launches
     achieved = flops_per_launch / (screen_ms * 1e-3) / 1e12 if screen_ms > 0 else 0.0
+    # HBM traffic of the screen kernel per launch, measured with rocprofv3 PMC passes for the SAME command and kept in
+    # profiles/r1_pmc_traffic.json: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes (FETCH_SIZE reads half the bytes of wide
+    # loads on gfx950 - MI355X_MICROARCH.md §HBM).  None when no profile exists for this config / GPU count.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
+            traffic = json.load(fh).get(args.config if world == 1 else "", {}).get("knn_screen_bytes_per_launch")
+    except OSError:
+        pass
     out = {
         "metric": "user-item pairs/sec scored (blend + L2-normalise + exact top-%d retrieval)" % K,
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -236,7 +246,7 @@ def main():
                    "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": "items row-sharded x%d, all-gather + merge" % world if world > 1 else "none"},
         "roofline": {"kernel": "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)", "bound": "mfma",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": None, "avg_launch_ms": screen_ms, "launches_per_step": launches},
+                     "traffic": traffic, "avg_launch_ms": screen_ms, "launches_per_step": launches},
         "kernels_ms": {"knn_screen": screen_ms, "knn_select_rerank": select_ms},
         "recall_latency_ms": ms_per_step, "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive,
         "parity_checked_queries": parity_n,

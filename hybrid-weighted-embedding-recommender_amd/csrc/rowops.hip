@@ -152,8 +152,12 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
                                                               int64_t ldt, const int32_t* const* __restrict__ row_idx,
                                                               const float* __restrict__ alpha, int alpha_per_row,
                                                               int T, int64_t R, int d4, float* __restrict__ out,
-                                                              int64_t ldo, float* __restrict__ out_norm) {
+                                                              int64_t ldo, float* __restrict__ out_norm, float audit_eps,
+                                                              unsigned long long* __restrict__ audit_counts,
+                                                              double* __restrict__ audit_absdev) {
     const RowGroup g(d4);
+    unsigned long long a_pos = 0, a_neg = 0, a_nan = 0;   // fused K11 audit of the rows this thread finishes
+    double a_dev = 0.0;
     const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
     for (int64_t r0 = group_global - g.sub; r0 < R; r0 += group_stride) {  // r0: wave-uniform base row
@@ -197,6 +201,33 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
             }
             if (out_norm && g.c0 == 0) out_norm[r] = nrm;
         }
+        if (audit_counts) {   // norm of the row as STORED (float32), exactly what a separate audit pass would read back
+            float s2 = 0.f;
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = g.c0 + i * g.L;
+                    if (c < d4) {
+                        const float ox = acc[i].x / nrm, oy = acc[i].y / nrm, oz = acc[i].z / nrm, ow = acc[i].w / nrm;
+                        s2 += ox * ox + oy * oy + oz * oz + ow * ow;
+                    }
+                }
+            }
+            s2 = group_sum(s2, g.L);
+            if (live && g.c0 == 0) {
+                const float n = sqrtf(s2);
+                a_pos += double(n) > 1.0 + double(audit_eps);
+                a_neg += double(n) < 1.0 - double(audit_eps);
+                a_nan += (n != n);
+                a_dev += fabs(double(n) - 1.0);
+            }
+        }
+    }
+    if (audit_counts) {   // counts are integers (deterministic); the |norm-1| sum is a float64 atomic (order-dependent ulps)
+        if (a_pos) atomicAdd(&audit_counts[0], a_pos);
+        if (a_neg) atomicAdd(&audit_counts[1], a_neg);
+        if (a_nan) atomicAdd(&audit_counts[2], a_nan);
+        if (a_dev != 0.0) atomicAdd(audit_absdev, a_dev);
     }
 }
 
@@ -504,9 +535,33 @@ int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, co
     return check_launch("content_tail");
 }
 
+static int blend_impl(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx, const float* alpha,
+                      int alpha_per_row, int T, int64_t R, int d, float* out, int64_t ldo, float* out_norm, float audit_eps,
+                      uint64_t* audit_counts, double* audit_absdev, void* stream);
+
 int hwer_blend_normalize_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx,
                              const float* alpha, int alpha_per_row, int T, int64_t R, int d, float* out,
                              int64_t ldo, float* out_norm, void* stream) {
+    return blend_impl(tables, ld_tables, row_idx, alpha, alpha_per_row, T, R, d, out, ldo, out_norm, 0.f, nullptr, nullptr, stream);
+}
+
+int hwer_blend_normalize_audit_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx,
+                                   const float* alpha, int alpha_per_row, int T, int64_t R, int d, float* out,
+                                   int64_t ldo, float eps, uint64_t* audit_counts, double* audit_absdev_sum, void* stream) {
+    if (!audit_counts || !audit_absdev_sum) return fail(HWER_EINVAL, "blend_normalize_audit: null audit output");
+    // one memset node when the two outputs are laid out back to back (counts[4] then the sum), else two
+    if (reinterpret_cast<const void*>(audit_absdev_sum) == reinterpret_cast<const void*>(audit_counts + 4)) {
+        if (hipMemsetAsync(audit_counts, 0, 48, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "blend_normalize_audit: memset failed");
+    } else {
+        if (hipMemsetAsync(audit_counts, 0, 32, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "blend_normalize_audit: memset failed");
+        if (hipMemsetAsync(audit_absdev_sum, 0, 8, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "blend_normalize_audit: memset failed");
+    }
+    return blend_impl(tables, ld_tables, row_idx, alpha, alpha_per_row, T, R, d, out, ldo, nullptr, eps, audit_counts, audit_absdev_sum, stream);
+}
+
+static int blend_impl(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx, const float* alpha,
+                      int alpha_per_row, int T, int64_t R, int d, float* out, int64_t ldo, float* out_norm, float audit_eps,
+                      uint64_t* audit_counts, double* audit_absdev, void* stream) {
     if (R == 0) return HWER_OK;
     if (!tables || !alpha || T < 1) return fail(HWER_EINVAL, "blend_normalize: null tables/alpha or T < 1");
     int rc;
@@ -514,7 +569,8 @@ int hwer_blend_normalize_f32(const float* const* tables, int64_t ld_tables, cons
     if (ld_tables % 4 != 0 || ld_tables < d) return fail(HWER_EINVAL, "blend_normalize: ld_tables must be a multiple of 4 and >= d");
     const int d4 = (d + 3) / 4;
     hipLaunchKernelGGL(blend_normalize_kernel, dim3(rows_grid(R, d4)), dim3(256), 0, as_stream(stream), tables,
-                       ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm);
+                       ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     return check_launch("blend_normalize");
 }
 

@@ -71,6 +71,12 @@ int hwer_blend_normalize_f32(const float* const* tables, int64_t ld_tables, cons
                              const float* alpha, int alpha_per_row, int T, int64_t R, int d, float* out,
                              int64_t ldo, float* out_norm, void* stream);
 
+/* Same, with the K11 unit-norm audit of the OUTPUT rows fused into the epilogue (one pass instead of three kernels):
+ * audit_counts[0..2] = rows with norm > 1+eps / < 1-eps / NaN (4 x uint64 buffer), audit_absdev_sum = sum |norm - 1|. */
+int hwer_blend_normalize_audit_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx,
+                                   const float* alpha, int alpha_per_row, int T, int64_t R, int d, float* out,
+                                   int64_t ldo, float eps, uint64_t* audit_counts, double* audit_absdev_sum, void* stream);
+
 /* Fused content tail — hwer/content_recommender.py:77-86 + :96 in one pass:
  *        out[n] = unit( (E[n] + mean_{m in adj(n)} E[m]) / 2 ).  CSR as hwer_segment_mean_f32. */
 int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N,

@@ -372,3 +372,61 @@ def test_merge_topk_matches_single_shard(hw):
     g_idx = torch.stack([p[0] for p in parts]); g_s = torch.stack([p[1] for p in parts]); g_d = torch.stack([p[2] for p in parts])
     idx, score, dist2 = merge_on_device(g_idx, g_s, g_d, True)
     assert torch.equal(idx, ref[0]) and torch.equal(score, ref[1]) and torch.equal(dist2, ref[2])
+
+
+def test_blend_with_fused_audit(hw):
+    """hwer_blend_normalize_audit_f32 == blend followed by the separate audit (counts exact)."""
+    import torch
+    from hwer import native
+    from hwer.device_index import DeviceIndex
+    lib = native.lib()
+    dev = torch.device("cuda")
+    R, d, T = 5000, 64, 2
+    tabs = [torch.from_numpy(unit_rows_f32(300 + t, R, d)).to(dev) for t in range(T)]
+    tabs[1][7] = -tabs[0][7]            # row 7 blends to zero -> NaN after normalisation
+    ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=dev)
+    alpha = torch.full((T,), 0.5, dtype=torch.float32, device=dev)
+    out = torch.zeros((R, d), dtype=torch.float32, device=dev)
+    counts = torch.zeros(4, dtype=torch.int64, device=dev)
+    devsum = torch.zeros(1, dtype=torch.float64, device=dev)
+    native.check(lib.hwer_blend_normalize_audit_f32(native.ptr(ptrs), d, None, native.ptr(alpha), 0, T, R, d, native.ptr(out), d,
+                                                    1e-4, native.ptr(counts), native.ptr(devsum), native.stream_ptr()))
+    ix = DeviceIndex(out, {}, audit=True)
+    v, mean_dev, pos, neg, nan = ix.audit_result
+    assert counts.tolist()[:3] == [pos, neg, nan] == [0, 0, 1]
+    ref = orc.blend_normalize([t.cpu().numpy() for t in tabs], [None, None], np.array([0.5, 0.5]))
+    ok = ~np.isnan(ref).any(1)
+    assert np.abs(out.cpu().numpy()[ok] - ref[ok]).max() <= 1e-6 and (~ok).sum() == 1
+
+
+def test_prepare_for_knn_and_gcn_index(golden, hw):
+    from hwer import GcnScoredIndex, Node, prepare_for_knn
+    g = golden("g1_knn_basic")
+    raw = (g["V32"] * np.linspace(0.5, 3.0, 576, dtype=np.float32)[:, None])      # un-normalised "collaborative" vectors
+    unit = prepare_for_knn(raw, 32)
+    assert unit.dtype == np.float32 and np.abs(unit - orc.unit_length(raw.astype(np.float64), axis=1)).max() <= 1e-6
+    with pytest.raises(ValueError):
+        prepare_for_knn(raw, 64)
+    assert prepare_for_knn(np.concatenate([raw, raw], axis=1), 32).shape == (576, 32)   # PCA when wider
+    nodes = [Node("user", i) for i in range(64)] + [Node("item", i) for i in range(512)]
+    m = GcnScoredIndex(node_types={"user", "item"}, n_dims=32)
+    m.fit(nodes, raw)
+    res = m.find_closest_neighbours("item", nodes[3], k=10)
+    V = unit                                                            # float32 flavour, score = (2 - dist)/2
+    o_idx, o_score, _ = orc.find_closest(V, np.arange(64, 576), 3, k=10, scoring="gcn")
+    assert [m.nodes_to_idx[n] for n, _ in res] == o_idx.tolist()
+    assert [s for _, s in res] == o_score.tolist()
+
+
+@pytest.mark.parametrize("N,k", [(5, 3), (1, 1), (33, 33), (31, 7)])
+def test_knn_tiny_catalogues(hw, knn_path, N, k):
+    d, U = 8, 3
+    V32 = np.concatenate([unit_rows_f32(401, U, d), unit_rows_f32(402 + N, N, d)])
+    V = V32.astype(np.float64)
+    ix = make_index(V, U, N)
+    idx, score, dist, flags = ix.search("item", np.arange(U), k=k)
+    for u in range(U):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(U, U + N), u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+    with pytest.raises(ValueError):
+        ix.search("item", np.arange(U), k=N + 1)
