@@ -17,6 +17,7 @@
 // HBM (streaming X once per query block) below that.
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 #include "knn_internal.h"
 
@@ -67,6 +68,7 @@ struct ScreenArgs {
     int scaled_first;    // 1: first compaction selects the sample-scaled rank (verified afterwards), 0: always K'
     int debug_nofilter;  // ablation only (HWER_SCREEN_NOFILTER=1): thresholds start at +inf, nothing is appended
     float debug_tau0;    // ablation only (HWER_SCREEN_TAU0=x): thresholds start at x instead of -inf
+    unsigned long long* debug_stamps;   // diagnostic build only (HWER_SCREEN_STAMPS=1): per-wave phase cycle sums
 };
 
 __device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t* p) {
@@ -191,6 +193,15 @@ __device__ __forceinline__ int coprime_step(int n) {
     }
 }
 
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define STAMP(var) if (a.debug_stamps) { var = stamp(); }
+
 // LDS image of an item tile: IB rows of CH = 2*NG 16-byte chunks, UNPADDED (the LDS-DMA writes 1 KiB per
 // wave-instruction linearly), XOR-swizzled so that the ds_read_b128 of the MFMA A fragments (16 lanes = 16
 // different rows, same logical chunk) hits 16 different 16-byte slots of the 256-byte bank row:
@@ -257,30 +268,33 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // LDS-DMA fill of tile t into ring slot (t & 1): every wave issues DMA_PER_WAVE pieces of 64 x 16 B.
     // Tiles are visited in the order perm(t) = (t * tile_mul) mod n_tiles (tile_mul coprime with n_tiles), so the
     // first tiles of a stream sample the whole list instead of its head (needed by the scaled first threshold).
+    // The permutation is advanced incrementally (add the step, subtract n_tiles on overflow): a modulo per tile would
+    // be a ~150-instruction software division on this hardware.
     const int tile_mul = (!DENSE && a.scaled_first) ? coprime_step(n_tiles) : 1;
-    auto perm = [&](int t) { return int((int64_t(t) * tile_mul) % max(n_tiles, 1)); };
+    auto perm_next = [&](int p) { p += tile_mul; return p >= n_tiles ? p - n_tiles : p; };
+    const int wi_mask = wi_n - 1;   // wi_n is 1, 2 or 4
     // The table is allocated with its row count padded to a multiple of 32 (zero rows whose half norm is +inf, see
     // hwer_pack_rows_f32), so tile reads never leave the allocation and pad rows can never pass the filter.
     // Per-lane byte offset of this lane's chunk inside a tile (piece 0); piece i adds i * PIECE_ROWS rows.
     constexpr int PIECE_ROWS = 64 / CH > 0 ? 64 / CH : 1;        // rows covered by one 1-KiB piece (CH <= 64)
     static_assert(CH <= 64, "one LDS-DMA piece must hold at least one whole row");
     const uint32_t row_bytes = uint32_t(a.ldx) * 4u;
-    auto tile_dma = [&](int t) {
-        const int64_t base = i_begin + int64_t(perm(t)) * IB;
+    // Piece p = wave + 4 i covers rows p * PIECE_ROWS + lane / CH.  For CH >= 16 the swizzle is row & 15 and
+    // PIECE_ROWS * 4 is a multiple of ... handled generically: the offset of piece i is recomputed from two lane
+    // constants with 32-bit integer ops only (v_mad_u32_u24-class: row < 32, row_bytes <= 1024).
+    const uint32_t lane_row = uint32_t(lane / CH), lane_chunk = uint32_t(lane % CH);
+    auto tile_dma = [&](int t, int ptile) {
+        const int64_t base = i_begin + int64_t(ptile) * IB;
         const uint32_t xb_addr = __builtin_amdgcn_readfirstlane(lds_addr(xs + (t & 1) * IB * CH * 4));
         const char* tile_ptr = reinterpret_cast<const char*>(a.X + base * a.ldx);    // wave-uniform
-        int ln = lane;
-        asm volatile("" : "+v"(ln));   // opaque: the per-piece offsets below are recomputed (a few VALU) rather than hoisted + spilled
+        uint32_t lr = lane_row, lc = lane_chunk;
+        asm volatile("" : "+v"(lr), "+v"(lc));   // opaque: keeps the per-piece offsets from being hoisted into (spilled) registers
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int piece = wave * DMA_PER_WAVE + i;       // wave-uniform
-            // chunk L = piece * 64 + lane lives at LDS row L / CH, physical position L % CH, and holds the logical chunk
-            // (L % CH) ^ swz(row); PIECE_ROWS is a multiple of the swizzle period or divides it evenly, so the XOR term
-            // is the same lane constant for every piece (rows piece * PIECE_ROWS + lane / CH: PIECE_ROWS in {8,4,2,1},
-            // swz period 16 rows -> the low row bits used by swz come from piece too when PIECE_ROWS < 16).
+            const int piece = wave + 4 * i;                  // wave-uniform
             if (piece * 64 < TILE_CHUNKS) {
-                const int row = piece * PIECE_ROWS + ln / CH;
-                const uint32_t off = uint32_t(row) * row_bytes + uint32_t(((ln % CH) ^ swz<CH>(row)) * 16);
+                const uint32_t row = uint32_t(piece * PIECE_ROWS) + lr;
+                const uint32_t off = __umul24(row, row_bytes) + ((lc ^ uint32_t(swz<CH>(int(row)))) << 4);
                 lds_dma16(tile_ptr, off, xb_addr + uint32_t(piece) * 1024u);
             }
         }
@@ -288,16 +302,24 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             lds_dma4(a.hnorm + base, uint32_t(lane) * 4u, __builtin_amdgcn_readfirstlane(lds_addr(hn + (t & 1) * IB)));
     };
 
-    if (n_tiles > 0) tile_dma(0);
+    __builtin_amdgcn_s_setprio(3);
+    int p_cur = 0;                       // perm(t)
+    int p_dma = perm_next(0);            // perm(t + 1), then perm(t + 2) while tile t is computed
+    if (n_tiles > 0) tile_dma(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // tile 0 has landed for every wave
-    if (n_tiles > 1) tile_dma(1);
+    if (n_tiles > 1) tile_dma(1, p_dma);
+    p_dma = perm_next(p_dma);
 
+    const bool getenv_calib = a.debug_nofilter == 2;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_pre = 0, acc_mfma = 0, acc_epi = 0, acc_wait = 0, acc_post = 0, acc_flush = 0, acc_dma = 0;
     for (int t = 0; t < n_tiles; ++t) {
+        STAMP(t0);
         const float* xb = xs + (t & 1) * IB * CH * 4;
         const float* hb = hn + (t & 1) * IB;
-        const int64_t i0 = i_begin + int64_t(perm(t)) * IB;
-        if (t % wi_n == wii) {   // wave-uniform: tiles are dealt round-robin over the wi waves that share these queries
+        const int64_t i0 = i_begin + int64_t(p_cur) * IB;
+        p_cur = perm_next(p_cur);
+        if ((t & wi_mask) == wii) {   // wave-uniform: tiles are dealt round-robin over the wi waves that share these queries
             f32x16 acc[TQ];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
@@ -321,6 +343,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             const float* abase = xb + r * (CH * 4) + 4 * (h ^ (sw & 1));
             auto a_ptr = [&](int g) { return abase + 8 * ((g & 7) ^ swh) + 64 * (g >> 3); };
             float4 av_next = *reinterpret_cast<const float4*>(a_ptr(0));
+            // MFMA phase at low priority, everything else at high priority: the co-resident wave's back-to-back MFMAs
+            // otherwise leave this wave about one issue slot per 64-cycle MFMA for its filter / bookkeeping code
+            // (measured: 8 compare+branch pairs took ~1500 cycles).  An MFMA needs the issue port for a few cycles only,
+            // so yielding to the other wave's scalar / vector work costs the MFMA stream nothing.
+            __builtin_amdgcn_s_setprio(0);
+            STAMP(t1);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const float4 av = av_next;
@@ -333,6 +361,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qf[b][g].w, acc[b], 0, 0, 0);
                 }
             }
+            __builtin_amdgcn_s_setprio(3);
+            if (a.debug_stamps) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
             if constexpr (DENSE) {
                 // small catalogues: keep every key (lane (r, h): query r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store)
 #pragma unroll
@@ -349,7 +379,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // ---- streaming filter ---------------------------------------------------------------------------------
             // Lane (r, h) holds 16 keys of query r.  Passing keys are rare (K'/n per key), so instead of 16 predicated
             // append blocks the lane builds a 16-bit pass mask, parks its 16 keys in LDS and pops set bits: the loop runs
-            // max-popcount-over-the-wave times (2-3 in steady state, 16 only during warm-up).
+            // max-popcount-over-the-wave times (2-3 in steady state, 16 only during warm-up).  (Measured against 16
+            // independent predicated blocks: 7.0K vs 10.0K cycles per tile.)
 #pragma unroll
             for (int b = 0; b < TQ; ++b) {
                 // pass mask, 2 VALU per key: tau - key is negative exactly when key > tau (strict), and a funnel shift
@@ -382,34 +413,46 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
             }   // !DENSE
         }
+        STAMP(t3);
         // ---- tile boundary ---------------------------------------------------------------------------------------------
         // Outstanding VMEM here: the DMA of tile t+1 and the previous flush, both issued a whole tile ago (appends of
         // this tile sit in LDS slots), so this wait is normally free.
         if constexpr (DENSE) {
             // the 4 * TQ key stores of this tile are YOUNGER than the DMA of tile t+1 (vmcnt retires in issue order):
             // wait for everything but them, so the DMA has landed while the stores stay in flight
-            if (t % wi_n == wii) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
+            if ((t & wi_mask) == wii) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        STAMP(t4);
         if constexpr (DENSE) {
-            if (t + 2 < n_tiles) tile_dma(t + 2);
+            if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);
+            p_dma = perm_next(p_dma);
             continue;
         }
+        {
+            uint64_t sv[TQ][SL];   // all LDS reads issue back to back (one latency), the stores are predicated afterwards
 #pragma unroll
-        for (int b = 0; b < TQ; ++b) {
+            for (int b = 0; b < TQ; ++b)
 #pragma unroll
-            for (int sidx = 0; sidx < SL; ++sidx) {
-                if (sidx < nloc[b]) {
-                    wg_cand[soff[b] + uint32_t(cnt[b])] = slots[(b * SL + sidx) * 64 + lane];
-                    ++cnt[b];
-                }
+                for (int sidx = 0; sidx < SL; ++sidx) sv[b][sidx] = slots[(b * SL + sidx) * 64 + lane];
+#pragma unroll
+            for (int b = 0; b < TQ; ++b) {
+#pragma unroll
+                for (int sidx = 0; sidx < SL; ++sidx)
+                    if (sidx < nloc[b]) wg_cand[soff[b] + uint32_t(cnt[b] + sidx)] = sv[b][sidx];
+                cnt[b] += nloc[b];
+                nloc[b] = 0;
             }
-            nloc[b] = 0;
         }
-        if (t + 2 < n_tiles) tile_dma(t + 2);      // refill the ring slot every wave has just finished reading
+        unsigned long long t4a = 0, t4b = 0;
+        STAMP(t4a);
+        if (a.debug_stamps && getenv_calib) { t4 = stamp(); t4a = stamp(); }   // calibration: flush := cost of one stamp
+        if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);      // refill the ring slot every wave has just finished reading
+        p_dma = perm_next(p_dma);
+        STAMP(t4b);
 #pragma unroll
         for (int b = 0; b < TQ; ++b) {
             // ---- keep every stream at least 16 slots from its end ------------------------------------------------
@@ -442,6 +485,15 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 need &= ~((1ull << jj) | (1ull << (jj + 32)));
             }
         }
+        if (a.debug_stamps) {
+            t5 = stamp();
+            acc_pre += t1 - t0; acc_mfma += t2 - t1; acc_epi += t3 - t2; acc_wait += t4 - t3; acc_post += t5 - t4;
+            acc_flush += t4a - t4; acc_dma += t4b - t4a;
+        }
+    }
+    if (a.debug_stamps && lane == 0) {
+        unsigned long long* o = a.debug_stamps + (size_t(blockIdx.x) * 4 + wave) * 8;
+        o[0] = acc_pre; o[1] = acc_mfma; o[2] = acc_epi; o[3] = acc_wait; o[4] = acc_post; o[5] = n_tiles; o[6] = acc_flush; o[7] = acc_dma;
     }
     if constexpr (DENSE) return;
 #pragma unroll
@@ -514,10 +566,11 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
 
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 waves x 64 lanes x 16 keys | append slots
-    const size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4 + size_t(4) * TQ * 4 * 64 * 8;
+    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 x 64 x 16 | append slots 4 x TQ x 4 x 64
+    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4 + size_t(4) * TQ * 4 * 64 * 8;
+    if (const char* e = getenv("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
     static bool attr_done = false;
-    if (!attr_done) {
+    if (!attr_done || getenv("HWER_SCREEN_LDS_PAD_KB")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, DENSE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -534,9 +587,25 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, hipStream_t stream) {
+    static unsigned long long* dbg = nullptr;
+    static int dbg_grid = 0;
+    if (getenv("HWER_SCREEN_STAMPS")) {
+        if (dbg) {   // print the previous launch's stamps
+            std::vector<unsigned long long> h(size_t(dbg_grid) * 32);
+            hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double tiles = 0; int n = 0;
+            for (int w = 0; w < dbg_grid * 4; ++w) { if (h[w * 8 + 5] == 0) continue; for (int c = 0; c < 8; ++c) sum[c] += double(h[w * 8 + c]); tiles += double(h[w * 8 + 5]); ++n; }
+            fprintf(stderr, "[stamps] waves=%d tiles/wave=%.0f cycles/tile: pre=%.0f mfma=%.0f epilogue=%.0f wait+barrier=%.0f post=%.0f (flush=%.0f dma=%.0f)\n", n, tiles / n,
+                    sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[6] / tiles, sum[7] / tiles);
+            hipFree(dbg);
+        }
+        dbg_grid = plan.n_qblocks * plan.n_splits;
+        hipMalloc(&dbg, size_t(dbg_grid) * 32 * 8);
+        hipMemset(dbg, 0, size_t(dbg_grid) * 32 * 8);
+    }
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
-                 plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? 1 : 0,
-                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY};
+                 plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? atoi(getenv("HWER_SCREEN_NOFILTER")) : 0,
+                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY, getenv("HWER_SCREEN_STAMPS") ? dbg : nullptr};
     const int key = plan.ng * 10 + plan.tq;
     switch (key) {
         case 41: return launch_screen_t<4, 1>(plan, a, stream);
