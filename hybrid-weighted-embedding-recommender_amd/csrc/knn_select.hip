@@ -7,6 +7,7 @@
 //   score : numpy `(a * b).sum(1)`             -> pairwise summation of the rounded products
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "knn_internal.h"
 
@@ -142,17 +143,12 @@ struct EmitArgs {
 // Wave-per-query back end.  One 64-lane wave owns one query from the candidate keys to the output rows; there
 // is no workgroup barrier anywhere (a 256-thread block is just four independent queries).
 // LDS per wave, for a candidate capacity kp (multiple of 64) and kp2 = pow2 >= kp:
-//   a64[d] f64 | q64[d] f64 | t_d2[kp] f64 | t_sc[kp] f64 | cand[kp] u32 | work = max(stage 64 x 20 f32, ent[kp2] 16 B)
+//   a64[d] f64 | q64[d] f64 | t_d2[kp] f64 | t_sc[kp] f64 | cand[kp] u32
 // ---------------------------------------------------------------------------------------------------
-constexpr int RR_CW = 16;            // columns staged per pass
-constexpr int RR_RS = RR_CW + 4;     // LDS row stride in floats (5 x 16 B: odd -> conflict-free ds_read_b128)
+constexpr int RR_CW = 16;            // columns per re-rank step
 __host__ __device__ inline int pow2ceil_h(int x) { int p = 2; while (p < x) p <<= 1; return p; }
-__host__ __device__ inline size_t wave_work_bytes(int kp) {
-    const size_t st = size_t(64) * RR_RS * 4, en = size_t(pow2ceil_h(kp)) * 16;
-    return st > en ? st : en;
-}
 __host__ __device__ inline size_t wave_lds_bytes(int d, int kp) {
-    return size_t(d) * 16 + size_t(kp) * (8 + 8 + 4) + wave_work_bytes(kp);
+    return (size_t(d) * 16 + size_t(kp) * (8 + 8 + 4) + 15) & ~size_t(15);
 }
 
 __device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
@@ -196,9 +192,6 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
     double* t_d2 = q64 + d;
     double* t_sc = t_d2 + kp;
     uint32_t* cand = reinterpret_cast<uint32_t*>(t_sc + kp);
-    unsigned char* work = reinterpret_cast<unsigned char*>(cand + kp);
-    float* stage = reinterpret_cast<float*>(work);
-    Ent* ent = reinterpret_cast<Ent*>(work);
 
     for (int j = lane; j < d; j += 64) {
         q64[j] = a.Q64[b * d + j];
@@ -223,38 +216,26 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         double acc = 0.0;
         double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, sA = 0.0;
         float f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0, fA = 0.f;
-        // staging map: 4 lanes x 16 B per row, 16 rows per instruction, 4 instructions per 16-column chunk.
-        // (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop in scratch)
-        const int srow = lane >> 2, scol = 4 * (lane & 3);
-        const float* src0 = a.X + int64_t(cand[min(g0 + 0 + srow, n_r - 1)]) * a.ldx + scol;
-        const float* src1 = a.X + int64_t(cand[min(g0 + 16 + srow, n_r - 1)]) * a.ldx + scol;
-        const float* src2 = a.X + int64_t(cand[min(g0 + 32 + srow, n_r - 1)]) * a.ldx + scol;
-        const float* src3 = a.X + int64_t(cand[min(g0 + 48 + srow, n_r - 1)]) * a.ldx + scol;
-        float* dst = stage + srow * RR_RS + scol;
-        // software pipeline: the gathers of chunk c + 1 are in flight while chunk c is reduced in float64
-        float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
-        float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
+        // every lane walks its own candidate row: 16 columns (4 x 16 B) per step, the loads of step c + 1 in flight while
+        // step c is reduced in float64 (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop
+        // in scratch).  Rows are ldx >= roundup16(d) floats long, so whole steps never leave the row.
+        const float* xrow = a.X + int64_t(it) * a.ldx;
+        float4 pre0 = *reinterpret_cast<const float4*>(xrow), pre1 = *reinterpret_cast<const float4*>(xrow + 4);
+        float4 pre2 = *reinterpret_cast<const float4*>(xrow + 8), pre3 = *reinterpret_cast<const float4*>(xrow + 12);
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
-            *reinterpret_cast<float4*>(dst) = pre0;
-            *reinterpret_cast<float4*>(dst + 16 * RR_RS) = pre1;
-            *reinterpret_cast<float4*>(dst + 32 * RR_RS) = pre2;
-            *reinterpret_cast<float4*>(dst + 48 * RR_RS) = pre3;
-            if (c + 1 < n_chunks) {
-                const int o = RR_CW * (c + 1);
-                pre0 = *reinterpret_cast<const float4*>(src0 + o);
-                pre1 = *reinterpret_cast<const float4*>(src1 + o);
-                pre2 = *reinterpret_cast<const float4*>(src2 + o);
-                pre3 = *reinterpret_cast<const float4*>(src3 + o);
-            }
-            wave_lds_sync();
             float xv[RR_CW];
-#pragma unroll
-            for (int t = 0; t < RR_CW / 4; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
-                xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
+            xv[0] = pre0.x; xv[1] = pre0.y; xv[2] = pre0.z; xv[3] = pre0.w;
+            xv[4] = pre1.x; xv[5] = pre1.y; xv[6] = pre1.z; xv[7] = pre1.w;
+            xv[8] = pre2.x; xv[9] = pre2.y; xv[10] = pre2.z; xv[11] = pre2.w;
+            xv[12] = pre3.x; xv[13] = pre3.y; xv[14] = pre3.z; xv[15] = pre3.w;
+            if (c + 1 < n_chunks) {
+                const float* nx = xrow + RR_CW * (c + 1);
+                pre0 = *reinterpret_cast<const float4*>(nx);
+                pre1 = *reinterpret_cast<const float4*>(nx + 4);
+                pre2 = *reinterpret_cast<const float4*>(nx + 8);
+                pre3 = *reinterpret_cast<const float4*>(nx + 12);
             }
-            wave_lds_sync();
             const int j0 = RR_CW * c;
             if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
 #pragma unroll
@@ -341,50 +322,80 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         wave_lds_sync();
     }
     // ---- ONE sort gives the output order: (score desc, dist2 asc, item asc) = the reference's stable sort by score of
-    // the distance-ordered list; or (dist2, item) when sort_by_score == 0.  Entry: hi = primary key, lo = slot; equal
-    // primaries are resolved by looking (dist2, item) up in LDS (rare).
-    const int nr2 = pow2ceil_h(n_r);
-    for (int i = lane; i < nr2; i += 64) {
-        Ent e;
-        e.hi = ~0ull;
-        e.lo = ~0ull;
-        if (i < n_r && cand[i] != 0xFFFFFFFFu) {
-            e.hi = a.sort_by_score ? ~f64_orderable(t_sc[i]) : f64_orderable(t_d2[i]);
-            e.lo = uint64_t(uint32_t(i));
-        }
-        ent[i] = e;
-    }
-    auto less = [&](const Ent& x, const Ent& y) {
-        if (x.hi != y.hi) return x.hi < y.hi;
-        if (x.lo == y.lo) return false;
-        if (x.lo == ~0ull || y.lo == ~0ull) return x.lo < y.lo;   // padding last
-        const uint64_t dx = f64_orderable(t_d2[uint32_t(x.lo)]), dy = f64_orderable(t_d2[uint32_t(y.lo)]);
+    // the distance-ordered list; or (dist2, item) when sort_by_score == 0.  The sort runs in REGISTERS (NE entries per
+    // lane, blocked layout: sorted position = NE * lane + j): strides below NE are register swaps, larger strides one
+    // cross-lane exchange per entry.  Entry: hi = primary key, lo = slot; equal primaries are resolved by looking
+    // (dist2, item) up in LDS (rare).
+    auto less = [&](uint64_t xh, uint32_t xl, uint64_t yh, uint32_t yl) {
+        if (xh != yh) return xh < yh;
+        if (xl == yl) return false;
+        if (xl == 0xFFFFFFFFu || yl == 0xFFFFFFFFu) return xl < yl;   // padding last
+        const uint64_t dx = f64_orderable(t_d2[xl]), dy = f64_orderable(t_d2[yl]);
         if (dx != dy) return dx < dy;
-        return cand[uint32_t(x.lo)] < cand[uint32_t(y.lo)];
+        return cand[xl] < cand[yl];
     };
-    for (int size = 2; size <= ((a.debug_skip & 2) ? 0 : nr2); size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            wave_lds_sync();
-            for (int t = lane; t < (nr2 >> 1); t += 64) {
-                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
-                const int hi = lo + stride;
-                const bool asc = (lo & size) == 0;
-                const Ent x = ent[lo], y = ent[hi];
-                if (less(y, x) == asc) {
-                    ent[lo] = y;
-                    ent[hi] = x;
+    auto sort_emit = [&](auto ne_tag) {
+        constexpr int NE = decltype(ne_tag)::value;
+        uint64_t hi[NE];
+        uint32_t lo[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int i = 64 * j + lane;   // any initial placement will do
+            hi[j] = ~0ull;
+            lo[j] = 0xFFFFFFFFu;
+            if (i < n_r && cand[i] != 0xFFFFFFFFu) {
+                hi[j] = a.sort_by_score ? ~f64_orderable(t_sc[i]) : f64_orderable(t_d2[i]);
+                lo[j] = uint32_t(i);
+            }
+        }
+        if (!(a.debug_skip & 2)) {
+#pragma unroll 1
+            for (int size = 2; size <= NE * 64; size <<= 1) {
+#pragma unroll 1
+                for (int stride = size >> 1; stride >= NE; stride >>= 1) {   // cross-lane exchanges
+                    const int lm = stride / NE;
+                    const bool lower = (lane & lm) == 0;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const bool asc = ((NE * lane + j) & size) == 0;
+                        const uint64_t oh = __shfl_xor(hi[j], lm, kWave);
+                        const uint32_t ol = __shfl_xor(lo[j], lm, kWave);
+                        const bool take = (lower == asc) ? less(oh, ol, hi[j], lo[j]) : less(hi[j], lo[j], oh, ol);
+                        if (take) { hi[j] = oh; lo[j] = ol; }
+                    }
+                }
+#pragma unroll
+                for (int stride = NE >> 1; stride > 0; stride >>= 1) {       // register swaps
+                    if (stride < size) {
+#pragma unroll
+                        for (int j = 0; j < NE; ++j) {
+                            if ((j & stride) == 0) {
+                                const bool asc = ((NE * lane + j) & size) == 0;
+                                const int j2 = j | stride;
+                                if (less(hi[j2], lo[j2], hi[j], lo[j]) == asc) {
+                                    const uint64_t th = hi[j]; hi[j] = hi[j2]; hi[j2] = th;
+                                    const uint32_t tl = lo[j]; lo[j] = lo[j2]; lo[j2] = tl;
+                                }
+                            }
+                        }
+                    }
                 }
             }
         }
-    }
-    wave_lds_sync();
-    for (int i = lane; i < k; i += 64) {
-        const uint32_t slot = uint32_t(ent[i].lo);
-        const uint32_t it = cand[slot];
-        a.out_idx[b * k + i] = a.row_ids ? a.row_ids[it] : a.id_base + int64_t(it);
-        a.out_score[b * k + i] = t_sc[slot];
-        a.out_dist2[b * k + i] = t_d2[slot];
-    }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int i = NE * lane + j;
+            if (i < k) {
+                const uint32_t slot = lo[j];
+                const uint32_t it = cand[slot];
+                a.out_idx[b * k + i] = a.row_ids ? a.row_ids[it] : a.id_base + int64_t(it);
+                a.out_score[b * k + i] = t_sc[slot];
+                a.out_dist2[b * k + i] = t_d2[slot];
+            }
+        }
+    };
+    if (n_r <= 256) sort_emit(std::integral_constant<int, 4>{});
+    else sort_emit(std::integral_constant<int, 8>{});
     if (lane == 0) a.out_flags[b] = flag;
 }
 
@@ -953,7 +964,8 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
     if (nq == 0) return HWER_OK;
     if (!X || !Q64 || !qsel_host || !out_idx || !out_score || !out_dist2 || !out_flags || !workspace)
         return fail(HWER_EINVAL, "knn_exact: null pointer");
-    if (d < 1 || d > 1024 || ldx < d) return fail(HWER_EINVAL, "knn_exact: bad d / ldx");
+    if (d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16)
+        return fail(HWER_EINVAL, "knn_exact: need 1 <= d <= 256 and ldx >= roundup16(d) (rows are read in 16-column steps)");
     if (k < 1 || k > K_MAX) return fail(HWER_EINVAL, "knn_exact: k=%d outside 1..%d", k, K_MAX);
     if (k > n_items) return fail(HWER_EINVAL, "knn_exact: k must be less than or equal to the number of training points");
     if (n_items >= (int64_t(1) << 32)) return fail(HWER_EINVAL, "knn_exact: n_items must be < 2^32");
