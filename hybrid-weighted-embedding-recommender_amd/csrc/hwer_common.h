@@ -81,21 +81,56 @@ __device__ __forceinline__ T np_pairwise(const T* p, int n, int k) {
 }
 constexpr int kPairwiseDepth = 3;  // d <= 1024
 
-// ---- wave-level selection by float bisection ---------------------------------------------------------------------
-// v[0..NV) per lane (entries that do not exist hold -inf).  Finds `lo` with rank <= count(v >= lo) <= rank + slack
-// whenever the data allows it (stops early when the interval is exhausted by ties: then count(>= lo) may be larger and
-// the caller trims the keys equal to lo).  Conflict-free: ballot counting (v_cmp + s_bcnt1) per register, no LDS.
+// ---- wave-level selection on register-resident floats ------------------------------------------------------------
+// v[0..NV) per lane (entries that do not exist hold -inf).  wave_find_rank returns `lo` with
+//   rank <= count(v >= lo) <= rank + slack
+// whenever the data allows it (it stops early when the interval is exhausted by ties: then count(>= lo) may be larger
+// and the caller trims).  Counting is one v_cmp per key with the popcount / sum on the scalar unit;
+// probes are placed by interpolating log(count) between the bracket ends (the keys of one query look like the tail of
+// a bell curve, where log-count is close to linear), with a plain bisection step every third probe as a safeguard.
 // Precondition: at least `rank` finite entries.
+__device__ __forceinline__ int wave_sum_i32(int c) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) c += __shfl_xor(c, off, kWave);
+    return c;
+}
 template <int NV>
 __device__ __forceinline__ int wave_count_ge(const float (&v)[NV], float t) {
-    // one v_cmp (-> SGPR pair) + s_bcnt1 + s_add per register: scalar counting, no cross-lane traffic
-    int c = 0;
+    int c = 0;   // ballot counting: one v_cmp per key, popcount and sum on the scalar unit
 #pragma unroll
     for (int i = 0; i < NV; ++i) c += __builtin_popcountll(__ballot(v[i] >= t));
     return c;
 }
+// CountGe: callable float -> wave-uniform count of keys >= t
+template <class CountGe>
+__device__ __forceinline__ float wave_find_rank_fn(CountGe count_ge, float vmin, float vmax, int rank, int slack, int& count_ge_lo) {
+    float lo = vmin, hi = vmax;   // invariants: count(>= lo) >= rank;  count(>= hi) = c_hi
+    int c_lo = count_ge(lo), c_hi = count_ge(hi);
+    if (c_hi >= rank) {           // the rank-th largest key IS the maximum (ties at the top)
+        count_ge_lo = c_hi;
+        return hi;
+    }
+    const float target = float(rank) + 0.5f * float(slack);
+    for (int iter = 0; iter < 96 && c_lo > rank + slack; ++iter) {
+        float f = 0.5f;
+        if (iter % 3 != 2) {
+            const float l0 = __logf(float(c_lo)), l1 = __logf(float(c_hi) + 0.5f);
+            f = (l0 - __logf(target)) / (l0 - l1);
+            f = fminf(fmaxf(f, 0.03f), 0.97f);
+        }
+        float mid = lo + f * (hi - lo);
+        if (!(mid > lo) || !(mid < hi)) {
+            mid = 0.5f * lo + 0.5f * hi;
+            if (!(mid > lo) || !(mid < hi)) break;   // hi is the next float above lo: the interval is exhausted
+        }
+        const int c = count_ge(mid);
+        if (c >= rank) { lo = mid; c_lo = c; } else { hi = mid; c_hi = c; }
+    }
+    count_ge_lo = c_lo;
+    return lo;
+}
 template <int NV>
-__device__ __forceinline__ float wave_bisect_rank(const float (&v)[NV], int rank, int slack, int& count_ge_lo) {
+__device__ __forceinline__ float wave_find_rank(const float (&v)[NV], int rank, int slack, int& count_ge_lo) {
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -107,27 +142,95 @@ __device__ __forceinline__ float wave_bisect_rank(const float (&v)[NV], int rank
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
-    float lo = vmin, hi = vmax;   // invariant: count(>= lo) >= rank
-    int c_lo = wave_count_ge<NV>(v, lo);
-    for (int iter = 0; iter < 64 && c_lo > rank + slack; ++iter) {
-        const float mid = 0.5f * lo + 0.5f * hi;
-        if (!(mid > lo) || !(mid < hi)) {   // hi is the next float above lo (or equal): try hi itself, then stop
-            const int c = wave_count_ge<NV>(v, hi);
-            if (c >= rank) { lo = hi; c_lo = c; }
-            break;
-        }
-        const int c = wave_count_ge<NV>(v, mid);
-        if (c >= rank) { lo = mid; c_lo = c; } else { hi = mid; }
-    }
-    count_ge_lo = c_lo;
-    return lo;
+    return wave_find_rank_fn([&](float t) { return wave_count_ge<NV>(v, t); }, vmin, vmax, rank, slack, count_ge_lo);
 }
 
-// make LDS traffic of one wave visible to its own lanes (no cross-wave sync)
+// ---- wave-level sort of NE u64 keys per lane, ascending, in registers ---------------------------------------------
+// Blocked layout: after the call, the key of sorted position p sits in lane p / NE, register p % NE.  Bitonic network:
+// strides >= NE are one cross-lane exchange per key, smaller strides are register swaps.
+template <int NE>
+__device__ __forceinline__ void wave_sort_u64(uint64_t (&key)[NE]) {
+    const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll 1
+    for (int size = 2; size <= NE * kWave; size <<= 1) {
+#pragma unroll 1
+        for (int stride = size >> 1; stride >= NE; stride >>= 1) {
+            const int lm = stride / NE;
+            const bool keep_min = ((lane & lm) == 0) == (((NE * lane) & size) == 0);   // size >= 2 NE here
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const uint64_t o = __shfl_xor(key[j], lm, kWave);
+                if ((o < key[j]) == keep_min) key[j] = o;   // equal keys are identical padding: either copy will do
+            }
+        }
+#pragma unroll
+        for (int stride = NE >> 1; stride > 0; stride >>= 1) {
+            if (stride < size) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    if ((j & stride) == 0) {
+                        const bool asc = ((NE * lane + j) & size) == 0;
+                        const uint64_t x = key[j], y = key[j | stride];
+                        if ((y < x) == asc) { key[j] = y; key[j | stride] = x; }
+                    }
+                }
+            }
+        }
+    }
+}
+// The keys sorted above are (approximation << 32 | payload) with a MONOTONE approximation of the exact sort key, so
+// only runs of equal approximations can be out of order.  Detect such runs (rare) and finish them with odd-even
+// transposition passes under the exact comparator `ex_less(key_x, key_y)`.  Approximation 0xFFFFFFFF = padding.
+template <int NE, class ExLess>
+__device__ __forceinline__ void wave_sort_fixup(uint64_t (&key)[NE], ExLess ex_less) {
+    static_assert(NE >= 2 && NE % 2 == 0, "blocked layout with an even number of keys per lane");
+    const int lane = threadIdx.x & (kWave - 1);
+    auto same = [](uint64_t x, uint64_t y) { return uint32_t(x >> 32) == uint32_t(y >> 32) && uint32_t(x >> 32) != 0xFFFFFFFFu; };
+    bool tie = false;
+#pragma unroll
+    for (int j = 0; j + 1 < NE; ++j) tie = tie || same(key[j], key[j + 1]);
+    {
+        const uint64_t dn = __shfl_down(key[0], 1, kWave);
+        tie = tie || (lane < kWave - 1 && same(key[NE - 1], dn));
+    }
+    if (!__any(tie)) return;
+#pragma unroll 1
+    for (int pass = 0; pass < NE * kWave; ++pass) {
+        bool swapped = false;
+#pragma unroll
+        for (int j = 0; j + 1 < NE; j += 2) {      // even positions
+            if (same(key[j], key[j + 1]) && ex_less(key[j + 1], key[j])) {
+                const uint64_t t = key[j]; key[j] = key[j + 1]; key[j + 1] = t;
+                swapped = true;
+            }
+        }
+#pragma unroll
+        for (int j = 1; j + 1 < NE; j += 2) {      // odd positions inside the lane
+            if (same(key[j], key[j + 1]) && ex_less(key[j + 1], key[j])) {
+                const uint64_t t = key[j]; key[j] = key[j + 1]; key[j + 1] = t;
+                swapped = true;
+            }
+        }
+        {                                          // odd position across the lane boundary: (lane's last, next lane's first)
+            const uint64_t up = __shfl_up(key[NE - 1], 1, kWave), dn = __shfl_down(key[0], 1, kWave);
+            const bool sa = lane > 0 && same(up, key[0]) && ex_less(key[0], up);
+            const bool sb = lane < kWave - 1 && same(key[NE - 1], dn) && ex_less(dn, key[NE - 1]);
+            if (sa) key[0] = up;
+            if (sb) key[NE - 1] = dn;
+            swapped = swapped || sa || sb;
+        }
+        if (!__any(swapped)) break;
+    }
+}
+
+// Order the LDS traffic of ONE wave (cross-lane hand-over through wave-private LDS).  The LDS pipeline executes the
+// instructions of a wave in issue order, so a ds_read issued after a ds_write already sees every lane's data: all that
+// is needed is to stop the COMPILER from reordering or caching the accesses.  (A workgroup-scope fence would also drain
+// vmcnt(0), i.e. wait for every global load in flight - fatal for software-pipelined gathers.)
 __device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("" ::: "memory");
 }
 
 }  // namespace hwer

@@ -34,9 +34,23 @@ struct ScreenPlan {
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k);
+
+// Header at the start of the k-NN workspace: the queries the last search could not certify (flag 0), appended by the
+// select kernels, consumed by the on-device exhaustive pass (hwer_knn_exact_device) without a host round trip.
+constexpr int WS_HEADER_BYTES = 4096;
+constexpr int UNCERT_LIST_MAX = 1000;   // ids kept in the header (the count keeps counting past it)
+constexpr int EXACT_DEVICE_MAXQ = 8;    // queries one hwer_knn_exact_device call recomputes
+struct WsHeader {
+    int32_t uncert_count;               // zeroed by the screen kernel of every search (with the tickets)
+    int32_t pad0;
+    int32_t tickets[EXACT_DEVICE_MAXQ]; // arrival counters of the exhaustive pass
+    int32_t pad[6];
+    int32_t uncert_list[UNCERT_LIST_MAX];
+};
+static_assert(sizeof(WsHeader) <= WS_HEADER_BYTES, "header must fit its slot");
 constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
-                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, hipStream_t stream);
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream);
 
 }  // namespace hwer

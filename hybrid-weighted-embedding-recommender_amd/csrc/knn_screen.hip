@@ -69,6 +69,7 @@ struct ScreenArgs {
     int debug_nofilter;  // ablation only (HWER_SCREEN_NOFILTER=1): thresholds start at +inf, nothing is appended
     float debug_tau0;    // ablation only (HWER_SCREEN_TAU0=x): thresholds start at x instead of -inf
     unsigned long long* debug_stamps;   // diagnostic build only (HWER_SCREEN_STAMPS=1): per-wave phase cycle sums
+    WsHeader* hdr;       // workspace header: the uncertified-query list of this search starts empty
 };
 
 __device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t* p) {
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    if (blockIdx.x == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list, idle tickets
     const int wq = a.wq, wi_n = 4 / wq;
     const int wqi = wave % wq, wii = wave / wq;
     const int qblock = blockIdx.x % a.n_qblocks, split = blockIdx.x / a.n_qblocks;
@@ -586,7 +588,7 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 }
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
-                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, hipStream_t stream) {
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream) {
     static unsigned long long* dbg = nullptr;
     static int dbg_grid = 0;
     if (getenv("HWER_SCREEN_STAMPS")) {
@@ -605,7 +607,7 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     }
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? atoi(getenv("HWER_SCREEN_NOFILTER")) : 0,
-                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY, getenv("HWER_SCREEN_STAMPS") ? dbg : nullptr};
+                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY, getenv("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr};
     const int key = plan.ng * 10 + plan.tq;
     switch (key) {
         case 41: return launch_screen_t<4, 1>(plan, a, stream);

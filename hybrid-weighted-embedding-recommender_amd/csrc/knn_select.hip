@@ -137,18 +137,21 @@ struct EmitArgs {
     double* out_score;
     double* out_dist2;
     int32_t* out_flags;
+    WsHeader* hdr;    // nullable: uncertified queries (flag 0) are appended to the header's list
 };
 
 // ---------------------------------------------------------------------------------------------------
 // Wave-per-query back end.  One 64-lane wave owns one query from the candidate keys to the output rows; there
 // is no workgroup barrier anywhere (a 256-thread block is just four independent queries).
 // LDS per wave, for a candidate capacity kp (multiple of 64) and kp2 = pow2 >= kp:
-//   a64[d] f64 | q64[d] f64 | t_d2[kp] f64 | t_sc[kp] f64 | cand[kp] u32
+//   t_d2[kp] f64 | t_sc[kp] f64 | cand[kp] u32 | stage 64 x 20 f32
 // ---------------------------------------------------------------------------------------------------
 constexpr int RR_CW = 16;            // columns per re-rank step
 __host__ __device__ inline int pow2ceil_h(int x) { int p = 2; while (p < x) p <<= 1; return p; }
+constexpr int RR_RS = RR_CW + 4;     // LDS row stride of the staging area in floats (5 x 16 B: odd -> conflict-free ds_read_b128)
 __host__ __device__ inline size_t wave_lds_bytes(int d, int kp) {
-    return (size_t(d) * 16 + size_t(kp) * (8 + 8 + 4) + 15) & ~size_t(15);
+    (void)d;
+    return size_t(kp) * (8 + 8 + 4) + size_t(64) * RR_RS * 4;
 }
 
 __device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
@@ -187,17 +190,23 @@ __device__ __forceinline__ void wave_bitonic_asc(Ent* a, int n2) {
 // of the distance-ordered list] or left in (dist2, item) order when sort_by_score == 0.
 __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int flag) {
     const int d = a.d, lane = threadIdx.x & 63;
-    double* a64 = reinterpret_cast<double*>(lds);
-    double* q64 = a64 + d;
-    double* t_d2 = q64 + d;
+    double* t_d2 = reinterpret_cast<double*>(lds);
     double* t_sc = t_d2 + kp;
     uint32_t* cand = reinterpret_cast<uint32_t*>(t_sc + kp);
+    float* stage = reinterpret_cast<float*>(cand + kp);
 
-    for (int j = lane; j < d; j += 64) {
-        q64[j] = a.Q64[b * d + j];
-        a64[j] = a.A32 ? double(a.A32[(a.a_idx ? int64_t(a.a_idx[b]) : b) * a.lda + j]) : 0.0;
-    }
-    wave_lds_sync();
+    // The query and the anchor row are wave-uniform: they are read with SCALAR loads straight from global memory and
+    // enter the float64 arithmetic as SGPR operands.  (Broadcasting them from LDS costs a full 1-KiB LDS return per
+    // 16 bytes of payload and made the LDS pipe the bottleneck of the whole kernel.)
+    const int64_t bu = (int64_t(__builtin_amdgcn_readfirstlane(int(uint64_t(b) >> 32))) << 32) |
+                       int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))));
+    // (constant address space: loads from it with a uniform address are selected as s_load; both arrays were written
+    // by earlier kernels and are read-only here)
+    typedef const __attribute__((address_space(4))) double* cdouble_p;
+    typedef const __attribute__((address_space(4))) float* cfloat_p;
+    const cdouble_p q64 = (cdouble_p)(a.Q64 + bu * d);
+    const int64_t arow = a.a_idx ? int64_t(__builtin_amdgcn_readfirstlane(a.a_idx[bu])) : bu;
+    const cfloat_p a32 = (cfloat_p)(a.A32 ? a.A32 + arow * a.lda : a.X);   // mode 2 never reads it
     // numpy pairwise structure for this d (d <= 256: at most two leaves)
     const bool two = d > 128;
     int n2 = d / 2;
@@ -216,26 +225,40 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         double acc = 0.0;
         double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, sA = 0.0;
         float f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0, fA = 0.f;
-        // every lane walks its own candidate row: 16 columns (4 x 16 B) per step, the loads of step c + 1 in flight while
-        // step c is reduced in float64 (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop
-        // in scratch).  Rows are ldx >= roundup16(d) floats long, so whole steps never leave the row.
-        const float* xrow = a.X + int64_t(it) * a.ldx;
-        float4 pre0 = *reinterpret_cast<const float4*>(xrow), pre1 = *reinterpret_cast<const float4*>(xrow + 4);
-        float4 pre2 = *reinterpret_cast<const float4*>(xrow + 8), pre3 = *reinterpret_cast<const float4*>(xrow + 12);
+        // staging map: 4 lanes x 16 B per row (whole 64-byte segments: the L1 serves 64 B per clock, per-lane row walks
+        // would use a quarter of each access), 16 rows per instruction, 4 instructions per 16-column chunk; the rows are
+        // transposed through wave-private LDS (row stride 80 B: conflict-free ds_read_b128).
+        // (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop in scratch)
+        const int srow = lane >> 2, scol = 4 * (lane & 3);
+        const float* src0 = a.X + int64_t(cand[min(g0 + 0 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src1 = a.X + int64_t(cand[min(g0 + 16 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src2 = a.X + int64_t(cand[min(g0 + 32 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src3 = a.X + int64_t(cand[min(g0 + 48 + srow, n_r - 1)]) * a.ldx + scol;
+        float* dst = stage + srow * RR_RS + scol;
+        // software pipeline: the gathers of chunk c + 1 are in flight while chunk c is reduced in float64
+        float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
+        float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
-            float xv[RR_CW];
-            xv[0] = pre0.x; xv[1] = pre0.y; xv[2] = pre0.z; xv[3] = pre0.w;
-            xv[4] = pre1.x; xv[5] = pre1.y; xv[6] = pre1.z; xv[7] = pre1.w;
-            xv[8] = pre2.x; xv[9] = pre2.y; xv[10] = pre2.z; xv[11] = pre2.w;
-            xv[12] = pre3.x; xv[13] = pre3.y; xv[14] = pre3.z; xv[15] = pre3.w;
+            *reinterpret_cast<float4*>(dst) = pre0;
+            *reinterpret_cast<float4*>(dst + 16 * RR_RS) = pre1;
+            *reinterpret_cast<float4*>(dst + 32 * RR_RS) = pre2;
+            *reinterpret_cast<float4*>(dst + 48 * RR_RS) = pre3;
             if (c + 1 < n_chunks) {
-                const float* nx = xrow + RR_CW * (c + 1);
-                pre0 = *reinterpret_cast<const float4*>(nx);
-                pre1 = *reinterpret_cast<const float4*>(nx + 4);
-                pre2 = *reinterpret_cast<const float4*>(nx + 8);
-                pre3 = *reinterpret_cast<const float4*>(nx + 12);
+                const int o = RR_CW * (c + 1);
+                pre0 = *reinterpret_cast<const float4*>(src0 + o);
+                pre1 = *reinterpret_cast<const float4*>(src1 + o);
+                pre2 = *reinterpret_cast<const float4*>(src2 + o);
+                pre3 = *reinterpret_cast<const float4*>(src3 + o);
             }
+            wave_lds_sync();
+            float xv[RR_CW];
+#pragma unroll
+            for (int t = 0; t < RR_CW / 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
+                xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
+            }
+            wave_lds_sync();
             const int j0 = RR_CW * c;
             if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
 #pragma unroll
@@ -260,19 +283,19 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
                         const bool first = g8 == 0 || g8 == gA;
                         const int jj = 8 * g8;
                         if (mode == 0) {
-                            const double p0 = __dmul_rn(a64[jj + 0], double(xv[8 * gg + 0])), p1 = __dmul_rn(a64[jj + 1], double(xv[8 * gg + 1]));
-                            const double p2 = __dmul_rn(a64[jj + 2], double(xv[8 * gg + 2])), p3 = __dmul_rn(a64[jj + 3], double(xv[8 * gg + 3]));
-                            const double p4 = __dmul_rn(a64[jj + 4], double(xv[8 * gg + 4])), p5 = __dmul_rn(a64[jj + 5], double(xv[8 * gg + 5]));
-                            const double p6 = __dmul_rn(a64[jj + 6], double(xv[8 * gg + 6])), p7 = __dmul_rn(a64[jj + 7], double(xv[8 * gg + 7]));
+                            const double p0 = __dmul_rn(double(a32[jj + 0]), double(xv[8 * gg + 0])), p1 = __dmul_rn(double(a32[jj + 1]), double(xv[8 * gg + 1]));
+                            const double p2 = __dmul_rn(double(a32[jj + 2]), double(xv[8 * gg + 2])), p3 = __dmul_rn(double(a32[jj + 3]), double(xv[8 * gg + 3]));
+                            const double p4 = __dmul_rn(double(a32[jj + 4]), double(xv[8 * gg + 4])), p5 = __dmul_rn(double(a32[jj + 5]), double(xv[8 * gg + 5]));
+                            const double p6 = __dmul_rn(double(a32[jj + 6]), double(xv[8 * gg + 6])), p7 = __dmul_rn(double(a32[jj + 7]), double(xv[8 * gg + 7]));
                             if (first) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; r5 = p5; r6 = p6; r7 = p7; }
                             else { r0 = __dadd_rn(r0, p0); r1 = __dadd_rn(r1, p1); r2 = __dadd_rn(r2, p2); r3 = __dadd_rn(r3, p3);
                                    r4 = __dadd_rn(r4, p4); r5 = __dadd_rn(r5, p5); r6 = __dadd_rn(r6, p6); r7 = __dadd_rn(r7, p7); }
                             if (g8 == gA - 1) sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
                         } else {
-                            const float p0 = __fmul_rn(float(a64[jj + 0]), xv[8 * gg + 0]), p1 = __fmul_rn(float(a64[jj + 1]), xv[8 * gg + 1]);
-                            const float p2 = __fmul_rn(float(a64[jj + 2]), xv[8 * gg + 2]), p3 = __fmul_rn(float(a64[jj + 3]), xv[8 * gg + 3]);
-                            const float p4 = __fmul_rn(float(a64[jj + 4]), xv[8 * gg + 4]), p5 = __fmul_rn(float(a64[jj + 5]), xv[8 * gg + 5]);
-                            const float p6 = __fmul_rn(float(a64[jj + 6]), xv[8 * gg + 6]), p7 = __fmul_rn(float(a64[jj + 7]), xv[8 * gg + 7]);
+                            const float p0 = __fmul_rn((a32[jj + 0]), xv[8 * gg + 0]), p1 = __fmul_rn((a32[jj + 1]), xv[8 * gg + 1]);
+                            const float p2 = __fmul_rn((a32[jj + 2]), xv[8 * gg + 2]), p3 = __fmul_rn((a32[jj + 3]), xv[8 * gg + 3]);
+                            const float p4 = __fmul_rn((a32[jj + 4]), xv[8 * gg + 4]), p5 = __fmul_rn((a32[jj + 5]), xv[8 * gg + 5]);
+                            const float p6 = __fmul_rn((a32[jj + 6]), xv[8 * gg + 6]), p7 = __fmul_rn((a32[jj + 7]), xv[8 * gg + 7]);
                             if (first) { f0 = p0; f1 = p1; f2 = p2; f3 = p3; f4 = p4; f5 = p5; f6 = p6; f7 = p7; }
                             else { f0 = __fadd_rn(f0, p0); f1 = __fadd_rn(f1, p1); f2 = __fadd_rn(f2, p2); f3 = __fadd_rn(f3, p3);
                                    f4 = __fadd_rn(f4, p4); f5 = __fadd_rn(f5, p5); f6 = __fadd_rn(f6, p6); f7 = __fadd_rn(f7, p7); }
@@ -286,12 +309,12 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         const float* xr = a.X + int64_t(it) * a.ldx;
         if (mode == 0) {
             double res = n_groups8 > 0 ? ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) : 0.0;
-            for (int j = lim; j < d; ++j) res = __dadd_rn(res, __dmul_rn(a64[j], double(xr[j])));   // <= 7 tail elements
+            for (int j = lim; j < d; ++j) res = __dadd_rn(res, __dmul_rn(double(a32[j]), double(xr[j])));   // <= 7 tail elements
             if (two) res = sA + res;
             sco = (res + 1.0) / 2.0;
         } else if (mode == 1) {
             float res = n_groups8 > 0 ? ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7)) : 0.f;
-            for (int j = lim; j < d; ++j) res = __fadd_rn(res, __fmul_rn(float(a64[j]), xr[j]));
+            for (int j = lim; j < d; ++j) res = __fadd_rn(res, __fmul_rn(a32[j], xr[j]));
             if (two) res = fA + res;
             sco = double((res + 1.0f) / 2.0f);
         } else {
@@ -303,100 +326,67 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         }
     }
     wave_lds_sync();
-    // ---- membership: drop the n_r - k largest (dist2, item) (n_r - k is tiny: the re-rank set is k + a few) -------------
+    // ---- membership and output order, two register sorts (NE keys per lane) ------------------------------------------------
+    // (1) by (dist2, item): positions < k are the members and the position is the KD-tree's return order;
+    // (2) by (score desc, position): the reference's stable sort by score.  Sort keys are 64-bit:
+    //     float32 rounding of the exact key (monotone) << 32 | payload, finished exactly where roundings collide.
     const int k = a.k;
-    for (int drop = n_r - k; drop > 0; --drop) {
-        uint64_t bh = 0, bl = 0;   // arg-max of (dist2, item) over live entries; dist2 >= 0 so orderable(dist2) > 0
-        for (int i = lane; i < n_r; i += 64) {
-            if (cand[i] != 0xFFFFFFFFu) {
-                const uint64_t h2 = f64_orderable(t_d2[i]), ll = (uint64_t(cand[i]) << 32) | uint32_t(i);
-                if (bh < h2 || (bh == h2 && bl < ll)) { bh = h2; bl = ll; }
-            }
-        }
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint64_t oh = __shfl_xor(bh, off, kWave), ol = __shfl_xor(bl, off, kWave);
-            if (bh < oh || (bh == oh && bl < ol)) { bh = oh; bl = ol; }
-        }
-        if (lane == 0) cand[uint32_t(bl)] = 0xFFFFFFFFu;   // low word of bl = slot
-        wave_lds_sync();
-    }
-    // ---- ONE sort gives the output order: (score desc, dist2 asc, item asc) = the reference's stable sort by score of
-    // the distance-ordered list; or (dist2, item) when sort_by_score == 0.  The sort runs in REGISTERS (NE entries per
-    // lane, blocked layout: sorted position = NE * lane + j): strides below NE are register swaps, larger strides one
-    // cross-lane exchange per entry.  Entry: hi = primary key, lo = slot; equal primaries are resolved by looking
-    // (dist2, item) up in LDS (rare).
-    auto less = [&](uint64_t xh, uint32_t xl, uint64_t yh, uint32_t yl) {
-        if (xh != yh) return xh < yh;
-        if (xl == yl) return false;
-        if (xl == 0xFFFFFFFFu || yl == 0xFFFFFFFFu) return xl < yl;   // padding last
-        const uint64_t dx = f64_orderable(t_d2[xl]), dy = f64_orderable(t_d2[yl]);
-        if (dx != dy) return dx < dy;
-        return cand[xl] < cand[yl];
-    };
-    auto sort_emit = [&](auto ne_tag) {
+    auto tail = [&](auto ne_tag) {
         constexpr int NE = decltype(ne_tag)::value;
-        uint64_t hi[NE];
-        uint32_t lo[NE];
+        uint64_t key[NE];
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int i = 64 * j + lane;   // any initial placement will do
-            hi[j] = ~0ull;
-            lo[j] = 0xFFFFFFFFu;
-            if (i < n_r && cand[i] != 0xFFFFFFFFu) {
-                hi[j] = a.sort_by_score ? ~f64_orderable(t_sc[i]) : f64_orderable(t_d2[i]);
-                lo[j] = uint32_t(i);
-            }
+            key[j] = i < n_r ? (uint64_t(f32_orderable(float(t_d2[i]))) << 32) | uint64_t(uint32_t(i)) : ~0ull;
         }
         if (!(a.debug_skip & 2)) {
-#pragma unroll 1
-            for (int size = 2; size <= NE * 64; size <<= 1) {
-#pragma unroll 1
-                for (int stride = size >> 1; stride >= NE; stride >>= 1) {   // cross-lane exchanges
-                    const int lm = stride / NE;
-                    const bool lower = (lane & lm) == 0;
+            wave_sort_u64<NE>(key);
+            wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
+                const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
+                const uint64_t dx = f64_orderable(t_d2[sx]), dy = f64_orderable(t_d2[sy]);
+                return dx < dy || (dx == dy && cand[sx] < cand[sy]);
+            });
+            if (a.sort_by_score) {
 #pragma unroll
-                    for (int j = 0; j < NE; ++j) {
-                        const bool asc = ((NE * lane + j) & size) == 0;
-                        const uint64_t oh = __shfl_xor(hi[j], lm, kWave);
-                        const uint32_t ol = __shfl_xor(lo[j], lm, kWave);
-                        const bool take = (lower == asc) ? less(oh, ol, hi[j], lo[j]) : less(hi[j], lo[j], oh, ol);
-                        if (take) { hi[j] = oh; lo[j] = ol; }
+                for (int j = 0; j < NE; ++j) {
+                    const int p = NE * lane + j;
+                    const uint32_t slot = uint32_t(key[j]) & 0xFFFFu;
+                    if (p < k) {
+                        const uint32_t ap = ~f32_orderable(float(t_sc[slot]));
+                        key[j] = (uint64_t(ap) << 32) | (uint64_t(uint32_t(p)) << 16) | uint64_t(slot);
+                    } else {
+                        key[j] = ~0ull;
                     }
                 }
-#pragma unroll
-                for (int stride = NE >> 1; stride > 0; stride >>= 1) {       // register swaps
-                    if (stride < size) {
-#pragma unroll
-                        for (int j = 0; j < NE; ++j) {
-                            if ((j & stride) == 0) {
-                                const bool asc = ((NE * lane + j) & size) == 0;
-                                const int j2 = j | stride;
-                                if (less(hi[j2], lo[j2], hi[j], lo[j]) == asc) {
-                                    const uint64_t th = hi[j]; hi[j] = hi[j2]; hi[j2] = th;
-                                    const uint32_t tl = lo[j]; lo[j] = lo[j2]; lo[j2] = tl;
-                                }
-                            }
-                        }
-                    }
-                }
+                wave_sort_u64<NE>(key);
+                wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
+                    const uint64_t ax = ~f64_orderable(t_sc[uint32_t(x) & 0xFFFFu]), ay = ~f64_orderable(t_sc[uint32_t(y) & 0xFFFFu]);
+                    return ax < ay || (ax == ay && (uint32_t(x) >> 16) < (uint32_t(y) >> 16));
+                });
             }
         }
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
-            const int i = NE * lane + j;
-            if (i < k) {
-                const uint32_t slot = lo[j];
+            const int p = NE * lane + j;
+            if (p < k) {
+                const uint32_t slot = uint32_t(key[j]) & 0xFFFFu;
                 const uint32_t it = cand[slot];
-                a.out_idx[b * k + i] = a.row_ids ? a.row_ids[it] : a.id_base + int64_t(it);
-                a.out_score[b * k + i] = t_sc[slot];
-                a.out_dist2[b * k + i] = t_d2[slot];
+                a.out_idx[b * k + p] = a.row_ids ? a.row_ids[it] : a.id_base + int64_t(it);
+                a.out_score[b * k + p] = t_sc[slot];
+                a.out_dist2[b * k + p] = t_d2[slot];
             }
         }
     };
-    if (n_r <= 256) sort_emit(std::integral_constant<int, 4>{});
-    else sort_emit(std::integral_constant<int, 8>{});
-    if (lane == 0) a.out_flags[b] = flag;
+    if (n_r <= 128) tail(std::integral_constant<int, 2>{});
+    else if (n_r <= 256) tail(std::integral_constant<int, 4>{});
+    else tail(std::integral_constant<int, 8>{});
+    if (lane == 0) {
+        a.out_flags[b] = flag;
+        if (flag == 0 && a.hdr) {   // rare: hand the query to the exhaustive pass (hwer_knn_exact_device / _f64)
+            const int p = atomicAdd(&a.hdr->uncert_count, 1);
+            if (p < UNCERT_LIST_MAX) a.hdr->uncert_list[p] = int(b);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -424,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
     const int d = a.emit.d, k = a.emit.k;
     const int kp = a.kcap;                                             // candidate capacity (multiple of 64)
     unsigned char* lds_emit = smem_raw + size_t(wave) * wave_lds_bytes(d, kp);
-    uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(d) * 16 + size_t(kp) * 16);   // = `cand` of wave_rerank_emit
+    uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);   // = `cand` of wave_rerank_emit
 
     const int c0r = a.cand_cnt[b * 2], c1r = a.cand_cnt[b * 2 + 1];
     const bool underfull = ((c0r | c1r) & CNT_UNDERFULL) != 0;
@@ -443,7 +433,7 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
 #pragma unroll
     for (int i = 0; i < RR_MAXR; ++i) sv[i] = key[i] != 0ull ? key_score(key[i]) : -INFINITY;
     int c_ge;
-    const float t_k = wave_bisect_rank<RR_MAXR>(sv, k, 12, c_ge);   // <= k-th largest key, <= 12 extra keys above it
+    const float t_k = wave_find_rank<RR_MAXR>(sv, k, 12, c_ge);   // <= k-th largest key, <= 12 extra keys above it
     // ---- re-rank set + certificate (float32 only) ------------------------------------------------------------------
     // Every item has |key32 - key| <= E32.  An item can belong to the true top-k only if key32 >= t_k - 2 E32: those
     // candidates form the re-rank set.  Items that never became candidates have key32 <= min candidate key; if some
@@ -493,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
     if (b >= a.B) return;   // no workgroup barrier below
     const int d = a.emit.d, k = a.emit.k, kp = a.kp;
     unsigned char* lds_emit = smem_raw + size_t(wave) * wave_lds_bytes(d, kp);
-    uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(d) * 16 + size_t(kp) * 16);
+    uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);
     const float4* row = reinterpret_cast<const float4*>(a.keys + b * a.ld);
     const int n4 = int(a.ld / 4);
     // The lane's slice of the key row lives in registers (rows up to 256 * MAXV keys): every load is in flight at once,
@@ -508,16 +498,13 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
         if (i < n4) v = row[i];
         kv[m][0] = v.x; kv[m][1] = v.y; kv[m][2] = v.z; kv[m][3] = v.w;
     }
-    const int n_m = (n4 + 63) / 64;   // live slices (wave-uniform)
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
     for (int m = 0; m < MAXV; ++m) {
-        if (m < n_m) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                vmax = fmaxf(vmax, kv[m][c]);
-                if (kv[m][c] > -INFINITY) vmin = fminf(vmin, kv[m][c]);
-            }
+        for (int c = 0; c < 4; ++c) {
+            vmax = fmaxf(vmax, kv[m][c]);
+            if (kv[m][c] > -INFINITY) vmin = fminf(vmin, kv[m][c]);
         }
     }
 #pragma unroll
@@ -526,26 +513,16 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
     auto count_ge = [&](float t) {
-        int c = 0;   // ballot counting: v_cmp -> s_bcnt1 -> s_add, no cross-lane traffic
+        int c = 0;   // ballot counting: one v_cmp per key, the popcount and the sum run on the scalar unit
 #pragma unroll
         for (int m = 0; m < MAXV; ++m) {
-            if (m < n_m) {
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc) c += __builtin_popcountll(__ballot(kv[m][cc] >= t));
-            }
+            for (int cc = 0; cc < 4; ++cc) c += __builtin_popcountll(__ballot(kv[m][cc] >= t));
         }
         return c;
     };
-    // invariant: count(>= lo) >= k (every finite key is >= vmin and there are >= k of them), count(>= hi) < k or hi > vmax
-    float lo = vmin, hi = vmax;
-    int c_lo = count_ge(lo);
-    for (int iter = 0; iter < 64 && c_lo > k + 12; ++iter) {
-        const float mid = 0.5f * lo + 0.5f * hi;
-        if (!(mid > lo) || !(mid < hi)) break;   // interval exhausted (ties at the cut): keep lo
-        const int c = count_ge(mid);
-        if (c >= k) { lo = mid; c_lo = c; } else { hi = mid; }
-    }
-    const float t_k = lo;   // <= k-th largest key, with at most c_lo - k extra keys above it
+    int c_lo;
+    const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo);   // <= k-th largest key, at most c_lo - k extra keys above it
     double Q2 = 0.0;
     {
         const double* q = a.emit.Q64 + b * d;
@@ -554,18 +531,46 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
         for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
     }
     const float thr = t_k - 2.0f * e32_bound(d, Q2, a.hnorm_max);
-    int n_r = 0;
-    bool overflow = false;
+    // re-rank set = keys >= thr (a few per lane): per-lane pass masks (2 VALU per key: the sign of key - thr is funnel-
+    // shifted into the mask), one wave scan for the write offsets, then every lane pops its set bits.
+    constexpr int NW = (4 * MAXV + 31) / 32;
+    uint32_t fail[NW];   // bit (31 - (e & 31)) of word e / 32 <-> key e = 4 m + c of this lane; set = below thr
+#pragma unroll
+    for (int w = 0; w < NW; ++w) fail[w] = 0u;
 #pragma unroll
     for (int m = 0; m < MAXV; ++m) {
-        if (m < n_m) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool in = kv[m][c] >= thr;
-                const uint64_t bal = __ballot(in);
-                const int pos = n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                if (in && pos < kp) cand_item[pos] = uint32_t(4 * (lane + 64 * m) + c);
-                n_r += __builtin_popcountll(bal);
+        for (int c = 0; c < 4; ++c) {
+            const int e = 4 * m + c;
+            // key - thr has its sign bit set exactly when key < thr (-inf keys included; key == thr gives +0)
+            fail[e / 32] = __builtin_amdgcn_alignbit(fail[e / 32], __float_as_uint(kv[m][c] - thr), 31);
+        }
+    }
+    int mine = 0;
+    uint32_t pass[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        pass[w] = ~fail[w];
+        mine += __builtin_popcount(pass[w]);
+    }
+    int incl = mine;   // inclusive scan over lanes
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += t;
+    }
+    int n_r = __shfl(incl, 63, kWave);
+    bool overflow = false;
+    int pos = incl - mine;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        while (__any(pass[w] != 0u)) {
+            if (pass[w] != 0u) {
+                const int bit = __builtin_ctz(pass[w]);
+                pass[w] &= pass[w] - 1u;
+                const int e = 32 * w + 31 - bit;
+                if (pos < kp) cand_item[pos] = uint32_t(4 * (lane + 64 * (e >> 2)) + (e & 3));
+                ++pos;
             }
         }
     }
@@ -676,13 +681,103 @@ __global__ __launch_bounds__(64) void exact_emit_kernel(const Ent* __restrict__ 
                                                         const EmitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int kp = ((a.k + 63) / 64) * 64;
-    uint32_t* c_item = reinterpret_cast<uint32_t*>(smem_raw + size_t(a.d) * 16 + size_t(kp) * 16);   // `cand` of wave_rerank_emit
+    uint32_t* c_item = reinterpret_cast<uint32_t*>(smem_raw + size_t(kp) * 16);   // `cand` of wave_rerank_emit
     int n_c = 0;
     for (int i = 0; i < n_sel; ++i) n_c += (sel[i].lo != ~0ull);  // padding entries sort last
     n_c = min(n_c, a.k);
     for (int i = threadIdx.x; i < n_c; i += 64) c_item[i] = uint32_t(sel[i].lo);
     wave_lds_sync();
     wave_rerank_emit(a, b, smem_raw, kp, n_c, 2);
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// On-device exhaustive pass: recomputes the queries listed in the workspace header (appended by the select kernels
+// when a certificate failed) without a host round trip.  Grid (item chunks, EXACT_DEVICE_MAXQ): block (c, qi) computes
+// the float64 distances of chunk c for listed query qi, sorts them and publishes its k best; the LAST block to arrive
+// (ticket) merges the per-chunk winners and emits.  With an empty list every block exits at once.
+// ---------------------------------------------------------------------------------------------------
+struct ExactDevArgs {
+    const float* X;
+    int64_t n_items;
+    int64_t ldx;
+    const double* Q64;
+    WsHeader* hdr;
+    Ent* cand;       // [EXACT_DEVICE_MAXQ][n_chunks][k]
+    int n_chunks;
+    int32_t* missed_accum;   // nullable device counter: += listed queries beyond EXACT_DEVICE_MAXQ (left flagged 0)
+    EmitArgs emit;
+};
+
+__global__ __launch_bounds__(256) void exact_device_kernel(const ExactDevArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ int s_last;
+    Ent* ent = reinterpret_cast<Ent*>(smem_raw);
+    unsigned char* lds_emit = smem_raw + size_t(EX_CHUNK) * sizeof(Ent);
+    const int qi = blockIdx.y, tid = threadIdx.x;
+    const int count = a.hdr->uncert_count;
+    if (blockIdx.x == 0 && qi == 0 && tid == 0 && count > EXACT_DEVICE_MAXQ && a.missed_accum) atomicAdd(a.missed_accum, count - EXACT_DEVICE_MAXQ);
+    if (qi >= count) return;   // block-uniform
+    const int64_t b = a.hdr->uncert_list[qi];
+    const int d = a.emit.d, k = a.emit.k;
+    const double* q = a.Q64 + b * d;
+    const int64_t base = int64_t(blockIdx.x) * EX_CHUNK;
+    for (int i = tid; i < EX_CHUNK; i += 256) {
+        Ent e;
+        e.hi = ~0ull;
+        e.lo = ~0ull;
+        const int64_t item = base + i;
+        if (item < a.n_items) {
+            const float* xr = a.X + item * a.ldx;
+            double acc = 0.0;
+            for (int j = 0; j < d; ++j) {
+                const double tmp = __dsub_rn(q[j], double(xr[j]));
+                acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+            }
+            e.hi = f64_orderable(acc);
+            e.lo = uint64_t(item);
+        }
+        ent[i] = e;
+    }
+    bitonic_asc_ent(ent, EX_CHUNK);
+    Ent* all = a.cand + int64_t(qi) * a.n_chunks * k;
+    for (int i = tid; i < k; i += 256) all[int64_t(blockIdx.x) * k + i] = ent[i];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&a.hdr->tickets[qi], 1) == a.n_chunks - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    // ---- last block: merge n_chunks * k winners down to k (rounds of EX_CHUNK entries, compacted in place) ------------
+    int64_t n = int64_t(a.n_chunks) * k;
+    while (n > k) {
+        const int64_t chunks = cdiv64(n, EX_CHUNK);
+        for (int64_t c = 0; c < chunks; ++c) {
+            __syncthreads();
+            for (int i = tid; i < EX_CHUNK; i += 256) {
+                Ent e;
+                e.hi = ~0ull;
+                e.lo = ~0ull;
+                if (c * EX_CHUNK + i < n) {   // written by other blocks: read through L2 (agent scope), never a stale L1 line
+                    const Ent* src = &all[c * EX_CHUNK + i];
+                    e.hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    e.lo = __hip_atomic_load(&src->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                ent[i] = e;
+            }
+            bitonic_asc_ent(ent, EX_CHUNK);
+            for (int i = tid; i < k; i += 256) all[c * k + i] = ent[i];   // c * k + k <= (c + 1) * EX_CHUNK: already consumed
+            __threadfence();
+        }
+        n = chunks * k;
+    }
+    __syncthreads();
+    // ent[0..k) = the k nearest items (n_items >= k), ascending (dist2, item)
+    const int kp = ((k + 63) / 64) * 64;
+    uint32_t* c_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);   // `cand` of wave_rerank_emit
+    for (int i = tid; i < k; i += 256) c_item[i] = uint32_t(ent[i].lo);
+    __syncthreads();
+    if (tid < 64) wave_rerank_emit(a.emit, b, lds_emit, kp, k, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -778,8 +873,11 @@ struct ProfSlot {
     std::vector<hipEvent_t> start, stop;
     size_t used = 0;
 };
-bool g_prof_on = false;
+int g_prof_period = 0;      // 0 = off, n = bracket every n-th hwer_knn_search_f32 call
+long g_prof_calls = 0;
+bool g_prof_on = false;    // decision for the current call
 ProfSlot g_prof[2];  // 0: knn_screen, 1: knn_select (+ reduce)
+void prof_next_call() { g_prof_on = g_prof_period > 0 && (g_prof_calls++ % g_prof_period) == 0; }
 
 struct ProfScope {
     int which;
@@ -807,7 +905,9 @@ struct ProfScope {
 }  // namespace
 
 extern "C" int hwer_profile_enable(int on) {
-    g_prof_on = on != 0;
+    g_prof_period = on > 0 ? on : 0;
+    g_prof_calls = 0;
+    g_prof_on = false;
     return HWER_OK;
 }
 // Sum of the event-bracketed durations since the last read.  Synchronises on the recorded events (call it outside
@@ -836,9 +936,10 @@ struct WsLayout {
 };
 static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     WsLayout w{};
-    size_t off = 0;
+    size_t off = WS_HEADER_BYTES;   // WsHeader first
     if (p.dense) {   // one (B, ld_dense) float matrix of keys
-        w.total = align256(size_t(p.bq) * size_t(p.ld_dense) * 4);   // bq >= B rows: the screen stores unconditionally
+        w.cand_a = off;
+        w.total = off + align256(size_t(p.bq) * size_t(p.ld_dense) * 4);   // bq >= B rows: the screen stores unconditionally
         return w;
     }
     w.cand_a = off;
@@ -890,31 +991,37 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     uint64_t* cand = reinterpret_cast<uint64_t*>(ws + w.cand_a);
     int32_t* cnt = reinterpret_cast<int32_t*>(ws + w.cnt_a);
+    WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
     int rc;
+    prof_next_call();
     {
         ProfScope ps(0, st);
-        rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, reinterpret_cast<float*>(ws), st);
+        rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st);
     }
     if (rc) return rc;
     ProfScope ps_select(1, st);
     if (plan.dense) {
         DenseSelectArgs da{};
-        da.keys = reinterpret_cast<const float*>(ws);
+        da.keys = reinterpret_cast<const float*>(ws + w.cand_a);
         da.ld = plan.ld_dense;
         da.B = B;
         da.kp = plan.kprime;
         da.hnorm_max = hnorm_max;
         da.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
-                           out_idx, out_score, out_dist2, out_flags};
+                           out_idx, out_score, out_dist2, out_flags, hdr};
         const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
-        if (plan.ld_dense <= 256 * 16) {
-            if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<16>), lds, "knn_select_dense"))) return rc;
-            hipLaunchKernelGGL(select_dense_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
-        } else {
-            static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
-            if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<32>), lds, "knn_select_dense"))) return rc;
-            hipLaunchKernelGGL(select_dense_kernel<32>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
-        }
+        static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
+        auto launch_dense = [&](auto mv) -> int {
+            constexpr int MV = decltype(mv)::value;
+            if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV>), lds, "knn_select_dense")) return e;
+            hipLaunchKernelGGL(select_dense_kernel<MV>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+            return HWER_OK;
+        };
+        if (plan.ld_dense <= 256 * 4) rc = launch_dense(std::integral_constant<int, 4>{});
+        else if (plan.ld_dense <= 256 * 8) rc = launch_dense(std::integral_constant<int, 8>{});
+        else if (plan.ld_dense <= 256 * 16) rc = launch_dense(std::integral_constant<int, 16>{});
+        else rc = launch_dense(std::integral_constant<int, 32>{});
+        if (rc) return rc;
         return check_launch("knn_select_dense");
     }
 
@@ -941,7 +1048,7 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     sa.kcap = plan.kprime;   // the screen's final compaction is exact: a list holds at most K' keys
     sa.hnorm_max = hnorm_max;
     sa.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
-                       out_idx, out_score, out_dist2, out_flags};
+                       out_idx, out_score, out_dist2, out_flags, hdr};
     const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel), lds, "knn_select"))) return rc;
     hipLaunchKernelGGL(select_rerank_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, sa);
@@ -997,12 +1104,50 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
             std::swap(in, out);
         } while (n > keep);
         EmitArgs ea{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
-                    out_idx, out_score, out_dist2, out_flags};
+                    out_idx, out_score, out_dist2, out_flags, nullptr};
         const size_t lds = wave_lds_bytes(d, ((k + 63) / 64) * 64);
         hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(64), lds, st, in, int(n), b, ea);
         if ((rc = check_launch("knn_exact(emit)"))) return rc;
     }
     return HWER_OK;
+}
+
+size_t hwer_knn_exact_device_workspace_bytes(int64_t n_items, int k) {
+    if (n_items < 1 || k < 1 || k > K_MAX) return 0;
+    return align256(size_t(EXACT_DEVICE_MAXQ) * size_t(cdiv64(n_items, EX_CHUNK)) * size_t(k) * sizeof(Ent));
+}
+
+int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
+                          int64_t lda, const int32_t* a_idx, int k, int score_mode, int sort_by_score,
+                          const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
+                          double* out_dist2, int32_t* out_flags, void* knn_workspace, int32_t* missed_accum,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    if (!X || !Q64 || !out_idx || !out_score || !out_dist2 || !out_flags || !knn_workspace || !workspace)
+        return fail(HWER_EINVAL, "knn_exact_device: null pointer");
+    if (d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16)
+        return fail(HWER_EINVAL, "knn_exact_device: need 1 <= d <= 256 and ldx >= roundup16(d)");
+    if (k < 1 || k > K_MAX) return fail(HWER_EINVAL, "knn_exact_device: k=%d outside 1..%d", k, K_MAX);
+    if (k > n_items) return fail(HWER_EINVAL, "knn_exact_device: k must be less than or equal to the number of training points");
+    if (n_items >= (int64_t(1) << 32)) return fail(HWER_EINVAL, "knn_exact_device: n_items must be < 2^32");
+    if (score_mode < 0 || score_mode > 2 || (score_mode != 2 && !A32)) return fail(HWER_EINVAL, "knn_exact_device: score_mode / A32");
+    const size_t need = hwer_knn_exact_device_workspace_bytes(n_items, k);
+    if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_exact_device: workspace %zu < %zu", workspace_bytes, need);
+    ExactDevArgs ea{};
+    ea.X = X;
+    ea.n_items = n_items;
+    ea.ldx = ldx;
+    ea.Q64 = Q64;
+    ea.hdr = reinterpret_cast<WsHeader*>(knn_workspace);
+    ea.cand = reinterpret_cast<Ent*>(workspace);
+    ea.n_chunks = int(cdiv64(n_items, EX_CHUNK));
+    ea.missed_accum = missed_accum;
+    ea.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
+                       out_idx, out_score, out_dist2, out_flags, nullptr};
+    const size_t lds = size_t(EX_CHUNK) * sizeof(Ent) + wave_lds_bytes(d, ((k + 63) / 64) * 64);
+    int rc;
+    if ((rc = set_max_lds(reinterpret_cast<const void*>(&exact_device_kernel), lds, "knn_exact_device"))) return rc;
+    hipLaunchKernelGGL(exact_device_kernel, dim3(unsigned(ea.n_chunks), EXACT_DEVICE_MAXQ), dim3(256), lds, as_stream(stream), ea);
+    return check_launch("knn_exact_device");
 }
 
 int hwer_merge_topk(const int64_t* idx, const double* score, const double* dist2, int n_lists, int64_t B, int k,

@@ -223,11 +223,35 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
             }
         }
     }
-    if (audit_counts) {   // counts are integers (deterministic); the |norm-1| sum is a float64 atomic (order-dependent ulps)
-        if (a_pos) atomicAdd(&audit_counts[0], a_pos);
-        if (a_neg) atomicAdd(&audit_counts[1], a_neg);
-        if (a_nan) atomicAdd(&audit_counts[2], a_nan);
-        if (a_dev != 0.0) atomicAdd(audit_absdev, a_dev);
+    if (audit_counts) {
+        // One set of atomics per BLOCK: thousands of float64 atomics on a single address serialise in L2 and were the
+        // whole cost of this kernel on small tables.  Counts are integers (deterministic); the |norm-1| sum is a float64
+        // atomic (order-dependent in the last ulps).
+        __shared__ unsigned long long s_cnt[4][3];
+        __shared__ double s_dev[4];
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            a_pos += __shfl_xor(a_pos, off, kWave);
+            a_neg += __shfl_xor(a_neg, off, kWave);
+            a_nan += __shfl_xor(a_nan, off, kWave);
+            a_dev += __shfl_xor(a_dev, off, kWave);
+        }
+        const int wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            s_cnt[wave][0] = a_pos; s_cnt[wave][1] = a_neg; s_cnt[wave][2] = a_nan;
+            s_dev[wave] = a_dev;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long p = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+            const unsigned long long n = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+            const unsigned long long q = s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2];
+            const double dv = (s_dev[0] + s_dev[1]) + (s_dev[2] + s_dev[3]);
+            if (p) atomicAdd(&audit_counts[0], p);
+            if (n) atomicAdd(&audit_counts[1], n);
+            if (q) atomicAdd(&audit_counts[2], q);
+            if (dv != 0.0) atomicAdd(audit_absdev, dv);
+        }
     }
 }
 
@@ -568,7 +592,8 @@ static int blend_impl(const float* const* tables, int64_t ld_tables, const int32
     if ((rc = check_table("blend_normalize(out)", out, ldo, d))) return rc;
     if (ld_tables % 4 != 0 || ld_tables < d) return fail(HWER_EINVAL, "blend_normalize: ld_tables must be a multiple of 4 and >= d");
     const int d4 = (d + 3) / 4;
-    hipLaunchKernelGGL(blend_normalize_kernel, dim3(rows_grid(R, d4)), dim3(256), 0, as_stream(stream), tables,
+    const int grid = rows_grid(R, d4);   // <= kMaxStreamBlocks: the fused audit costs at most that many atomics per counter
+    hipLaunchKernelGGL(blend_normalize_kernel, dim3(grid), dim3(256), 0, as_stream(stream), tables,
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     return check_launch("blend_normalize");
@@ -579,20 +604,18 @@ int64_t hwer_unit_audit_ws_floats(int64_t N) { return ((N + 3) / 4) * 4 + (AUDIT
 // number of queries whose flag is 0 (uncertified) -> out[0]; lets the host decide on the exhaustive pass with one
 // 4-byte read instead of a device-wide nonzero()
 __global__ __launch_bounds__(256) void count_zero_flags_kernel(const int32_t* __restrict__ flags, int64_t B, int32_t* __restrict__ out) {
-    __shared__ int s[256];
     int c = 0;
-    for (int64_t i = threadIdx.x; i < B; i += 256) c += flags[i] == 0;
-    s[threadIdx.x] = c;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {
-        if (threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[0] = s[0];
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < B; i += int64_t(gridDim.x) * 256) c += flags[i] == 0;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) c += __shfl_xor(c, off, kWave);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);   // uncertified queries are rare: normally no atomic at all
 }
 int hwer_knn_count_uncertified(const int32_t* flags, int64_t B, int32_t* out_count, void* stream) {
     if (!flags || !out_count || B < 0) return fail(HWER_EINVAL, "count_uncertified: bad argument");
-    hipLaunchKernelGGL(count_zero_flags_kernel, dim3(1), dim3(256), 0, as_stream(stream), flags, B, out_count);
+    if (hipMemsetAsync(out_count, 0, sizeof(int32_t), as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "count_uncertified: memset failed");
+    if (B == 0) return HWER_OK;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(512, cdiv64(B, 1024))));
+    hipLaunchKernelGGL(count_zero_flags_kernel, dim3(grid), dim3(256), 0, as_stream(stream), flags, B, out_count);
     return check_launch("count_uncertified");
 }
 

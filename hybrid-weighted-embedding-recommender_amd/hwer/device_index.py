@@ -173,6 +173,12 @@ class DeviceIndex:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def _exact_workspace(self, nbytes):
+        torch = _torch()
+        if getattr(self, "_ws_exact", None) is None or self._ws_exact.numel() < nbytes:
+            self._ws_exact = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws_exact
+
     def search_queries(self, node_type: str, Q64, Q32, k: int, anchors_dev=None, score_mode: Optional[int] = None,
                        sort_by_score: bool = True, id_base: Optional[int] = None):
         """Exact k nearest rows of `node_type` for B query vectors already on the device.
@@ -204,6 +210,15 @@ class DeviceIndex:
                 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
                 tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]),
                 native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), native.stream_ptr()), "knn_search")
+            # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
+            # to 8 per call; anything beyond that is picked up by the host-driven pass below
+            wse = self._exact_workspace(self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
+            native.check(self.lib.hwer_knn_exact_device(
+                native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64[b0:b1]), native.ptr(self.V) if score_mode != 2 else None,
+                self.ldv, native.ptr(a_sub), k, score_mode, 1 if sort_by_score else 0,
+                native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), native.ptr(idx[b0:b1]),
+                native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]), native.ptr(flags[b0:b1]), native.ptr(ws), None,
+                native.ptr(wse), wse.numel(), native.stream_ptr()), "knn_exact_device")
         n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
         native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr()), "count_uncertified")
         if int(n_bad.item()):

@@ -34,8 +34,9 @@ extern "C" {
 /* library identity / diagnostics */
 int hwer_abi_version(void);
 const char* hwer_last_error(void);
-/* Optional kernel timing: when enabled, hwer_knn_search_f32 brackets its screen kernel (which = 0) and its select /
- * re-rank kernels (which = 1) with HIP events recorded on the launch stream.  hwer_profile_read sums and clears. */
+/* Optional kernel timing: hwer_profile_enable(n), n >= 1, makes every n-th hwer_knn_search_f32 call bracket its screen
+ * kernel (which = 0) and its select / re-rank kernels (which = 1) with HIP events recorded on the launch stream
+ * (n = 0: off).  hwer_profile_read sums the bracketed durations, reports how many there were, and clears. */
 int hwer_profile_enable(int on);
 int hwer_profile_read(int which, double* total_ms, int64_t* launches);
 
@@ -153,6 +154,19 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
 /* out_count[0] = number of queries with flags == 0 (device int32): one 4-byte read tells the host whether the
  * exhaustive pass is needed. */
 int hwer_knn_count_uncertified(const int32_t* flags, int64_t B, int32_t* out_count, void* stream);
+
+/* On-device exhaustive pass (no host round trip).  hwer_knn_search_f32 keeps, in the first 4 KiB of its workspace, the
+ * list of queries it could not certify (flag 0).  This call, stream-ordered right after the search and given the SAME
+ * `knn_workspace`, recomputes up to 8 of them exhaustively in float64 (rows overwritten, flags set to 2); with an empty
+ * list its blocks exit at once.  Listed queries beyond the 8th stay flagged 0 and are counted into `missed_accum` (a
+ * device int32 the caller zero-initialises once; NULL = not counted): those still need hwer_knn_exact_f64.
+ * Same argument meaning as hwer_knn_search_f32 / hwer_knn_exact_f64. */
+size_t hwer_knn_exact_device_workspace_bytes(int64_t n_items, int k);
+int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
+                          int64_t lda, const int32_t* a_idx, int k, int score_mode, int sort_by_score,
+                          const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
+                          double* out_dist2, int32_t* out_flags, void* knn_workspace, int32_t* missed_accum,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* Exhaustive float64 k-NN for the (rare) queries whose certificate failed; same outputs / order as above.
  * `qsel` (nq) lists the query rows to recompute; their output rows are overwritten and flags set to 2. */

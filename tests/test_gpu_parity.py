@@ -265,6 +265,47 @@ def test_knn_exact_fallback_kernel(hw, knn_path):
         assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
 
 
+def test_knn_exact_device_pass(hw, knn_path):
+    """the on-device exhaustive pass (hwer_knn_exact_device) fixes up to 8 uncertified queries per search without a host
+    round trip; the host-driven pass takes the rest.  12 queries sit on an 800-fold duplicated row."""
+    d, N, k = 32, 3000, 20
+    X = unit_rows_f32(56, N, d)
+    X[100:900] = X[50]
+    users = np.concatenate([np.repeat(X[[50]], 12, axis=0), X[[51, 52, 53]]])
+    B = len(users)
+    V = np.concatenate([users, X]).astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags[:12] == 2).all() and (flags[12:] == 1).all(), flags
+    for u in range(B):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+    # the device pass alone (no host fallback): exactly 8 of the 12 get fixed, the rest stay flagged 0 and are counted
+    import torch
+    from hwer import native
+    lib = native.lib()
+    Q64, Q32, a = ix.build_queries(np.arange(B))
+    tt = ix.tables["item"]
+    o_i = torch.empty((B, k), dtype=torch.int64, device=ix.device)
+    o_s = torch.empty((B, k), dtype=torch.float64, device=ix.device)
+    o_d = torch.empty((B, k), dtype=torch.float64, device=ix.device)
+    o_f = torch.empty(B, dtype=torch.int32, device=ix.device)
+    ws = torch.empty(lib.hwer_knn_workspace_bytes(B, N, d, k), dtype=torch.uint8, device=ix.device)
+    wse = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(N, k), dtype=torch.uint8, device=ix.device)
+    missed = torch.zeros(1, dtype=torch.int32, device=ix.device)
+    P, S = native.ptr, native.stream_ptr
+    for rep in range(2):   # twice: the header (list, tickets) must be reusable
+        native.check(lib.hwer_knn_search_f32(P(tt.X), P(tt.hnorm), N, d, ix.ldx, P(Q32), P(Q64), P(ix.V), ix.ldv, P(a), B, k, 0, 1,
+                                             P(tt.rows_dev), 0, tt.hnorm_max, P(o_i), P(o_s), P(o_d), P(o_f), P(ws), ws.numel(), S()), "search")
+        assert int((o_f == 0).sum()) == 12
+        native.check(lib.hwer_knn_exact_device(P(tt.X), N, d, ix.ldx, P(Q64), P(ix.V), ix.ldv, P(a), k, 0, 1, P(tt.rows_dev), 0,
+                                               P(o_i), P(o_s), P(o_d), P(o_f), P(ws), P(missed), P(wse), wse.numel(), S()), "exact_device")
+        f = o_f.cpu().numpy()
+        assert int((f == 2).sum()) == 8 and int((f == 0).sum()) == 4 and int(missed.item()) == 4 * (rep + 1)
+        fixed = np.nonzero(f == 2)[0]
+        assert np.array_equal(o_i.cpu().numpy()[fixed], idx[fixed]) and np.array_equal(o_s.cpu().numpy()[fixed], score[fixed])
+
+
 def test_multiknn_query_arbitrary_vector(golden, hw):
     from hwer import MultiKNN, Node
     from hwer.recommendation_base import BiMap
