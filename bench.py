@@ -136,6 +136,8 @@ def main():
     hnorm_max = 0.5 * (1.0 + 1e-4) ** 2
     id_base = U + rank * I          # global row id of this rank's first item (users first, then shards in rank order)
     arith = 0                       # float64 score arithmetic (ContentRecommendation flavour)
+    # find_closest_neighbours returns (node, score): distances are an output only where the shards' results are merged
+    want_dist = world > 1
 
     def step():
         # blend + L2-normalise with the unit-norm audit of the output rows fused into the same pass
@@ -148,7 +150,7 @@ def main():
             b1 = min(U, b0 + CH)
             native.check(lib.hwer_knn_search_f32(P(X), P(hnorm), I, d, ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(V), ldv,
                                                  P(anchors[b0:b1]), b1 - b0, K, arith, 1 if world == 1 else 0, None, id_base,
-                                                 hnorm_max, P(o_idx[b0:b1]), P(o_score[b0:b1]), P(o_dist2[b0:b1]),
+                                                 hnorm_max, P(o_idx[b0:b1]), P(o_score[b0:b1]), P(o_dist2[b0:b1]) if want_dist else None,
                                                  P(o_flags[b0:b1]), P(ws), ws.numel(), S()), "knn_search")
             # queries the screen could not certify (rare: near-ties at the cut, or a sample-scaled threshold that was too
             # tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the device (no host round trip):
@@ -156,7 +158,7 @@ def main():
             # (checked after the timed region: must stay 0).
             native.check(lib.hwer_knn_exact_device(P(X), I, d, ldx, P(Q64[b0:b1]), P(V), ldv, P(anchors[b0:b1]), K, arith,
                                                    1 if world == 1 else 0, None, id_base, P(o_idx[b0:b1]), P(o_score[b0:b1]),
-                                                   P(o_dist2[b0:b1]), P(o_flags[b0:b1]), P(ws), P(missed), P(ws_exact), ws_exact.numel(), S()),
+                                                   P(o_dist2[b0:b1]) if want_dist else None, P(o_flags[b0:b1]), P(ws), P(missed), P(ws_exact), ws_exact.numel(), S()),
                          "knn_exact_device")
         if world > 1:
             g = all_gather_results(o_idx, o_score, o_dist2)

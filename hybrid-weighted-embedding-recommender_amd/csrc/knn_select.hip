@@ -121,6 +121,7 @@ __device__ __forceinline__ T np_dot(FA a_at, FX x_at, int j0, int n) {
 // ---------------------------------------------------------------------------------------------------
 struct EmitArgs {
     const float* X;
+    uint32_t item_max;   // n_items - 1: item ids are clamped before they address X (a logic error must never fault)
     int64_t ldx;
     int d;
     const double* Q64;
@@ -188,7 +189,12 @@ __device__ __forceinline__ void wave_bitonic_asc(Ent* a, int n2) {
 //   score: numpy pairwise summation of the rounded products (8 chains per <=128-element leaf, then the tail)
 // then: the k smallest (dist2, item), ordered by (score desc, distance rank) [= the reference's stable sort by score
 // of the distance-ordered list] or left in (dist2, item) order when sort_by_score == 0.
-__device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int flag) {
+// Lazy distances: when the caller does not ask for distances (out_dist2 == NULL, score order, score_mode 0/1), only the
+// first n_b candidates - the BOUNDARY of the float32 screen, whose membership in the top-k is undecided - get their
+// exact float64 distance; the others are provably members (their screen key clears the k-th key by more than the
+// float32 error bound) and only need their score.  Distances are 60 % of the float64 work of a full re-rank.  Should two
+// members tie exactly in score with an unknown distance between them, the query is redone with all distances (rare).
+__device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int n_b, int flag) {
     const int d = a.d, lane = threadIdx.x & 63;
     double* t_d2 = reinterpret_cast<double*>(lds);
     double* t_sc = t_d2 + kp;
@@ -216,12 +222,16 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
     const int n_groups8 = lim / 8;
     const int mode = a.score_mode;
     const int n_chunks = (d + RR_CW - 1) / RR_CW;
+    bool lazy = a.out_dist2 == nullptr && a.sort_by_score && mode != 2 && n_b < n_r;
 
 #pragma unroll 1
+  for (int attempt = 0; attempt < 2; ++attempt) {
+#pragma unroll 1
     for (int g0 = 0; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += 64) {   // wave-uniform rounds of 64 candidates
+        const bool need_d2 = !lazy || g0 < n_b;   // wave-uniform
         const int ci = g0 + lane;
         const bool live = ci < n_r;
-        const uint32_t it = cand[live ? ci : g0];
+        const uint32_t it = min(cand[live ? ci : g0], a.item_max);
         double acc = 0.0;
         double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0, sA = 0.0;
         float f0 = 0, f1 = 0, f2 = 0, f3 = 0, f4 = 0, f5 = 0, f6 = 0, f7 = 0, fA = 0.f;
@@ -230,10 +240,10 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         // transposed through wave-private LDS (row stride 80 B: conflict-free ds_read_b128).
         // (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop in scratch)
         const int srow = lane >> 2, scol = 4 * (lane & 3);
-        const float* src0 = a.X + int64_t(cand[min(g0 + 0 + srow, n_r - 1)]) * a.ldx + scol;
-        const float* src1 = a.X + int64_t(cand[min(g0 + 16 + srow, n_r - 1)]) * a.ldx + scol;
-        const float* src2 = a.X + int64_t(cand[min(g0 + 32 + srow, n_r - 1)]) * a.ldx + scol;
-        const float* src3 = a.X + int64_t(cand[min(g0 + 48 + srow, n_r - 1)]) * a.ldx + scol;
+        const float* src0 = a.X + int64_t(min(cand[min(g0 + 0 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
+        const float* src1 = a.X + int64_t(min(cand[min(g0 + 16 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
+        const float* src2 = a.X + int64_t(min(cand[min(g0 + 32 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
+        const float* src3 = a.X + int64_t(min(cand[min(g0 + 48 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
         float* dst = stage + srow * RR_RS + scol;
         // software pipeline: the gathers of chunk c + 1 are in flight while chunk c is reduced in float64
         float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
@@ -260,7 +270,8 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
             }
             wave_lds_sync();
             const int j0 = RR_CW * c;
-            if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
+            if (!need_d2) {
+            } else if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
 #pragma unroll
                 for (int t = 0; t < RR_CW; ++t) {
                     const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
@@ -321,7 +332,7 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
             sco = (-1.0 * sqrt(acc) + 2.0) / 2.0;  // hwer/gcn_ncf.py:381
         }
         if (live) {
-            t_d2[ci] = acc;
+            t_d2[ci] = need_d2 ? acc : -1.0;   // -1: distance not computed (a provable member)
             t_sc[ci] = sco;
         }
     }
@@ -331,13 +342,21 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
     // (2) by (score desc, position): the reference's stable sort by score.  Sort keys are 64-bit:
     //     float32 rounding of the exact key (monotone) << 32 | payload, finished exactly where roundings collide.
     const int k = a.k;
-    auto tail = [&](auto ne_tag) {
+    auto tail = [&](auto ne_tag) -> bool {
         constexpr int NE = decltype(ne_tag)::value;
         uint64_t key[NE];
+        bool need_full = false;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int i = 64 * j + lane;   // any initial placement will do
-            key[j] = i < n_r ? (uint64_t(f32_orderable(float(t_d2[i]))) << 32) | uint64_t(uint32_t(i)) : ~0ull;
+            key[j] = ~0ull;
+            if (i < n_r) {
+                const double d2 = t_d2[i];
+                // unknown distances (provable members) sort first, with distinct approximations (their slot: below the
+                // orderable bits of any non-negative float) so that they never look like a tie
+                const uint32_t ap = d2 < 0.0 ? uint32_t(i) : f32_orderable(float(d2));
+                key[j] = (uint64_t(ap) << 32) | uint64_t(uint32_t(i));
+            }
         }
         if (!(a.debug_skip & 2)) {
             wave_sort_u64<NE>(key);
@@ -360,26 +379,36 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
                 }
                 wave_sort_u64<NE>(key);
                 wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
-                    const uint64_t ax = ~f64_orderable(t_sc[uint32_t(x) & 0xFFFFu]), ay = ~f64_orderable(t_sc[uint32_t(y) & 0xFFFFu]);
-                    return ax < ay || (ax == ay && (uint32_t(x) >> 16) < (uint32_t(y) >> 16));
+                    const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
+                    const uint64_t ax = ~f64_orderable(t_sc[sx]), ay = ~f64_orderable(t_sc[sy]);
+                    if (ax != ay) return ax < ay;
+                    if (lazy && (t_d2[sx] < 0.0 || t_d2[sy] < 0.0)) need_full = true;   // exact score tie, distance order unknown
+                    return (uint32_t(x) >> 16) < (uint32_t(y) >> 16);
                 });
             }
         }
+        if (lazy && __any(need_full)) return true;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int p = NE * lane + j;
             if (p < k) {
                 const uint32_t slot = uint32_t(key[j]) & 0xFFFFu;
-                const uint32_t it = cand[slot];
+                const uint32_t it = min(cand[slot], a.item_max);
                 a.out_idx[b * k + p] = a.row_ids ? a.row_ids[it] : a.id_base + int64_t(it);
                 a.out_score[b * k + p] = t_sc[slot];
-                a.out_dist2[b * k + p] = t_d2[slot];
+                if (a.out_dist2) a.out_dist2[b * k + p] = t_d2[slot];
             }
         }
+        return false;
     };
-    if (n_r <= 128) tail(std::integral_constant<int, 2>{});
-    else if (n_r <= 256) tail(std::integral_constant<int, 4>{});
-    else tail(std::integral_constant<int, 8>{});
+    bool redo;
+    if (n_r <= 128) redo = tail(std::integral_constant<int, 2>{});
+    else if (n_r <= 256) redo = tail(std::integral_constant<int, 4>{});
+    else redo = tail(std::integral_constant<int, 8>{});
+    if (!redo) break;
+    lazy = false;   // second attempt: every distance
+    wave_lds_sync();
+  }
     if (lane == 0) {
         a.out_flags[b] = flag;
         if (flag == 0 && a.hdr) {   // rare: hand the query to the exhaustive pass (hwer_knn_exact_device / _f64)
@@ -445,19 +474,29 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
     }
-    const float thr = t_k - 2.0f * e32_bound(d, Q2, a.hnorm_max);
-    int n_r = 0;
+    const float e32 = e32_bound(d, Q2, a.hnorm_max);
+    const float thr = t_k - 2.0f * e32;
+    // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) <= k - such an item cannot be beaten by k others
+    float s_sure = INFINITY;
+    if (a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2 &&
+        wave_count_ge<RR_MAXR>(sv, t_k + 2.0f * e32) <= k)
+        s_sure = t_k + 4.0f * e32;
+    int n_r = 0, n_b = 0;
 #pragma unroll
-    for (int i = 0; i < RR_MAXR; ++i) {
-        const bool in = sv[i] >= thr;
-        const uint64_t bal = __ballot(in);
-        if (in) cand_item[n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = key_item(key[i]);
-        n_r += __builtin_popcountll(bal);
+    for (int pass = 0; pass < 2; ++pass) {   // boundary candidates first, then the sure ones
+#pragma unroll
+        for (int i = 0; i < RR_MAXR; ++i) {
+            const bool in = pass == 0 ? (sv[i] >= thr && !(sv[i] >= s_sure)) : (sv[i] >= s_sure);
+            const uint64_t bal = __ballot(in);
+            if (in) cand_item[n_r + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = key_item(key[i]);
+            n_r += __builtin_popcountll(bal);
+        }
+        if (pass == 0) n_b = n_r;
     }
     wave_lds_sync();
     const bool exhaustive = M < a.kprime && !underfull;   // no stream ever compacted: the candidates are ALL the items
     const int flag = (!underfull && (exhaustive || n_r < M)) ? 1 : 0;
-    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, flag);
+    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, n_b, flag);
 }
 
 
@@ -530,56 +569,74 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
     }
-    const float thr = t_k - 2.0f * e32_bound(d, Q2, a.hnorm_max);
-    // re-rank set = keys >= thr (a few per lane): per-lane pass masks (2 VALU per key: the sign of key - thr is funnel-
-    // shifted into the mask), one wave scan for the write offsets, then every lane pops its set bits.
+    const float e32 = e32_bound(d, Q2, a.hnorm_max);
+    const float thr = t_k - 2.0f * e32;
+    // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) <= k - such an item cannot be beaten by k others
+    float s_sure = INFINITY;
+    if (a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2 && count_ge(t_k + 2.0f * e32) <= k)
+        s_sure = t_k + 4.0f * e32;
+    // re-rank set = keys >= thr (a few per lane): per-lane pass masks (2 VALU per key and class: the sign of key - thr is
+    // funnel-shifted into the mask), wave scans for the write offsets, then every lane pops its set bits.  The BOUNDARY
+    // candidates (thr <= key < s) go first, the sure ones after them.
     constexpr int NW = (4 * MAXV + 31) / 32;
-    uint32_t fail[NW];   // bit (31 - (e & 31)) of word e / 32 <-> key e = 4 m + c of this lane; set = below thr
+    constexpr int KW = 4 * MAXV < 32 ? 4 * MAXV : 32;   // keys per mask word (MAXV = 4: one half-filled word)
+    constexpr uint32_t WMASK = KW == 32 ? 0xFFFFFFFFu : ((1u << KW) - 1u);
+    uint32_t fail[NW], fail_s[NW];   // bit (KW - 1 - (e % KW)) of word e / KW <-> key e = 4 m + c of this lane; set = below the bound
 #pragma unroll
-    for (int w = 0; w < NW; ++w) fail[w] = 0u;
+    for (int w = 0; w < NW; ++w) fail[w] = fail_s[w] = 0u;
 #pragma unroll
     for (int m = 0; m < MAXV; ++m) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int e = 4 * m + c;
-            // key - thr has its sign bit set exactly when key < thr (-inf keys included; key == thr gives +0)
+            // key - bound has its sign bit set exactly when key < bound (-inf keys included; key == bound gives +0)
             fail[e / 32] = __builtin_amdgcn_alignbit(fail[e / 32], __float_as_uint(kv[m][c] - thr), 31);
+            fail_s[e / 32] = __builtin_amdgcn_alignbit(fail_s[e / 32], __float_as_uint(kv[m][c] - s_sure), 31);
         }
     }
-    int mine = 0;
-    uint32_t pass[NW];
+    int mine_b = 0, mine_s = 0;
+    uint32_t pass_b[NW], pass_s[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-        pass[w] = ~fail[w];
-        mine += __builtin_popcount(pass[w]);
+        pass_s[w] = ~fail_s[w] & WMASK;
+        pass_b[w] = ~fail[w] & fail_s[w] & WMASK;
+        mine_b += __builtin_popcount(pass_b[w]);
+        mine_s += __builtin_popcount(pass_s[w]);
     }
-    int incl = mine;   // inclusive scan over lanes
+    int incl = (mine_b << 16) | mine_s;   // inclusive scan over lanes of both counts at once (each < 2^15)
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const int t = __shfl_up(incl, off, kWave);
         if (lane >= off) incl += t;
     }
-    int n_r = __shfl(incl, 63, kWave);
+    const int tot = __shfl(incl, 63, kWave);
+    int n_b = tot >> 16;
+    int n_r = n_b + (tot & 0xFFFF);
     bool overflow = false;
-    int pos = incl - mine;
+    int pos_b = (incl >> 16) - mine_b, pos_s = n_b + (incl & 0xFFFF) - mine_s;
+    auto pop = [&](uint32_t (&pm)[NW], int& pos) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        while (__any(pass[w] != 0u)) {
-            if (pass[w] != 0u) {
-                const int bit = __builtin_ctz(pass[w]);
-                pass[w] &= pass[w] - 1u;
-                const int e = 32 * w + 31 - bit;
-                if (pos < kp) cand_item[pos] = uint32_t(4 * (lane + 64 * (e >> 2)) + (e & 3));
-                ++pos;
+        for (int w = 0; w < NW; ++w) {
+            while (__any(pm[w] != 0u)) {
+                if (pm[w] != 0u) {
+                    const int bit = __builtin_ctz(pm[w]);
+                    pm[w] &= pm[w] - 1u;
+                    const int e = KW * w + KW - 1 - bit;
+                    if (pos < kp) cand_item[pos] = uint32_t(4 * (lane + 64 * (e >> 2)) + (e & 3));
+                    ++pos;
+                }
             }
         }
-    }
+    };
+    pop(pass_b, pos_b);
+    pop(pass_s, pos_s);
     if (n_r > kp) {   // more near-ties than the re-rank capacity: not certifiable here
         overflow = true;
         n_r = kp;
+        n_b = min(n_b, kp);
     }
     wave_lds_sync();
-    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, overflow ? 0 : 1);
+    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, n_b, overflow ? 0 : 1);
 }
 
 // pre-reduction when a query has more than MAX_LISTS_DIRECT lists: groups of 8 lists -> one list of K' keys
@@ -687,7 +744,7 @@ __global__ __launch_bounds__(64) void exact_emit_kernel(const Ent* __restrict__ 
     n_c = min(n_c, a.k);
     for (int i = threadIdx.x; i < n_c; i += 64) c_item[i] = uint32_t(sel[i].lo);
     wave_lds_sync();
-    wave_rerank_emit(a, b, smem_raw, kp, n_c, 2);
+    wave_rerank_emit(a, b, smem_raw, kp, n_c, n_c, 2);
 }
 
 
@@ -777,7 +834,7 @@ __global__ __launch_bounds__(256) void exact_device_kernel(const ExactDevArgs a)
     uint32_t* c_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);   // `cand` of wave_rerank_emit
     for (int i = tid; i < k; i += 256) c_item[i] = uint32_t(ent[i].lo);
     __syncthreads();
-    if (tid < 64) wave_rerank_emit(a.emit, b, lds_emit, kp, k, 2);
+    if (tid < 64) wave_rerank_emit(a.emit, b, lds_emit, kp, k, k, 2);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -971,8 +1028,10 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
                         double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                         size_t workspace_bytes, void* stream) {
     if (B == 0) return HWER_OK;
-    if (!X || !hnorm || !Q32 || !Q64 || !out_idx || !out_score || !out_dist2 || !out_flags || !workspace)
+    if (!X || !hnorm || !Q32 || !Q64 || !out_idx || !out_score || !out_flags || !workspace)
         return fail(HWER_EINVAL, "knn_search: null pointer");
+    if (!out_dist2 && (score_mode == 2 || !sort_by_score))
+        return fail(HWER_EINVAL, "knn_search: out_dist2 may only be NULL with score_mode 0/1 and sort_by_score");
     const int dp = hwer_knn_padded_dim(d);
     if (dp < 0) return fail(HWER_EINVAL, "knn_search: d=%d unsupported (1..256)", d);
     if (ldx != dp) return fail(HWER_EINVAL, "knn_search: ldx must be hwer_knn_padded_dim(d)=%d (got %lld)", dp, (long long)ldx);
@@ -1007,7 +1066,7 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         da.B = B;
         da.kp = plan.kprime;
         da.hnorm_max = hnorm_max;
-        da.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
+        da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                            out_idx, out_score, out_dist2, out_flags, hdr};
         const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
         static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
@@ -1047,7 +1106,7 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     sa.kprime = plan.kprime;
     sa.kcap = plan.kprime;   // the screen's final compaction is exact: a list holds at most K' keys
     sa.hnorm_max = hnorm_max;
-    sa.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
+    sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, hdr};
     const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel), lds, "knn_select"))) return rc;
@@ -1069,7 +1128,7 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
                        double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes,
                        void* stream) {
     if (nq == 0) return HWER_OK;
-    if (!X || !Q64 || !qsel_host || !out_idx || !out_score || !out_dist2 || !out_flags || !workspace)
+    if (!X || !Q64 || !qsel_host || !out_idx || !out_score || !out_flags || !workspace)
         return fail(HWER_EINVAL, "knn_exact: null pointer");
     if (d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16)
         return fail(HWER_EINVAL, "knn_exact: need 1 <= d <= 256 and ldx >= roundup16(d) (rows are read in 16-column steps)");
@@ -1103,7 +1162,7 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
             n = chunks * keep;
             std::swap(in, out);
         } while (n > keep);
-        EmitArgs ea{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
+        EmitArgs ea{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
                     out_idx, out_score, out_dist2, out_flags, nullptr};
         const size_t lds = wave_lds_bytes(d, ((k + 63) / 64) * 64);
         hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(64), lds, st, in, int(n), b, ea);
@@ -1122,7 +1181,7 @@ int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, c
                           const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
                           double* out_dist2, int32_t* out_flags, void* knn_workspace, int32_t* missed_accum,
                           void* workspace, size_t workspace_bytes, void* stream) {
-    if (!X || !Q64 || !out_idx || !out_score || !out_dist2 || !out_flags || !knn_workspace || !workspace)
+    if (!X || !Q64 || !out_idx || !out_score || !out_flags || !knn_workspace || !workspace)
         return fail(HWER_EINVAL, "knn_exact_device: null pointer");
     if (d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16)
         return fail(HWER_EINVAL, "knn_exact_device: need 1 <= d <= 256 and ldx >= roundup16(d)");
@@ -1141,7 +1200,7 @@ int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, c
     ea.cand = reinterpret_cast<Ent*>(workspace);
     ea.n_chunks = int(cdiv64(n_items, EX_CHUNK));
     ea.missed_accum = missed_accum;
-    ea.emit = EmitArgs{X, ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
+    ea.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, nullptr};
     const size_t lds = size_t(EX_CHUNK) * sizeof(Ent) + wave_lds_bytes(d, ((k + 63) / 64) * 64);
     int rc;

@@ -180,9 +180,10 @@ class DeviceIndex:
         return self._ws_exact
 
     def search_queries(self, node_type: str, Q64, Q32, k: int, anchors_dev=None, score_mode: Optional[int] = None,
-                       sort_by_score: bool = True, id_base: Optional[int] = None):
+                       sort_by_score: bool = True, id_base: Optional[int] = None, want_dist: bool = True):
         """Exact k nearest rows of `node_type` for B query vectors already on the device.
-        -> torch tensors (idx (B,k) int64 global ids, score (B,k) f64, dist2 (B,k) f64, flags (B) int32)."""
+        -> torch tensors (idx (B,k) int64 global ids, score (B,k) f64, dist2 (B,k) f64 or None, flags (B) int32).
+        want_dist=False (score order, base scoring only) skips the distances the result does not depend on."""
         torch = _torch()
         tt = self.tables[node_type]
         B = Q64.shape[0]
@@ -192,7 +193,9 @@ class DeviceIndex:
             score_mode = self.arith
         idx = torch.empty((B, k), dtype=torch.int64, device=self.device)
         score = torch.empty((B, k), dtype=torch.float64, device=self.device)
-        dist2 = torch.empty((B, k), dtype=torch.float64, device=self.device)
+        if not want_dist and (score_mode == 2 or not sort_by_score):
+            want_dist = True
+        dist2 = torch.empty((B, k), dtype=torch.float64, device=self.device) if want_dist else None
         flags = torch.empty(B, dtype=torch.int32, device=self.device)
         use_rows = id_base is None
         for b0 in range(0, B, self.QUERY_CHUNK):
@@ -208,7 +211,7 @@ class DeviceIndex:
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,
                 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
-                tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]),
+                tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None,
                 native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), native.stream_ptr()), "knn_search")
             # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
             # to 8 per call; anything beyond that is picked up by the host-driven pass below
@@ -217,7 +220,7 @@ class DeviceIndex:
                 native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64[b0:b1]), native.ptr(self.V) if score_mode != 2 else None,
                 self.ldv, native.ptr(a_sub), k, score_mode, 1 if sort_by_score else 0,
                 native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), native.ptr(idx[b0:b1]),
-                native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]), native.ptr(flags[b0:b1]), native.ptr(ws), None,
+                native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None, native.ptr(flags[b0:b1]), native.ptr(ws), None,
                 native.ptr(wse), wse.numel(), native.stream_ptr()), "knn_exact_device")
         n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
         native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr()), "count_uncertified")
@@ -238,17 +241,17 @@ class DeviceIndex:
             native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64), native.ptr(self.V) if score_mode != 2 else None,
             self.ldv, native.ptr(anchors_dev), qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), k, score_mode,
             1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
-            native.ptr(idx), native.ptr(score), native.ptr(dist2), native.ptr(flags), native.ptr(ws), ws.numel(),
+            native.ptr(idx), native.ptr(score), native.ptr(dist2) if dist2 is not None else None, native.ptr(flags), native.ptr(ws), ws.numel(),
             native.stream_ptr()), "knn_exact")
 
     def search(self, node_type: str, anchors: np.ndarray, k: int = 200, positive=None, negative=None,
-               scoring: str = "base", sort_by_score: bool = True):
+               scoring: str = "base", sort_by_score: bool = True, want_dist: bool = True):
         """Batched find_closest_neighbours on resolved indices.
-        -> numpy (idx (B,k) int64, score (B,k) in the reference's dtype, dist (B,k) float64, flags (B))."""
+        -> numpy (idx (B,k) int64, score (B,k) in the reference's dtype, dist (B,k) float64 or None, flags (B))."""
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
         mode = 2 if scoring == "gcn" else self.arith
-        idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score)
+        idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist)
         sc = score.cpu().numpy()
         if mode == 1:
             sc = sc.astype(np.float32)  # exact: the kernel widened float32 values
-        return idx.cpu().numpy(), sc, np.sqrt(dist2.cpu().numpy()), flags.cpu().numpy()
+        return idx.cpu().numpy(), sc, (np.sqrt(dist2.cpu().numpy()) if dist2 is not None else None), flags.cpu().numpy()

@@ -252,7 +252,10 @@ class RecommendationBase(metaclass=abc.ABCMeta):
             raise NodeNotFoundException("Node = %s, was not provided in training" % missing)
         pos = None if positive is None else [_resolve(self.nodes_to_idx, p or []) for p in positive]
         neg = None if negative is None else [_resolve(self.nodes_to_idx, n or []) for n in negative]
-        idx, score, _, _ = self.knn.index.search(node_type, a, k=k, positive=pos, negative=neg, scoring=self.scoring)
+        # the result is (node, score): distances are not an output of find_closest_neighbours (the kernel then only
+        # computes the ones the membership / order of the result depends on)
+        idx, score, _, _ = self.knn.index.search(node_type, a, k=k, positive=pos, negative=neg, scoring=self.scoring,
+                                                 want_dist=False)
         return idx, score
 
     def find_closest_neighbours(self, node_type: str, anchor: Node, positive: List[Node] = None,

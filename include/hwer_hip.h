@@ -140,7 +140,10 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
  *              (pass the whole vector table as A32 and the anchors' global ids as a_idx)
  *   row_ids  : (n_items) local->global id map or NULL (then id = id_base + local)
  *   hnorm_max: max(hnorm) over the table (enters the float32 error bound of the certificate)
- *   outputs  : out_idx (B,k) int64, out_score (B,k) double, out_dist2 (B,k) double, out_flags (B) int32
+ *   outputs  : out_idx (B,k) int64, out_score (B,k) double, out_dist2 (B,k) double, out_flags (B) int32.
+ *              out_dist2 may be NULL with score_mode 0/1 and sort_by_score (find_closest_neighbours only returns scores):
+ *              then only the candidates whose membership the float32 screen leaves undecided get an exact distance
+ *              (results are identical; the re-rank does ~40 % of the float64 work).
  * ------------------------------------------------------------------------------------------------- */
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k);
 int hwer_knn_max_k(void);

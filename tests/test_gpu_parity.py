@@ -228,13 +228,49 @@ def test_knn_random_vs_oracle(hw, knn_path, d, N, B, k):
     for arith, V in ((0, V32.astype(np.float64)), (1, V32)):
         ix = make_index(V, U, N, arith)
         idx, score, dist, flags = ix.search("item", np.arange(U), k=k)
-        assert (flags > 0).all()
+        assert (flags == 1).all()   # random rows: every query must be CERTIFIED by the screen (2 = exhaustive pass)
         for u in range(0, U, max(1, U // 40)):
             o_idx, o_score, o_dist = orc.find_closest(V, rows, u, k=k)
             assert np.array_equal(idx[u], o_idx), (d, arith, u)
             assert np.array_equal(score[u], o_score)
             assert np.array_equal(dist[u], o_dist)
         assert (np.diff(score, axis=1) <= 0).all()
+
+
+@pytest.mark.parametrize("d,N,B,k", [(64, 5000, 300, 200), (128, 9000, 257, 200), (32, 700, 33, 392), (128, 150, 40, 150), (66, 2500, 70, 33)])
+def test_knn_without_distances_matches(hw, knn_path, d, N, B, k):
+    """want_dist=False (find_closest_neighbours' own output: ids + scores): the kernel computes exact distances only for the
+    candidates the float32 screen leaves undecided - indices and scores must not change."""
+    U = B
+    V32 = np.concatenate([unit_rows_f32(15 + d, U, d), unit_rows_f32(16 + d, N, d)])
+    rows = np.arange(U, U + N)
+    for arith, V in ((0, V32.astype(np.float64)), (1, V32)):
+        ix = make_index(V, U, N, arith)
+        idx, score, dist, flags = ix.search("item", np.arange(U), k=k, want_dist=False)
+        assert dist is None and (flags == 1).all()
+        idx_f, score_f, _, _ = ix.search("item", np.arange(U), k=k)
+        assert np.array_equal(idx, idx_f) and np.array_equal(score, score_f)
+        for u in range(0, U, max(1, U // 25)):
+            o_idx, o_score, _ = orc.find_closest(V, rows, u, k=k)
+            assert np.array_equal(idx[u], o_idx), (d, arith, u)
+            assert np.array_equal(score[u], o_score)
+
+
+def test_knn_without_distances_score_ties(hw, knn_path):
+    """exact score ties between provable members need their distance order: the lazy path must detect them and redo
+    the query with all distances.  Duplicate item rows give exact ties in both score and distance (order = row id)."""
+    d, N, B, k = 32, 2000, 16, 50
+    X = unit_rows_f32(77, N, d)
+    X[1000:1400] = X[:400]            # every item in the first 400 has a twin 1000 rows later
+    users = unit_rows_f32(78, B, d)
+    for arith, V in ((0, np.concatenate([users, X]).astype(np.float64)), (1, np.concatenate([users, X]))):
+        ix = make_index(V, B, N, arith)
+        idx, score, dist, flags = ix.search("item", np.arange(B), k=k, want_dist=False)
+        idx_f, score_f, _, _ = ix.search("item", np.arange(B), k=k)
+        assert np.array_equal(idx, idx_f) and np.array_equal(score, score_f)
+        for u in range(B):
+            o_idx, o_score, _ = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+            assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score)
 
 
 def test_knn_multi_split_lists(hw):
