@@ -101,21 +101,26 @@ __device__ __forceinline__ int wave_count_ge(const float (&v)[NV], float t) {
     for (int i = 0; i < NV; ++i) c += __builtin_popcountll(__ballot(v[i] >= t));
     return c;
 }
-// CountGe: callable float -> wave-uniform count of keys >= t
+// CountGe: callable float -> wave-uniform count of keys >= t.  `hi_out` (nullable): a key bound with count(>= hi) < rank,
+// tightened until count(>= hi) >= rank - slack when `tighten_hi` (callers use it to tell provable members apart).
 template <class CountGe>
-__device__ __forceinline__ float wave_find_rank_fn(CountGe count_ge, float vmin, float vmax, int rank, int slack, int& count_ge_lo) {
-    float lo = vmin, hi = vmax;   // invariants: count(>= lo) >= rank;  count(>= hi) = c_hi
+__device__ __forceinline__ float wave_find_rank_fn(CountGe count_ge, float vmin, float vmax, int rank, int slack, int& count_ge_lo,
+                                                  float* hi_out = nullptr, bool tighten_hi = false) {
+    float lo = vmin, hi = vmax;   // invariants: count(>= lo) >= rank;  count(>= hi) = c_hi < rank (after the first test)
     int c_lo = count_ge(lo), c_hi = count_ge(hi);
+    if (hi_out) *hi_out = INFINITY;
     if (c_hi >= rank) {           // the rank-th largest key IS the maximum (ties at the top)
         count_ge_lo = c_hi;
         return hi;
     }
     const float target = float(rank) + 0.5f * float(slack);
-    for (int iter = 0; iter < 96 && c_lo > rank + slack; ++iter) {
+    for (int iter = 0; iter < 96 && (c_lo > rank + slack || (tighten_hi && c_hi < rank - slack)); ++iter) {
         float f = 0.5f;
         if (iter % 3 != 2) {
+            // aim at the side that is still loose: just above the rank for lo, just below it for hi
+            const float tg = c_lo > rank + slack ? target : float(rank) - 0.5f * float(slack);
             const float l0 = __logf(float(c_lo)), l1 = __logf(float(c_hi) + 0.5f);
-            f = (l0 - __logf(target)) / (l0 - l1);
+            f = (l0 - __logf(tg)) / (l0 - l1);
             f = fminf(fmaxf(f, 0.03f), 0.97f);
         }
         float mid = lo + f * (hi - lo);
@@ -127,10 +132,12 @@ __device__ __forceinline__ float wave_find_rank_fn(CountGe count_ge, float vmin,
         if (c >= rank) { lo = mid; c_lo = c; } else { hi = mid; c_hi = c; }
     }
     count_ge_lo = c_lo;
+    if (hi_out) *hi_out = hi;
     return lo;
 }
 template <int NV>
-__device__ __forceinline__ float wave_find_rank(const float (&v)[NV], int rank, int slack, int& count_ge_lo) {
+__device__ __forceinline__ float wave_find_rank(const float (&v)[NV], int rank, int slack, int& count_ge_lo, float* hi_out = nullptr,
+                                               bool tighten_hi = false) {
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -142,7 +149,7 @@ __device__ __forceinline__ float wave_find_rank(const float (&v)[NV], int rank, 
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
-    return wave_find_rank_fn([&](float t) { return wave_count_ge<NV>(v, t); }, vmin, vmax, rank, slack, count_ge_lo);
+    return wave_find_rank_fn([&](float t) { return wave_count_ge<NV>(v, t); }, vmin, vmax, rank, slack, count_ge_lo, hi_out, tighten_hi);
 }
 
 // ---- wave-level sort of NE u64 keys per lane, ascending, in registers ---------------------------------------------

@@ -193,8 +193,9 @@ __device__ __forceinline__ void wave_bitonic_asc(Ent* a, int n2) {
 // first n_b candidates - the BOUNDARY of the float32 screen, whose membership in the top-k is undecided - get their
 // exact float64 distance; the others are provably members (their screen key clears the k-th key by more than the
 // float32 error bound) and only need their score.  Distances are 60 % of the float64 work of a full re-rank.  Should two
-// members tie exactly in score with an unknown distance between them, the query is redone with all distances (rare).
-__device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int n_b, int flag) {
+// members tie exactly in score with an unknown distance between them, the lanes that hold them compute it on the spot.
+template <int MODE>   // score_mode as a compile-time constant: the float64 and float32 score chains never share registers
+__device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int n_b, int flag) {
     const int d = a.d, lane = threadIdx.x & 63;
     double* t_d2 = reinterpret_cast<double*>(lds);
     double* t_sc = t_d2 + kp;
@@ -220,12 +221,10 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
     const int gA = two ? n2 / 8 : -1;          // first 8-group of the second leaf
     const int lim = d - (d & 7);               // elements >= lim form the sequential tail of the last leaf
     const int n_groups8 = lim / 8;
-    const int mode = a.score_mode;
+    constexpr int mode = MODE;
     const int n_chunks = (d + RR_CW - 1) / RR_CW;
-    bool lazy = a.out_dist2 == nullptr && a.sort_by_score && mode != 2 && n_b < n_r;
+    const bool lazy = a.out_dist2 == nullptr && a.sort_by_score && mode != 2 && n_b < n_r;
 
-#pragma unroll 1
-  for (int attempt = 0; attempt < 2; ++attempt) {
 #pragma unroll 1
     for (int g0 = 0; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += 64) {   // wave-uniform rounds of 64 candidates
         const bool need_d2 = !lazy || g0 < n_b;   // wave-uniform
@@ -286,14 +285,14 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
                     }
                 }
             }
-            if (mode != 2) {
+            if constexpr (mode != 2) {
 #pragma unroll
                 for (int gg = 0; gg < RR_CW / 8; ++gg) {
                     const int g8 = (RR_CW / 8) * c + gg;
                     if (g8 < n_groups8) {   // uniform
                         const bool first = g8 == 0 || g8 == gA;
                         const int jj = 8 * g8;
-                        if (mode == 0) {
+                        if constexpr (mode == 0) {
                             const double p0 = __dmul_rn(double(a32[jj + 0]), double(xv[8 * gg + 0])), p1 = __dmul_rn(double(a32[jj + 1]), double(xv[8 * gg + 1]));
                             const double p2 = __dmul_rn(double(a32[jj + 2]), double(xv[8 * gg + 2])), p3 = __dmul_rn(double(a32[jj + 3]), double(xv[8 * gg + 3]));
                             const double p4 = __dmul_rn(double(a32[jj + 4]), double(xv[8 * gg + 4])), p5 = __dmul_rn(double(a32[jj + 5]), double(xv[8 * gg + 5]));
@@ -318,12 +317,12 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
         }
         double sco;
         const float* xr = a.X + int64_t(it) * a.ldx;
-        if (mode == 0) {
+        if constexpr (mode == 0) {
             double res = n_groups8 > 0 ? ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) : 0.0;
             for (int j = lim; j < d; ++j) res = __dadd_rn(res, __dmul_rn(double(a32[j]), double(xr[j])));   // <= 7 tail elements
             if (two) res = sA + res;
             sco = (res + 1.0) / 2.0;
-        } else if (mode == 1) {
+        } else if constexpr (mode == 1) {
             float res = n_groups8 > 0 ? ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7)) : 0.f;
             for (int j = lim; j < d; ++j) res = __fadd_rn(res, __fmul_rn(a32[j], xr[j]));
             if (two) res = fA + res;
@@ -342,10 +341,24 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
     // (2) by (score desc, position): the reference's stable sort by score.  Sort keys are 64-bit:
     //     float32 rounding of the exact key (monotone) << 32 | payload, finished exactly where roundings collide.
     const int k = a.k;
-    auto tail = [&](auto ne_tag) -> bool {
+    // distance of ONE candidate by ONE lane (divergent, rare): exact score ties between members whose distance was not
+    // computed are ordered by (distance, item) like every other tie
+    auto ensure_d2 = [&](uint32_t slot) -> double {
+        double d2 = t_d2[slot];
+        if (d2 < 0.0) {
+            const float* xr = a.X + int64_t(min(cand[slot], a.item_max)) * a.ldx;
+            d2 = 0.0;
+            for (int j = 0; j < d; ++j) {
+                const double tmp = __dsub_rn(q64[j], double(xr[j]));
+                d2 = __dadd_rn(d2, __dmul_rn(tmp, tmp));
+            }
+            t_d2[slot] = d2;
+        }
+        return d2;
+    };
+    auto tail = [&](auto ne_tag) {
         constexpr int NE = decltype(ne_tag)::value;
         uint64_t key[NE];
-        bool need_full = false;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int i = 64 * j + lane;   // any initial placement will do
@@ -382,12 +395,12 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
                     const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
                     const uint64_t ax = ~f64_orderable(t_sc[sx]), ay = ~f64_orderable(t_sc[sy]);
                     if (ax != ay) return ax < ay;
-                    if (lazy && (t_d2[sx] < 0.0 || t_d2[sy] < 0.0)) need_full = true;   // exact score tie, distance order unknown
-                    return (uint32_t(x) >> 16) < (uint32_t(y) >> 16);
+                    if (!lazy) return (uint32_t(x) >> 16) < (uint32_t(y) >> 16);   // position in the distance order
+                    const uint64_t dx = f64_orderable(ensure_d2(sx)), dy = f64_orderable(ensure_d2(sy));
+                    return dx < dy || (dx == dy && cand[sx] < cand[sy]);
                 });
             }
         }
-        if (lazy && __any(need_full)) return true;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int p = NE * lane + j;
@@ -399,22 +412,24 @@ __device__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* ld
                 if (a.out_dist2) a.out_dist2[b * k + p] = t_d2[slot];
             }
         }
-        return false;
     };
-    bool redo;
-    if (n_r <= 128) redo = tail(std::integral_constant<int, 2>{});
-    else if (n_r <= 256) redo = tail(std::integral_constant<int, 4>{});
-    else redo = tail(std::integral_constant<int, 8>{});
-    if (!redo) break;
-    lazy = false;   // second attempt: every distance
-    wave_lds_sync();
-  }
+    if (n_r <= 128) tail(std::integral_constant<int, 2>{});
+    else if (n_r <= 256) tail(std::integral_constant<int, 4>{});
+    else tail(std::integral_constant<int, 8>{});
     if (lane == 0) {
         a.out_flags[b] = flag;
         if (flag == 0 && a.hdr) {   // rare: hand the query to the exhaustive pass (hwer_knn_exact_device / _f64)
             const int p = atomicAdd(&a.hdr->uncert_count, 1);
             if (p < UNCERT_LIST_MAX) a.hdr->uncert_list[p] = int(b);
         }
+    }
+}
+
+__device__ __forceinline__ void wave_rerank_emit(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int n_b, int flag) {
+    switch (a.score_mode) {   // wave-uniform
+        case 0: wave_rerank_emit_t<0>(a, b, lds, kp, n_r, n_b, flag); break;
+        case 1: wave_rerank_emit_t<1>(a, b, lds, kp, n_r, n_b, flag); break;
+        default: wave_rerank_emit_t<2>(a, b, lds, kp, n_r, n_b, flag); break;
     }
 }
 
@@ -435,7 +450,8 @@ struct SelectArgs {
     EmitArgs emit;
 };
 
-__global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs a) {
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void select_rerank_kernel(const SelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = int64_t(blockIdx.x) * 4 + wave;
@@ -462,7 +478,9 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
 #pragma unroll
     for (int i = 0; i < RR_MAXR; ++i) sv[i] = key[i] != 0ull ? key_score(key[i]) : -INFINITY;
     int c_ge;
-    const float t_k = wave_find_rank<RR_MAXR>(sv, k, 12, c_ge);   // <= k-th largest key, <= 12 extra keys above it
+    const bool lazy_ok = a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2;
+    float t_hi;   // count(key32 >= t_hi) < k (and >= k - 12 when lazy_ok)
+    const float t_k = wave_find_rank<RR_MAXR>(sv, k, 12, c_ge, &t_hi, lazy_ok);   // <= k-th largest key, <= 12 extra keys above it
     // ---- re-rank set + certificate (float32 only) ------------------------------------------------------------------
     // Every item has |key32 - key| <= E32.  An item can belong to the true top-k only if key32 >= t_k - 2 E32: those
     // candidates form the re-rank set.  Items that never became candidates have key32 <= min candidate key; if some
@@ -476,11 +494,8 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
     }
     const float e32 = e32_bound(d, Q2, a.hnorm_max);
     const float thr = t_k - 2.0f * e32;
-    // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) <= k - such an item cannot be beaten by k others
-    float s_sure = INFINITY;
-    if (a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2 &&
-        wave_count_ge<RR_MAXR>(sv, t_k + 2.0f * e32) <= k)
-        s_sure = t_k + 4.0f * e32;
+    // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) < k - such an item cannot be beaten by k others
+    const float s_sure = lazy_ok ? t_hi + 2.0f * e32 : INFINITY;
     int n_r = 0, n_b = 0;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {   // boundary candidates first, then the sure ones
@@ -496,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void select_rerank_kernel(const SelectArgs 
     wave_lds_sync();
     const bool exhaustive = M < a.kprime && !underfull;   // no stream ever compacted: the candidates are ALL the items
     const int flag = (!underfull && (exhaustive || n_r < M)) ? 1 : 0;
-    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, n_b, flag);
+    wave_rerank_emit_t<MODE>(a.emit, b, lds_emit, kp, n_r, n_b, flag);
 }
 
 
@@ -514,8 +529,8 @@ struct DenseSelectArgs {
     EmitArgs emit;
 };
 
-template <int MAXV>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys
-__global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectArgs a) {
+template <int MAXV, int MODE>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys; score mode
+__global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(const DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = int64_t(blockIdx.x) * 4 + wave;
@@ -561,7 +576,9 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
         return c;
     };
     int c_lo;
-    const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo);   // <= k-th largest key, at most c_lo - k extra keys above it
+    const bool lazy_ok = a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2;
+    float t_hi;   // count(key32 >= t_hi) < k (and >= k - 12 when lazy_ok)
+    const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo, &t_hi, lazy_ok);   // <= k-th largest key, at most c_lo - k extra keys above it
     double Q2 = 0.0;
     {
         const double* q = a.emit.Q64 + b * d;
@@ -571,10 +588,8 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
     }
     const float e32 = e32_bound(d, Q2, a.hnorm_max);
     const float thr = t_k - 2.0f * e32;
-    // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) <= k - such an item cannot be beaten by k others
-    float s_sure = INFINITY;
-    if (a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2 && count_ge(t_k + 2.0f * e32) <= k)
-        s_sure = t_k + 4.0f * e32;
+    // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) < k - such an item cannot be beaten by k others
+    const float s_sure = lazy_ok ? t_hi + 2.0f * e32 : INFINITY;
     // re-rank set = keys >= thr (a few per lane): per-lane pass masks (2 VALU per key and class: the sign of key - thr is
     // funnel-shifted into the mask), wave scans for the write offsets, then every lane pops its set bits.  The BOUNDARY
     // candidates (thr <= key < s) go first, the sure ones after them.
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(256, 2) void select_dense_kernel(const DenseSelectA
         n_b = min(n_b, kp);
     }
     wave_lds_sync();
-    wave_rerank_emit(a.emit, b, lds_emit, kp, n_r, n_b, overflow ? 0 : 1);
+    wave_rerank_emit_t<MODE>(a.emit, b, lds_emit, kp, n_r, n_b, overflow ? 0 : 1);
 }
 
 // pre-reduction when a query has more than MAX_LISTS_DIRECT lists: groups of 8 lists -> one list of K' keys
@@ -1070,11 +1085,18 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
                            out_idx, out_score, out_dist2, out_flags, hdr};
         const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
         static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
-        auto launch_dense = [&](auto mv) -> int {
-            constexpr int MV = decltype(mv)::value;
-            if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV>), lds, "knn_select_dense")) return e;
-            hipLaunchKernelGGL(select_dense_kernel<MV>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+        auto launch_dense2 = [&](auto mv, auto md) -> int {
+            constexpr int MV = decltype(mv)::value, MD = decltype(md)::value;
+            if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV, MD>), lds, "knn_select_dense")) return e;
+            hipLaunchKernelGGL((select_dense_kernel<MV, MD>), dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
             return HWER_OK;
+        };
+        auto launch_dense = [&](auto mv) -> int {
+            switch (score_mode) {
+                case 0: return launch_dense2(mv, std::integral_constant<int, 0>{});
+                case 1: return launch_dense2(mv, std::integral_constant<int, 1>{});
+                default: return launch_dense2(mv, std::integral_constant<int, 2>{});
+            }
         };
         if (plan.ld_dense <= 256 * 4) rc = launch_dense(std::integral_constant<int, 4>{});
         else if (plan.ld_dense <= 256 * 8) rc = launch_dense(std::integral_constant<int, 8>{});
@@ -1109,8 +1131,18 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, hdr};
     const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
-    if ((rc = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel), lds, "knn_select"))) return rc;
-    hipLaunchKernelGGL(select_rerank_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, sa);
+    auto launch_select = [&](auto md) -> int {
+        constexpr int MD = decltype(md)::value;
+        if (int e = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel<MD>), lds, "knn_select")) return e;
+        hipLaunchKernelGGL(select_rerank_kernel<MD>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, sa);
+        return HWER_OK;
+    };
+    switch (score_mode) {
+        case 0: rc = launch_select(std::integral_constant<int, 0>{}); break;
+        case 1: rc = launch_select(std::integral_constant<int, 1>{}); break;
+        default: rc = launch_select(std::integral_constant<int, 2>{}); break;
+    }
+    if (rc) return rc;
     return check_launch("knn_select");
 }
 
