@@ -53,4 +53,51 @@ constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream);
 
+// LDS-DMA (global -> LDS without a register destination) issued through inline asm: hipcc counts a builtin
+// global_load_lds as a pending LDS write and drains vmcnt(0) before the NEXT ds_read, which would serialise the
+// prefetch with the tile that is being computed.  An asm statement is invisible to that bookkeeping; the kernel waits
+// for it explicitly (s_waitcnt vmcnt(0) right before the tile barrier).  M0 carries the wave-uniform LDS byte
+// address and is saved / restored inside the same statement (it is compiler-reserved).
+// scalar 64-bit base (wave-uniform) + 32-bit per-lane byte offset: keeps the per-lane address state to ONE VGPR
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ void lds_dma4(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)(p)));
+}
+
+// LDS image of an item tile: IB rows of CH = 2*NG 16-byte chunks, UNPADDED (the LDS-DMA writes 1 KiB per
+// wave-instruction linearly), XOR-swizzled so that the ds_read_b128 of the MFMA A fragments (16 lanes = 16
+// different rows, same logical chunk) hits 16 different 16-byte slots of the 256-byte bank row:
+//   physical chunk = logical chunk ^ swz(row)
+template <int CH>
+__device__ __forceinline__ int swz(int row) {
+    if constexpr (CH >= 16) return row & 15;
+    else return (row >> 1) & (CH - 1);   // CH == 8: two 128-byte rows share a bank row
+}
+
+// small-batch path (knn_small.hip): B <= SMALL_MAX_QUERIES queries over a catalogue too large for the dense select
+constexpr int SMALL_MAX_QUERIES = 256;
+constexpr int SMALL_LIST_CAP = 4096;      // candidate keys one query may collect between its sampled threshold and the select
+constexpr int SMALL_SAMPLE = 16384;       // keys sampled per query for the threshold
+struct SmallPlan {
+    int ng, tq, n_qblocks;   // query blocks of 32 * tq
+    int64_t bq;              // B rounded up to whole query blocks (rows of the key matrix)
+    int64_t ld;              // key matrix row stride = item rows padded to 32
+    int kprime;
+};
+SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k);
+bool use_small_path(int64_t B, int64_t n_items);
+size_t small_ws_bytes(const SmallPlan& p);   // without the header
+// keys -> per-query candidate streams in the layout select_rerank_kernel reads (cand / cand_cnt, one list)
+int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
+                 unsigned char* ws_after_header, uint64_t** cand_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream);
+
 }  // namespace hwer

@@ -29,26 +29,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 #define HWER_SCREEN_SLOTS 0
 #endif
 
-// LDS-DMA (global -> LDS without a register destination) issued through inline asm: hipcc counts a builtin
-// global_load_lds as a pending LDS write and drains vmcnt(0) before the NEXT ds_read, which would serialise the
-// prefetch with the tile that is being computed.  An asm statement is invisible to that bookkeeping; the kernel waits
-// for it explicitly (s_waitcnt vmcnt(0) right before the tile barrier).  M0 carries the wave-uniform LDS byte
-// address and is saved / restored inside the same statement (it is compiler-reserved).
-// scalar 64-bit base (wave-uniform) + 32-bit per-lane byte offset: keeps the per-lane address state to ONE VGPR
-__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-}
-__device__ __forceinline__ void lds_dma4(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr(const void* p) {
-    return uint32_t(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)(p)));
-}
-
 struct ScreenArgs {
     const float* X;
     const float* hnorm;
@@ -202,16 +182,6 @@ __device__ __forceinline__ unsigned long long stamp() {
     return t;
 }
 #define STAMP(var) if (a.debug_stamps) { var = stamp(); }
-
-// LDS image of an item tile: IB rows of CH = 2*NG 16-byte chunks, UNPADDED (the LDS-DMA writes 1 KiB per
-// wave-instruction linearly), XOR-swizzled so that the ds_read_b128 of the MFMA A fragments (16 lanes = 16
-// different rows, same logical chunk) hits 16 different 16-byte slots of the 256-byte bank row:
-//   physical chunk = logical chunk ^ swz(row)
-template <int CH>
-__device__ __forceinline__ int swz(int row) {
-    if constexpr (CH >= 16) return row & 15;
-    else return (row >> 1) & (CH - 1);   // CH == 8: two 128-byte rows share a bank row
-}
 
 template <int NG, int TQ, bool DENSE>
 __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {

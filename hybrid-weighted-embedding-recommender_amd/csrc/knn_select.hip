@@ -1027,6 +1027,24 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     return w;
 }
 
+static int launch_select_rerank(const SelectArgs& sa, int d, int score_mode, hipStream_t st) {
+    const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
+    auto launch_select = [&](auto md) -> int {
+        constexpr int MD = decltype(md)::value;
+        if (int e = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel<MD>), lds, "knn_select")) return e;
+        hipLaunchKernelGGL(select_rerank_kernel<MD>, dim3(unsigned(cdiv64(sa.B, 4))), dim3(256), lds, st, sa);
+        return HWER_OK;
+    };
+    int rc;
+    switch (score_mode) {
+        case 0: rc = launch_select(std::integral_constant<int, 0>{}); break;
+        case 1: rc = launch_select(std::integral_constant<int, 1>{}); break;
+        default: rc = launch_select(std::integral_constant<int, 2>{}); break;
+    }
+    if (rc) return rc;
+    return check_launch("knn_select");
+}
+
 extern "C" {
 
 int hwer_knn_max_k(void) { return K_MAX; }
@@ -1034,6 +1052,7 @@ int hwer_knn_max_k(void) { return K_MAX; }
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) {
     const int ldx = hwer_knn_padded_dim(d);
     if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
+    if (use_small_path(B, n_items)) return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k));
     return ws_layout(make_screen_plan(B, n_items, ldx, k), B).total;
 }
 
@@ -1058,11 +1077,38 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Q32) & 15) ||
         (reinterpret_cast<uintptr_t>(workspace) & 255))
         return fail(HWER_EINVAL, "knn_search: X/Q32 must be 16-byte and workspace 256-byte aligned");
+    hipStream_t st = as_stream(stream);
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    if (use_small_path(B, n_items)) {   // a handful of queries over a large catalogue: HBM-bound path (knn_small.hip)
+        const SmallPlan sp = make_small_plan(B, n_items, int(ldx), k);
+        const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp);
+        if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, need);
+        WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
+        uint64_t* cand = nullptr;
+        int32_t* cnt = nullptr;
+        int rc;
+        prof_next_call();
+        {
+            ProfScope ps(0, st);
+            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &cand, &cnt, hdr, st);
+        }
+        if (rc) return rc;
+        ProfScope ps_select(1, st);
+        SelectArgs sa{};
+        sa.cand = cand;
+        sa.cand_cnt = cnt;
+        sa.bq = sp.bq;
+        sa.B = B;
+        sa.kprime = sp.kprime;
+        sa.kcap = sp.kprime;
+        sa.hnorm_max = hnorm_max;
+        sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
+                           out_idx, out_score, out_dist2, out_flags, hdr};
+        return launch_select_rerank(sa, d, score_mode, st);
+    }
     const ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);
     const WsLayout w = ws_layout(plan, B);
     if (workspace_bytes < w.total) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, w.total);
-    hipStream_t st = as_stream(stream);
-    unsigned char* ws = static_cast<unsigned char*>(workspace);
     uint64_t* cand = reinterpret_cast<uint64_t*>(ws + w.cand_a);
     int32_t* cnt = reinterpret_cast<int32_t*>(ws + w.cnt_a);
     WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
@@ -1130,21 +1176,10 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
     sa.hnorm_max = hnorm_max;
     sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, hdr};
-    const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
-    auto launch_select = [&](auto md) -> int {
-        constexpr int MD = decltype(md)::value;
-        if (int e = set_max_lds(reinterpret_cast<const void*>(&select_rerank_kernel<MD>), lds, "knn_select")) return e;
-        hipLaunchKernelGGL(select_rerank_kernel<MD>, dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, sa);
-        return HWER_OK;
-    };
-    switch (score_mode) {
-        case 0: rc = launch_select(std::integral_constant<int, 0>{}); break;
-        case 1: rc = launch_select(std::integral_constant<int, 1>{}); break;
-        default: rc = launch_select(std::integral_constant<int, 2>{}); break;
-    }
-    if (rc) return rc;
-    return check_launch("knn_select");
+    return launch_select_rerank(sa, d, score_mode, st);
 }
+
+
 
 size_t hwer_knn_exact_workspace_bytes(int64_t n_items, int k) {
     if (n_items < 1 || k < 1 || k > K_MAX) return 0;

@@ -273,6 +273,41 @@ def test_knn_without_distances_score_ties(hw, knn_path):
             assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score)
 
 
+@pytest.mark.parametrize("d,N,B,k", [(128, 20000, 1, 200), (64, 9000, 7, 200), (32, 30000, 33, 50), (256, 12000, 70, 200),
+                                     (128, 16000, 200, 100), (66, 8500, 256, 392), (128, 70000, 5, 10)])
+def test_knn_small_batch_path(hw, d, N, B, k):
+    """a handful of queries over a catalogue beyond the dense select: barrier-free HBM-bound screen + sampled-threshold
+    row select (knn_small.hip).  Bit-exact against the oracle, with and without the distances."""
+    V32 = np.concatenate([unit_rows_f32(25 + d, B, d), unit_rows_f32(26 + d, N, d)])
+    rows = np.arange(B, B + N)
+    for arith, V in ((0, V32.astype(np.float64)), (1, V32)):
+        ix = make_index(V, B, N, arith)
+        idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+        assert (flags == 1).all()
+        idx_l, score_l, _, flags_l = ix.search("item", np.arange(B), k=k, want_dist=False)
+        assert np.array_equal(idx, idx_l) and np.array_equal(score, score_l) and (flags_l == 1).all()
+        for u in range(0, B, max(1, B // 12)):
+            o_idx, o_score, o_dist = orc.find_closest(V, rows, u, k=k)
+            assert np.array_equal(idx[u], o_idx), (d, arith, u)
+            assert np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+
+
+def test_knn_small_batch_duplicates(hw):
+    """heavy duplication defeats the sampled threshold (list overflow / ties at the cut): the queries must come back
+    through the exhaustive pass, still exact."""
+    d, N, B, k = 64, 12000, 4, 30
+    X = unit_rows_f32(88, N, d)
+    X[2000:9000] = X[100]                       # 7000 copies of one row
+    users = np.concatenate([X[[100, 101]], unit_rows_f32(89, 2, d)])
+    V = np.concatenate([users, X]).astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all() and flags[0] == 2
+    for u in range(B):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+
+
 def test_knn_multi_split_lists(hw):
     """few queries x many items: the item range is split over many workgroups / lists (reduce path)."""
     d, N, B, k = 64, 60000, 3, 100
