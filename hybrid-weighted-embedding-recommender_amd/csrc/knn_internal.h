@@ -84,7 +84,8 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 // small-batch path (knn_small.hip): B <= SMALL_MAX_QUERIES queries over a catalogue too large for the dense select
-constexpr int SMALL_MAX_QUERIES = 256;
+constexpr int SMALL_MAX_QUERIES = 1024;   // and the key matrix (B x items x 4 B) at most SMALL_MAX_KEY_BYTES
+constexpr int64_t SMALL_MAX_KEY_BYTES = int64_t(8) << 30;
 constexpr int SMALL_LIST_CAP = 4096;      // candidate keys one query may collect between its sampled threshold and the select
 constexpr int SMALL_SAMPLE = 16384;       // keys sampled per query for the threshold
 struct SmallPlan {
@@ -96,8 +97,8 @@ struct SmallPlan {
 SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k);
 bool use_small_path(int64_t B, int64_t n_items);
 size_t small_ws_bytes(const SmallPlan& p);   // without the header
-// keys -> per-query candidate streams in the layout select_rerank_kernel reads (cand / cand_cnt, one list)
+// keys -> per-query candidate lists: list_out (B, SMALL_LIST_CAP) packed keys, cnt_out (B) appended counts
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
-                 unsigned char* ws_after_header, uint64_t** cand_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream);
+                 unsigned char* ws_after_header, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream);
 
 }  // namespace hwer

@@ -527,9 +527,17 @@ struct DenseSelectArgs {
     int kp;              // re-rank capacity (multiple of 64)
     float hnorm_max;
     EmitArgs emit;
+    // LIST variant (small-batch path): the "row" of query b is its candidate list of packed keys
+    const uint64_t* list;        // (B, list_cap)
+    const int32_t* list_count;   // (B) appended keys (may exceed the capacity: overflow)
+    int list_cap;
+    int list_min;                // K': a list shorter than this came from a threshold that was too high
 };
 
-template <int MAXV, int MODE>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys; score mode
+// LIST = false: dense select over the key row written by the DENSE screen (every item is a candidate).
+// LIST = true : the same selection over a candidate LIST of packed keys (knn_small.hip); items that are not in the list
+//               have keys below every list key, so the usual certificate applies (some candidate below t_k - 2 E32).
+template <int MAXV, int MODE, bool LIST>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys; score mode
 __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(const DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -545,12 +553,28 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     // step).  A byte-radix histogram in LDS is the wrong tool here: thousands of keys share their top bytes, so every
     // LDS atomic would serialise 64 lanes on one bin.
     float kv[MAXV][4];   // slices beyond the row hold -inf (below every real key; pad items are -inf too)
+    const uint64_t* lst = nullptr;
+    int n_list = 0, cnt_raw = 0;
+    if constexpr (LIST) {
+        lst = a.list + b * a.list_cap;
+        cnt_raw = a.list_count[b];
+        n_list = min(cnt_raw, a.list_cap);
 #pragma unroll
-    for (int m = 0; m < MAXV; ++m) {
-        const int i = lane + 64 * m;
-        float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        if (i < n4) v = row[i];
-        kv[m][0] = v.x; kv[m][1] = v.y; kv[m][2] = v.z; kv[m][3] = v.w;
+        for (int m = 0; m < MAXV; ++m) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = 4 * (lane + 64 * m) + c;
+                kv[m][c] = j < n_list ? key_score(lst[j]) : -INFINITY;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < MAXV; ++m) {
+            const int i = lane + 64 * m;
+            float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (i < n4) v = row[i];
+            kv[m][0] = v.x; kv[m][1] = v.y; kv[m][2] = v.z; kv[m][3] = v.w;
+        }
     }
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
@@ -637,7 +661,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
                     const int bit = __builtin_ctz(pm[w]);
                     pm[w] &= pm[w] - 1u;
                     const int e = KW * w + KW - 1 - bit;
-                    if (pos < kp) cand_item[pos] = uint32_t(4 * (lane + 64 * (e >> 2)) + (e & 3));
+                    const uint32_t j = uint32_t(4 * (lane + 64 * (e >> 2)) + (e & 3));   // position in the row / list
+                    if (pos < kp) cand_item[pos] = LIST ? key_item(lst[j]) : j;
                     ++pos;
                 }
             }
@@ -651,7 +676,14 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         n_b = min(n_b, kp);
     }
     wave_lds_sync();
-    wave_rerank_emit_t<MODE>(a.emit, b, lds_emit, kp, n_r, n_b, overflow ? 0 : 1);
+    int flag = overflow ? 0 : 1;
+    if constexpr (LIST) {
+        // the list must be complete (no overflow, not cut short by a threshold above the K'-th key) and reach below the
+        // re-rank bound; with fewer than k valid keys there is nothing to select from (k-th key = -inf)
+        if (cnt_raw < a.list_min || cnt_raw > a.list_cap || n_r >= n_list) flag = 0;
+        if (n_list < k) { n_r = 0; n_b = 0; }
+    }
+    wave_rerank_emit_t<MODE>(a.emit, b, lds_emit, kp, n_r, n_b, flag);
 }
 
 // pre-reduction when a query has more than MAX_LISTS_DIRECT lists: groups of 8 lists -> one list of K' keys
@@ -1027,6 +1059,25 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     return w;
 }
 
+static int launch_select_list(const DenseSelectArgs& da, int d, int score_mode, hipStream_t st) {
+    static_assert(SMALL_LIST_CAP == 256 * 16, "the list select keeps 16 float4-equivalents of the list per lane");
+    const size_t lds = size_t(4) * wave_lds_bytes(d, da.kp);
+    auto launch = [&](auto md) -> int {
+        constexpr int MD = decltype(md)::value;
+        if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<16, MD, true>), lds, "knn_select_list")) return e;
+        hipLaunchKernelGGL((select_dense_kernel<16, MD, true>), dim3(unsigned(cdiv64(da.B, 4))), dim3(256), lds, st, da);
+        return HWER_OK;
+    };
+    int rc;
+    switch (score_mode) {
+        case 0: rc = launch(std::integral_constant<int, 0>{}); break;
+        case 1: rc = launch(std::integral_constant<int, 1>{}); break;
+        default: rc = launch(std::integral_constant<int, 2>{}); break;
+    }
+    if (rc) return rc;
+    return check_launch("knn_select_list");
+}
+
 static int launch_select_rerank(const SelectArgs& sa, int d, int score_mode, hipStream_t st) {
     const size_t lds = size_t(4) * wave_lds_bytes(d, sa.kcap);
     auto launch_select = [&](auto md) -> int {
@@ -1084,27 +1135,27 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp);
         if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, need);
         WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
-        uint64_t* cand = nullptr;
+        uint64_t* list = nullptr;
         int32_t* cnt = nullptr;
         int rc;
         prof_next_call();
         {
             ProfScope ps(0, st);
-            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &cand, &cnt, hdr, st);
+            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &list, &cnt, hdr, st);
         }
         if (rc) return rc;
         ProfScope ps_select(1, st);
-        SelectArgs sa{};
-        sa.cand = cand;
-        sa.cand_cnt = cnt;
-        sa.bq = sp.bq;
-        sa.B = B;
-        sa.kprime = sp.kprime;
-        sa.kcap = sp.kprime;
-        sa.hnorm_max = hnorm_max;
-        sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
+        DenseSelectArgs da{};
+        da.B = B;
+        da.kp = sp.kprime;
+        da.hnorm_max = hnorm_max;
+        da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
                            out_idx, out_score, out_dist2, out_flags, hdr};
-        return launch_select_rerank(sa, d, score_mode, st);
+        da.list = list;
+        da.list_count = cnt;
+        da.list_cap = SMALL_LIST_CAP;
+        da.list_min = sp.kprime;
+        return launch_select_list(da, d, score_mode, st);
     }
     const ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);
     const WsLayout w = ws_layout(plan, B);
@@ -1133,8 +1184,8 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
         auto launch_dense2 = [&](auto mv, auto md) -> int {
             constexpr int MV = decltype(mv)::value, MD = decltype(md)::value;
-            if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV, MD>), lds, "knn_select_dense")) return e;
-            hipLaunchKernelGGL((select_dense_kernel<MV, MD>), dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
+            if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV, MD, false>), lds, "knn_select_dense")) return e;
+            hipLaunchKernelGGL((select_dense_kernel<MV, MD, false>), dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
             return HWER_OK;
         };
         auto launch_dense = [&](auto mv) -> int {

@@ -1,4 +1,4 @@
-// Small-batch path of the exact k-NN (K5): a handful of queries (B <= 256) against a catalogue too large for the
+// Small-batch path of the exact k-NN (K5): up to ~1000 queries against a catalogue too large for the
 // dense select.  The problem is HBM-bound (the catalogue streams once per block of 32 * TQ queries), so:
 //
 //   1. small_screen_kernel   every WAVE streams its own item tiles HBM -> LDS by LDS-DMA (wave-private double buffer,
@@ -7,10 +7,10 @@
 //   2. small_threshold_kernel per query: the r-th largest of a strided SAMPLE of its key row -> a threshold that leaves
 //                            about 4.75 K' keys (K' <= count <= list capacity with overwhelming probability).
 //   3. small_collect_kernel   all workgroups scan the key rows and append keys >= threshold to the query's list.
-//   4. small_final_kernel     per query (one wave): the K' best of the list -> the candidate stream read by
-//                            select_rerank_kernel (float64 re-rank, certificate, sort: knn_select.hip).
-// A list that ends short of K' keys (or overflows) is flagged UNDERFULL: the select kernel then refuses to certify and
-// the query goes to the exhaustive pass - the sampling can cost time, never exactness.
+//   4. select_dense_kernel<.., LIST> (knn_select.hip) per query (one wave): k-th key of the list, float64 re-rank,
+//                            certificate, sort.
+// A list that ends short of K' keys (or overflows) is not certified: the query goes to the exhaustive pass - the
+// sampling can cost time, never exactness.
 #include <algorithm>
 
 #include "knn_internal.h"
@@ -32,8 +32,10 @@ struct SmallArgs {
     WsHeader* hdr;
 };
 
-// One wave = one stream of tiles.  NW waves per workgroup only share the CU (LDS budget: NW * 2 tiles).
-template <int NG, int TQ, int NW>
+// One wave = one stream of tiles through a wave-private ring of NSLOT tiles (NSLOT - 1 tiles in flight while one is
+// computed: with a single tile in flight the kernel is bound by HBM latency, 16 KB per wave per ~4 us).  NW waves per
+// workgroup only share the CU (LDS budget: NW * NSLOT tiles <= 160 KB).
+template <int NG, int TQ, int NW, int NSLOT>
 __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArgs a) {
     constexpr int IB = 32;
     constexpr int CH = 2 * NG;                    // 16-byte chunks per row
@@ -46,8 +48,8 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list
-    float* ring = reinterpret_cast<float*>(smem_raw + size_t(wave) * (2 * TILE_BYTES + 2 * IB * 4));   // [2][IB][CH*4] wave-private
-    float* hn = ring + 2 * IB * CH * 4;                                                               // [2][IB] half norms
+    float* ring = reinterpret_cast<float*>(smem_raw + size_t(wave) * (NSLOT * TILE_BYTES + NSLOT * IB * 4));   // [NSLOT][IB][CH*4] wave-private
+    float* hn = ring + NSLOT * IB * CH * 4;                                                                   // [NSLOT][IB] half norms
     const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
 
     float4 qf[TQ][NG];
@@ -79,18 +81,21 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
     };
 
     int t = blockIdx.x * NW + wave;
-    if (t < a.n_tiles) tile_dma(t, 0);
+#pragma unroll
+    for (int j = 0; j < NSLOT - 1; ++j)   // fill the pipeline (DMA pieces past the last tile are simply not issued)
+        if (t + j * n_waves < a.n_tiles) tile_dma(t + j * n_waves, j);
     int slot = 0;
-    for (; t < a.n_tiles; t += n_waves, slot ^= 1) {
+    for (; t < a.n_tiles; t += n_waves, slot = (slot + 1 == NSLOT ? 0 : slot + 1)) {
         const int64_t i0 = int64_t(t) * IB;
-        const int t_next = t + n_waves;
-        if (t_next < a.n_tiles) {
-            tile_dma(t_next, slot ^ 1);
-            // vmcnt retires in issue order: everything older than the DMA pieces just issued (this tile's DMA, the previous
-            // tile's key stores) has landed once at most DMA_PER_TILE + 1 operations are outstanding
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE + 1) : "memory");
+        const int t_pre = t + (NSLOT - 1) * n_waves;
+        const int slot_pre = slot == 0 ? NSLOT - 1 : slot - 1;   // the slot computed in the previous iteration
+        if (t_pre < a.n_tiles) {
+            tile_dma(t_pre, slot_pre);
+            // Loads retire in issue order: if any piece of this tile's DMA were still pending, so would be all
+            // (NSLOT - 1) (DMA_PER_TILE + 1) younger pieces.  (Key stores in flight only make the wait more conservative.)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * (DMA_PER_TILE + 1)) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // pipeline drain: the last NSLOT - 1 tiles
         }
         const float* xb = ring + slot * (IB * CH * 4);
         const float* hb = hn + slot * IB;
@@ -146,8 +151,6 @@ struct SmallSelectArgs {
     float* thr;         // (B)
     int32_t* count;     // (B) list lengths (may exceed the capacity: overflow)
     uint64_t* list;     // (B, SMALL_LIST_CAP) packed keys
-    uint64_t* cand;     // streams for select_rerank_kernel: (bq, 2, CAPH)
-    int32_t* cand_cnt;  // (bq, 2)
 };
 
 // threshold of one query from a strided sample of its key row: the r-th largest sample key, r chosen so that about
@@ -206,15 +209,21 @@ __global__ __launch_bounds__(256) void small_threshold_kernel(const SmallSelectA
     }
 }
 
-// every workgroup scans 256 * 64 keys of one query's row and appends the keys >= threshold to the query's list
+// every workgroup scans 256 * 64 keys of one query's row; the keys >= threshold are gathered in LDS and appended to the
+// query's list with ONE reservation per workgroup (per-wave atomics on a handful of counters serialise in L2)
 __global__ __launch_bounds__(256) void small_collect_kernel(const SmallSelectArgs a) {
+    constexpr int LCAP = 1024;   // per-block staging capacity; beyond it the block falls back to direct appends
+    __shared__ uint64_t s_keys[LCAP];
+    __shared__ int s_n, s_base;
     const int64_t b = blockIdx.y;
     const float* row = a.keys + b * a.ld;
     const float thr = a.thr[b];
     const int lane = threadIdx.x & 63;
-    const int64_t base4 = (int64_t(blockIdx.x) * 256 * 16) ;   // float4 index of this block's first slice
+    const int64_t base4 = int64_t(blockIdx.x) * 256 * 16;   // float4 index of this block's first slice
     const int64_t n4 = a.ld / 4;
     uint64_t* list = a.list + b * SMALL_LIST_CAP;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
 #pragma unroll 4
     for (int m = 0; m < 16; ++m) {
         const int64_t i4 = base4 + int64_t(m) * 256 + threadIdx.x;
@@ -228,48 +237,27 @@ __global__ __launch_bounds__(256) void small_collect_kernel(const SmallSelectArg
             if (bal != 0ull) {   // wave-uniform, rare
                 const int n_in = __builtin_popcountll(bal);
                 int pos0 = 0;
-                if (lane == 0) pos0 = atomicAdd(&a.count[b], n_in);
+                if (lane == 0) pos0 = atomicAdd(&s_n, n_in);   // LDS atomic
                 pos0 = __shfl(pos0, 0, kWave);
                 const int pos = pos0 + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-                if (in && pos < SMALL_LIST_CAP) list[pos] = pack_key(vv[c], uint32_t(4 * i4 + c));
+                if (in) {
+                    const uint64_t key = pack_key(vv[c], uint32_t(4 * i4 + c));
+                    if (pos < LCAP) {
+                        s_keys[pos] = key;
+                    } else {   // staging full (massive ties): append directly
+                        const int g = atomicAdd(&a.count[b], 1);
+                        if (g < SMALL_LIST_CAP) list[g] = key;
+                    }
+                }
             }
         }
     }
-}
-
-// one wave per query: the K' best keys of its list -> stream 0 of the query (stream 1 stays empty)
-__global__ __launch_bounds__(64) void small_final_kernel(const SmallSelectArgs a) {
-    constexpr int PER = SMALL_LIST_CAP / 64;   // 64 keys per lane
-    const int64_t b = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int cnt_raw = a.count[b];
-    const int n = min(cnt_raw, SMALL_LIST_CAP);
-    const uint64_t* list = a.list + b * SMALL_LIST_CAP;
-    float sv[PER];
-#pragma unroll
-    for (int m = 0; m < PER; ++m) {
-        const int i = lane + 64 * m;
-        sv[m] = i < n ? key_score(list[i]) : -INFINITY;
-    }
-    uint64_t* s0 = a.cand + (b * 2) * CAPH;
-    // the list must hold at least K' keys (else the threshold was too high) and must not have overflowed
-    const bool bad = cnt_raw < a.kprime || cnt_raw > SMALL_LIST_CAP;
-    int c_ge = 0;
-    float t_k = -INFINITY;
-    if (n >= a.kprime) t_k = wave_find_rank<PER>(sv, a.kprime, 0, c_ge);
-    int n_out = 0;
-#pragma unroll
-    for (int m = 0; m < PER; ++m) {
-        const bool in = sv[m] >= t_k && sv[m] > -INFINITY;
-        const uint64_t bal = __ballot(in);
-        const int pos = n_out + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-        if (in && pos < a.kprime) s0[pos] = list[lane + 64 * m];   // ties at the cut beyond K' keys are dropped (<= every kept key)
-        n_out += __builtin_popcountll(bal);
-    }
-    if (lane == 0) {
-        a.cand_cnt[b * 2] = min(n_out, a.kprime) | (bad ? CNT_UNDERFULL : 0);
-        a.cand_cnt[b * 2 + 1] = 0;
-    }
+    __syncthreads();
+    const int n = min(s_n, LCAP);
+    if (threadIdx.x == 0) s_base = n > 0 ? atomicAdd(&a.count[b], n) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256)
+        if (s_base + i < SMALL_LIST_CAP) list[s_base + i] = s_keys[i];
 }
 
 // =====================================================================================================
@@ -277,7 +265,9 @@ static size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 
 bool use_small_path(int64_t B, int64_t n_items) {
     if (getenv("HWER_NO_SMALL")) return false;
-    return B <= SMALL_MAX_QUERIES && n_items > DENSE_MAX_ITEMS;
+    int64_t maxq = SMALL_MAX_QUERIES;
+    if (const char* e = getenv("HWER_SMALL_MAXQ")) maxq = atoi(e);   // tuning override
+    return B <= maxq && n_items > DENSE_MAX_ITEMS && B * n_items * 4 <= SMALL_MAX_KEY_BYTES;
 }
 
 SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k) {
@@ -291,7 +281,7 @@ SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k) {
     return p;
 }
 
-struct SmallLayout { size_t keys, thr, count, list, cand, cnt, total; };
+struct SmallLayout { size_t keys, thr, count, list, total; };
 static SmallLayout small_layout(const SmallPlan& p) {
     SmallLayout w{};
     size_t off = 0;
@@ -299,52 +289,49 @@ static SmallLayout small_layout(const SmallPlan& p) {
     w.thr = off;   off += al256(size_t(p.bq) * 4);
     w.count = off; off += al256(size_t(p.bq) * 4);
     w.list = off;  off += al256(size_t(p.bq) * SMALL_LIST_CAP * 8);
-    w.cand = off;  off += al256(size_t(p.bq) * 2 * CAPH * 8);
-    w.cnt = off;   off += al256(size_t(p.bq) * 2 * 4);
     w.total = off;
     return w;
 }
 size_t small_ws_bytes(const SmallPlan& p) { return small_layout(p).total; }
 
-template <int NG, int TQ, int NW>
+template <int NG, int TQ, int NW, int NSLOT>
 static int launch_small_screen(const SmallPlan& p, const SmallArgs& a, hipStream_t stream) {
-    const size_t lds = size_t(NW) * (2 * 32 * NG * 32 + 2 * 32 * 4);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_screen_kernel<NG, TQ, NW>),
+    const size_t lds = size_t(NW) * NSLOT * (32 * NG * 32 + 32 * 4);
+    static_assert(size_t(NW) * NSLOT * (32 * NG * 32 + 32 * 4) <= 160 * 1024, "ring must fit the CU's LDS");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_screen_kernel<NG, TQ, NW, NSLOT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_small: hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one workgroup per CU (LDS-limited); query blocks share the CUs: grid.x * grid.y ~ 256
     const int gx = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_tiles, NW), std::max(1, 256 / p.n_qblocks))));
-    hipLaunchKernelGGL((small_screen_kernel<NG, TQ, NW>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
+    hipLaunchKernelGGL((small_screen_kernel<NG, TQ, NW, NSLOT>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
     return check_launch("knn_small(screen)");
 }
 
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
-                 unsigned char* ws, uint64_t** cand_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream) {
+                 unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream) {
     const SmallLayout w = small_layout(p);
     SmallArgs a{X, hnorm, n_items, ldx, Q32, B, reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr};
     int rc;
     switch (p.ng * 10 + p.tq) {
-        case 41: rc = launch_small_screen<4, 1, 4>(p, a, stream); break;
-        case 42: rc = launch_small_screen<4, 2, 4>(p, a, stream); break;
-        case 81: rc = launch_small_screen<8, 1, 4>(p, a, stream); break;
-        case 82: rc = launch_small_screen<8, 2, 4>(p, a, stream); break;
-        case 161: rc = launch_small_screen<16, 1, 4>(p, a, stream); break;
-        case 162: rc = launch_small_screen<16, 2, 4>(p, a, stream); break;
-        case 321: rc = launch_small_screen<32, 1, 2>(p, a, stream); break;
+        // waves x ring slots per CU: (NSLOT - 1) tiles in flight per wave, ~96 KB in flight per CU
+        case 41: rc = launch_small_screen<4, 1, 4, 8>(p, a, stream); break;      // 4 KB tiles
+        case 42: rc = launch_small_screen<4, 2, 4, 8>(p, a, stream); break;
+        case 81: rc = launch_small_screen<8, 1, 4, 4>(p, a, stream); break;      // 8 KB tiles
+        case 82: rc = launch_small_screen<8, 2, 4, 4>(p, a, stream); break;
+        case 161: rc = launch_small_screen<16, 1, 3, 3>(p, a, stream); break;    // 16 KB tiles
+        case 162: rc = launch_small_screen<16, 2, 3, 3>(p, a, stream); break;
+        case 321: rc = launch_small_screen<32, 1, 2, 2>(p, a, stream); break;    // 32 KB tiles
         default: return fail(HWER_EINVAL, "knn_small: unsupported padded dim %d / tq %d", p.ng * 8, p.tq);
     }
     if (rc) return rc;
     SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, reinterpret_cast<float*>(ws + w.thr),
-                       reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list),
-                       reinterpret_cast<uint64_t*>(ws + w.cand), reinterpret_cast<int32_t*>(ws + w.cnt)};
+                       reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list)};
     hipLaunchKernelGGL(small_threshold_kernel, dim3(unsigned(B)), dim3(256), 0, stream, sa);
     if ((rc = check_launch("knn_small(threshold)"))) return rc;
     hipLaunchKernelGGL(small_collect_kernel, dim3(unsigned(cdiv64(p.ld / 4, 256 * 16)), unsigned(B)), dim3(256), 0, stream, sa);
     if ((rc = check_launch("knn_small(collect)"))) return rc;
-    hipLaunchKernelGGL(small_final_kernel, dim3(unsigned(B)), dim3(64), 0, stream, sa);
-    if ((rc = check_launch("knn_small(final)"))) return rc;
-    *cand_out = sa.cand;
-    *cnt_out = sa.cand_cnt;
+    *list_out = sa.list;
+    *cnt_out = sa.count;
     return HWER_OK;
 }
 

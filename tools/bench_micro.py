@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--items", type=int, default=1250000)
     ap.add_argument("--d", type=int, default=128)
     ap.add_argument("--k", type=int, default=200)
+    ap.add_argument("--batches", default="1,8,64,512,4096")
     args = ap.parse_args()
     import torch
     from hwer import native
@@ -121,7 +122,7 @@ def main():
         o_sc = torch.empty((Bmax, K), dtype=torch.float64, device=dev)
         o_d2 = torch.empty((Bmax, K), dtype=torch.float64, device=dev)
         o_fl = torch.empty(Bmax, dtype=torch.int32, device=dev)
-        for B in (1, 8, 64, 512, 4096):
+        for B in [int(x) for x in args.batches.split(",")]:
             wsb = lib.hwer_knn_workspace_bytes(B, I, d, K)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
             fn = lambda: native.check(lib.hwer_knn_search_f32(P(X), P(hn), I, d, ldx, P(Q32), P(Q64), P(Vq), d, P(anchors), B, K, 0, 1, None, 0,  # noqa: E731
