@@ -255,6 +255,23 @@ def main():
         "parity_checked_queries": parity_n,
     }
 
+    # ---------------- per-query latency: one anchor against this rank's catalogue, outside the timed region ----
+    if world == 1:
+        ws1 = torch.empty(lib.hwer_knn_workspace_bytes(1, I, d, K), dtype=torch.uint8, device=dev)
+
+        def one_query():
+            native.check(lib.hwer_knn_search_f32(P(X), P(hnorm), I, d, ldx, P(Q32), P(Q64), P(V), ldv, P(anchors), 1, K, arith, 1, None,
+                                                 id_base, hnorm_max, P(o_idx), P(o_score), None, P(o_flags), P(ws1), ws1.numel(), S()), "knn_search(B=1)")
+        for _ in range(3):
+            one_query()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            one_query()
+        e1.record()
+        torch.cuda.synchronize()
+        out["query_latency_ms"] = {"batch": 1, "value": e0.elapsed_time(e1) / 20.0, "note": "one anchor, exact top-%d, catalogue resident" % K}
+
     # ---------------- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) -------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle

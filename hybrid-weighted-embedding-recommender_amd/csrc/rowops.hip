@@ -255,6 +255,66 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
     }
 }
 
+
+// K12: the post-filter of validation.extraction_efficiency (hwer/validation.py:133-141) on the device.
+// One wave per user: walk its ranked list (score order), drop the items the user has seen in training (binary search in a
+// sorted CSR row), keep the first `cut_max` survivors in order, mark which of them are validation truth, and set the
+// coverage bit of every survivor ("diversity").  The float metrics (recall, NDCG) are finished on the host from these
+// integers with the reference's own numpy expressions, so they stay bit-identical.
+__device__ __forceinline__ bool csr_contains(const int64_t* __restrict__ v, int64_t lo, int64_t hi, int64_t x) {
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t y = v[mid];
+        if (y == x) return true;
+        if (y < x) lo = mid + 1; else hi = mid;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void rank_filter_seen_kernel(const int64_t* __restrict__ ranked, int64_t B, int k,
+                                                              const int64_t* __restrict__ seen_ptr, const int64_t* __restrict__ seen_idx,
+                                                              const int64_t* __restrict__ truth_ptr, const int64_t* __restrict__ truth_idx,
+                                                              int cut_max, int64_t* __restrict__ out_unseen, int32_t* __restrict__ out_len,
+                                                              uint64_t* __restrict__ out_hits, int n_hit_words,
+                                                              uint32_t* __restrict__ cover_bits, int64_t cover_base, int64_t cover_n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t s0 = seen_ptr ? seen_ptr[b] : 0, s1 = seen_ptr ? seen_ptr[b + 1] : 0;
+    const int64_t t0 = truth_ptr ? truth_ptr[b] : 0, t1 = truth_ptr ? truth_ptr[b + 1] : 0;
+    int n_out = 0;
+    uint64_t h0 = 0ull, h1 = 0ull;   // hit bits of survivor positions 0..63 and 64..127 (cut_max <= 128)
+    for (int c0 = 0; c0 < k && n_out < cut_max; c0 += 64) {   // wave-uniform
+        const int i = c0 + lane;
+        const int64_t id = i < k ? ranked[b * k + i] : -1;
+        const bool keep = id >= 0 && !csr_contains(seen_idx, s0, s1, id);
+        const uint64_t bal = __ballot(keep);
+        const int pos = n_out + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+        if (keep && pos < cut_max) {
+            out_unseen[b * cut_max + pos] = id;
+            if (cover_bits && id >= cover_base && id - cover_base < cover_n)
+                atomicOr(&cover_bits[(id - cover_base) >> 5], 1u << uint32_t((id - cover_base) & 31));
+            if (csr_contains(truth_idx, t0, t1, id)) {
+                if (pos < 64) h0 |= 1ull << uint32_t(pos);
+                else h1 |= 1ull << uint32_t(pos - 64);
+            }
+        }
+        n_out += __builtin_popcountll(bal);
+    }
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        h0 |= __shfl_xor(h0, off, kWave);
+        h1 |= __shfl_xor(h1, off, kWave);
+    }
+    if (lane == 0) {
+        out_hits[b * n_hit_words] = h0;
+        if (n_hit_words > 1) out_hits[b * n_hit_words + 1] = h1;
+    }
+    n_out = min(n_out, cut_max);
+    for (int i = n_out + lane; i < cut_max; i += 64) out_unseen[b * cut_max + i] = -1;
+    if (lane == 0) out_len[b] = n_out;
+}
+
 // K8 and the fused tail.  FUSE = false: out = mean_adj(E);  FUSE = true: out = unit((E + mean_adj(E))/2)
 template <bool FUSE>
 __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ E, int64_t lde,
@@ -597,6 +657,21 @@ static int blend_impl(const float* const* tables, int64_t ld_tables, const int32
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     return check_launch("blend_normalize");
+}
+
+int hwer_rank_filter_seen(const int64_t* ranked, int64_t B, int k, const int64_t* seen_ptr, const int64_t* seen_idx,
+                          const int64_t* truth_ptr, const int64_t* truth_idx, int cut_max, int64_t* out_unseen,
+                          int32_t* out_len, uint64_t* out_hits, uint32_t* cover_bits, int64_t cover_base, int64_t cover_n,
+                          void* stream) {
+    if (B == 0) return HWER_OK;
+    if (!ranked || !out_unseen || !out_len || !out_hits) return fail(HWER_EINVAL, "rank_filter_seen: null pointer");
+    if (k < 1 || cut_max < 1 || cut_max > 128) return fail(HWER_EINVAL, "rank_filter_seen: need k >= 1 and 1 <= cut_max <= 128");
+    if ((seen_ptr && !seen_idx) || (truth_ptr && !truth_idx)) return fail(HWER_EINVAL, "rank_filter_seen: ptr without idx");
+    if (cover_bits && cover_n < 1) return fail(HWER_EINVAL, "rank_filter_seen: cover_n < 1");
+    const int n_words = (cut_max + 63) / 64;
+    hipLaunchKernelGGL(rank_filter_seen_kernel, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, as_stream(stream), ranked, B, k, seen_ptr,
+                       seen_idx, truth_ptr, truth_idx, cut_max, out_unseen, out_len, out_hits, n_words, cover_bits, cover_base, cover_n);
+    return check_launch("rank_filter_seen");
 }
 
 int64_t hwer_unit_audit_ws_floats(int64_t N) { return ((N + 3) / 4) * 4 + (AUDIT_BLOCKS * 4 * 2) + 8; }

@@ -42,6 +42,7 @@ PROTOTYPES = {
     "hwer_knn_exact_device_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "hwer_knn_exact_device": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, c_int, c_int, c_int,
                                       _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "hwer_rank_filter_seen": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, _P]),
     "hwer_merge_topk": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
 }
 

@@ -79,7 +79,142 @@ def link_prediction_accuracy(model, nodes: List[Node], train_edges: List[Edge], 
 def extraction_efficiency(model, train_edges: List[Edge], validation_edges: List[Edge], get_topk, node_type: NodeType):
     """Recall@K / NDCG / diversity of the retrieval sweep (reference: hwer/validation.py:100-187): anchors are
     every edge source; a user's train items are filtered out of its 200 neighbours before the @10/@20/@50/@100
-    cuts; the truth is the user's validation items not seen in train."""
+    cuts; the truth is the user's validation items not seen in train.
+
+    With the default retrieval hook the whole post-processing (seen-item filter, cuts, hit marking, coverage) runs on
+    the device (hwer_rank_filter_seen) and only integers come back; a custom `get_topk` takes the host path below."""
+    if get_topk in (model_get_topk, model_get_topk_knn) and getattr(getattr(model, "knn", None), "index", None) is not None:
+        return _extraction_efficiency_device(model, train_edges, validation_edges, node_type)
+    return _extraction_efficiency_host(model, train_edges, validation_edges, get_topk, node_type)
+
+
+def _csr_rows(lists):
+    """list of 1-D int arrays -> (ptr int64 (n+1), flat int64) with every row sorted ascending."""
+    ptr = np.zeros(len(lists) + 1, dtype=np.int64)
+    for i, l in enumerate(lists):
+        ptr[i + 1] = ptr[i] + len(l)
+    flat = np.concatenate([np.sort(np.asarray(l, dtype=np.int64)) for l in lists]) if len(lists) and ptr[-1] else np.zeros(0, dtype=np.int64)
+    return ptr, flat
+
+
+_CUTS = (10, 20, 50, 100)
+
+
+def _extraction_efficiency_device(model, train_edges, validation_edges, node_type, k: int = 200):
+    import torch
+    from . import native
+    lib = native.lib()
+    ix = model.knn.index
+    n2i = model.nodes_to_idx
+    train_items_of = defaultdict(set)
+    train_scores = defaultdict(dict)
+    for u, i, r in train_edges:
+        train_items_of[u].add(i)
+        train_scores[u][i] = r
+    train_users = list({u for u, _, _ in train_edges})
+    validation_users = list({u for u, _, _ in validation_edges})
+    all_users = list(set(train_users) | set(validation_users))
+    all_items = [i for i in ({i for _, i, _ in train_edges} | {i for _, i, _ in validation_edges}) if i.node_type == node_type]
+    val_pairs = defaultdict(list)
+    for u, i, r in validation_edges:
+        val_pairs[u].append((i, r))
+    val_scores, val_actuals = {}, {}
+    for u, lst in val_pairs.items():
+        kept = [(i, r) for i, r in sorted(lst, key=operator.itemgetter(1), reverse=True) if i not in train_items_of[u]]
+        val_scores[u] = dict(kept)
+        val_actuals[u] = [i for i, _ in kept]
+
+    # ---- retrieval: one batched search, results stay on the device ------------------------------------------------------
+    model._check_query(node_type)
+    for u in all_users:
+        if u not in n2i:
+            from .utils import NodeNotFoundException
+            raise NodeNotFoundException("Node = %s, was not provided in training" % u)
+    a = np.asarray([n2i[u] for u in all_users], dtype=np.int64)
+    t0 = time.time()
+    Q64, Q32, a_dev = ix.build_queries(a)
+    idx_dev, score_dev, _, _ = ix.search_queries(node_type, Q64, Q32, k, a_dev, 2 if model.scoring == "gcn" else ix.arith,
+                                                 want_dist=False)
+    torch.cuda.synchronize()
+    retrieval_time = time.time() - t0
+
+    # ---- seen filter + cuts + hits + coverage on the device (K12) ------------------------------------------------------------
+    B = len(all_users)
+    unknown = lambda n: n2i.get(n, -1)   # noqa: E731  (items that were never registered cannot be retrieved)
+    seen_ptr, seen_idx = _csr_rows([[x for x in (unknown(i) for i in train_items_of.get(u, ())) if x >= 0] for u in all_users])
+    truth_ptr, truth_idx = _csr_rows([[x for x in (unknown(i) for i in val_actuals.get(u, ())) if x >= 0] for u in all_users])
+    rows = ix.tables[node_type].rows
+    cover_base, cover_n = int(rows.min()), int(rows.max() - rows.min() + 1)
+    dev = ix.device
+    T = lambda x: torch.from_numpy(x).to(dev)   # noqa: E731
+    d_sp, d_si, d_tp, d_ti = T(seen_ptr), T(seen_idx if len(seen_idx) else np.zeros(1, np.int64)), T(truth_ptr), T(truth_idx if len(truth_idx) else np.zeros(1, np.int64))
+    cmax = max(_CUTS)
+    unseen = torch.empty((B, cmax), dtype=torch.int64, device=dev)
+    ulen = torch.empty(B, dtype=torch.int32, device=dev)
+    hits = torch.empty((B, (cmax + 63) // 64), dtype=torch.int64, device=dev)
+    cover = torch.zeros((cover_n + 31) // 32, dtype=torch.int32, device=dev)
+    native.check(lib.hwer_rank_filter_seen(native.ptr(idx_dev), B, k, native.ptr(d_sp), native.ptr(d_si), native.ptr(d_tp), native.ptr(d_ti),
+                                           cmax, native.ptr(unseen), native.ptr(ulen), native.ptr(hits), native.ptr(cover), cover_base,
+                                           cover_n, native.stream_ptr()), "rank_filter_seen")
+    unseen_h, ulen_h = unseen.cpu().numpy(), ulen.cpu().numpy().astype(np.int64)
+    hits_h = hits.cpu().numpy().view(np.uint64)
+    n_covered = int(np.unpackbits(cover.cpu().numpy().view(np.uint8)).sum())
+    idx_h = idx_dev[:, :100].cpu().numpy()
+
+    # ---- float metrics from the integers, with the reference's own numpy expressions (utils.py:101-121) -------------------------
+    pos_of = {u: j for j, u in enumerate(all_users)}
+    vrow = np.asarray([pos_of[u] for u in validation_users], dtype=np.int64)
+    hitbits = np.zeros((len(vrow), cmax), dtype=np.int64)   # hitbits[v, p] = the p-th survivor of user v is truth
+    for w in range(hits_h.shape[1]):
+        word = hits_h[vrow, w]
+        for bit in range(min(64, cmax - 64 * w)):
+            hitbits[:, 64 * w + bit] = (word >> np.uint64(bit)) & np.uint64(1)
+    n_true = np.asarray([len(val_scores.get(u, ())) for u in validation_users], dtype=np.int64)
+    n_pred = ulen_h[vrow]
+
+    def recall_at(c):
+        lp = np.minimum(n_pred, c)
+        h = (hitbits[:, :c] * (np.arange(c)[None, :] < lp[:, None])).sum(1)
+        return np.mean([hh / max(min(int(l), int(t)), 1.0) for hh, l, t in zip(h.tolist(), lp.tolist(), n_true.tolist())])
+
+    def binary_ndcg_at(c):
+        vals = []
+        for v in range(len(vrow)):
+            lp = int(min(n_pred[v], c))
+            gains = hitbits[v, :lp]
+            discounts = np.log2(np.arange(lp) + 2)
+            ideal = [1] * min(int(n_true[v]), lp)
+            idcg = np.sum((np.power(2, ideal) - 1) / np.log2(np.arange(len(ideal)) + 2))
+            dcg = np.sum((np.power(2, gains) - 1) / discounts)
+            vals.append(dcg / (idcg + 1e-8))
+        return np.mean(vals)
+
+    table = model.knn.idx_to_node()
+    cuts100 = {u: [table[i] for i in unseen_h[j, :ulen_h[j]].tolist()] for j, u in enumerate(all_users)}
+    train_predictions = {u: [table[i] for i in idx_h[j].tolist()] for j, u in enumerate(all_users)}
+    train_actuals = {u: [i for i, _ in sorted(d.items(), key=operator.itemgetter(1), reverse=True)]
+                     for u, d in train_scores.items()}
+
+    def mean_over(fn, truth, c):
+        return np.mean([fn(truth[u], cuts100[u][:c]) for u in validation_users])
+
+    metrics = {"retrieval_time": retrieval_time,
+               "recall@100": recall_at(100),
+               "ndcg_b@100": binary_ndcg_at(100),
+               "ndcg_b@10": binary_ndcg_at(10),
+               "recall@10": recall_at(10),
+               "diversity": n_covered / len(all_items),
+               **ncf_eval(model, train_edges, validation_edges, all_items)}
+    return {"actuals": val_actuals, "predictions": cuts100, "train_actuals": train_actuals,
+            "train_predictions": train_predictions, "train_actuals_score_dict": dict(train_scores),
+            "validation_actuals_score_dict": val_scores, "metrics": metrics,
+            "extra": {"mrr": mean_over(reciprocal_rank, val_actuals, 100),
+                      "ndcg@100": mean_over(ndcg, val_scores, 100),
+                      "recall@20": recall_at(20)}}
+
+
+def _extraction_efficiency_host(model, train_edges: List[Edge], validation_edges: List[Edge], get_topk, node_type: NodeType):
+    """Host post-processing (any `get_topk` returning {anchor: [(Node, score)]}), the reference's own structure."""
     train_items_of = defaultdict(set)
     train_scores = defaultdict(dict)
     for u, i, r in train_edges:

@@ -182,6 +182,23 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * K12    seen-item filter + cuts of the Recall@K evaluation — replaces the per-user list comprehensions of
+ *        validation.extraction_efficiency (hwer/validation.py:133-141):
+ *          unseen = [i for i in ranked[b] if i not in seen(b)][:cut_max]
+ *   ranked   : (B, k) int64 ids in score order (out_idx of hwer_knn_search_f32); negative ids are skipped
+ *   seen_*   : CSR of each user's training items, every row sorted ascending (NULL = nothing seen)
+ *   truth_*  : CSR of each user's validation truth, rows sorted ascending (NULL = no hit marking)
+ *   outputs  : out_unseen (B, cut_max) ids padded with -1, out_len (B), out_hits (B, ceil(cut_max/64)) bit p = the p-th
+ *              survivor is a truth item; cover_bits (nullable, caller-zeroed, ceil(cover_n/32) words): bit (id - cover_base)
+ *              set for every survivor ("diversity", hwer/validation.py:177).
+ *   The float metrics (utils.recall / ndcg, hwer/utils.py:101-121) are computed from these integers by the caller.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_rank_filter_seen(const int64_t* ranked, int64_t B, int k, const int64_t* seen_ptr, const int64_t* seen_idx,
+                          const int64_t* truth_ptr, const int64_t* truth_idx, int cut_max, int64_t* out_unseen,
+                          int32_t* out_len, uint64_t* out_hits, uint32_t* cover_bits, int64_t cover_base, int64_t cover_n,
+                          void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * X1     multi-GPU merge (no reference counterpart): n_lists per-shard results, each
  *        (B,k) ascending (dist2, id), gathered as (n_lists, B, k) -> global k nearest, then the same
  *        optional stable sort by score.

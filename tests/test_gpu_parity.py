@@ -463,6 +463,37 @@ def test_extraction_efficiency_g9(golden, hw):
     assert 0 <= res["metrics"]["ncf_hr"] <= 1 and res["metrics"]["retrieval_time"] > 0
 
 
+def test_extraction_efficiency_device_matches_host(hw):
+    """the on-device seen-filter / cuts / hit marking (hwer_rank_filter_seen) against the host post-processing on random
+    interactions: identical prediction lists and bit-identical metrics."""
+    import random
+    from hwer import Edge, Node, VectorIndex, validation
+    rng = np.random.default_rng(5)
+    U, I, d = 90, 700, 24
+    V = np.concatenate([unit_rows_f32(301, U, d), unit_rows_f32(302, I, d)]).astype(np.float64)
+    users = [Node("user", i) for i in range(U)]
+    items = [Node("item", i) for i in range(I)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=d)
+    m.fit(users + items, V)
+    train, valid = [], []
+    for u in range(U):
+        near = np.argsort(-(V[U:] @ V[u]))[:150]          # interactions among the nearest items: the seen filter has work to do
+        picks = rng.choice(near, size=int(rng.integers(5, 120)), replace=False)
+        for j, it in enumerate(picks):
+            (valid if j % 7 == 0 and u % 3 != 0 else train).append(Edge(users[u], items[int(it)], float(rng.integers(1, 6))))
+    random.seed(1)
+    dev = validation.extraction_efficiency(m, train, valid, validation.model_get_topk, "item")
+    random.seed(1)
+    host = validation._extraction_efficiency_host(m, train, valid, validation.model_get_topk, "item")
+    assert dev["predictions"] == host["predictions"] and dev["train_predictions"] == host["train_predictions"]
+    assert dev["actuals"] == host["actuals"]
+    for key in host["metrics"]:
+        if key != "retrieval_time":
+            assert dev["metrics"][key] == host["metrics"][key], key
+    for key in host["extra"]:
+        assert dev["extra"][key] == host["extra"][key], key
+
+
 # ------------------------------------------------------------------------------------------------- merge (X1)
 def test_merge_topk_matches_single_shard(hw):
     import torch
