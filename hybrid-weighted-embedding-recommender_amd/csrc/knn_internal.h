@@ -84,7 +84,7 @@ __device__ __forceinline__ int swz(int row) {
 }
 
 // small-batch path (knn_small.hip): B <= SMALL_MAX_QUERIES queries over a catalogue too large for the dense select
-constexpr int SMALL_MAX_QUERIES = 1024;   // and the key matrix (B x items x 4 B) at most SMALL_MAX_KEY_BYTES
+constexpr int SMALL_MAX_QUERIES = 1024;   // always below this many queries (see use_small_path); key matrix (B x items x 4 B) <= SMALL_MAX_KEY_BYTES
 constexpr int64_t SMALL_MAX_KEY_BYTES = int64_t(8) << 30;
 constexpr int SMALL_LIST_CAP = 4096;      // candidate keys one query may collect between its sampled threshold and the select
 constexpr int SMALL_SAMPLE = 16384;       // keys sampled per query for the threshold

@@ -510,8 +510,10 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     // >= 4096 items per list (shorter lists were measured slower: more list-reduce work than the extra parallelism buys).  Callers chunk B to multiples of 512 * qb queries (DeviceIndex.QUERY_CHUNK).
     const int64_t slots = 512;
     int64_t splits = std::max<int64_t>(1, slots / p.n_qblocks);
-    if (const char* e = getenv("HWER_SCREEN_SPLITS")) splits = std::max(1, atoi(e));  // tuning / ablation override
-    const int64_t max_splits = std::max<int64_t>(1, n_items / (4096 * wi));
+    int64_t min_list = 4096;
+    if (const char* e = getenv("HWER_SCREEN_SPLITS")) splits = std::max(1, atoi(e));  // tuning / ablation overrides
+    if (const char* e = getenv("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
+    const int64_t max_splits = std::max<int64_t>(1, n_items / (min_list * wi));
     splits = std::min(splits, max_splits);
     const int ib = 32;
     int64_t per = cdiv64(cdiv64(n_items, splits), ib) * ib;

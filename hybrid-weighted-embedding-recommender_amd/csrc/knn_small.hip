@@ -265,9 +265,15 @@ static size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 
 bool use_small_path(int64_t B, int64_t n_items) {
     if (getenv("HWER_NO_SMALL")) return false;
-    int64_t maxq = SMALL_MAX_QUERIES;
-    if (const char* e = getenv("HWER_SMALL_MAXQ")) maxq = atoi(e);   // tuning override
-    return B <= maxq && n_items > DENSE_MAX_ITEMS && B * n_items * 4 <= SMALL_MAX_KEY_BYTES;
+    if (n_items <= DENSE_MAX_ITEMS || B * n_items * 4 > SMALL_MAX_KEY_BYTES) return false;
+    if (const char* e = getenv("HWER_SMALL_MAXQ")) return B <= atoi(e);   // tuning override
+    if (B <= SMALL_MAX_QUERIES) return true;
+    // Beyond that the streaming screen wins once its launch can fill the machine: 512 workgroup slots, one workgroup per
+    // 256 queries and item split, lists of at least 4096 items.  A launch that cannot (e.g. the last 7 421 of C3's users
+    // against 26 744 items: 29 query blocks x 6 splits) is 1.8x faster through the dense-key path.
+    const int64_t n_qb = cdiv64(B, 256);
+    const int64_t splits = std::min<int64_t>(std::max<int64_t>(1, 512 / n_qb), std::max<int64_t>(1, n_items / 4096));
+    return n_qb * splits < 384;
 }
 
 SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k) {
