@@ -189,14 +189,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     constexpr int CH = 2 * NG;                     // 16-byte chunks per row
     constexpr int TILE_CHUNKS = IB * CH;
     constexpr int DMA_PER_WAVE = TILE_CHUNKS / 256 > 0 ? TILE_CHUNKS / 256 : 1;   // 1-KiB LDS-DMA pieces per wave and tile
-    constexpr int SL = 4;                          // LDS append slots per lane and query subtile
     static_assert(TILE_CHUNKS % 64 == 0, "tile must be a whole number of 1-KiB pieces");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);                         // [2][IB][CH*4]
     float* hn = xs + 2 * IB * CH * 4;                                       // [2][IB]
     uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);          // [4][256] radix histograms of the compaction
     float* keypark_all = reinterpret_cast<float*>(hist_all + 4 * 256);      // [4][64][16]: a wave's 16 keys per lane
-    uint64_t* slots_all = reinterpret_cast<uint64_t*>(keypark_all + 4 * 64 * 16);   // [4][TQ][SL][64] append slots
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -209,12 +207,11 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int64_t qw0 = int64_t(qblock) * (wq * 32 * TQ) + int64_t(wqi) * 32 * TQ;  // wave's first query
     uint32_t* hist = hist_all + wave * 256;
     float* keypark = keypark_all + wave * (64 * 16);
-    uint64_t* slots = slots_all + wave * (TQ * SL * 64);
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
     float4 qf[TQ][NG];
     float tau[TQ];
-    int cnt[TQ], nloc[TQ];
+    int cnt[TQ];
     bool first[TQ], scaled[TQ];
     uint32_t soff[TQ];   // this lane's stream = wg_cand[soff .. soff + CAPH)
     uint64_t* const wg_cand = a.cand + ((int64_t(list) * a.bq + qw0) * 2) * CAPH;   // wave-uniform base
@@ -227,7 +224,6 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             qf[b][g] = live ? *reinterpret_cast<const float4*>(a.Q + q * a.ldx + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
         tau[b] = (live && !a.debug_nofilter) ? a.debug_tau0 : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
-        nloc[b] = 0;
         first[b] = true;
         scaled[b] = false;
         soff[b] = (uint32_t(32 * b + r) * 2u + uint32_t(h)) * CAPH;
@@ -335,6 +331,10 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
             __builtin_amdgcn_s_setprio(3);
             if (a.debug_stamps) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
+            // Streaming mode: outstanding VMEM here = the DMA of tile t+1 (issued a whole MFMA phase ago) and the appends
+            // of the previous tile (a whole tile ago): this wait is free, and it lets this tile's appends go straight to
+            // HBM and stay in flight across the barrier below (no LDS staging of the appends, no flush).
+            if constexpr (!DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (DENSE) {
                 // small catalogues: keep every key (lane (r, h): query r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store)
 #pragma unroll
@@ -372,13 +372,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                             const int q = 15 - __builtin_ctz(mask);
                             mask &= mask - 1u;
                             const uint64_t key = pack_key(park[q], item0 + (q & 3) + 8 * (q >> 2));
-                            if (nloc[b] < SL) {
-                                slots[(b * SL + nloc[b]) * 64 + lane] = key;   // flushed to HBM after the tile barrier
-                                ++nloc[b];
-                            } else {
-                                wg_cand[soff[b] + uint32_t(cnt[b])] = key;      // warm-up / bursts
-                                ++cnt[b];
-                            }
+                            wg_cand[soff[b] + uint32_t(cnt[b])] = key;
+                            ++cnt[b];
                         }
                     }
                 }
@@ -387,15 +382,14 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         }
         STAMP(t3);
         // ---- tile boundary ---------------------------------------------------------------------------------------------
-        // Outstanding VMEM here: the DMA of tile t+1 and the previous flush, both issued a whole tile ago (appends of
-        // this tile sit in LDS slots), so this wait is normally free.
         if constexpr (DENSE) {
             // the 4 * TQ key stores of this tile are YOUNGER than the DMA of tile t+1 (vmcnt retires in issue order):
             // wait for everything but them, so the DMA has landed while the stores stay in flight
             if ((t & wi_mask) == wii) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // waves that computed this tile waited for the DMA of tile t+1 before their appends; the others do it here
+            if ((t & wi_mask) != wii) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         STAMP(t4);
@@ -403,21 +397,6 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);
             p_dma = perm_next(p_dma);
             continue;
-        }
-        {
-            uint64_t sv[TQ][SL];   // all LDS reads issue back to back (one latency), the stores are predicated afterwards
-#pragma unroll
-            for (int b = 0; b < TQ; ++b)
-#pragma unroll
-                for (int sidx = 0; sidx < SL; ++sidx) sv[b][sidx] = slots[(b * SL + sidx) * 64 + lane];
-#pragma unroll
-            for (int b = 0; b < TQ; ++b) {
-#pragma unroll
-                for (int sidx = 0; sidx < SL; ++sidx)
-                    if (sidx < nloc[b]) wg_cand[soff[b] + uint32_t(cnt[b] + sidx)] = sv[b][sidx];
-                cnt[b] += nloc[b];
-                nloc[b] = 0;
-            }
         }
         unsigned long long t4a = 0, t4b = 0;
         STAMP(t4a);
@@ -540,8 +519,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
 
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 x 64 x 16 | append slots 4 x TQ x 4 x 64
-    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4 + size_t(4) * TQ * 4 * 64 * 8;
+    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 x 64 x 16
+    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4;
     if (const char* e = getenv("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
     static bool attr_done = false;
     if (!attr_done || getenv("HWER_SCREEN_LDS_PAD_KB")) {
