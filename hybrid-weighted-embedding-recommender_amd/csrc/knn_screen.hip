@@ -251,23 +251,29 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // PIECE_ROWS * 4 is a multiple of ... handled generically: the offset of piece i is recomputed from two lane
     // constants with 32-bit integer ops only (v_mad_u32_u24-class: row < 32, row_bytes <= 1024).
     const uint32_t lane_row = uint32_t(lane / CH), lane_chunk = uint32_t(lane % CH);
+    // wave-uniform loop invariants of the fill, as plain integers / byte pointers (no generic-pointer conversions, no
+    // 64-bit multiplies per tile): LDS byte address of this wave's first piece in ring slot 0, byte size of a tile in
+    // HBM, and the split's first row.
+    static_assert(TILE_CHUNKS % 256 == 0, "every wave issues the same number of pieces");
+    const uint32_t xs_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(xs)) + uint32_t(wave) * 1024u;
+    const uint32_t hn_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(hn));
+    const char* const x_split = reinterpret_cast<const char*>(a.X + i_begin * a.ldx);
+    const float* const hn_split = a.hnorm + i_begin;
+    const uint32_t tile_bytes = uint32_t(IB) * row_bytes;
     auto tile_dma = [&](int t, int ptile) {
-        const int64_t base = i_begin + int64_t(ptile) * IB;
-        const uint32_t xb_addr = __builtin_amdgcn_readfirstlane(lds_addr(xs + (t & 1) * IB * CH * 4));
-        const char* tile_ptr = reinterpret_cast<const char*>(a.X + base * a.ldx);    // wave-uniform
+        const uint32_t xb_addr = xs_addr0 + uint32_t(t & 1) * uint32_t(IB * CH * 16);
+        const char* tile_ptr = x_split + uint64_t(uint32_t(ptile)) * tile_bytes;    // wave-uniform
         uint32_t lr = lane_row, lc = lane_chunk;
         asm volatile("" : "+v"(lr), "+v"(lc));   // opaque: keeps the per-piece offsets from being hoisted into (spilled) registers
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
-            const int piece = wave + 4 * i;                  // wave-uniform
-            if (piece * 64 < TILE_CHUNKS) {
-                const uint32_t row = uint32_t(piece * PIECE_ROWS) + lr;
-                const uint32_t off = __umul24(row, row_bytes) + ((lc ^ uint32_t(swz<CH>(int(row)))) << 4);
-                lds_dma16(tile_ptr, off, xb_addr + uint32_t(piece) * 1024u);
-            }
+            // piece = wave + 4 i covers rows piece * PIECE_ROWS + lane / CH
+            const uint32_t row = uint32_t(wave * PIECE_ROWS) + uint32_t(4 * i * PIECE_ROWS) + lr;
+            const uint32_t off = __umul24(row, row_bytes) + ((lc ^ uint32_t(swz<CH>(int(row)))) << 4);
+            lds_dma16(tile_ptr, off, xb_addr + uint32_t(i) * 4096u);
         }
         if (wave == 0 && lane < IB)   // half norms of the tile rows: one 4-byte piece, lanes 0..31
-            lds_dma4(a.hnorm + base, uint32_t(lane) * 4u, __builtin_amdgcn_readfirstlane(lds_addr(hn + (t & 1) * IB)));
+            lds_dma4(hn_split + int64_t(ptile) * IB, uint32_t(lane) * 4u, hn_addr0 + uint32_t(t & 1) * uint32_t(IB * 4));
     };
 
     __builtin_amdgcn_s_setprio(3);
