@@ -12,7 +12,8 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
 Default (N = 1): BASELINE.json configs[1] — ML-1M-shaped synthetic, 6040 users x 3706 items, d = 128, two tables,
 alpha = 0.5.  N > 1 (launched by torch.distributed.run, one rank per GPU): the item catalogue is row-sharded, every
 rank holds a shard of the SAME size as the N = 1 catalogue (weak scaling), queries are replicated, and the local
-top-K are exchanged with one RCCL all-gather followed by the merge kernel on every rank.
+top-K are exchanged in ONE step over RCCL - user-partitioned: every rank receives the lists of its slice of the users
+from all ranks (all_to_all_single) and merges those; HWER_BENCH_EXCHANGE=all_gather selects the replicated variant.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md §6 for the roofline arithmetic.
 """
@@ -63,7 +64,7 @@ def main():
     import torch.distributed as dist
     from hwer import native
     from hwer.device_index import roundup
-    from hwer.distributed import all_gather_results, merge_on_device
+    from hwer.distributed import all_gather_results, exchange_by_query, merge_on_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -161,11 +162,14 @@ def main():
                                                    P(o_dist2[b0:b1]) if want_dist else None, P(o_flags[b0:b1]), P(ws), P(missed), P(ws_exact), ws_exact.numel(), S()),
                          "knn_exact_device")
         if world > 1:
-            g = all_gather_results(o_idx, o_score, o_dist2)
+            # ONE exchange step: user-partitioned (every rank receives the local lists of ITS slice of the users from all
+            # ranks and merges those - 1/N of the all-gather's bytes per xGMI link), or the all-gather variant
+            g = exchange_by_query(o_idx, o_score, o_dist2) if exchange == "by_query" else all_gather_results(o_idx, o_score, o_dist2)
             return merge_on_device(*g, True)
         return o_idx, o_score, o_dist2
 
     missed = torch.zeros(1, dtype=torch.int32, device=dev)
+    exchange = os.environ.get("HWER_BENCH_EXCHANGE", "by_query")
     ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
 
     def barrier():
@@ -246,7 +250,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "users": U, "items_per_gpu": I, "items_total": total_items, "d": d, "k": K,
-                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": "items row-sharded x%d, all-gather + merge" % world if world > 1 else "none"},
+                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": ("items row-sharded x%d, %s + merge" % (world, "user-partitioned exchange" if exchange == "by_query" else "all-gather")) if world > 1 else "none"},
         "roofline": {"kernel": "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)", "bound": "mfma",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "avg_launch_ms": screen_ms, "launches_per_step": launches},

@@ -2,9 +2,11 @@
 "nccl" is RCCL on ROCm).  No reference counterpart — the reference is single process.
 
 Each rank holds rows [lo, hi) of the retrieved type's table and answers every query against its shard with the
-single-GPU kernels (exact local k nearest in (dist2, id) order).  ONE collective — an all-gather of the packed
-local results over xGMI — is followed by a k-way merge kernel on every rank.  Because the local lists and the
-merge use the same total order (dist2 asc, global id asc), the merged result is identical to the 1-GPU result.
+single-GPU kernels (exact local k nearest in (dist2, id) order).  ONE exchange step over xGMI follows — either an
+all-gather of the packed local results (every rank ends with the full result) or the user-partitioned exchange
+(every rank receives only the lists of ITS slice of the queries and merges those: 1/G of the bytes per link) — and
+then a k-way merge kernel.  Because the local lists and the merge use the same total order (dist2 asc, global id
+asc), the merged result is identical to the 1-GPU result.
 """
 from __future__ import annotations
 
@@ -44,6 +46,54 @@ def all_gather_results(idx, score, dist2, group=None):
     return g_idx, g_score, g_dist2
 
 
+def query_slice(n_queries: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Queries whose merged result `rank` owns in the user-partitioned exchange (contiguous, ceil(B/G) per rank)."""
+    return shard_bounds(n_queries, world_size, rank)
+
+
+def exchange_by_query(idx, score, dist2, group=None):
+    """User-partitioned exchange (SURVEY.md §8e variant): rank r receives, from every rank g, g's local results for the
+    queries of r's slice -> three (G, Bs, k) tensors, Bs = ceil(B/G) (rows beyond the slice are padding: ids -1,
+    dist2 +inf).  Per link this moves 1/G of what the all-gather moves: xGMI is point-to-point, so the exchange is G
+    concurrent sends of B k 24 / G bytes instead of G broadcasts of B k 24 bytes.  RCCL: one all_to_all_single; other
+    backends (gloo in the CPU tests): the same exchange as batched point-to-point operations."""
+    import torch
+    import torch.distributed as dist
+    G = dist.get_world_size(group)
+    r = dist.get_rank(group)
+    B, k = idx.shape
+    Bs = (B + G - 1) // G
+    pad = Bs * G - B
+    packed = torch.stack([idx, score.view(torch.int64), dist2.view(torch.int64)], dim=0)   # (3, B, k) int64 bit patterns
+    if pad:
+        filler = torch.empty((3, pad, k), dtype=torch.int64, device=idx.device)
+        filler[0] = -1
+        filler[1] = 0
+        filler[2] = torch.full((pad, k), float("inf"), dtype=torch.float64, device=idx.device).view(torch.int64)
+        packed = torch.cat([packed, filler], dim=1)
+    send = packed.view(3, G, Bs, k).permute(1, 0, 2, 3).contiguous()   # (G, 3, Bs, k): slice g goes to rank g
+    staged = send.is_cuda and dist.get_backend(group) != "nccl"        # test harness only: ranks sharing a GPU over gloo
+    if staged:
+        send = send.cpu()
+    recv = torch.empty_like(send)
+    if dist.get_backend(group) == "nccl":
+        dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)   # equal splits: slice g <-> rank g
+    else:
+        recv[r] = send[r]
+        ops = []
+        for g in range(G):
+            if g != r:
+                peer = dist.get_global_rank(group, g) if group is not None else g
+                ops.append(dist.P2POp(dist.isend, send[g], peer, group))
+                ops.append(dist.P2POp(dist.irecv, recv[g], peer, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+    if staged:
+        recv = recv.to(idx.device)
+    return recv[:, 0].contiguous(), recv[:, 1].contiguous().view(torch.float64), recv[:, 2].contiguous().view(torch.float64)
+
+
 def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True):
     """hwer_merge_topk over gathered (G, B, k) tensors -> (idx, score, dist2) (B, k) tensors."""
     import torch
@@ -67,7 +117,7 @@ class ShardedSearch:
     Both are injectable so that the collective plumbing is testable on CPU (gloo) without a GPU."""
 
     def __init__(self, n_rows: int, local_search: Callable, merge: Callable = merge_on_device, group=None,
-                 pad_value: float = float("inf")):
+                 pad_value: float = float("inf"), exchange: str = "all_gather"):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
@@ -76,6 +126,8 @@ class ShardedSearch:
         self.lo, self.hi = shard_bounds(n_rows, self.world, self.rank)
         self.local_search, self.merge = local_search, merge
         self.pad_value = pad_value
+        assert exchange in ("all_gather", "by_query")
+        self.exchange = exchange   # "by_query": every rank ends up with the merged result of ITS query slice only
 
     def search(self, Q64, Q32, k: int, sort_by_score: bool = True):
         import torch
@@ -90,6 +142,11 @@ class ShardedSearch:
         if k_local > 0:
             li, ls, ld = self.local_search(Q64, Q32, k_local)
             idx[:, :k_local], score[:, :k_local], dist2[:, :k_local] = li, ls, ld
+        if self.exchange == "by_query":
+            g = exchange_by_query(idx, score, dist2, self.group)
+            m_idx, m_score, m_dist2 = self.merge(*g, sort_by_score)
+            lo, hi = query_slice(B, self.world, self.rank)
+            return m_idx[:hi - lo], m_score[:hi - lo], m_dist2[:hi - lo]   # rows of queries [lo, hi)
         g = all_gather_results(idx, score, dist2, self.group)
         return self.merge(*g, sort_by_score)
 

@@ -28,7 +28,7 @@ def _worker(rank, world, port, n_items, k, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hwer.distributed import ShardedSearch, shard_bounds
     from oracle import hwer_oracle as orc
-    B, d, U = 6, 16, 6
+    B, d, U = 6, 16, 6   # B is re-bound inside `merge` (the by_query exchange merges a slice)
     V = np.concatenate([_unit_rows(1, U, d), _unit_rows(2, n_items, d)]).astype(np.float64)
     Q = np.stack([orc.query_vector(V, u) for u in range(U)])
     lo, hi = shard_bounds(n_items, world, rank)
@@ -43,7 +43,7 @@ def _worker(rank, world, port, n_items, k, out_dir):
         return torch.from_numpy(idx), torch.from_numpy(sc), torch.from_numpy(d2)
 
     def merge(g_idx, g_score, g_dist2, sort_by_score):   # stand-in for hwer_merge_topk
-        G = g_idx.shape[0]
+        G, B = g_idx.shape[0], g_idx.shape[1]
         o_i = np.empty((B, k), np.int64); o_s = np.empty((B, k)); o_d = np.empty((B, k))
         for b in range(B):
             dd = np.concatenate([g_dist2[g, b].numpy() for g in range(G)])
@@ -66,6 +66,14 @@ def _worker(rank, world, port, n_items, k, out_dir):
         assert np.array_equal(np.sqrt(dist2[b].numpy()), o_dist)
     with pytest.raises(ValueError):
         sh.search(torch.from_numpy(Q), torch.from_numpy(Q.astype(np.float32)), n_items + 1)
+    # user-partitioned exchange: this rank ends with the merged rows of its own query slice only
+    from hwer.distributed import query_slice
+    B = 6
+    shq = ShardedSearch(n_items, local_search, merge, exchange="by_query")
+    idx_q, score_q, dist2_q = shq.search(torch.from_numpy(Q), torch.from_numpy(Q.astype(np.float32)), k)
+    q_lo, q_hi = query_slice(B, world, rank)
+    assert idx_q.shape[0] == q_hi - q_lo
+    assert torch.equal(idx_q, idx[q_lo:q_hi]) and torch.equal(score_q, score[q_lo:q_hi]) and torch.equal(dist2_q, dist2[q_lo:q_hi])
     open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 
