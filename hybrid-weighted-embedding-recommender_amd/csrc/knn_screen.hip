@@ -484,6 +484,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     p.kprime = ((k + SLACK + 63) / 64) * 64;
     // queries per wave: TQ = 2 subtiles while the B fragments fit the register budget (NG * TQ float4 <= 32 float4)
     p.tq = (p.ng <= 16 && B > 32) ? 2 : 1;
+    if (const char* e = getenv("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : p.tq;   // tuning override
     const int qpw = 32 * p.tq;
     p.wq = B > 2 * qpw ? 4 : (B > qpw ? 2 : 1);
     p.qb = p.wq * qpw;

@@ -463,6 +463,56 @@ def test_extraction_efficiency_g9(golden, hw):
     assert 0 <= res["metrics"]["ncf_hr"] <= 1 and res["metrics"]["retrieval_time"] > 0
 
 
+@pytest.mark.parametrize("B,k,cut", [(1, 200, 100), (37, 200, 100), (64, 50, 100), (9, 130, 128), (5, 3, 1)])
+def test_rank_filter_seen_kernel(hw, B, k, cut):
+    """hwer_rank_filter_seen against a plain-Python restatement of hwer/validation.py:133-141: survivors in order, lengths,
+    hit bits, coverage bits; empty seen / truth rows, ranked lists shorter than the cut, negative (padding) ids."""
+    import torch
+    from hwer import native
+    lib = native.lib()
+    rng = np.random.default_rng(B * 1000 + k)
+    n_ids, base = 5000, 1000
+    ranked = np.stack([rng.permutation(n_ids)[:k] + base for _ in range(B)]).astype(np.int64)
+    if k > 10:
+        ranked[0, 7] = -1                                    # padding entries are skipped
+    seen = [np.sort(rng.choice(ranked[b][ranked[b] >= 0], size=int(rng.integers(0, min(k, 60))), replace=False)) if b % 4 else
+            np.zeros(0, np.int64) for b in range(B)]
+    truth = [np.sort(rng.choice(np.arange(base, base + n_ids), size=int(rng.integers(0, 40)), replace=False)) if b % 3 else
+             np.sort(ranked[b][ranked[b] >= 0][:5]) for b in range(B)]
+    ptr = lambda rows: np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)   # noqa: E731
+    cat = lambda rows: np.concatenate(rows + [np.zeros(1, np.int64)]).astype(np.int64)              # noqa: E731
+    dev = torch.device("cuda")
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)   # noqa: E731
+    d_r, d_sp, d_si, d_tp, d_ti = T(ranked), T(ptr(seen)), T(cat(seen)), T(ptr(truth)), T(cat(truth))
+    nw = (cut + 63) // 64
+    unseen = torch.empty((B, cut), dtype=torch.int64, device=dev)
+    ulen = torch.empty(B, dtype=torch.int32, device=dev)
+    hits = torch.empty((B, nw), dtype=torch.int64, device=dev)
+    cover = torch.zeros((n_ids + 31) // 32, dtype=torch.int32, device=dev)
+    native.check(lib.hwer_rank_filter_seen(native.ptr(d_r), B, k, native.ptr(d_sp), native.ptr(d_si), native.ptr(d_tp), native.ptr(d_ti), cut,
+                                           native.ptr(unseen), native.ptr(ulen), native.ptr(hits), native.ptr(cover), base, n_ids,
+                                           native.stream_ptr()), "rank_filter_seen")
+    u_h, l_h, h_h = unseen.cpu().numpy(), ulen.cpu().numpy(), hits.cpu().numpy().view(np.uint64)
+    covered = set()
+    for b in range(B):
+        want = [int(i) for i in ranked[b] if i >= 0 and i not in set(seen[b].tolist())][:cut]
+        assert l_h[b] == len(want) and u_h[b, :len(want)].tolist() == want and (u_h[b, len(want):] == -1).all()
+        tset = set(truth[b].tolist())
+        for p, i in enumerate(want):
+            assert bool((int(h_h[b, p // 64]) >> (p % 64)) & 1) == (i in tset), (b, p)
+        assert all(((int(h_h[b, p // 64]) >> (p % 64)) & 1) == 0 for p in range(len(want), 64 * nw))
+        covered.update(want)
+    bits = np.unpackbits(cover.cpu().numpy().view(np.uint8), bitorder="little")[:n_ids]
+    assert set((np.nonzero(bits)[0] + base).tolist()) == covered
+    # no seen / truth CSR at all
+    native.check(lib.hwer_rank_filter_seen(native.ptr(d_r), B, k, None, None, None, None, cut, native.ptr(unseen), native.ptr(ulen),
+                                           native.ptr(hits), None, 0, 0, native.stream_ptr()), "rank_filter_seen")
+    assert (hits.cpu().numpy() == 0).all()
+    for b in range(B):
+        want = [int(i) for i in ranked[b] if i >= 0][:cut]
+        assert ulen.cpu().numpy()[b] == len(want) and unseen.cpu().numpy()[b, :len(want)].tolist() == want
+
+
 def test_extraction_efficiency_device_matches_host(hw):
     """the on-device seen-filter / cuts / hit marking (hwer_rank_filter_seen) against the host post-processing on random
     interactions: identical prediction lists and bit-identical metrics."""
