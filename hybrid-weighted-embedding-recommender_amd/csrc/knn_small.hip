@@ -155,18 +155,21 @@ struct SmallSelectArgs {
 
 // threshold of one query from a strided sample of its key row: the r-th largest sample key, r chosen so that about
 // 4.75 K' keys of the row clear it (never fewer than 16 sample keys: the row count then has a relative spread <= 25 %)
-__global__ __launch_bounds__(256) void small_threshold_kernel(const SmallSelectArgs a) {
-    constexpr int PER = SMALL_SAMPLE / 256;   // samples per thread (64)
-    __shared__ int s_cnt[4];
+__global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelectArgs a) {
+    constexpr int NT = 1024, NWV = NT / 64;
+    constexpr int PER = SMALL_SAMPLE / NT;   // samples per thread (16): a probe is 16 compares + one block reduction
+    __shared__ int s_cnt[NWV];
+    __shared__ float s_mm[2 * NWV];
     const int64_t b = blockIdx.x;
     const float* row = a.keys + b * a.ld;
     const int64_t n = a.n_items;
     const int64_t S = n < SMALL_SAMPLE ? n : SMALL_SAMPLE;
     const double step = double(n) / double(S);
+    const int wave = threadIdx.x >> 6;
     float v[PER];
 #pragma unroll
     for (int m = 0; m < PER; ++m) {
-        const int64_t j = int64_t(threadIdx.x) + 256 * m;
+        const int64_t j = int64_t(threadIdx.x) + NT * m;
         v[m] = j < S ? row[min(int64_t(double(j) * step), n - 1)] : -INFINITY;
     }
     float vmax = -INFINITY, vmin = INFINITY;
@@ -175,24 +178,28 @@ __global__ __launch_bounds__(256) void small_threshold_kernel(const SmallSelectA
         vmax = fmaxf(vmax, v[m]);
         if (v[m] > -INFINITY) vmin = fminf(vmin, v[m]);
     }
-    __shared__ float s_mm[8];
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
-    if ((threadIdx.x & 63) == 0) { s_mm[threadIdx.x >> 6] = vmax; s_mm[4 + (threadIdx.x >> 6)] = vmin; }
+    if ((threadIdx.x & 63) == 0) { s_mm[wave] = vmax; s_mm[NWV + wave] = vmin; }
     __syncthreads();
-    vmax = fmaxf(fmaxf(s_mm[0], s_mm[1]), fmaxf(s_mm[2], s_mm[3]));
-    vmin = fminf(fminf(s_mm[4], s_mm[5]), fminf(s_mm[6], s_mm[7]));
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        vmax = fmaxf(vmax, s_mm[w]);
+        vmin = fminf(vmin, s_mm[NWV + w]);
+    }
     __syncthreads();
     auto count_ge = [&](float t) {   // block-uniform result
         int c = 0;
 #pragma unroll
         for (int m = 0; m < PER; ++m) c += __builtin_popcountll(__ballot(v[m] >= t));
-        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+        if ((threadIdx.x & 63) == 0) s_cnt[wave] = c;
         __syncthreads();
-        const int tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) tot += s_cnt[w];
         __syncthreads();
         return tot;
     };
@@ -332,7 +339,7 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
     if (rc) return rc;
     SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, reinterpret_cast<float*>(ws + w.thr),
                        reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list)};
-    hipLaunchKernelGGL(small_threshold_kernel, dim3(unsigned(B)), dim3(256), 0, stream, sa);
+    hipLaunchKernelGGL(small_threshold_kernel, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     if ((rc = check_launch("knn_small(threshold)"))) return rc;
     hipLaunchKernelGGL(small_collect_kernel, dim3(unsigned(cdiv64(p.ld / 4, 256 * 16)), unsigned(B)), dim3(256), 0, stream, sa);
     if ((rc = check_launch("knn_small(collect)"))) return rc;
