@@ -809,6 +809,7 @@ struct ExactDevArgs {
     WsHeader* hdr;
     Ent* cand;       // [EXACT_DEVICE_MAXQ][n_chunks][k]
     int n_chunks;
+    int chunk;       // items per stage-A block (power of two, k <= chunk <= EX_CHUNK)
     int32_t* missed_accum;   // nullable device counter: += listed queries beyond EXACT_DEVICE_MAXQ (left flagged 0)
     EmitArgs emit;
 };
@@ -825,8 +826,8 @@ __global__ __launch_bounds__(256) void exact_device_kernel(const ExactDevArgs a)
     const int64_t b = a.hdr->uncert_list[qi];
     const int d = a.emit.d, k = a.emit.k;
     const double* q = a.Q64 + b * d;
-    const int64_t base = int64_t(blockIdx.x) * EX_CHUNK;
-    for (int i = tid; i < EX_CHUNK; i += 256) {
+    const int64_t base = int64_t(blockIdx.x) * a.chunk;
+    for (int i = tid; i < a.chunk; i += 256) {
         Ent e;
         e.hi = ~0ull;
         e.lo = ~0ull;
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256) void exact_device_kernel(const ExactDevArgs a)
         }
         ent[i] = e;
     }
-    bitonic_asc_ent(ent, EX_CHUNK);
+    bitonic_asc_ent(ent, a.chunk);
     Ent* all = a.cand + int64_t(qi) * a.n_chunks * k;
     for (int i = tid; i < k; i += 256) all[int64_t(blockIdx.x) * k + i] = ent[i];
     __threadfence();
@@ -1289,9 +1290,18 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
     return HWER_OK;
 }
 
+// Stage-A chunk of the on-device exhaustive pass: about 64 blocks per query on small catalogues (more parallelism, shorter
+// sorts), EX_CHUNK items on large ones; always a power of two >= k so that a block can hand over k entries.
+static int exact_device_chunk(int64_t n_items, int k) {
+    int c = 1024;
+    while (c < EX_CHUNK && int64_t(c) * 64 < n_items) c <<= 1;
+    while (c < k) c <<= 1;
+    return c;
+}
+
 size_t hwer_knn_exact_device_workspace_bytes(int64_t n_items, int k) {
     if (n_items < 1 || k < 1 || k > K_MAX) return 0;
-    return align256(size_t(EXACT_DEVICE_MAXQ) * size_t(cdiv64(n_items, EX_CHUNK)) * size_t(k) * sizeof(Ent));
+    return align256(size_t(EXACT_DEVICE_MAXQ) * size_t(cdiv64(n_items, exact_device_chunk(n_items, k))) * size_t(k) * sizeof(Ent));
 }
 
 int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
@@ -1316,7 +1326,8 @@ int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, c
     ea.Q64 = Q64;
     ea.hdr = reinterpret_cast<WsHeader*>(knn_workspace);
     ea.cand = reinterpret_cast<Ent*>(workspace);
-    ea.n_chunks = int(cdiv64(n_items, EX_CHUNK));
+    ea.chunk = exact_device_chunk(n_items, k);
+    ea.n_chunks = int(cdiv64(n_items, ea.chunk));
     ea.missed_accum = missed_accum;
     ea.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, nullptr};

@@ -216,6 +216,44 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
     }
 }
 
+// Same threshold by ONE wave per query (no workgroup barriers) from a sample of 64 * PER keys taken as 16-key segments
+// (64 contiguous bytes each) spread evenly over the row: a strided single-key sample would touch nearly every cache line
+// of a short row.  Enough whenever the sample rank stays >= 16.  Four queries per 256-thread block.
+template <int PER>   // keys per lane: 16 (1024-key sample) or 64 (4096-key sample)
+__global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSelectArgs a) {
+    constexpr int NSEG = 64 * PER / 16;
+    const int lane = threadIdx.x & 63;
+    const int64_t b = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;
+    const float* row = a.keys + b * a.ld;
+    const int64_t n = a.n_items;      // rows are padded to a multiple of 32 keys (pad keys are -inf): segments stay in the row
+    const double step = n > 16 ? double(n - 16) / double(NSEG - 1) : 0.0;
+    float v[PER];
+    int64_t n_sample = 0;
+#pragma unroll
+    for (int m = 0; m < PER / 16; ++m) {
+        const int seg = lane + 64 * m;
+        const int64_t p0 = (int64_t(double(seg) * step) >> 2) << 2;   // 16-byte aligned start
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 x = *reinterpret_cast<const float4*>(row + p0 + 4 * c);
+            v[16 * m + 4 * c + 0] = x.x; v[16 * m + 4 * c + 1] = x.y; v[16 * m + 4 * c + 2] = x.z; v[16 * m + 4 * c + 3] = x.w;
+        }
+        n_sample += 16;
+    }
+    const double S = double(64 * PER);   // segments may overlap on rows shorter than the sample: the rank only gets safer
+    const double want = 4.75 * double(a.kprime) * S / double(n > 64 * PER ? n : 64 * PER);
+    int rank = int(want + 0.5);
+    if (rank < 16) rank = 16;
+    if (rank > 64 * PER) rank = 64 * PER;
+    int c_lo;
+    const float t = wave_find_rank<PER>(v, rank, rank / 8, c_lo);
+    if (lane == 0) {
+        a.thr[b] = t;
+        a.count[b] = 0;
+    }
+}
+
 // every workgroup scans 256 * 64 keys of one query's row; the keys >= threshold are gathered in LDS and appended to the
 // query's list with ONE reservation per workgroup (per-wave atomics on a handful of counters serialise in L2)
 __global__ __launch_bounds__(256) void small_collect_kernel(const SmallSelectArgs a) {
@@ -339,7 +377,13 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
     if (rc) return rc;
     SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, reinterpret_cast<float*>(ws + w.thr),
                        reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list)};
-    hipLaunchKernelGGL(small_threshold_kernel, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    // sample rank = 4.75 K' S / N must stay >= 16 (kept >= 32 here): one wave per query with a 1024- or 4096-key sample
+    if (double(n_items) * 32.0 <= 1024.0 * 4.75 * double(p.kprime))
+        hipLaunchKernelGGL(small_threshold_wave_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (double(n_items) * 32.0 <= 4096.0 * 4.75 * double(p.kprime))
+        hipLaunchKernelGGL(small_threshold_wave_kernel<64>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else
+        hipLaunchKernelGGL(small_threshold_kernel, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     if ((rc = check_launch("knn_small(threshold)"))) return rc;
     hipLaunchKernelGGL(small_collect_kernel, dim3(unsigned(cdiv64(p.ld / 4, 256 * 16)), unsigned(B)), dim3(256), 0, stream, sa);
     if ((rc = check_launch("knn_small(collect)"))) return rc;
