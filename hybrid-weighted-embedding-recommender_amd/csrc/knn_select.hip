@@ -1101,19 +1101,31 @@ extern "C" {
 
 int hwer_knn_max_k(void) { return K_MAX; }
 
-size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) {
+size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options) {
     const int ldx = hwer_knn_padded_dim(d);
     if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
-    if (use_small_path(B, n_items)) return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k));
+    const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
+    if (!conservative && use_small_path(B, n_items)) return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k));
     return ws_layout(make_screen_plan(B, n_items, ldx, k), B).total;
 }
+size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) { return hwer_knn_workspace_bytes_opts(B, n_items, d, k, 0); }
 
 int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                         const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k, int score_mode,
                         int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
                         double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                         size_t workspace_bytes, void* stream) {
+    return hwer_knn_search_opts_f32(X, hnorm, n_items, d, ldx, Q32, Q64, A32, lda, a_idx, B, k, score_mode, sort_by_score, row_ids,
+                                    id_base, hnorm_max, out_idx, out_score, out_dist2, out_flags, workspace, workspace_bytes, 0, stream);
+}
+
+int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
+                             const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k, int score_mode,
+                             int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
+                             double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                             size_t workspace_bytes, uint32_t options, void* stream) {
     if (B == 0) return HWER_OK;
+    const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
     if (!X || !hnorm || !Q32 || !Q64 || !out_idx || !out_score || !out_flags || !workspace)
         return fail(HWER_EINVAL, "knn_search: null pointer");
     if (!out_dist2 && (score_mode == 2 || !sort_by_score))
@@ -1131,7 +1143,7 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         return fail(HWER_EINVAL, "knn_search: X/Q32 must be 16-byte and workspace 256-byte aligned");
     hipStream_t st = as_stream(stream);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
-    if (use_small_path(B, n_items)) {   // a handful of queries over a large catalogue: HBM-bound path (knn_small.hip)
+    if (!conservative && use_small_path(B, n_items)) {   // a handful of queries over a large catalogue: HBM-bound path (knn_small.hip)
         const SmallPlan sp = make_small_plan(B, n_items, int(ldx), k);
         const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp);
         if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, need);
@@ -1158,7 +1170,8 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
         da.list_min = sp.kprime;
         return launch_select_list(da, d, score_mode, st);
     }
-    const ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);
+    ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);
+    if (conservative) plan.scaled_first = 0;   // every threshold is an exact K'-th key: a list can only fail on genuine ties
     const WsLayout w = ws_layout(plan, B);
     if (workspace_bytes < w.total) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, w.total);
     uint64_t* cand = reinterpret_cast<uint64_t*>(ws + w.cand_a);

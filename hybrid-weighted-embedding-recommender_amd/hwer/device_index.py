@@ -226,9 +226,51 @@ class DeviceIndex:
         native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr()), "count_uncertified")
         if int(n_bad.item()):
             bad = torch.nonzero(flags == 0).flatten()
-            self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
-                                 dist2, flags)
+            if bad.numel() > self.RETRY_MIN:
+                # many uncertified queries = the sampled thresholds were defeated (e.g. a catalogue sorted by cluster): run
+                # them again with exact thresholds before falling back to the exhaustive pass query by query
+                self._retry_exact_thresholds(tt, bad, Q64, Q32, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base,
+                                             idx, score, dist2, flags)
+                bad = torch.nonzero(flags == 0).flatten()
+            if bad.numel():
+                self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
+                                     dist2, flags)
         return idx, score, dist2, flags
+
+    #: more uncertified queries than this go through the exact-threshold retry first
+    RETRY_MIN = 16
+
+    def _retry_exact_thresholds(self, tt, bad, Q64, Q32, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base,
+                                idx, score, dist2, flags):
+        torch = _torch()
+        nb = int(bad.numel())
+        q64, q32 = Q64.index_select(0, bad).contiguous(), Q32.index_select(0, bad).contiguous()
+        a_sub = anchors_dev.index_select(0, bad).contiguous() if anchors_dev is not None else None
+        if a_sub is None and score_mode != 2:
+            a_sub = bad.to(torch.int32)   # anchor row of query b defaults to row b of the table
+        r_idx = torch.empty((nb, k), dtype=torch.int64, device=self.device)
+        r_score = torch.empty((nb, k), dtype=torch.float64, device=self.device)
+        r_dist2 = torch.empty((nb, k), dtype=torch.float64, device=self.device) if dist2 is not None else None
+        r_flags = torch.empty(nb, dtype=torch.int32, device=self.device)
+        opt = 1   # HWER_KNN_EXACT_THRESHOLDS
+        for b0 in range(0, nb, self.QUERY_CHUNK):
+            b1 = min(nb, b0 + self.QUERY_CHUNK)
+            wsb = self.lib.hwer_knn_workspace_bytes_opts(b1 - b0, tt.n, self.d, k, opt)
+            ws = self._workspace(wsb)
+            native.check(self.lib.hwer_knn_search_opts_f32(
+                native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(q32[b0:b1]), native.ptr(q64[b0:b1]),
+                native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub[b0:b1]) if a_sub is not None else None,
+                b1 - b0, k, score_mode, 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None,
+                0 if use_rows else int(id_base), tt.hnorm_max, native.ptr(r_idx[b0:b1]), native.ptr(r_score[b0:b1]),
+                native.ptr(r_dist2[b0:b1]) if r_dist2 is not None else None, native.ptr(r_flags[b0:b1]), native.ptr(ws), ws.numel(),
+                opt, native.stream_ptr()), "knn_search(exact thresholds)")
+        good = torch.nonzero(r_flags > 0).flatten()
+        rows = bad.index_select(0, good)
+        idx.index_copy_(0, rows, r_idx.index_select(0, good))
+        score.index_copy_(0, rows, r_score.index_select(0, good))
+        if dist2 is not None:
+            dist2.index_copy_(0, rows, r_dist2.index_select(0, good))
+        flags.index_copy_(0, rows, r_flags.index_select(0, good))
 
     def _exact_fallback(self, tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
                         dist2, flags):

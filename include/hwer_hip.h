@@ -154,6 +154,18 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
                         double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                         size_t workspace_bytes, void* stream);
 
+/* Same search with options.  HWER_KNN_EXACT_THRESHOLDS: no sampled shortcuts (the streaming filter raises its thresholds
+ * only to exact K'-th keys, the sampled small-batch path is not taken).  Slower, but a query can then only stay
+ * uncertified on genuine near-ties: the retry tier for catalogues whose row order defeats the sampling (e.g. sorted by
+ * cluster), before the exhaustive pass.  Workspace size: hwer_knn_workspace_bytes_opts with the same options. */
+#define HWER_KNN_EXACT_THRESHOLDS 1u
+size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
+int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
+                             const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
+                             int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max,
+                             int64_t* out_idx, double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                             size_t workspace_bytes, uint32_t options, void* stream);
+
 /* out_count[0] = number of queries with flags == 0 (device int32): one 4-byte read tells the host whether the
  * exhaustive pass is needed. */
 int hwer_knn_count_uncertified(const int32_t* flags, int64_t B, int32_t* out_count, void* stream);

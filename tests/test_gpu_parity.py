@@ -308,6 +308,26 @@ def test_knn_small_batch_duplicates(hw):
         assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
 
 
+def test_knn_cluster_sorted_catalogue_retry(hw):
+    """a catalogue sorted by cluster defeats the sample-scaled thresholds of the streaming filter for a few per cent of the
+    queries; they must come back exact through the exact-threshold retry (flag 1), not one by one through the exhaustive
+    pass."""
+    rng = np.random.default_rng(3)
+    d, N, B, k = 64, 120000, 3000, 100
+    x = rng.standard_normal((N, d))
+    lab = np.sort(rng.integers(0, 40, N))
+    x = 0.6 * x + rng.standard_normal((40, d))[lab]
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    V = np.concatenate([unit_rows_f32(401, B, d), x.astype(np.float32)]).astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all() and int((flags == 2).sum()) <= 16, np.bincount(flags)
+    rows = np.arange(B, B + N)
+    for u in range(0, B, 97):
+        o_idx, o_score, o_dist = orc.find_closest(V, rows, u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
+
+
 def test_knn_multi_split_lists(hw):
     """few queries x many items: the item range is split over many workgroups / lists (reduce path)."""
     d, N, B, k = 64, 60000, 3, 100

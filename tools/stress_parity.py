@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Large-shape parity stress (GPU box only): every path of hwer_knn_search_f32 against the oracle's C restatement
+(oracle/hwer_oracle.c, OpenMP) on ALL queries of each case, float64 flavour, with and without the distances.
+
+    python tools/stress_parity.py [--quick]
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "hybrid-weighted-embedding-recommender_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def unit_rows(seed, n, d, clustered=False):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, d), dtype=np.float32).astype(np.float64)
+    if clustered:   # catalogue sorted by cluster: the adversarial order for sampled thresholds
+        centres = rng.standard_normal((40, d))
+        lab = np.sort(rng.integers(0, 40, n))
+        x = 0.6 * x + centres[lab]
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    args = ap.parse_args()
+    from hwer.device_index import DeviceIndex
+    from oracle import c_oracle
+    from oracle import hwer_oracle as orc
+    cases = [  # (name, B, N, d, k, clustered)
+        ("streaming, 1 list", 4096 * 8, 26744, 128, 200, False),
+        ("streaming, item splits", 4096, 300000, 128, 200, False),
+        ("streaming, d=64 k=50", 20000, 50000, 64, 50, False),
+        ("streaming, d=256", 6000, 120000, 256, 200, False),
+        ("small path, tail-like", 7421, 26744, 128, 200, False),
+        ("small path, few queries", 33, 400000, 128, 200, False),
+        ("small path, clustered catalogue", 200, 200000, 64, 100, True),
+        ("streaming, clustered catalogue", 9000, 200000, 64, 100, True),
+        ("dense", 5000, 8000, 128, 200, False),
+    ]
+    if args.quick:
+        cases = cases[:2] + cases[4:6]
+    cores = os.cpu_count() or 1
+    bad = 0
+    for name, B, N, d, k, clustered in cases:
+        users = unit_rows(1, B, d)
+        items = unit_rows(2, N, d, clustered)
+        V = np.concatenate([users, items]).astype(np.float64)
+        ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}, arith=0)
+        t0 = time.time()
+        idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+        idx_l, score_l, _, flags_l = ix.search("item", np.arange(B), k=k, want_dist=False)
+        t_gpu = time.time() - t0
+        V64 = V[:B]
+        Qh = np.stack([orc.query_vector(V, int(u)) for u in range(min(B, 64))])   # numpy's own unit(anchor) for a subset
+        Q_all = V64 / np.sqrt((V64 * V64).sum(1))[:, None]
+        Q_all[:len(Qh)] = Qh
+        # queries as the device built them (bit-identical to numpy's, checked by the unit tests): read them back
+        Q64_dev, _, _ = ix.build_queries(np.arange(B))
+        Q_all = Q64_dev.cpu().numpy()
+        t0 = time.time()
+        o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(items, Q_all, V64, k, threads=cores)
+        t_cpu = time.time() - t0
+        ok = (np.array_equal(idx, o_idx + B) and np.array_equal(score, o_sc) and np.array_equal(dist, np.sqrt(o_d2))
+              and np.array_equal(idx_l, idx) and np.array_equal(score_l, score))
+        n_ex = int((flags == 2).sum()), int((flags_l == 2).sum())
+        print("%-34s B=%6d N=%7d d=%3d k=%3d  %s  exhaustive=%s  gpu %.2fs cpu %.2fs" % (name, B, N, d, k, "OK" if ok else "MISMATCH", n_ex, t_gpu, t_cpu), flush=True)
+        if not ok:
+            bad += 1
+            rows = np.nonzero((idx != o_idx + B).any(1) | (score != o_sc).any(1))[0]
+            print("   first mismatching queries:", rows[:10], "of", len(rows))
+        assert (flags > 0).all() and (flags_l > 0).all()
+        del ix
+    if bad:
+        raise SystemExit("%d case(s) differ from the oracle" % bad)
+    print("all cases bit-identical to the oracle")
+
+
+if __name__ == "__main__":
+    main()
