@@ -83,6 +83,13 @@ __device__ __forceinline__ int swz(int row) {
     else return (row >> 1) & (CH - 1);   // CH == 8: two 128-byte rows share a bank row
 }
 
+// Queries in MFMA-fragment order (built once per search by repack_queries): Qf[(s * NG + g) * 64 + lane] (float4) =
+// Q[32 s + (lane & 31)][8 g + 4 (lane >> 5) .. + 3], zero for queries >= B.  A wave then loads the B fragment of query
+// subtile s and k-group g with ONE fully coalesced 1-KiB instruction; reading the row-major Q32 directly costs 32
+// quarter-line requests per instruction, repeated by every workgroup that shares the query block.
+size_t repacked_queries_bytes(int64_t B, int ldx);
+int repack_queries(const float* Q32, int64_t B, int64_t B_padded, int ldx, float* Qf, hipStream_t stream);   // B_padded: multiple of 32, rows >= B are zero
+
 // small-batch path (knn_small.hip): B <= SMALL_MAX_QUERIES queries over a catalogue too large for the dense select
 constexpr int SMALL_MAX_QUERIES = 1024;   // always below this many queries (see use_small_path); key matrix (B x items x 4 B) <= SMALL_MAX_KEY_BYTES
 constexpr int64_t SMALL_MAX_KEY_BYTES = int64_t(8) << 30;

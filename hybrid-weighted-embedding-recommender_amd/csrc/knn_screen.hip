@@ -34,7 +34,7 @@ struct ScreenArgs {
     const float* hnorm;
     int64_t n_items;
     int64_t ldx;
-    const float* Q;
+    const float* Q;      // queries in fragment order (repack_queries)
     int64_t B;
     float* dense;        // DENSE mode: every key is written to dense[q * ld_dense + item] instead of being filtered
     int64_t ld_dense;
@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    const unsigned long long rt_entry = a.debug_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (blockIdx.x == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list, idle tickets
     const int wq = a.wq, wi_n = 4 / wq;
     const int wqi = wave % wq, wii = wave / wq;
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         const bool live = q < a.B;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            qf[b][g] = live ? *reinterpret_cast<const float4*>(a.Q + q * a.ldx + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[b][g] = reinterpret_cast<const float4*>(a.Q)[((qw0 / 32 + b) * NG + g) * 64 + lane];   // fragment order: 1 KiB per instruction
         tau[b] = (live && !a.debug_nofilter) ? a.debug_tau0 : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
         first[b] = true;
@@ -286,6 +287,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     p_dma = perm_next(p_dma);
 
     const bool getenv_calib = a.debug_nofilter == 2;
+    unsigned long long clk0 = 0, rt0 = 0;
+    if (a.debug_stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_pre = 0, acc_mfma = 0, acc_epi = 0, acc_wait = 0, acc_post = 0, acc_flush = 0, acc_dma = 0;
     for (int t = 0; t < n_tiles; ++t) {
         STAMP(t0);
@@ -402,6 +405,10 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         if constexpr (DENSE) {
             if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);
             p_dma = perm_next(p_dma);
+            if (a.debug_stamps) {
+                t5 = stamp();
+                acc_pre += t1 - t0; acc_mfma += t2 - t1; acc_epi += t3 - t2; acc_wait += t4 - t3; acc_post += t5 - t4;
+            }
             continue;
         }
         unsigned long long t4a = 0, t4b = 0;
@@ -450,7 +457,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     }
     if (a.debug_stamps && lane == 0) {
         unsigned long long* o = a.debug_stamps + (size_t(blockIdx.x) * 4 + wave) * 8;
-        o[0] = acc_pre; o[1] = acc_mfma; o[2] = acc_epi; o[3] = acc_wait; o[4] = acc_post; o[5] = n_tiles; o[6] = acc_flush; o[7] = acc_dma;
+        o[0] = rt0 - rt_entry; o[1] = acc_mfma; o[2] = acc_epi; o[3] = acc_wait; o[4] = acc_post; o[5] = n_tiles;   // o[0]: prologue in 10-ns ticks
+        o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel clock = o[6] / o[7] x 100 MHz
     }
     if constexpr (DENSE) return;
 #pragma unroll
@@ -473,6 +481,28 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         const int64_t q = qw0 + 32 * b + r;
         a.cand_cnt[(int64_t(list) * a.bq + q) * 2 + h] = cnt[b] | (underfull ? (1 << 30) : 0);
     }
+}
+
+__global__ __launch_bounds__(256) void repack_queries_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, float4* __restrict__ Qf, int64_t n_out) {
+    const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (o >= n_out) return;
+    const int lane = int(o & 63);
+    const int64_t sg = o >> 6;
+    const int g = int(sg % ng);
+    const int64_t q = (sg / ng) * 32 + (lane & 31);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < B) v = *reinterpret_cast<const float4*>(Q + q * ldx + 8 * g + 4 * (lane >> 5));
+    Qf[o] = v;
+}
+
+size_t repacked_queries_bytes(int64_t B, int ldx) { return size_t(cdiv64(B, 32)) * 32 * size_t(ldx) * 4; }
+
+int repack_queries(const float* Q32, int64_t B, int64_t B_padded, int ldx, float* Qf, hipStream_t stream) {
+    const int ng = ldx / 8;
+    const int64_t n_out = cdiv64(B_padded, 32) * ng * 64;
+    hipLaunchKernelGGL(repack_queries_kernel, dim3(unsigned(cdiv64(n_out, 256))), dim3(256), 0, stream, Q32, B, ldx, ng,
+                       reinterpret_cast<float4*>(Qf), n_out);
+    return check_launch("knn_repack_queries");
 }
 
 // =====================================================================================================
@@ -555,8 +585,8 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
             hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double tiles = 0; int n = 0;
             for (int w = 0; w < dbg_grid * 4; ++w) { if (h[w * 8 + 5] == 0) continue; for (int c = 0; c < 8; ++c) sum[c] += double(h[w * 8 + c]); tiles += double(h[w * 8 + 5]); ++n; }
-            fprintf(stderr, "[stamps] waves=%d tiles/wave=%.0f cycles/tile: pre=%.0f mfma=%.0f epilogue=%.0f wait+barrier=%.0f post=%.0f (flush=%.0f dma=%.0f)\n", n, tiles / n,
-                    sum[0] / tiles, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[6] / tiles, sum[7] / tiles);
+            fprintf(stderr, "[stamps] waves=%d tiles/wave=%.0f prologue=%.1f us; cycles/tile: mfma=%.0f epilogue=%.0f wait+barrier=%.0f post=%.0f; loop %.0f cycles in %.1f us -> in-kernel clock %.2f GHz\n", n, tiles / n,
+                    sum[0] / n / 100.0, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[6] / n, sum[7] / n / 100.0, sum[7] > 0 ? sum[6] / sum[7] * 0.1 : 0.0);
             hipFree(dbg);
         }
         dbg_grid = plan.n_qblocks * plan.n_splits;

@@ -1037,11 +1037,13 @@ extern "C" int hwer_profile_read(int which, double* total_ms, int64_t* launches)
 static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct WsLayout {
-    size_t cand_a, cnt_a, cand_b, cnt_b, total;
+    size_t qf, cand_a, cnt_a, cand_b, cnt_b, total;
 };
 static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     WsLayout w{};
     size_t off = WS_HEADER_BYTES;   // WsHeader first
+    w.qf = off;                     // queries in fragment order
+    off += align256(repacked_queries_bytes(p.bq, p.ng * 8));
     if (p.dense) {   // one (B, ld_dense) float matrix of keys
         w.cand_a = off;
         w.total = off + align256(size_t(p.bq) * size_t(p.ld_dense) * 4);   // bq >= B rows: the screen stores unconditionally
@@ -1179,9 +1181,11 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
     int rc;
     prof_next_call();
+    float* qf = reinterpret_cast<float*>(ws + w.qf);
+    if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) return rc;
     {
         ProfScope ps(0, st);
-        rc = launch_screen(plan, X, hnorm, n_items, ldx, Q32, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st);
+        rc = launch_screen(plan, X, hnorm, n_items, ldx, qf, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st);
     }
     if (rc) return rc;
     ProfScope ps_select(1, st);

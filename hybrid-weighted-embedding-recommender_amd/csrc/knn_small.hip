@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
         const bool live = q < a.B;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            qf[b][g] = live ? *reinterpret_cast<const float4*>(a.Q + q * a.ldx + 8 * g + 4 * h) : make_float4(0.f, 0.f, 0.f, 0.f);
+            qf[b][g] = reinterpret_cast<const float4*>(a.Q)[((q0 / 32 + b) * NG + g) * 64 + lane];   // fragment order (repack_queries)
     }
     const int n_waves = gridDim.x * NW;
     const uint32_t row_bytes = uint32_t(a.ldx) * 4u;
@@ -332,10 +332,11 @@ SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k) {
     return p;
 }
 
-struct SmallLayout { size_t keys, thr, count, list, total; };
+struct SmallLayout { size_t qf, keys, thr, count, list, total; };
 static SmallLayout small_layout(const SmallPlan& p) {
     SmallLayout w{};
     size_t off = 0;
+    w.qf = off;    off += al256(size_t(p.bq) * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32)
     w.keys = off;  off += al256(size_t(p.bq) * size_t(p.ld) * 4);
     w.thr = off;   off += al256(size_t(p.bq) * 4);
     w.count = off; off += al256(size_t(p.bq) * 4);
@@ -361,8 +362,10 @@ static int launch_small_screen(const SmallPlan& p, const SmallArgs& a, hipStream
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
                  unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream) {
     const SmallLayout w = small_layout(p);
-    SmallArgs a{X, hnorm, n_items, ldx, Q32, B, reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr};
+    float* qf = reinterpret_cast<float*>(ws + w.qf);
     int rc;
+    if ((rc = repack_queries(Q32, B, p.bq, int(ldx), qf, stream))) return rc;
+    SmallArgs a{X, hnorm, n_items, ldx, qf, B, reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr};
     switch (p.ng * 10 + p.tq) {
         // waves x ring slots per CU: (NSLOT - 1) tiles in flight per wave, ~96 KB in flight per CU
         case 41: rc = launch_small_screen<4, 1, 4, 8>(p, a, stream); break;      // 4 KB tiles
