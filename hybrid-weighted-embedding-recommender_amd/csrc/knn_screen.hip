@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     float* xs = reinterpret_cast<float*>(smem_raw);                         // [2][IB][CH*4]
     float* hn = xs + 2 * IB * CH * 4;                                       // [2][IB]
     uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);          // [4][256] radix histograms of the compaction
-    float* keypark_all = reinterpret_cast<float*>(hist_all + 4 * 256);      // [4][64][16]: a wave's 16 keys per lane
+    float* keypark_all = reinterpret_cast<float*>(hist_all + 4 * 256);      // [4][64][16 * TQ]: a wave's keys per lane
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int list = split * wi_n + wii;
     const int64_t qw0 = int64_t(qblock) * (wq * 32 * TQ) + int64_t(wqi) * 32 * TQ;  // wave's first query
     uint32_t* hist = hist_all + wave * 256;
-    float* keypark = keypark_all + wave * (64 * 16);
+    float* keypark = keypark_all + wave * (64 * 16 * TQ);
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
     float4 qf[TQ][NG];
@@ -362,27 +362,40 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // append blocks the lane builds a 16-bit pass mask, parks its 16 keys in LDS and pops set bits: the loop runs
             // max-popcount-over-the-wave times (2-3 in steady state, 16 only during warm-up).  (Measured against 16
             // independent predicated blocks: 7.0K vs 10.0K cycles per tile.)
+            // pass masks, 2 VALU per key: tau - key is negative exactly when key > tau (strict), and a funnel shift
+            // (v_alignbit) pushes that sign bit into the mask.  Bit (15 - q) of half-word b <-> accumulator register q of
+            // query subtile b.  Both subtiles share ONE park and ONE pop loop: the loop runs max-over-lanes of the lane's
+            // total pops, not the sum of the per-subtile maxima.
+            uint32_t mask = 0;
 #pragma unroll
-            for (int b = 0; b < TQ; ++b) {
-                // pass mask, 2 VALU per key: tau - key is negative exactly when key > tau (strict), and a funnel shift
-                // (v_alignbit) pushes that sign bit into the mask.  Bit (15 - q) <-> accumulator register q.
-                uint32_t mask = 0;
+            for (int b = TQ - 1; b >= 0; --b) {
 #pragma unroll
                 for (int q = 0; q < 16; ++q)
                     mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(tau[b] - acc[b][q]), 31);
-                if (__any(mask != 0u)) {
-                    const uint32_t item0 = uint32_t(i0) + 4 * h;
-                    float* park = keypark + lane * 16;
+            }
+            if (__any(mask != 0u)) {
+                const uint32_t item0 = uint32_t(i0) + 4 * h;
+                // park layout [16 TQ key slots][64 lanes]: every access is 64 consecutive words, conflict-free whatever slot a
+                // lane pops (a lane-major layout puts all lanes on the same few banks)
+                float* park = keypark + lane;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        *reinterpret_cast<float4*>(park + 4 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
-                    while (__any(mask != 0u)) {
-                        if (mask != 0u) {
-                            const int q = 15 - __builtin_ctz(mask);
-                            mask &= mask - 1u;
-                            const uint64_t key = pack_key(park[q], item0 + (q & 3) + 8 * (q >> 2));
-                            wg_cand[soff[b] + uint32_t(cnt[b])] = key;
-                            ++cnt[b];
+                for (int b = 0; b < TQ; ++b)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) park[(16 * b + q) * 64] = acc[b][q];
+                while (__any(mask != 0u)) {
+                    if (mask != 0u) {
+                        const int bit = __builtin_ctz(mask);
+                        mask &= mask - 1u;
+                        const int q = 15 - (bit & 15);
+                        const uint64_t key = pack_key(park[((bit & 16) + q) * 64], item0 + (q & 3) + 8 * (q >> 2));
+                        if constexpr (TQ == 1) {
+                            wg_cand[soff[0] + uint32_t(cnt[0])] = key;
+                            ++cnt[0];
+                        } else {
+                            const bool second = (bit & 16) != 0;   // half-word 1 = subtile 1
+                            wg_cand[(second ? soff[1] : soff[0]) + uint32_t(second ? cnt[1] : cnt[0])] = key;
+                            cnt[0] += second ? 0 : 1;
+                            cnt[1] += second ? 1 : 0;
                         }
                     }
                 }
@@ -556,8 +569,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
 
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 x 64 x 16
-    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * 4;
+    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 x 64 x 16 TQ
+    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * TQ * 4;
     if (const char* e = getenv("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
     static bool attr_done = false;
     if (!attr_done || getenv("HWER_SCREEN_LDS_PAD_KB")) {
