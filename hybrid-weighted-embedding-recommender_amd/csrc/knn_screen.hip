@@ -430,10 +430,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);      // refill the ring slot every wave has just finished reading
         p_dma = perm_next(p_dma);
         STAMP(t4b);
+        // ---- stream capacity: a lane appends at most 16 keys per tile, so checking every SECOND tile against CAPH - 32
+        // keeps every stream within its CAPH slots; a compaction leaves at most K' <= 448 <= CAPH - 32 keys in a stream.
+        if (t & 1) {
 #pragma unroll
         for (int b = 0; b < TQ; ++b) {
-            // ---- keep every stream at least 16 slots from its end ------------------------------------------------
-            uint64_t need = __ballot(cnt[b] > CAPH - 16);
+            uint64_t need = __ballot(cnt[b] > CAPH - 32);
             while (need != 0ull) {
                 const int jj = (__builtin_ctzll(need)) & 31;
                 const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 need &= ~((1ull << jj) | (1ull << (jj + 32)));
             }
         }
+        }   // capacity check on odd tiles
         if (a.debug_stamps) {
             t5 = stamp();
             acc_pre += t1 - t0; acc_mfma += t2 - t1; acc_epi += t3 - t2; acc_wait += t4 - t3; acc_post += t5 - t4;
