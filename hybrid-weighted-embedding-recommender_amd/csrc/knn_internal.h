@@ -8,7 +8,7 @@ namespace hwer {
 // keys each, living in the caller's workspace:  cand[((list * Bq + q) * 2 + half) * CAPH + pos].
 constexpr int CAPH = 512;            // entries per stream
 constexpr int KPRIME_MAX = 448;      // a compaction retains K' entries, possibly all in ONE stream, and must leave
-                                     // that stream below the trigger (CAPH - 16): K' <= CAPH - 16, rounded to 64
+                                     // that stream below the trigger (CAPH - 32, checked every second tile): rounded to 64
 constexpr int SLACK = 56;            // K' = roundup64(k + SLACK)
 constexpr int COMPACT_SLACK = 32;    // a compaction keeps between K' and K' + 32 keys (bisection stops early)
 constexpr int KEEP_MAX = KPRIME_MAX + COMPACT_SLACK;   // most keys one list hands to the select stage (480)

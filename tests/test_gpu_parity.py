@@ -564,6 +564,26 @@ def test_extraction_efficiency_device_matches_host(hw):
         assert dev["extra"][key] == host["extra"][key], key
 
 
+def test_persisted_model_roundtrip(hw, tmp_path):
+    """save_model / restore_model (hwer.persist): the restored index returns the same neighbours and scores."""
+    from hwer import Node, VectorIndex, GcnScoredIndex, persist
+    U, I, d = 40, 900, 48
+    V32 = np.concatenate([unit_rows_f32(501, U, d), unit_rows_f32(502, I, d)])
+    nodes = [Node("user", i) for i in range(U)] + [Node("item", "i%d" % i) for i in range(I)]
+    for cls, V in ((VectorIndex, V32.astype(np.float64)), (GcnScoredIndex, V32)):
+        m = cls(node_types={"user", "item"}, n_dims=d)
+        m.fit(nodes, V)
+        path = str(tmp_path / ("m_%s.npz" % cls.__name__))
+        persist.save_model(path, m)
+        m2 = persist.restore_model(path)
+        assert type(m2) is cls and m2.scoring == m.scoring
+        for u in (0, 7, 39):
+            a = m.find_closest_neighbours("item", nodes[u], k=60)
+            b = m2.find_closest_neighbours("item", nodes[u], k=60)
+            assert [n for n, _ in a] == [n for n, _ in b] and [s for _, s in a] == [s for _, s in b]
+        assert np.array_equal(m.predict([(nodes[1], nodes[50]), (nodes[2], nodes[99])]), m2.predict([(nodes[1], nodes[50]), (nodes[2], nodes[99])]))
+
+
 # ------------------------------------------------------------------------------------------------- merge (X1)
 def test_merge_topk_matches_single_shard(hw):
     import torch

@@ -86,3 +86,27 @@ def test_metrics_match_oracle(golden):
     got = np.asarray(utils.unit_length_violations(g8["rows"], axis=1), dtype=np.float64)
     assert np.array_equal(got, g8["viol_rows"])
     assert np.array_equal(utils.unit_length(g8["rows_zero"], axis=1), g8["unit_zero"], equal_nan=True)
+
+
+def test_persisted_index_format_roundtrip(tmp_path):
+    """hwer.persist: the on-disk index format (host side only - no GPU needed)."""
+    from hwer import Node
+    from hwer import persist
+    rng = np.random.default_rng(0)
+    v = rng.standard_normal((30, 7)).astype(np.float64)
+    nodes = [Node("user" if i % 3 == 0 else "item", i) for i in range(30)]
+    rows = {"user": np.arange(0, 30, 3), "item": np.array([i for i in range(30) if i % 3])}
+    path = str(tmp_path / "ix.npz")
+    persist.save_index(path, v, rows, arith=0, scoring="base", nodes=nodes)
+    z = persist.load_index(path)
+    assert z["vectors"].dtype == np.float32 and np.array_equal(z["vectors"], v.astype(np.float32))
+    assert z["arith"] == 0 and z["scoring"] == "base" and set(z["type_rows"]) == {"user", "item"}
+    assert all(np.array_equal(z["type_rows"][t], rows[t]) for t in rows)
+    assert z["node_types"].tolist() == [n.node_type for n in nodes] and z["node_ids"].tolist() == [str(i) for i in range(30)]
+    with pytest.raises(ValueError):
+        persist.save_index(path, v, {"user": np.array([3, 2])}, 0)          # not ascending
+    with pytest.raises(ValueError):
+        persist.save_index(path, v, {"user": np.array([0, 31])}, 0)         # out of range
+    np.savez(open(path, "wb"), format=np.array("something-else"))
+    with pytest.raises(ValueError):
+        persist.load_index(path)
