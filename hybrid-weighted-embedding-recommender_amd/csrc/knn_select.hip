@@ -359,6 +359,37 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     auto tail = [&](auto ne_tag) {
         constexpr int NE = decltype(ne_tag)::value;
         uint64_t key[NE];
+        // Lazy mode with a one-round boundary (the usual case): no distance sort at all.  Every provable member is in;
+        // of the n_b <= 64 boundary candidates (slots 0 .. n_b - 1, one per lane) the k - n_sure nearest are in, found
+        // by counting, per candidate, the boundary candidates that beat it.
+        const bool rank_boundary = lazy && n_b <= 64 && !(a.debug_skip & 2);
+        if (rank_boundary) {
+            const int n_keep = k - (n_r - n_b);
+            const bool mine = lane < n_b;
+            const uint64_t dm = mine ? f64_orderable(t_d2[lane]) : ~0ull;
+            const uint32_t im = mine ? cand[lane] : 0xFFFFFFFFu;
+            int rank = 0;
+            for (int j = 0; j < n_b; ++j) {   // wave-uniform; LDS broadcast reads
+                const uint64_t dj = f64_orderable(t_d2[j]);
+                const uint32_t ij = cand[j];
+                rank += (dj < dm || (dj == dm && ij < im)) ? 1 : 0;
+            }
+            const bool member_b = mine && rank < n_keep;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int i = 64 * j + lane;
+                const bool member = i < n_r && (i >= n_b || (j == 0 && member_b));
+                key[j] = member ? (uint64_t(~f32_orderable(float(t_sc[i]))) << 32) | uint64_t(uint32_t(i)) : ~0ull;
+            }
+            wave_sort_u64<NE>(key);
+            wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
+                const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
+                const uint64_t ax = ~f64_orderable(t_sc[sx]), ay = ~f64_orderable(t_sc[sy]);
+                if (ax != ay) return ax < ay;
+                const uint64_t dx = f64_orderable(ensure_d2(sx)), dy = f64_orderable(ensure_d2(sy));
+                return dx < dy || (dx == dy && cand[sx] < cand[sy]);
+            });
+        } else {
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int i = 64 * j + lane;   // any initial placement will do
@@ -401,6 +432,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 });
             }
         }
+        }   // !rank_boundary
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int p = NE * lane + j;
