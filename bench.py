@@ -276,6 +276,28 @@ def main():
         torch.cuda.synchronize()
         out["query_latency_ms"] = {"batch": 1, "value": e0.elapsed_time(e1) / 20.0, "note": "one anchor, exact top-%d, catalogue resident" % K}
 
+        # ---------------- pair scoring (P / t), outside the timed region: P random (user, item) pairs of this table ----
+        n_pairs = 1000209 if args.config in ("c1", "c2") else 16000000
+        gp = torch.Generator(device=dev).manual_seed(4001)
+        p_src = torch.randint(0, U, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
+        p_dst = torch.randint(U, N, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
+        p_out = torch.empty(n_pairs, dtype=torch.float64, device=dev)
+
+        def score_pairs():
+            native.check(lib.hwer_pair_score_f64(P(V), N, d, ldv, P(p_src), P(p_dst), n_pairs, P(p_out), S()), "pair_score")
+        for _ in range(3):
+            score_pairs()
+        e0.record()
+        for _ in range(20):
+            score_pairs()
+        e1.record()
+        torch.cuda.synchronize()
+        ps_ms = e0.elapsed_time(e1) / 20.0
+        ps_bytes = n_pairs * (8.0 * d + 8 + 8)     # two rows + two int32 ids + one float64 result per pair
+        out["pair_score"] = {"pairs": n_pairs, "value": n_pairs / ps_ms * 1e3, "unit": "pairs/s", "ms": ps_ms, "dtype": "f64",
+                             "roofline": {"bound": "hbm", "achieved": ps_bytes / ps_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": ps_bytes / ps_ms / 1e6 / HBM_PEAK_GBS}}
+
     # ---------------- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) -------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle
