@@ -9,9 +9,9 @@
 // Work split: a workgroup = 4 waves = `wq` waves along queries x `wi = 4 / wq` waves along the item subtiles.
 // A wave owns 32*TQ queries for the whole launch (their MFMA B fragments stay in registers: NG*TQ float4) and a
 // private pair of candidate streams per query (one per lane half), so the filter needs no atomics and no
-// cross-lane traffic.  Item tiles (IB rows) stream HBM -> registers -> LDS (double buffered, one barrier per
-// tile).  When a stream is about to overflow, the wave radix-selects the exact K'-th key of that query (ballot /
-// LDS histogram), compacts both streams in place and raises the threshold.
+// cross-lane traffic.  Item tiles (IB rows) stream HBM -> LDS by LDS-DMA (double buffered, one barrier per
+// tile).  When a stream is about to overflow, the wave brackets the K'-th key of that query with a few counting
+// probes on register-resident keys, compacts both streams in place and raises the threshold.
 //
 // Bound: fp32 MFMA (v_mfma_f32_32x32x2_f32, 64 cycles / SIMD) once a workgroup keeps >= ~50 queries resident;
 // HBM (streaming X once per query block) below that.
@@ -59,13 +59,15 @@ __device__ __forceinline__ uint64_t ld_u64_l2(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Exact K'-selection over the two streams (s0: c0 entries, s1: c1 entries) of one query, by the whole wave.
-// All keys are fetched in ONE batch of loads (16 x 8 B per lane, a single L2 round trip) and stay in registers;
-// the K'-th largest score is found by a 4-pass byte radix select (ballot-free LDS histogram), then both streams
-// are rewritten in place.  Afterwards the streams hold exactly `kprime` entries in total (all keys > T plus the
-// first few == T) and T (orderable bits of the K'-th largest score) is the new strict threshold.
-__device__ __forceinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0, int c1, int kprime, uint32_t* hist,
-                                           uint32_t& T_out, int& n0_out, int& n1_out) {
+// Selection over the two streams (s0: c0 entries, s1: c1 entries) of one query, by the whole wave.  All keys are fetched
+// in ONE batch of loads (16 x 8 B per lane, a single L2 round trip) and stay in registers; a key t with
+//   rank <= count(score >= t) <= rank + slack          (more only when scores tie at t)
+// is bracketed by a handful of counting probes (wave_find_rank: one v_cmp per key, interpolated probe positions - a
+// third of the instructions of a byte-wise radix select with an LDS histogram), then both streams are rewritten in
+// place with every key > t plus as many of the keys == t as fit `rank + slack`.  t is the new strict threshold: later
+// keys equal to it are dropped, which is safe - they are not better than the smallest key kept.
+__device__ __forceinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0, int c1, int rank, int slack,
+                                           float& t_out, int& n0_out, int& n1_out) {
     constexpr int NCH = CAPH / 64;
     const int lane = threadIdx.x & 63;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -77,76 +79,24 @@ __device__ __forceinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0
         key[c] = e < c0 ? ld_u64_l2(s0 + e) : 0ull;
         key[NCH + c] = e < c1 ? ld_u64_l2(s1 + e) : 0ull;
     }
-    // bytes on which every valid key agrees need no histogram pass (the keys of one query sit in a narrow score
-    // range: sign and most exponent bits are shared, and hammering one LDS bin with 64-lane atomics is slow)
-    uint32_t all_or = 0u, all_and = 0xFFFFFFFFu;
+    float sv[2 * NCH];
 #pragma unroll
-    for (int i = 0; i < 2 * NCH; ++i) {
-        const uint32_t sv = uint32_t(key[i] >> 32);
-        if (key[i] != 0ull) {
-            all_or |= sv;
-            all_and &= sv;
-        }
-    }
+    for (int i = 0; i < 2 * NCH; ++i) sv[i] = key[i] != 0ull ? key_score(key[i]) : -INFINITY;
+    int c_ge;
+    const float t = wave_find_rank<2 * NCH>(sv, rank, slack, c_ge);   // the streams hold >= rank valid keys
+    int c_gt = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        all_or |= __shfl_xor(all_or, off, kWave);
-        all_and &= __shfl_xor(all_and, off, kWave);
-    }
-    const uint32_t differ = all_or ^ all_and;
-    uint32_t prefix = 0, mask = 0;
-    int want = kprime;
-#pragma unroll 1
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (((differ >> shift) & 0xFFu) == 0u) {   // wave-uniform
-            prefix |= all_and & (0xFFu << shift);
-            mask |= 0xFFu << shift;
-            continue;
-        }
-        *reinterpret_cast<uint4*>(hist + 4 * lane) = make_uint4(0, 0, 0, 0);
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < 2 * NCH; ++i) {
-            const uint32_t sv = uint32_t(key[i] >> 32);
-            if (key[i] != 0ull && (sv & mask) == prefix) atomicAdd(&hist[(sv >> shift) & 255u], 1u);
-        }
-        wave_lds_sync();
-        const uint4 h4 = *reinterpret_cast<const uint4*>(hist + 4 * lane);
-        const int s = int(h4.x + h4.y + h4.z + h4.w);
-        int S = s;  // inclusive suffix sum over lanes (bins descending)
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_down(S, off, kWave);
-            if (lane + off < 64) S += t;
-        }
-        const uint64_t bal = __ballot(S >= want);
-        const int lstar = 63 - __builtin_clzll(bal);  // bal != 0: the streams hold >= kprime valid keys
-        int bstar, want_new;
-        {
-            int cum = S - s;  // keys in the bins above this lane's four
-            const int h3 = int(h4.w), h2 = int(h4.z), h1 = int(h4.y);
-            if (cum + h3 >= want) { bstar = 4 * lane + 3; want_new = want - cum; }
-            else if (cum + h3 + h2 >= want) { bstar = 4 * lane + 2; want_new = want - cum - h3; }
-            else if (cum + h3 + h2 + h1 >= want) { bstar = 4 * lane + 1; want_new = want - cum - h3 - h2; }
-            else { bstar = 4 * lane; want_new = want - cum - h3 - h2 - h1; }
-        }
-        bstar = __shfl(bstar, lstar, kWave);
-        want = __shfl(want_new, lstar, kWave);
-        prefix |= uint32_t(bstar) << shift;
-        mask |= 0xFFu << shift;
-    }
-    const uint32_t T = prefix;  // exact K'-th largest orderable score; keep `want` of the entries equal to it
+    for (int i = 0; i < 2 * NCH; ++i) c_gt += __builtin_popcountll(__ballot(sv[i] > t));
+    const int want_eq = min(c_ge - c_gt, rank + slack - c_gt);   // >= 1: count(> t) < rank + slack and count(>= t) >= rank
     int eq_seen = 0;
     int out0 = 0, out1 = 0;
 #pragma unroll
     for (int i = 0; i < 2 * NCH; ++i) {
-        const uint32_t sv = uint32_t(key[i] >> 32);
-        const bool valid = key[i] != 0ull;
-        const bool gt = valid && sv > T;
-        const bool eq = valid && sv == T;
+        const bool gt = sv[i] > t;
+        const bool eq = sv[i] == t;
         const uint64_t be = __ballot(eq);
-        const int rank = eq_seen + __builtin_popcountll(be & lt_mask);
-        const bool keep = gt || (eq && rank < want);
+        const int erank = eq_seen + __builtin_popcountll(be & lt_mask);
+        const bool keep = gt || (eq && erank < want_eq);
         const uint64_t bk = __ballot(keep);
         const int pos = __builtin_popcountll(bk & lt_mask);
         if (i < NCH) {
@@ -158,7 +108,7 @@ __device__ __forceinline__ void compact_query(uint64_t* s0, uint64_t* s1, int c0
         }
         eq_seen += __builtin_popcountll(be);
     }
-    T_out = T;
+    t_out = t;
     n0_out = out0;
     n1_out = out1;
 }
@@ -193,8 +143,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* xs = reinterpret_cast<float*>(smem_raw);                         // [2][IB][CH*4]
     float* hn = xs + 2 * IB * CH * 4;                                       // [2][IB]
-    uint32_t* hist_all = reinterpret_cast<uint32_t*>(hn + 2 * IB);          // [4][256] radix histograms of the compaction
-    float* keypark_all = reinterpret_cast<float*>(hist_all + 4 * 256);      // [4][64][16 * TQ]: a wave's keys per lane
+    float* keypark_all = hn + 2 * IB;                                       // [4][64][16 * TQ]: a wave's keys per lane
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -206,7 +155,6 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int qblock = blockIdx.x % a.n_qblocks, split = blockIdx.x / a.n_qblocks;
     const int list = split * wi_n + wii;
     const int64_t qw0 = int64_t(qblock) * (wq * 32 * TQ) + int64_t(wqi) * 32 * TQ;  // wave's first query
-    uint32_t* hist = hist_all + wave * 256;
     float* keypark = keypark_all + wave * (64 * 16 * TQ);
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
@@ -452,11 +400,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     const int mrank = int(mu + 4.0f * sqrtf(mu) + 5.0f);
                     if (2 * mrank < a.kprime) rank = mrank;
                 }
-                uint32_t T;
+                float T;
                 int n0, n1;
-                compact_query(s0, s0 + CAPH, c0, c1, rank, hist, T, n0, n1);
+                // in-loop compactions may keep up to 32 keys more than asked (a stream then holds <= K' + 32 <= CAPH - 32)
+                compact_query(s0, s0 + CAPH, c0, c1, rank, rank == a.kprime ? COMPACT_SLACK : min(COMPACT_SLACK, rank / 4 + 1), T, n0, n1);
                 if (r == jj) {
-                    tau[b] = f32_from_orderable(T);
+                    tau[b] = T;
                     cnt[b] = h == 0 ? n0 : n1;
                     scaled[b] = scaled[b] || (rank != a.kprime);
                     first[b] = false;
@@ -488,9 +437,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             const int jj = __builtin_ctzll(need);
             const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
             uint64_t* s0 = wg_cand + (uint32_t(32 * b + jj) * 2u) * CAPH;
-            uint32_t T;
+            float T;
             int n0, n1;
-            compact_query(s0, s0 + CAPH, c0, c1, a.kprime, hist, T, n0, n1);   // exact: a list hands over <= K' keys
+            compact_query(s0, s0 + CAPH, c0, c1, a.kprime, 0, T, n0, n1);   // exact: a list hands over <= K' keys
             if (r == jj) cnt[b] = h == 0 ? n0 : n1;
             need &= ~(1ull << jj);
         }
@@ -572,8 +521,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
 
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | histograms 4 x 256 | key park 4 x 64 x 16 TQ
-    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + 4 * 256 * 4 + size_t(4) * 64 * 16 * TQ * 4;
+    // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | key park 4 x 64 x 16 TQ
+    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
     if (const char* e = getenv("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
     static bool attr_done = false;
     if (!attr_done || getenv("HWER_SCREEN_LDS_PAD_KB")) {
