@@ -564,6 +564,7 @@ struct DenseSelectArgs {
     const int32_t* list_count;   // (B) appended keys (may exceed the capacity: overflow)
     int list_cap;
     int list_min;                // K': a list shorter than this came from a threshold that was too high
+    float key_rel_err;           // extra |key error| / (||q|| ||x||max) of the screen that produced the keys (float16 screen: ~2^-10)
 };
 
 // LIST = false: dense select over the key row written by the DENSE screen (every item is a candidate).
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
     }
-    const float e32 = e32_bound(d, Q2, a.hnorm_max);
+    const float e32 = e32_bound(d, Q2, a.hnorm_max) + a.key_rel_err * float(sqrt(Q2)) * sqrtf(2.0f * a.hnorm_max) * 1.0001f;
     const float thr = t_k - 2.0f * e32;
     // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) < k - such an item cannot be beaten by k others
     const float s_sure = lazy_ok ? t_hi + 2.0f * e32 : INFINITY;
@@ -1135,6 +1136,15 @@ extern "C" {
 
 int hwer_knn_max_k(void) { return K_MAX; }
 
+int hwer_knn_f16_scale_exp(float hnorm_max) { return f16_scale_exp(hnorm_max); }
+
+int hwer_pack_rows_f16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, void* stream) {
+    if (!X || !X16) return fail(HWER_EINVAL, "pack_rows_f16: null pointer");
+    if (n_rows_padded < 0 || n_rows_padded % 32 != 0 || hwer_knn_padded_dim(int(ldx)) != ldx)
+        return fail(HWER_EINVAL, "pack_rows_f16: expects the padded table of hwer_pack_rows_f32 (rows % 32 == 0, ldx in {32,64,128,256})");
+    return pack_rows16(X, n_rows_padded, ldx, x_exp, X16, as_stream(stream));
+}
+
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options) {
     const int ldx = hwer_knn_padded_dim(d);
     if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
@@ -1150,14 +1160,14 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
                         double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                         size_t workspace_bytes, void* stream) {
     return hwer_knn_search_opts_f32(X, hnorm, n_items, d, ldx, Q32, Q64, A32, lda, a_idx, B, k, score_mode, sort_by_score, row_ids,
-                                    id_base, hnorm_max, out_idx, out_score, out_dist2, out_flags, workspace, workspace_bytes, 0, stream);
+                                    id_base, hnorm_max, out_idx, out_score, out_dist2, out_flags, workspace, workspace_bytes, 0, nullptr, 0, stream);
 }
 
 int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k, int score_mode,
                              int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
                              double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
-                             size_t workspace_bytes, uint32_t options, void* stream) {
+                             size_t workspace_bytes, uint32_t options, const void* X16, int x16_exp, void* stream) {
     if (B == 0) return HWER_OK;
     const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
     if (!X || !hnorm || !Q32 || !Q64 || !out_idx || !out_score || !out_flags || !workspace)
@@ -1188,7 +1198,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         prof_next_call();
         {
             ProfScope ps(0, st);
-            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &list, &cnt, hdr, st);
+            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &list, &cnt, hdr, X16, x16_exp, st);
         }
         if (rc) return rc;
         ProfScope ps_select(1, st);
@@ -1202,6 +1212,8 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.list_count = cnt;
         da.list_cap = SMALL_LIST_CAP;
         da.list_min = sp.kprime;
+        // float16 screen: two float16 roundings per product (2^-11 each) on top of the float32 accumulation error
+        da.key_rel_err = X16 ? 1.02f * 0.0009765625f : 0.f;
         return launch_select_list(da, d, score_mode, st);
     }
     ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);

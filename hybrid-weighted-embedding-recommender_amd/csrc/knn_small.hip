@@ -141,6 +141,180 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// float16 storage variant of the screen: the same wave-private streaming, but the item rows come from a
+// float16 copy of the table (half the HBM bytes, the bound of this path) and the tile product runs on
+// v_mfma_f32_32x32x8_f16 (float32 accumulation).  Rows and queries are scaled by powers of two before the rounding
+// (sx for the table, 2^qexp[b] per query) so that no element falls into float16's subnormal range; the accumulator is
+// seeded with -hnorm * scale and rescaled at the end (exact).  The keys then differ from the float32 keys by at most
+// ~2^-10 ||q|| ||x|| (two float16 roundings per product): the select stage widens its error bound accordingly, re-ranks
+// from the float32 rows in float64 as always, and the results stay bit-identical.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+template <int NG>
+__device__ __forceinline__ int swz16(int row) {   // 16-byte chunk swizzle of a row of NG chunks (2 NG bytes x 8)
+    if constexpr (NG >= 16) return row & 15;
+    else if constexpr (NG == 8) return (row >> 1) & 7;
+    else return (row >> 2) & 3;
+}
+
+struct Small16Args {
+    const _Float16* X16;   // (Np, ldx) float16, scaled by 2^x_exp
+    const float* hnorm;
+    int64_t ldx;
+    const half4_t* Qf16;   // query fragments, scaled per query by 2^qexp[q]
+    const int32_t* qexp;   // (bq)
+    int x_exp;
+    int64_t B;
+    float* keys;
+    int64_t ld;
+    int n_tiles;
+    WsHeader* hdr;
+};
+
+template <int NG, int TQ, int NW, int NSLOT>
+__global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small16Args a) {
+    constexpr int IB = 32;
+    constexpr int TILE_BYTES = IB * NG * 16;         // rows of NG 16-byte chunks
+    constexpr int DMA_PER_TILE = IB * NG / 64;       // 1-KiB pieces
+    constexpr int PIECE_ROWS = 64 / NG;              // NG <= 32: at least two rows per piece
+    static_assert(NG >= 4 && NG <= 32, "rows of 64 .. 512 bytes");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list
+    unsigned char* ring = smem_raw + size_t(wave) * (NSLOT * TILE_BYTES + NSLOT * IB * 4);   // [NSLOT][IB][NG * 16 B] wave-private
+    float* hn = reinterpret_cast<float*>(ring + NSLOT * TILE_BYTES);                       // [NSLOT][IB] half norms
+    const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
+
+    half4_t qf[TQ][NG];
+    int e_tot[TQ];
+#pragma unroll
+    for (int b = 0; b < TQ; ++b) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qf[b][g] = a.Qf16[((q0 / 32 + b) * NG + g) * 64 + lane];
+        e_tot[b] = a.x_exp + a.qexp[q0 + 32 * b + r];
+    }
+    const int n_waves = gridDim.x * NW;
+    const uint32_t row_bytes = uint32_t(a.ldx) * 2u;
+    const uint32_t lane_row = uint32_t(lane / NG), lane_chunk = uint32_t(lane % NG);
+    auto tile_dma = [&](int t, int slot) {
+        const char* tile_ptr = reinterpret_cast<const char*>(a.X16 + int64_t(t) * IB * a.ldx);   // wave-uniform
+        const uint32_t base = __builtin_amdgcn_readfirstlane(lds_addr(ring + slot * TILE_BYTES));
+        uint32_t lr = lane_row, lc = lane_chunk;
+        asm volatile("" : "+v"(lr), "+v"(lc));
+#pragma unroll
+        for (int p = 0; p < DMA_PER_TILE; ++p) {
+            const uint32_t row = uint32_t(p * PIECE_ROWS) + lr;
+            const uint32_t off = __umul24(row, row_bytes) + ((lc ^ uint32_t(swz16<NG>(int(row)))) << 4);
+            lds_dma16(tile_ptr, off, base + uint32_t(p) * 1024u);
+        }
+        if (lane < IB) lds_dma4(a.hnorm + int64_t(t) * IB, uint32_t(lane) * 4u, __builtin_amdgcn_readfirstlane(lds_addr(hn + slot * IB)));
+    };
+
+    int t = blockIdx.x * NW + wave;
+#pragma unroll
+    for (int j = 0; j < NSLOT - 1; ++j)
+        if (t + j * n_waves < a.n_tiles) tile_dma(t + j * n_waves, j);
+    int slot = 0;
+    for (; t < a.n_tiles; t += n_waves, slot = (slot + 1 == NSLOT ? 0 : slot + 1)) {
+        const int64_t i0 = int64_t(t) * IB;
+        const int t_pre = t + (NSLOT - 1) * n_waves;
+        const int slot_pre = slot == 0 ? NSLOT - 1 : slot - 1;
+        if (t_pre < a.n_tiles) {
+            tile_dma(t_pre, slot_pre);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSLOT - 1) * (DMA_PER_TILE + 1)) : "memory");   // see small_screen_kernel
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned char* xb = ring + slot * TILE_BYTES;
+        const float* hb = hn + slot * IB;
+        f32x16 acc[TQ];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
+#pragma unroll
+            for (int b = 0; b < TQ; ++b) {
+                acc[b][4 * rg + 0] = -ldexpf(hv.x, e_tot[b]);
+                acc[b][4 * rg + 1] = -ldexpf(hv.y, e_tot[b]);
+                acc[b][4 * rg + 2] = -ldexpf(hv.z, e_tot[b]);
+                acc[b][4 * rg + 3] = -ldexpf(hv.w, e_tot[b]);
+            }
+        }
+        // A fragment of k-group g: the 8 bytes of half h of logical chunk g of row r, stored at chunk g ^ swz16(r)
+        int sw = swz16<NG>(r);
+        asm volatile("" : "+v"(sw));
+        const unsigned char* abase = xb + r * (NG * 16) + 8 * h;
+        auto a_ptr = [&](int g) { return abase + 16 * (g ^ sw); };
+        half4_t av_next = *reinterpret_cast<const half4_t*>(a_ptr(0));
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const half4_t av = av_next;
+            if (g + 1 < NG) av_next = *reinterpret_cast<const half4_t*>(a_ptr(g + 1));
+#pragma unroll
+            for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x8f16(av, qf[b][g], acc[b], 0, 0, 0);
+        }
+#pragma unroll
+        for (int b = 0; b < TQ; ++b) {
+            float* row = a.keys + (q0 + 32 * b + r) * a.ld + i0 + 4 * h;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(ldexpf(acc[b][4 * rg], -e_tot[b]), ldexpf(acc[b][4 * rg + 1], -e_tot[b]),
+                                                                      ldexpf(acc[b][4 * rg + 2], -e_tot[b]), ldexpf(acc[b][4 * rg + 3], -e_tot[b]));
+        }
+    }
+}
+
+// queries -> float16 MFMA fragments, each query scaled by the power of two that puts its largest element in
+// [2^13, 2^14).  One 256-thread block per 32-query subtile: 8 threads scan a query row for its maximum.
+__global__ __launch_bounds__(256) void repack_queries16_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, half4_t* __restrict__ Qf16,
+                                                              int32_t* __restrict__ qexp) {
+    __shared__ int s_exp[32];
+    const int64_t s = blockIdx.x;
+    const int ql = threadIdx.x >> 3, part = threadIdx.x & 7;
+    const int64_t q = s * 32 + ql;
+    float m = 0.f;
+    if (q < B)
+        for (int j = part; j < ldx; j += 8) m = fmaxf(m, fabsf(Q[q * ldx + j]));
+    m = fmaxf(m, __shfl_xor(m, 1, kWave));
+    m = fmaxf(m, __shfl_xor(m, 2, kWave));
+    m = fmaxf(m, __shfl_xor(m, 4, kWave));
+    if (part == 0) {
+        int e = 0;
+        if (m > 0.f && m < INFINITY) {
+            int me;
+            frexpf(m, &me);        // m = f * 2^me, f in [0.5, 1)  ->  m * 2^(14 - me) in [2^13, 2^14)
+            e = 14 - me;
+        }
+        s_exp[ql] = e;
+        qexp[q] = e;               // qexp has bq >= 32 * gridDim.x entries
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < ng * 64; o += 256) {
+        const int g = o >> 6, lane = o & 63;
+        const int64_t qq = s * 32 + (lane & 31);
+        half4_t v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (qq < B) {
+            const float4 x = *reinterpret_cast<const float4*>(Q + qq * ldx + 8 * g + 4 * (lane >> 5));
+            const int e = s_exp[lane & 31];
+            v[0] = (_Float16)ldexpf(x.x, e); v[1] = (_Float16)ldexpf(x.y, e); v[2] = (_Float16)ldexpf(x.z, e); v[3] = (_Float16)ldexpf(x.w, e);
+        }
+        Qf16[(s * ng + g) * 64 + lane] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_rows16_kernel(const float4* __restrict__ X, int64_t n4, int x_exp, half4_t* __restrict__ X16) {
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n4; i += int64_t(gridDim.x) * 256) {
+        const float4 x = X[i];
+        half4_t v;
+        v[0] = (_Float16)ldexpf(x.x, x_exp); v[1] = (_Float16)ldexpf(x.y, x_exp); v[2] = (_Float16)ldexpf(x.z, x_exp); v[3] = (_Float16)ldexpf(x.w, x_exp);
+        X16[i] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 struct SmallSelectArgs {
     const float* keys;
@@ -332,11 +506,12 @@ SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k) {
     return p;
 }
 
-struct SmallLayout { size_t qf, keys, thr, count, list, total; };
+struct SmallLayout { size_t qf, qexp, keys, thr, count, list, total; };
 static SmallLayout small_layout(const SmallPlan& p) {
     SmallLayout w{};
     size_t off = 0;
-    w.qf = off;    off += al256(size_t(p.bq) * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32)
+    w.qf = off;    off += al256(size_t(p.bq) * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32); float16 variant: half of it
+    w.qexp = off;  off += al256(size_t(p.bq) * 4);                      // per-query scale exponents of the float16 variant
     w.keys = off;  off += al256(size_t(p.bq) * size_t(p.ld) * 4);
     w.thr = off;   off += al256(size_t(p.bq) * 4);
     w.count = off; off += al256(size_t(p.bq) * 4);
@@ -359,11 +534,60 @@ static int launch_small_screen(const SmallPlan& p, const SmallArgs& a, hipStream
     return check_launch("knn_small(screen)");
 }
 
+template <int NG, int TQ, int NW, int NSLOT>
+static int launch_small_screen16(const SmallPlan& p, const Small16Args& a, hipStream_t stream) {
+    const size_t lds = size_t(NW) * NSLOT * (32 * NG * 16 + 32 * 4);
+    static_assert(size_t(NW) * NSLOT * (32 * NG * 16 + 32 * 4) <= 160 * 1024, "ring must fit the CU's LDS");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_screen16_kernel<NG, TQ, NW, NSLOT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_small16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    const int gx = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_tiles, NW), std::max(1, 256 / p.n_qblocks))));
+    hipLaunchKernelGGL((small_screen16_kernel<NG, TQ, NW, NSLOT>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
+    return check_launch("knn_small(screen16)");
+}
+
+int f16_scale_exp(float hnorm_max) {
+    // largest power of two that keeps every element of a row (|x_i| <= ||x|| <= sqrt(2 hnorm_max)) below 2^14 after scaling
+    const float xmax = sqrtf(2.0f * hnorm_max) * 1.0001f;
+    if (!(xmax > 0.f) || !(xmax < INFINITY)) return 0;
+    int me;
+    frexpf(xmax, &me);   // xmax = f 2^me, f in [0.5, 1)
+    return 14 - me;
+}
+
+int pack_rows16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, hipStream_t stream) {
+    const int64_t n4 = n_rows_padded * ldx / 4;
+    if (n4 == 0) return HWER_OK;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(n4, 256), 4096)));
+    hipLaunchKernelGGL(pack_rows16_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const float4*>(X), n4, x_exp,
+                       reinterpret_cast<half4_t*>(X16));
+    return check_launch("pack_rows16");
+}
+
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
-                 unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, hipStream_t stream) {
+                 unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16, int x_exp, hipStream_t stream) {
     const SmallLayout w = small_layout(p);
-    float* qf = reinterpret_cast<float*>(ws + w.qf);
     int rc;
+    if (X16) {   // float16 storage: half the HBM bytes for the catalogue stream
+        half4_t* qf16 = reinterpret_cast<half4_t*>(ws + w.qf);
+        int32_t* qexp = reinterpret_cast<int32_t*>(ws + w.qexp);
+        hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(p.bq / 32)), dim3(256), 0, stream, Q32, B, int(ldx), p.ng, qf16, qexp);
+        if ((rc = check_launch("knn_small(repack16)"))) return rc;
+        Small16Args a16{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, qf16, qexp, x_exp, B, reinterpret_cast<float*>(ws + w.keys), p.ld,
+                        int(p.ld / 32), hdr};
+        switch (p.ng * 10 + p.tq) {   // float16 tiles are half as large: more ring slots per wave
+            case 41: rc = launch_small_screen16<4, 1, 4, 8>(p, a16, stream); break;
+            case 42: rc = launch_small_screen16<4, 2, 4, 8>(p, a16, stream); break;
+            case 81: rc = launch_small_screen16<8, 1, 4, 8>(p, a16, stream); break;
+            case 82: rc = launch_small_screen16<8, 2, 4, 8>(p, a16, stream); break;
+            case 161: rc = launch_small_screen16<16, 1, 4, 4>(p, a16, stream); break;
+            case 162: rc = launch_small_screen16<16, 2, 4, 4>(p, a16, stream); break;
+            case 321: rc = launch_small_screen16<32, 1, 4, 2>(p, a16, stream); break;
+            default: return fail(HWER_EINVAL, "knn_small16: unsupported padded dim %d / tq %d", p.ng * 8, p.tq);
+        }
+        if (rc) return rc;
+    } else {
+    float* qf = reinterpret_cast<float*>(ws + w.qf);
     if ((rc = repack_queries(Q32, B, p.bq, int(ldx), qf, stream))) return rc;
     SmallArgs a{X, hnorm, n_items, ldx, qf, B, reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr};
     switch (p.ng * 10 + p.tq) {
@@ -378,6 +602,7 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         default: return fail(HWER_EINVAL, "knn_small: unsupported padded dim %d / tq %d", p.ng * 8, p.tq);
     }
     if (rc) return rc;
+    }
     SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, reinterpret_cast<float*>(ws + w.thr),
                        reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list)};
     // sample rank = 4.75 K' S / N must stay >= 16 (kept >= 32 here): one wave per query with a 1024- or 4096-key sample

@@ -37,7 +37,7 @@ def roundup(x, m):
 
 
 class _TypeTable:
-    __slots__ = ("rows", "rows_dev", "X", "hnorm", "hnorm_max", "n", "id_base")
+    __slots__ = ("rows", "rows_dev", "X", "hnorm", "hnorm_max", "n", "id_base", "X16", "x16_exp")
 
     def __init__(self):
         self.rows = None
@@ -47,6 +47,8 @@ class _TypeTable:
         self.hnorm_max = 0.0
         self.n = 0
         self.id_base = 0
+        self.X16 = None      # float16 storage of X for the HBM-bound small-batch screen (built on first use)
+        self.x16_exp = 0
 
 
 class DeviceIndex:
@@ -167,6 +169,22 @@ class DeviceIndex:
                                              native.ptr(Q64), native.ptr(Q32), self.ldx, native.stream_ptr()), "query_mix")
         return Q64, Q32, a
 
+    #: catalogues above this many rows keep a float16 copy of their table for small query batches
+    F16_MIN_ROWS = 8193
+    use_f16_storage = True
+
+    def _x16(self, tt):
+        """float16 copy of the type's table, built on first use (half the bytes streamed by the small-batch screen)."""
+        if not self.use_f16_storage or tt.n < self.F16_MIN_ROWS:
+            return None, 0
+        if tt.X16 is None:
+            torch = _torch()
+            tt.x16_exp = int(self.lib.hwer_knn_f16_scale_exp(float(tt.hnorm_max)))
+            tt.X16 = torch.empty(tt.X.shape, dtype=torch.float16, device=self.device)
+            native.check(self.lib.hwer_pack_rows_f16(native.ptr(tt.X), tt.X.shape[0], self.ldx, tt.x16_exp, native.ptr(tt.X16),
+                                                     native.stream_ptr()), "pack_rows_f16")
+        return tt.X16, tt.x16_exp
+
     def _workspace(self, nbytes):
         torch = _torch()
         if self._ws is None or self._ws.numel() < nbytes:
@@ -207,12 +225,13 @@ class DeviceIndex:
                                              (nb, tt.n, self.d, k, self.lib.hwer_knn_max_k()))
             ws = self._workspace(wsb)
             a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
-            native.check(self.lib.hwer_knn_search_f32(
+            x16, x16_exp = self._x16(tt) if nb <= 1024 else (None, 0)   # only the small-batch screen reads the float16 copy
+            native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,
                 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
                 tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None,
-                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), native.stream_ptr()), "knn_search")
+                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), 0, native.ptr(x16), x16_exp, native.stream_ptr()), "knn_search")
             # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
             # to 8 per call; anything beyond that is picked up by the host-driven pass below
             wse = self._exact_workspace(self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
@@ -263,7 +282,7 @@ class DeviceIndex:
                 b1 - b0, k, score_mode, 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None,
                 0 if use_rows else int(id_base), tt.hnorm_max, native.ptr(r_idx[b0:b1]), native.ptr(r_score[b0:b1]),
                 native.ptr(r_dist2[b0:b1]) if r_dist2 is not None else None, native.ptr(r_flags[b0:b1]), native.ptr(ws), ws.numel(),
-                opt, native.stream_ptr()), "knn_search(exact thresholds)")
+                opt, None, 0, native.stream_ptr()), "knn_search(exact thresholds)")
         good = torch.nonzero(r_flags > 0).flatten()
         rows = bad.index_select(0, good)
         idx.index_copy_(0, rows, r_idx.index_select(0, good))

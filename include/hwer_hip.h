@@ -164,7 +164,15 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
                              int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max,
                              int64_t* out_idx, double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
-                             size_t workspace_bytes, uint32_t options, void* stream);
+                             size_t workspace_bytes, uint32_t options, const void* X16 /*nullable*/, int x16_exp, void* stream);
+
+/* float16 STORAGE of the item table for the HBM-bound small-batch path.  X16 = the padded float32 table
+ * X scaled by 2^x_exp (x_exp = hwer_knn_f16_scale_exp(hnorm_max): no element leaves float16's normal range) and rounded
+ * to float16.  When passed to hwer_knn_search_opts_f32, small query batches screen against it with the float16 MFMA (half
+ * the bytes streamed); the select stage widens its error bound by 2^-10 ||q|| ||x||max and the float64 re-rank still
+ * reads the float32 rows, so the results are identical.  X16: n_rows_padded * ldx * 2 bytes. */
+int hwer_knn_f16_scale_exp(float hnorm_max);
+int hwer_pack_rows_f16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, void* stream);
 
 /* out_count[0] = number of queries with flags == 0 (device int32): one 4-byte read tells the host whether the
  * exhaustive pass is needed. */

@@ -292,6 +292,29 @@ def test_knn_small_batch_path(hw, d, N, B, k):
             assert np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
 
 
+@pytest.mark.parametrize("d,N,B,k", [(128, 50000, 5, 200), (64, 20000, 64, 100), (256, 12000, 33, 200), (32, 40000, 200, 50)])
+def test_knn_small_batch_f16_storage_is_invisible(hw, d, N, B, k):
+    """the float16 storage of the small-batch screen (half the bytes streamed) must not change a single bit of the result:
+    same ids / scores / distances with and without it, both certified; non-unit row norms included."""
+    from hwer.device_index import DeviceIndex
+    X = unit_rows_f32(35 + d, N, d)
+    users = unit_rows_f32(36 + d, B, d)
+    V = np.concatenate([users, X]).astype(np.float64)
+    type_rows = {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}
+    res = []
+    for f16 in (True, False):
+        ix = DeviceIndex(V, type_rows, arith=0)
+        ix.use_f16_storage = f16
+        res.append(ix.search("item", np.arange(B), k=k))
+        assert (ix.tables["item"].X16 is not None) == f16
+    for a, b in zip(res[0], res[1]):
+        assert np.array_equal(a, b)
+    assert (res[0][3] == 1).all()
+    for u in range(0, B, max(1, B // 6)):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(res[0][0][u], o_idx) and np.array_equal(res[0][1][u], o_score) and np.array_equal(res[0][2][u], o_dist)
+
+
 def test_knn_small_batch_duplicates(hw):
     """heavy duplication defeats the sampled threshold (list overflow / ties at the cut): the queries must come back
     through the exhaustive pass, still exact."""

@@ -122,16 +122,21 @@ def main():
         o_sc = torch.empty((Bmax, K), dtype=torch.float64, device=dev)
         o_d2 = torch.empty((Bmax, K), dtype=torch.float64, device=dev)
         o_fl = torch.empty(Bmax, dtype=torch.int32, device=dev)
-        for B in [int(x) for x in args.batches.split(",")]:
+        hmax = 0.5 * (1 + 1e-4) ** 2
+        x16_exp = lib.hwer_knn_f16_scale_exp(hmax)
+        X16 = torch.empty((Ip, ldx), dtype=torch.float16, device=dev)
+        native.check(lib.hwer_pack_rows_f16(P(X), Ip, ldx, x16_exp, P(X16), S()), "pack16")
+        for B, f16 in [(int(x), f) for x in args.batches.split(",") for f in ((True, False) if int(x) <= int(os.environ.get("HWER_SMALL_MAXQ", "1024")) else (False,))]:
             wsb = lib.hwer_knn_workspace_bytes(B, I, d, K)
             ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
-            fn = lambda: native.check(lib.hwer_knn_search_f32(P(X), P(hn), I, d, ldx, P(Q32), P(Q64), P(Vq), d, P(anchors), B, K, 0, 1, None, 0,  # noqa: E731
-                                                              0.5 * (1 + 1e-4) ** 2, P(o_idx), P(o_sc), P(o_d2), P(o_fl), P(ws), wsb, S()), "knn")
+            fn = lambda: native.check(lib.hwer_knn_search_opts_f32(P(X), P(hn), I, d, ldx, P(Q32), P(Q64), P(Vq), d, P(anchors), B, K, 0, 1, None, 0,  # noqa: E731
+                                                                   hmax, P(o_idx), P(o_sc), P(o_d2), P(o_fl), P(ws), wsb, 0,
+                                                                   P(X16) if f16 else None, x16_exp, S()), "knn")
             ms = timeit(torch, fn, iters=10)
             bad = int((o_fl[:B] == 0).sum().item())
             x_bytes = 4.0 * ldx * I
             flops = 2.0 * B * I * d
-            print(json.dumps({"kernel": "knn_search", "case": "%d queries x %d items, d=%d, k=%d" % (B, I, d, K), "ms": ms,
+            print(json.dumps({"kernel": "knn_search", "case": "%d queries x %d items, d=%d, k=%d%s" % (B, I, d, K, ", float16 storage" if f16 else ""), "ms": ms,
                               "latency_ms_per_batch": ms, "pairs_per_s": B * float(I) / ms * 1e3, "uncertified": bad,
                               "hbm_GBs_on_X": x_bytes / ms / 1e6, "hbm_frac": x_bytes / ms / 1e6 / HBM_PEAK_GBS,
                               "mfma_TFs": flops / ms / 1e9, "workspace_MB": wsb / 1e6}))
