@@ -17,7 +17,9 @@ LIB = os.path.join(LIBDIR, "libhwer_hip.so")
 SOURCES = ["rowops.hip", "knn_screen.hip", "knn_small.hip", "knn_select.hip"]
 HEADERS = ["hwer_common.h", "knn_internal.h", os.path.join(ROOT, "include", "hwer_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-         "-I" + os.path.join(ROOT, "include"), "-I" + HERE, "-Wno-unused-result"]
+         "-I" + os.path.join(ROOT, "include"), "-I" + HERE, "-Wno-unused-result"] + os.environ.get("HIPCC_EXTRA", "").split()
+# HIPCC_EXTRA=-DHWER_DIAG_STAMPS builds the screen kernel with its s_memtime phase stamps (diagnosis only: the stamps carry
+# scheduling barriers; the production build has none)
 
 
 def _digest():

@@ -131,7 +131,12 @@ __device__ __forceinline__ unsigned long long stamp() {
     __builtin_amdgcn_sched_barrier(0);
     return t;
 }
-#define STAMP(var) if (a.debug_stamps) { var = stamp(); }
+#ifdef HWER_DIAG_STAMPS
+#define DIAG_STAMPS (a.debug_stamps != nullptr)
+#else
+#define DIAG_STAMPS false
+#endif
+#define STAMP(var) if (DIAG_STAMPS) { var = stamp(); }
 
 template <int NG, int TQ, bool DENSE>
 __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const unsigned long long rt_entry = a.debug_stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    const unsigned long long rt_entry = DIAG_STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     if (blockIdx.x == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list, idle tickets
     const int wq = a.wq, wi_n = 4 / wq;
     const int wqi = wave % wq, wii = wave / wq;
@@ -236,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 
     const bool getenv_calib = a.debug_nofilter == 2;
     unsigned long long clk0 = 0, rt0 = 0;
-    if (a.debug_stamps) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    if (DIAG_STAMPS) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_pre = 0, acc_mfma = 0, acc_epi = 0, acc_wait = 0, acc_post = 0, acc_flush = 0, acc_dma = 0;
     for (int t = 0; t < n_tiles; ++t) {
         STAMP(t0);
@@ -287,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 }
             }
             __builtin_amdgcn_s_setprio(3);
-            if (a.debug_stamps) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
+            if (DIAG_STAMPS) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
             // Streaming mode: outstanding VMEM here = the DMA of tile t+1 (issued a whole MFMA phase ago) and the appends
             // of the previous tile (a whole tile ago): this wait is free, and it lets this tile's appends go straight to
             // HBM and stay in flight across the barrier below (no LDS staging of the appends, no flush).
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         if constexpr (DENSE) {
             if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);
             p_dma = perm_next(p_dma);
-            if (a.debug_stamps) {
+            if (DIAG_STAMPS) {
                 t5 = stamp();
                 acc_pre += t1 - t0; acc_mfma += t2 - t1; acc_epi += t3 - t2; acc_wait += t4 - t3; acc_post += t5 - t4;
             }
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         }
         unsigned long long t4a = 0, t4b = 0;
         STAMP(t4a);
-        if (a.debug_stamps && getenv_calib) { t4 = stamp(); t4a = stamp(); }   // calibration: flush := cost of one stamp
+        if (DIAG_STAMPS && getenv_calib) { t4 = stamp(); t4a = stamp(); }   // calibration: flush := cost of one stamp
         if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);      // refill the ring slot every wave has just finished reading
         p_dma = perm_next(p_dma);
         STAMP(t4b);
@@ -414,13 +419,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
         }
         }   // capacity check on odd tiles
-        if (a.debug_stamps) {
+        if (DIAG_STAMPS) {
             t5 = stamp();
             acc_pre += t1 - t0; acc_mfma += t2 - t1; acc_epi += t3 - t2; acc_wait += t4 - t3; acc_post += t5 - t4;
             acc_flush += t4a - t4; acc_dma += t4b - t4a;
         }
     }
-    if (a.debug_stamps && lane == 0) {
+    if (DIAG_STAMPS && lane == 0) {
         unsigned long long* o = a.debug_stamps + (size_t(blockIdx.x) * 4 + wave) * 8;
         o[0] = rt0 - rt_entry; o[1] = acc_mfma; o[2] = acc_epi; o[3] = acc_wait; o[4] = acc_post; o[5] = n_tiles;   // o[0]: prologue in 10-ns ticks
         o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel clock = o[6] / o[7] x 100 MHz
@@ -544,6 +549,9 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream) {
     static unsigned long long* dbg = nullptr;
     static int dbg_grid = 0;
+#ifndef HWER_DIAG_STAMPS
+    if (getenv("HWER_SCREEN_STAMPS")) fprintf(stderr, "[stamps] this library was built without -DHWER_DIAG_STAMPS (HIPCC_EXTRA=-DHWER_DIAG_STAMPS python csrc/build.py --force)\n");
+#endif
     if (getenv("HWER_SCREEN_STAMPS")) {
         if (dbg) {   // print the previous launch's stamps
             std::vector<unsigned long long> h(size_t(dbg_grid) * 32);
