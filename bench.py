@@ -104,7 +104,9 @@ def main():
         tables.append(torch.cat([users, items]).contiguous())
     if cfg["per_row"]:
         g = torch.Generator(device="cpu").manual_seed(5005)
-        alpha = torch.distributions.Dirichlet(torch.ones(T)).sample((N,)).to(torch.float32)
+        # Dirichlet(1, .., 1) = normalised unit exponentials, drawn from the seeded generator (torch.distributions has no generator argument)
+        alpha = -torch.log(torch.rand((N, T), generator=g, dtype=torch.float64).clamp_min(1e-300))
+        alpha = (alpha / alpha.sum(1, keepdim=True)).to(torch.float32)
         cold = torch.rand(N, generator=g) < 0.2
         alpha[cold, T - 1] = 0.0
         alpha = (alpha / alpha.sum(1, keepdim=True)).to(dev).contiguous()

@@ -38,15 +38,21 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k);
 // Header at the start of the k-NN workspace: the queries the last search could not certify (flag 0), appended by the
 // select kernels, consumed by the on-device exhaustive pass (hwer_knn_exact_device) without a host round trip.
 constexpr int WS_HEADER_BYTES = 4096;
-constexpr int UNCERT_LIST_MAX = 1000;   // ids kept in the header (the count keeps counting past it)
+constexpr int UNCERT_LIST_MAX = 256;    // ids kept in the header (the count keeps counting past it)
 constexpr int EXACT_DEVICE_MAXQ = 8;    // queries one hwer_knn_exact_device call recomputes
+constexpr int EXACT_DEVICE_GROUPS = 64; // first-level merge groups of the exhaustive pass (per query)
 struct WsHeader {
-    int32_t uncert_count;               // zeroed by the screen kernel of every search (with the tickets)
+    int32_t uncert_count;               // } zeroed by the screen kernel of every search (hdr_reset), with all tickets
     int32_t pad0;
-    int32_t tickets[EXACT_DEVICE_MAXQ]; // arrival counters of the exhaustive pass
-    int32_t pad[6];
+    int32_t tickets[EXACT_DEVICE_MAXQ];                            // second-level arrival counters of the exhaustive pass
+    int32_t group_tickets[EXACT_DEVICE_MAXQ][EXACT_DEVICE_GROUPS]; // first-level arrival counters
     int32_t uncert_list[UNCERT_LIST_MAX];
 };
+constexpr int HDR_RESET_INTS = 2 + EXACT_DEVICE_MAXQ + EXACT_DEVICE_MAXQ * EXACT_DEVICE_GROUPS;
+// called by block 0 of the first kernel of every search: empty uncertified list, idle tickets
+__device__ __forceinline__ void hdr_reset(WsHeader* hdr, int tid, int n_threads) {
+    for (int i = tid; i < HDR_RESET_INTS; i += n_threads) reinterpret_cast<int32_t*>(hdr)[i] = 0;
+}
 static_assert(sizeof(WsHeader) <= WS_HEADER_BYTES, "header must fit its slot");
 constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
 

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const unsigned long long rt_entry = DIAG_STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
-    if (blockIdx.x == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list, idle tickets
+    if (blockIdx.x == 0) hdr_reset(a.hdr, tid, 256);   // empty uncertified list, idle tickets
     const int wq = a.wq, wi_n = 4 / wq;
     const int wqi = wave % wq, wii = wave / wq;
     const int qblock = blockIdx.x % a.n_qblocks, split = blockIdx.x / a.n_qblocks;

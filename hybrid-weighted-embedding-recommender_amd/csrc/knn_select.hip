@@ -843,6 +843,8 @@ struct ExactDevArgs {
     Ent* cand;       // [EXACT_DEVICE_MAXQ][n_chunks][k]
     int n_chunks;
     int chunk;       // items per stage-A block (power of two, k <= chunk <= EX_CHUNK)
+    int chunks_per_group, n_groups;   // first-level merge groups (n_groups <= EXACT_DEVICE_GROUPS)
+    Ent* cand2;      // [EXACT_DEVICE_MAXQ][n_groups][k]
     int32_t* missed_accum;   // nullable device counter: += listed queries beyond EXACT_DEVICE_MAXQ (left flagged 0)
     EmitArgs emit;
 };
@@ -858,57 +860,121 @@ __global__ __launch_bounds__(256) void exact_device_kernel(const ExactDevArgs a)
     if (qi >= count) return;   // block-uniform
     const int64_t b = a.hdr->uncert_list[qi];
     const int d = a.emit.d, k = a.emit.k;
-    const double* q = a.Q64 + b * d;
     const int64_t base = int64_t(blockIdx.x) * a.chunk;
-    for (int i = tid; i < a.chunk; i += 256) {
-        Ent e;
-        e.hi = ~0ull;
-        e.lo = ~0ull;
-        const int64_t item = base + i;
-        if (item < a.n_items) {
-            const float* xr = a.X + item * a.ldx;
+    {
+        // Stage A: float64 distances of the chunk's items in scikit-learn's sequential order.  Each wave takes rounds of 64
+        // items: rows are gathered 64 B per 4 lanes (coalesced segments) and transposed through wave-private LDS, every
+        // lane then walks ITS item - the same data path as the re-rank; the query comes in through scalar loads.
+        const int lane = tid & 63, wave = tid >> 6;
+        float* stage = reinterpret_cast<float*>(lds_emit) + wave * (64 * RR_RS);
+        typedef const __attribute__((address_space(4))) double* cdouble_p;
+        const int64_t bu = (int64_t(__builtin_amdgcn_readfirstlane(int(uint64_t(b) >> 32))) << 32) |
+                           int64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))));
+        const cdouble_p q64 = (cdouble_p)(a.Q64 + bu * d);
+        const int n_steps = (d + RR_CW - 1) / RR_CW;
+        const int srow = lane >> 2, scol = 4 * (lane & 3);
+        const int64_t last = a.n_items - 1;
+#pragma unroll 1
+        for (int r0 = wave * 64; r0 < a.chunk; r0 += 256) {
+            const int64_t item = base + r0 + lane;
+            const float* src0 = a.X + min(base + r0 + 0 + srow, last) * a.ldx + scol;
+            const float* src1 = a.X + min(base + r0 + 16 + srow, last) * a.ldx + scol;
+            const float* src2 = a.X + min(base + r0 + 32 + srow, last) * a.ldx + scol;
+            const float* src3 = a.X + min(base + r0 + 48 + srow, last) * a.ldx + scol;
+            float* dst = stage + srow * RR_RS + scol;
+            float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
+            float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
             double acc = 0.0;
-            for (int j = 0; j < d; ++j) {
-                const double tmp = __dsub_rn(q[j], double(xr[j]));
-                acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+#pragma unroll 1
+            for (int c = 0; c < n_steps; ++c) {
+                *reinterpret_cast<float4*>(dst) = pre0;
+                *reinterpret_cast<float4*>(dst + 16 * RR_RS) = pre1;
+                *reinterpret_cast<float4*>(dst + 32 * RR_RS) = pre2;
+                *reinterpret_cast<float4*>(dst + 48 * RR_RS) = pre3;
+                if (c + 1 < n_steps) {
+                    const int o = RR_CW * (c + 1);
+                    pre0 = *reinterpret_cast<const float4*>(src0 + o);
+                    pre1 = *reinterpret_cast<const float4*>(src1 + o);
+                    pre2 = *reinterpret_cast<const float4*>(src2 + o);
+                    pre3 = *reinterpret_cast<const float4*>(src3 + o);
+                }
+                wave_lds_sync();
+                float xv[RR_CW];
+#pragma unroll
+                for (int t = 0; t < RR_CW / 4; ++t) {
+                    const float4 v = *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
+                    xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
+                }
+                wave_lds_sync();
+                const int j0 = RR_CW * c;
+#pragma unroll
+                for (int t = 0; t < RR_CW; ++t) {
+                    if (j0 + t < d) {   // uniform
+                        const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
+                        acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                    }
+                }
             }
-            e.hi = f64_orderable(acc);
-            e.lo = uint64_t(item);
+            Ent e;
+            e.hi = ~0ull;
+            e.lo = ~0ull;
+            if (item < a.n_items) {
+                e.hi = f64_orderable(acc);
+                e.lo = uint64_t(item);
+            }
+            ent[r0 + lane] = e;
         }
-        ent[i] = e;
     }
+    __syncthreads();
     bitonic_asc_ent(ent, a.chunk);
-    Ent* all = a.cand + int64_t(qi) * a.n_chunks * k;
+    // ---- two-level merge: the last block of every GROUP of chunks merges the group's winners, the last of those group
+    // mergers merges the groups' winners.  (One flat merge by the last block costs ~2 ms on a 1.25 M-row catalogue.)
+    // merge_rounds: n sorted-by-block entries at `src` -> the k smallest at src[0..k) and in ent[0..k), by this block.
+    auto merge_rounds = [&](Ent* src, int64_t n) {
+        while (n > k) {
+            const int64_t chunks = cdiv64(n, EX_CHUNK);
+            for (int64_t c = 0; c < chunks; ++c) {
+                __syncthreads();
+                for (int i = tid; i < EX_CHUNK; i += 256) {
+                    Ent e;
+                    e.hi = ~0ull;
+                    e.lo = ~0ull;
+                    if (c * EX_CHUNK + i < n) {   // written by other blocks: read through L2 (agent scope), never a stale L1 line
+                        const Ent* p = &src[c * EX_CHUNK + i];
+                        e.hi = __hip_atomic_load(&p->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        e.lo = __hip_atomic_load(&p->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ent[i] = e;
+                }
+                bitonic_asc_ent(ent, EX_CHUNK);
+                for (int i = tid; i < k; i += 256) src[c * k + i] = ent[i];   // c * k + k <= (c + 1) * EX_CHUNK: already consumed
+                __threadfence();
+            }
+            n = chunks * k;
+        }
+        __syncthreads();
+    };
+    const int grp = blockIdx.x / a.chunks_per_group;
+    const int g_first = grp * a.chunks_per_group;
+    const int g_chunks = min(a.chunks_per_group, a.n_chunks - g_first);
+    Ent* all = a.cand + int64_t(qi) * a.n_chunks * k;        // level 1: k entries per chunk
+    Ent* all2 = a.cand2 + int64_t(qi) * a.n_groups * k;      // level 2: k entries per group
     for (int i = tid; i < k; i += 256) all[int64_t(blockIdx.x) * k + i] = ent[i];
     __threadfence();
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&a.hdr->tickets[qi], 1) == a.n_chunks - 1;
+    if (tid == 0) s_last = atomicAdd(&a.hdr->group_tickets[qi][grp], 1) == g_chunks - 1;
     __syncthreads();
     if (!s_last) return;
     __threadfence();
-    // ---- last block: merge n_chunks * k winners down to k (rounds of EX_CHUNK entries, compacted in place) ------------
-    int64_t n = int64_t(a.n_chunks) * k;
-    while (n > k) {
-        const int64_t chunks = cdiv64(n, EX_CHUNK);
-        for (int64_t c = 0; c < chunks; ++c) {
-            __syncthreads();
-            for (int i = tid; i < EX_CHUNK; i += 256) {
-                Ent e;
-                e.hi = ~0ull;
-                e.lo = ~0ull;
-                if (c * EX_CHUNK + i < n) {   // written by other blocks: read through L2 (agent scope), never a stale L1 line
-                    const Ent* src = &all[c * EX_CHUNK + i];
-                    e.hi = __hip_atomic_load(&src->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    e.lo = __hip_atomic_load(&src->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                ent[i] = e;
-            }
-            bitonic_asc_ent(ent, EX_CHUNK);
-            for (int i = tid; i < k; i += 256) all[c * k + i] = ent[i];   // c * k + k <= (c + 1) * EX_CHUNK: already consumed
-            __threadfence();
-        }
-        n = chunks * k;
-    }
+    if (g_chunks > 1) merge_rounds(all + int64_t(g_first) * k, int64_t(g_chunks) * k);   // else ent still holds this block's sorted chunk
+    for (int i = tid; i < k; i += 256) all2[int64_t(grp) * k + i] = ent[i];
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&a.hdr->tickets[qi], 1) == a.n_groups - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (a.n_groups > 1) merge_rounds(all2, int64_t(a.n_groups) * k);
     __syncthreads();
     // ent[0..k) = the k nearest items (n_items >= k), ascending (dist2, item)
     const int kp = ((k + 63) / 64) * 64;
@@ -1360,9 +1426,18 @@ static int exact_device_chunk(int64_t n_items, int k) {
     return c;
 }
 
+// chunks per first-level group: as many as one 4096-entry sort takes, more when that would give over 64 groups
+static int exact_device_group(int64_t n_chunks, int k) {
+    const int64_t by_sort = std::max<int64_t>(1, EX_CHUNK / k);
+    return int(std::max<int64_t>(by_sort, cdiv64(n_chunks, EXACT_DEVICE_GROUPS)));
+}
+
 size_t hwer_knn_exact_device_workspace_bytes(int64_t n_items, int k) {
     if (n_items < 1 || k < 1 || k > K_MAX) return 0;
-    return align256(size_t(EXACT_DEVICE_MAXQ) * size_t(cdiv64(n_items, exact_device_chunk(n_items, k))) * size_t(k) * sizeof(Ent));
+    const int64_t n_chunks = cdiv64(n_items, exact_device_chunk(n_items, k));
+    const int64_t n_groups = cdiv64(n_chunks, exact_device_group(n_chunks, k));
+    return align256(size_t(EXACT_DEVICE_MAXQ) * size_t(n_chunks) * size_t(k) * sizeof(Ent)) +
+           align256(size_t(EXACT_DEVICE_MAXQ) * size_t(n_groups) * size_t(k) * sizeof(Ent));
 }
 
 int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
@@ -1389,10 +1464,14 @@ int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, c
     ea.cand = reinterpret_cast<Ent*>(workspace);
     ea.chunk = exact_device_chunk(n_items, k);
     ea.n_chunks = int(cdiv64(n_items, ea.chunk));
+    ea.chunks_per_group = exact_device_group(ea.n_chunks, k);
+    ea.n_groups = int(cdiv64(ea.n_chunks, ea.chunks_per_group));
+    ea.cand2 = reinterpret_cast<Ent*>(static_cast<unsigned char*>(workspace) + align256(size_t(EXACT_DEVICE_MAXQ) * size_t(ea.n_chunks) * size_t(k) * sizeof(Ent)));
     ea.missed_accum = missed_accum;
     ea.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, nullptr};
-    const size_t lds = size_t(EX_CHUNK) * sizeof(Ent) + wave_lds_bytes(d, ((k + 63) / 64) * 64);
+    // sort area | max(re-rank area of the emitting wave, four waves' staging areas of stage A)
+    const size_t lds = size_t(EX_CHUNK) * sizeof(Ent) + std::max(wave_lds_bytes(d, ((k + 63) / 64) * 64), size_t(4) * 64 * RR_RS * 4);
     int rc;
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&exact_device_kernel), lds, "knn_exact_device"))) return rc;
     hipLaunchKernelGGL(exact_device_kernel, dim3(unsigned(ea.n_chunks), EXACT_DEVICE_MAXQ), dim3(256), lds, as_stream(stream), ea);

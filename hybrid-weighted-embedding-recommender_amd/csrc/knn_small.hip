@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list
+    if (blockIdx.x == 0 && blockIdx.y == 0) hdr_reset(a.hdr, tid, 64 * NW);   // empty uncertified list, idle tickets
     float* ring = reinterpret_cast<float*>(smem_raw + size_t(wave) * (NSLOT * TILE_BYTES + NSLOT * IB * 4));   // [NSLOT][IB][CH*4] wave-private
     float* hn = ring + NSLOT * IB * CH * 4;                                                                   // [NSLOT][IB] half norms
     const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 2 + EXACT_DEVICE_MAXQ) reinterpret_cast<int32_t*>(a.hdr)[tid] = 0;   // empty uncertified list
+    if (blockIdx.x == 0 && blockIdx.y == 0) hdr_reset(a.hdr, tid, 64 * NW);   // empty uncertified list, idle tickets
     unsigned char* ring = smem_raw + size_t(wave) * (NSLOT * TILE_BYTES + NSLOT * IB * 4);   // [NSLOT][IB][NG * 16 B] wave-private
     float* hn = reinterpret_cast<float*>(ring + NSLOT * TILE_BYTES);                       // [NSLOT][IB] half norms
     const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
