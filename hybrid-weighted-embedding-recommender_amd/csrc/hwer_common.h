@@ -89,11 +89,6 @@ constexpr int kPairwiseDepth = 3;  // d <= 1024
 // probes are placed by interpolating log(count) between the bracket ends (the keys of one query look like the tail of
 // a bell curve, where log-count is close to linear), with a plain bisection step every third probe as a safeguard.
 // Precondition: at least `rank` finite entries.
-__device__ __forceinline__ int wave_sum_i32(int c) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) c += __shfl_xor(c, off, kWave);
-    return c;
-}
 template <int NV>
 __device__ __forceinline__ int wave_count_ge(const float (&v)[NV], float t) {
     int c = 0;   // ballot counting: one v_cmp per key, popcount and sum on the scalar unit

@@ -25,10 +25,6 @@ namespace hwer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-#ifndef HWER_SCREEN_SLOTS
-#define HWER_SCREEN_SLOTS 0
-#endif
-
 struct ScreenArgs {
     const float* X;
     const float* hnorm;
@@ -52,9 +48,7 @@ struct ScreenArgs {
     WsHeader* hdr;       // workspace header: the uncertified-query list of this search starts empty
 };
 
-__device__ __forceinline__ uint32_t ld_u32_l2(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: served by L2, never by a stale L1 line
-}
+// sc1 load: served by L2, never by a stale L1 line
 __device__ __forceinline__ uint64_t ld_u64_l2(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -71,52 +71,6 @@ __device__ __forceinline__ int pow2ceil_i(int x) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// per-thread restatements of the reference's summation orders
-// ---------------------------------------------------------------------------------------------------
-// numpy pairwise sum of p_j = A_j * X_j, j in [0, n), evaluated by ONE thread (8 chains in registers).
-template <typename T, typename FA, typename FX>
-__device__ __forceinline__ T np_dot_leaf(FA a_at, FX x_at, int j0, int n) {
-    if (n < 8) {
-        T r = T(0);
-        for (int i = 0; i < n; ++i) r = r + T(a_at(j0 + i)) * T(x_at(j0 + i));
-        return r;
-    }
-    T r0, r1, r2, r3, r4, r5, r6, r7;
-    {
-        r0 = T(a_at(j0 + 0)) * T(x_at(j0 + 0)); r1 = T(a_at(j0 + 1)) * T(x_at(j0 + 1));
-        r2 = T(a_at(j0 + 2)) * T(x_at(j0 + 2)); r3 = T(a_at(j0 + 3)) * T(x_at(j0 + 3));
-        r4 = T(a_at(j0 + 4)) * T(x_at(j0 + 4)); r5 = T(a_at(j0 + 5)) * T(x_at(j0 + 5));
-        r6 = T(a_at(j0 + 6)) * T(x_at(j0 + 6)); r7 = T(a_at(j0 + 7)) * T(x_at(j0 + 7));
-    }
-    const int lim = n - (n & 7);
-    for (int i = 8; i < lim; i += 8) {
-        // products are rounded separately from the adds (the reference materialises a*b first): no FMA
-        const T p0 = T(a_at(j0 + i + 0)) * T(x_at(j0 + i + 0)), p1 = T(a_at(j0 + i + 1)) * T(x_at(j0 + i + 1));
-        const T p2 = T(a_at(j0 + i + 2)) * T(x_at(j0 + i + 2)), p3 = T(a_at(j0 + i + 3)) * T(x_at(j0 + i + 3));
-        const T p4 = T(a_at(j0 + i + 4)) * T(x_at(j0 + i + 4)), p5 = T(a_at(j0 + i + 5)) * T(x_at(j0 + i + 5));
-        const T p6 = T(a_at(j0 + i + 6)) * T(x_at(j0 + i + 6)), p7 = T(a_at(j0 + i + 7)) * T(x_at(j0 + i + 7));
-        r0 = r0 + p0; r1 = r1 + p1; r2 = r2 + p2; r3 = r3 + p3;
-        r4 = r4 + p4; r5 = r5 + p5; r6 = r6 + p6; r7 = r7 + p7;
-    }
-    T res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (int i = lim; i < n; ++i) res = res + T(a_at(j0 + i)) * T(x_at(j0 + i));
-    return res;
-}
-template <typename T, int DEPTH, typename FA, typename FX>
-__device__ __forceinline__ T np_dot(FA a_at, FX x_at, int j0, int n) {
-    if constexpr (DEPTH == 0) {
-        return np_dot_leaf<T>(a_at, x_at, j0, n);
-    } else {
-        if (n <= 128) return np_dot_leaf<T>(a_at, x_at, j0, n);
-        int n2 = n / 2;
-        n2 -= n2 & 7;
-        const T s0 = np_dot<T, DEPTH - 1>(a_at, x_at, j0, n2);
-        const T s1 = np_dot<T, DEPTH - 1>(a_at, x_at, j0 + n2, n - n2);
-        return s0 + s1;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // shared tail: given `n_c` candidate items in LDS (c_item), compute exact dist2 / score, sort, certify, emit
 // ---------------------------------------------------------------------------------------------------
 struct EmitArgs {
@@ -148,7 +102,6 @@ struct EmitArgs {
 //   t_d2[kp] f64 | t_sc[kp] f64 | cand[kp] u32 | stage 64 x 20 f32
 // ---------------------------------------------------------------------------------------------------
 constexpr int RR_CW = 16;            // columns per re-rank step
-__host__ __device__ inline int pow2ceil_h(int x) { int p = 2; while (p < x) p <<= 1; return p; }
 constexpr int RR_RS = RR_CW + 4;     // LDS row stride of the staging area in floats (5 x 16 B: odd -> conflict-free ds_read_b128)
 __host__ __device__ inline size_t wave_lds_bytes(int d, int kp) {
     (void)d;
@@ -161,27 +114,6 @@ __device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
     const double u = 5.9604644775390625e-08;  // 2^-24
     const double xn = sqrt(2.0 * double(hnorm_max)) * (1.0 + 1e-6);
     return float((2.0 * d + 16.0) * u * (sqrt(Q2) * xn + double(hnorm_max)) * (1.0 + 1e-6));
-}
-
-// ascending bitonic sort of n2 (power of two) 16-byte entries in wave-private LDS, by ONE wave
-__device__ __forceinline__ void wave_bitonic_asc(Ent* a, int n2) {
-    const int lane = threadIdx.x & 63;
-    for (int size = 2; size <= n2; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            wave_lds_sync();
-            for (int t = lane; t < (n2 >> 1); t += 64) {
-                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
-                const int hi = lo + stride;
-                const bool asc = (lo & size) == 0;
-                const Ent x = a[lo], y = a[hi];
-                if (ent_less(y, x) == asc) {
-                    a[lo] = y;
-                    a[hi] = x;
-                }
-            }
-        }
-    }
-    wave_lds_sync();
 }
 
 // Re-rank + emit for ONE query by ONE wave.  cand[0..n_r) (wave-private LDS, part of `lds`): local item ids, n_r >= k.
