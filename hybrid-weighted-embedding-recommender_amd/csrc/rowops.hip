@@ -652,7 +652,10 @@ static int blend_impl(const float* const* tables, int64_t ld_tables, const int32
     if ((rc = check_table("blend_normalize(out)", out, ldo, d))) return rc;
     if (ld_tables % 4 != 0 || ld_tables < d) return fail(HWER_EINVAL, "blend_normalize: ld_tables must be a multiple of 4 and >= d");
     const int d4 = (d + 3) / 4;
-    const int grid = rows_grid(R, d4);   // <= kMaxStreamBlocks: the fused audit costs at most that many atomics per counter
+    // every block ends with one float64 atomic on the audit sum (same address for all blocks: they serialise in L2), so small
+    // tables use fewer, longer blocks: about 32 rows per block, at least one block per CU, at most kMaxStreamBlocks
+    int grid = rows_grid(R, d4);
+    if (audit_counts) grid = std::min(grid, int(std::max<int64_t>(256, cdiv64(R, 32))));
     hipLaunchKernelGGL(blend_normalize_kernel, dim3(grid), dim3(256), 0, as_stream(stream), tables,
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
