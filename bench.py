@@ -327,6 +327,20 @@ def main():
                                "sample": "%d of %d users x %d items, %d passes, exact float64 brute force + re-score + sort (oracle/hwer_oracle.c, OpenMP)" % (n_s, U, I, passes),
                                "seconds": t_all, "single_thread_value": n_1 * float(I) / t_one}
         out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        # the reference-SHAPED loop (scikit-learn KD-tree + per-anchor Python loop, one thread: SURVEY.md §8d), on a small sample
+        if I <= 50000:
+            try:
+                n_ref = 48
+                ref_sel = np.linspace(0, U - 1, n_ref).astype(np.int64)
+                t1 = time.perf_counter()
+                r_idx, r_sc = orc.reference_shaped_sweep(V64, np.arange(U, U + I), ref_sel.tolist(), K)
+                t_ref = time.perf_counter() - t1
+                same = bool(np.array_equal(r_idx, idx_h[ref_sel])) if world == 1 else None
+                out["cpu_baseline"]["reference_shaped"] = {"value": n_ref * float(I) / t_ref, "unit": "pairs/s", "cores": 1,
+                                                           "ms_per_anchor": t_ref / n_ref * 1e3, "includes": "KD-tree build + %d anchors" % n_ref,
+                                                           "same_neighbours_as_gpu": same}
+            except ImportError:
+                pass
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -366,3 +366,25 @@ class OracleRecommender:
         idx, score, _ = find_closest(self.vectors, self.type_rows[node_type], self.nodes_to_idx[anchor],
                                      self._idx(positive or []), self._idx(negative or []), k, self.scoring)
         return [(self.idx_to_node[i], s) for i, s in zip(idx, score)]
+
+
+def reference_shaped_sweep(V: np.ndarray, item_rows: np.ndarray, anchors, k: int = 200):
+    """The reference's own retrieval loop, structure for structure, for TIMING the CPU path beside the GPU path (SURVEY.md
+    §8d "reference-shaped loop"): one scikit-learn KD-tree over the item rows (hwer/recommendation_base.py:74,
+    leaf_size=128), then per anchor - in a Python loop like hwer/validation.py:30-35 - unit(anchor) (:153-155,164),
+    `tree.query(k)` (:79), the re-score of every candidate against the anchor (:141-143,172) and the stable sort by score
+    (:173).  Single thread.  Returns (global idx (len(anchors), k), score).  Needs scikit-learn (test / bench hosts only)."""
+    from sklearn.neighbors import KDTree
+    X = V[item_rows]
+    tree = KDTree(X, leaf_size=128)
+    out_idx = np.empty((len(anchors), k), dtype=np.int64)
+    out_sc = np.empty((len(anchors), k), dtype=V.dtype)
+    for n, a in enumerate(anchors):
+        emb = unit_length(np.average(V[[a]], axis=0))
+        dist, loc = tree.query([emb], k=k)
+        rows = item_rows[loc[0]]
+        sc = ((V[[a] * k] * V[rows]).sum(1) + 1) / 2
+        order = sorted(range(k), key=lambda i: sc[i], reverse=True)
+        out_idx[n] = rows[order]
+        out_sc[n] = sc[order]
+    return out_idx, out_sc
