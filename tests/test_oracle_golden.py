@@ -247,3 +247,17 @@ def test_c_oracle_matches_golden_and_numpy(golden):
             score = ((Vd[:7].astype(np.float64)[b] * Vd[10:].astype(np.float64)[loc]).sum(1) + 1) / 2
             order = np.argsort(-score, kind="stable")
             assert np.array_equal(idx[b], loc[order]) and np.array_equal(sc[b], score[order]) and np.array_equal(d2[b], (dist ** 2)[order]) or np.allclose(np.sqrt(d2[b]), dist[order], rtol=0, atol=0)
+
+
+def test_reference_shaped_loop_agrees_with_oracle():
+    """oracle.reference_shaped_sweep (scikit-learn KD-tree + per-anchor loop: the bench's secondary CPU baseline) returns
+    the oracle's neighbours and scores on tie-free data."""
+    pytest.importorskip("sklearn")
+    rng = np.random.default_rng(11)
+    V = rng.standard_normal((400, 24))
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    rows = np.arange(30, 400)
+    idx, sc = orc.reference_shaped_sweep(V, rows, list(range(8)), k=25)
+    for u in range(8):
+        o_idx, o_sc, _ = orc.find_closest(V, rows, u, k=25)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(sc[u], o_sc)
