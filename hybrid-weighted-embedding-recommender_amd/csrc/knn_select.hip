@@ -702,63 +702,9 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// exhaustive float64 fallback: (1) dist2 of every item, (2) chunk-wise sort keeps k per chunk, repeat, (3) emit
+// exhaustive float64 pass (exact_device_kernel below; the host-driven entry point feeds it query lists of 8)
 // ---------------------------------------------------------------------------------------------------
 constexpr int EX_CHUNK = 4096;
-
-__global__ __launch_bounds__(256) void exact_dist2_kernel(const float* __restrict__ X, int64_t n_items, int64_t ldx,
-                                                          int d, const double* __restrict__ q64, Ent* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double* q = reinterpret_cast<double*>(smem_raw);
-    for (int j = threadIdx.x; j < d; j += blockDim.x) q[j] = q64[j];
-    __syncthreads();
-    for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_items; i += int64_t(gridDim.x) * blockDim.x) {
-        const float* xr = X + i * ldx;
-        double acc = 0.0;
-        for (int j = 0; j < d; ++j) {
-            const double tmp = __dsub_rn(q[j], double(xr[j]));
-            acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
-        }
-        Ent e;
-        e.hi = f64_orderable(acc);
-        e.lo = uint64_t(i);
-        out[i] = e;
-    }
-}
-
-// each block sorts one chunk of EX_CHUNK entries and writes its `keep` smallest to out[block * keep ..]
-__global__ __launch_bounds__(256) void exact_chunk_select_kernel(const Ent* __restrict__ in, int64_t n, int keep,
-                                                                 Ent* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    Ent* ent = reinterpret_cast<Ent*>(smem_raw);
-    const int64_t base = int64_t(blockIdx.x) * EX_CHUNK;
-    for (int i = threadIdx.x; i < EX_CHUNK; i += blockDim.x) {
-        Ent e;
-        if (base + i < n) {
-            e = in[base + i];
-        } else {
-            e.hi = ~0ull;
-            e.lo = ~0ull;
-        }
-        ent[i] = e;
-    }
-    bitonic_asc_ent(ent, EX_CHUNK);
-    for (int i = threadIdx.x; i < keep; i += blockDim.x) out[int64_t(blockIdx.x) * keep + i] = ent[i];
-}
-
-__global__ __launch_bounds__(64) void exact_emit_kernel(const Ent* __restrict__ sel, int n_sel, int64_t b,
-                                                        const EmitArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int kp = ((a.k + 63) / 64) * 64;
-    uint32_t* c_item = reinterpret_cast<uint32_t*>(smem_raw + size_t(kp) * 16);   // `cand` of wave_rerank_emit
-    int n_c = 0;
-    for (int i = 0; i < n_sel; ++i) n_c += (sel[i].lo != ~0ull);  // padding entries sort last
-    n_c = min(n_c, a.k);
-    for (int i = threadIdx.x; i < n_c; i += 64) c_item[i] = uint32_t(sel[i].lo);
-    wave_lds_sync();
-    wave_rerank_emit(a, b, smem_raw, kp, n_c, n_c, 2);
-}
-
 
 // ---------------------------------------------------------------------------------------------------
 // On-device exhaustive pass: recomputes the queries listed in the workspace header (appended by the select kernels
@@ -914,6 +860,15 @@ __global__ __launch_bounds__(256) void exact_device_kernel(const ExactDevArgs a)
     for (int i = tid; i < k; i += 256) c_item[i] = uint32_t(ent[i].lo);
     __syncthreads();
     if (tid < 64) wave_rerank_emit(a.emit, b, lds_emit, kp, k, k, 2);
+}
+
+// host-driven entry (hwer_knn_exact_f64): up to 8 query ids arrive as kernel arguments and become the header's list
+struct ExactIds { int32_t id[EXACT_DEVICE_MAXQ]; };
+__global__ __launch_bounds__(256) void exact_list_init_kernel(WsHeader* hdr, int n, ExactIds ids) {
+    hdr_reset(hdr, threadIdx.x, 256);
+    __syncthreads();
+    if (threadIdx.x < n) hdr->uncert_list[threadIdx.x] = ids.id[threadIdx.x];
+    if (threadIdx.x == 0) hdr->uncert_count = n;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1292,63 +1247,6 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
 
 
 
-size_t hwer_knn_exact_workspace_bytes(int64_t n_items, int k) {
-    if (n_items < 1 || k < 1 || k > K_MAX) return 0;
-    // level 0: n_items entries; level 1: ceil(n/CHUNK) * keep entries (ping-pong with level 0)
-    const size_t l0 = align256(size_t(n_items) * sizeof(Ent));
-    const size_t l1 = align256(size_t(cdiv64(n_items, EX_CHUNK)) * size_t(k) * sizeof(Ent) + sizeof(Ent) * EX_CHUNK);
-    return l0 + l1;
-}
-
-int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
-                       int64_t lda, const int32_t* a_idx, const int32_t* qsel_host, int64_t nq, int k, int score_mode, int sort_by_score,
-                       const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
-                       double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes,
-                       void* stream) {
-    if (nq == 0) return HWER_OK;
-    if (!X || !Q64 || !qsel_host || !out_idx || !out_score || !out_flags || !workspace)
-        return fail(HWER_EINVAL, "knn_exact: null pointer");
-    if (d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16)
-        return fail(HWER_EINVAL, "knn_exact: need 1 <= d <= 256 and ldx >= roundup16(d) (rows are read in 16-column steps)");
-    if (k < 1 || k > K_MAX) return fail(HWER_EINVAL, "knn_exact: k=%d outside 1..%d", k, K_MAX);
-    if (k > n_items) return fail(HWER_EINVAL, "knn_exact: k must be less than or equal to the number of training points");
-    if (n_items >= (int64_t(1) << 32)) return fail(HWER_EINVAL, "knn_exact: n_items must be < 2^32");
-    if (score_mode < 0 || score_mode > 2 || (score_mode != 2 && !A32)) return fail(HWER_EINVAL, "knn_exact: score_mode / A32");
-    const size_t need = hwer_knn_exact_workspace_bytes(n_items, k);
-    if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_exact: workspace %zu < %zu", workspace_bytes, need);
-    hipStream_t st = as_stream(stream);
-    unsigned char* ws = static_cast<unsigned char*>(workspace);
-    Ent* bufA = reinterpret_cast<Ent*>(ws);
-    Ent* bufB = reinterpret_cast<Ent*>(ws + align256(size_t(n_items) * sizeof(Ent)));
-    int rc;
-    const size_t lds_chunk = size_t(EX_CHUNK) * sizeof(Ent);
-    if ((rc = set_max_lds(reinterpret_cast<const void*>(&exact_chunk_select_kernel), lds_chunk, "knn_exact"))) return rc;
-    for (int64_t qi = 0; qi < nq; ++qi) {
-        const int64_t b = qsel_host[qi];
-        const int grid = int(std::min<int64_t>(cdiv64(n_items, 256), 4096));
-        hipLaunchKernelGGL(exact_dist2_kernel, dim3(grid), dim3(256), size_t(d) * 8, st, X, n_items, ldx, d,
-                           Q64 + b * d, bufA);
-        if ((rc = check_launch("knn_exact(dist2)"))) return rc;
-        Ent* in = bufA;
-        Ent* out = bufB;
-        int64_t n = n_items;
-        const int keep = k;
-        do {
-            const int64_t chunks = cdiv64(n, EX_CHUNK);
-            hipLaunchKernelGGL(exact_chunk_select_kernel, dim3(unsigned(chunks)), dim3(256), lds_chunk, st, in, n, keep, out);
-            if ((rc = check_launch("knn_exact(select)"))) return rc;
-            n = chunks * keep;
-            std::swap(in, out);
-        } while (n > keep);
-        EmitArgs ea{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
-                    out_idx, out_score, out_dist2, out_flags, nullptr};
-        const size_t lds = wave_lds_bytes(d, ((k + 63) / 64) * 64);
-        hipLaunchKernelGGL(exact_emit_kernel, dim3(1), dim3(64), lds, st, in, int(n), b, ea);
-        if ((rc = check_launch("knn_exact(emit)"))) return rc;
-    }
-    return HWER_OK;
-}
-
 // Stage-A chunk of the on-device exhaustive pass: about 64 blocks per query on small catalogues (more parallelism, shorter
 // sorts), EX_CHUNK items on large ones; always a power of two >= k so that a block can hand over k entries.
 static int exact_device_chunk(int64_t n_items, int k) {
@@ -1408,6 +1306,40 @@ int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, c
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&exact_device_kernel), lds, "knn_exact_device"))) return rc;
     hipLaunchKernelGGL(exact_device_kernel, dim3(unsigned(ea.n_chunks), EXACT_DEVICE_MAXQ), dim3(256), lds, as_stream(stream), ea);
     return check_launch("knn_exact_device");
+}
+
+size_t hwer_knn_exact_workspace_bytes(int64_t n_items, int k) {
+    const size_t dev = hwer_knn_exact_device_workspace_bytes(n_items, k);
+    return dev ? WS_HEADER_BYTES + dev : 0;   // its own list header + the device pass's buffers
+}
+
+// Host-driven exhaustive pass: the listed queries go through the same kernel as hwer_knn_exact_device, 8 per launch.
+int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32,
+                       int64_t lda, const int32_t* a_idx, const int32_t* qsel_host, int64_t nq, int k, int score_mode, int sort_by_score,
+                       const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
+                       double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    if (nq == 0) return HWER_OK;
+    if (!qsel_host || !workspace) return fail(HWER_EINVAL, "knn_exact: null pointer");
+    const size_t need = hwer_knn_exact_workspace_bytes(n_items, k);
+    if (need == 0) return fail(HWER_EINVAL, "knn_exact: k=%d outside 1..%d or empty catalogue", k, K_MAX);
+    if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_exact: workspace %zu < %zu", workspace_bytes, need);
+    if (reinterpret_cast<uintptr_t>(workspace) & 255) return fail(HWER_EINVAL, "knn_exact: workspace must be 256-byte aligned");
+    unsigned char* ws = static_cast<unsigned char*>(workspace);
+    WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
+    for (int64_t q0 = 0; q0 < nq; q0 += EXACT_DEVICE_MAXQ) {
+        const int n = int(std::min<int64_t>(EXACT_DEVICE_MAXQ, nq - q0));
+        ExactIds ids{};
+        for (int i = 0; i < n; ++i) ids.id[i] = qsel_host[q0 + i];
+        hipLaunchKernelGGL(exact_list_init_kernel, dim3(1), dim3(256), 0, as_stream(stream), hdr, n, ids);
+        int rc;
+        if ((rc = check_launch("knn_exact(list)"))) return rc;
+        if ((rc = hwer_knn_exact_device(X, n_items, d, ldx, Q64, A32, lda, a_idx, k, score_mode, sort_by_score, row_ids, id_base, out_idx,
+                                        out_score, out_dist2, out_flags, ws, nullptr, ws + WS_HEADER_BYTES, workspace_bytes - WS_HEADER_BYTES,
+                                        stream)))
+            return rc;
+    }
+    return HWER_OK;
 }
 
 int hwer_merge_topk(const int64_t* idx, const double* score, const double* dist2, int n_lists, int64_t B, int k,
