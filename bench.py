@@ -127,10 +127,12 @@ def main():
     hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
     Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
     Q32 = torch.empty((U, ldx), dtype=torch.float32, device=dev)
-    o_idx = torch.empty((U, K), dtype=torch.int64, device=dev)
-    o_score = torch.empty((U, K), dtype=torch.float64, device=dev)
-    o_dist2 = torch.empty((U, K), dtype=torch.float64, device=dev)
-    o_flags = torch.empty(U, dtype=torch.int32, device=dev)
+    # N > 1: two result sets, so that the exchange + merge of step i (side stream) overlaps the search of step i + 1
+    n_sets = 2 if world > 1 else 1
+    sets = [dict(idx=torch.empty((U, K), dtype=torch.int64, device=dev), score=torch.empty((U, K), dtype=torch.float64, device=dev),
+                 dist2=torch.empty((U, K), dtype=torch.float64, device=dev), flags=torch.empty(U, dtype=torch.int32, device=dev))
+            for _ in range(n_sets)]
+    o_idx, o_score, o_dist2, o_flags = sets[0]["idx"], sets[0]["score"], sets[0]["dist2"], sets[0]["flags"]
     CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
     ws_bytes = lib.hwer_knn_workspace_bytes(min(U, CH), I, d, K)
     assert ws_bytes > 0
@@ -142,34 +144,58 @@ def main():
     # find_closest_neighbours returns (node, score): distances are an output only where the shards' results are merged
     want_dist = world > 1
 
-    def step():
+    def search_into(o):
         # blend + L2-normalise with the unit-norm audit of the output rows fused into the same pass
         native.check(lib.hwer_blend_normalize_audit_f32(P(tab_ptrs), d, None, P(alpha), 1 if cfg["per_row"] else 0, T, N, d,
                                                         P(V), ldv, 1e-4, P(audit_counts), P(audit_dev), S()), "blend+audit")
         native.check(lib.hwer_pack_rows_f32(P(V), N, d, ldv, P(item_rows), I, P(X), ldx, P(hnorm), S()), "pack")
         native.check(lib.hwer_query_mix(P(V), N, d, ldv, P(anchors), None, None, None, None, U, arith, P(Q64), P(Q32),
                                         ldx, S()), "query_mix")
+        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
         for b0 in range(0, U, CH):
             b1 = min(U, b0 + CH)
             native.check(lib.hwer_knn_search_f32(P(X), P(hnorm), I, d, ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(V), ldv,
                                                  P(anchors[b0:b1]), b1 - b0, K, arith, 1 if world == 1 else 0, None, id_base,
-                                                 hnorm_max, P(o_idx[b0:b1]), P(o_score[b0:b1]), P(o_dist2[b0:b1]) if want_dist else None,
-                                                 P(o_flags[b0:b1]), P(ws), ws.numel(), S()), "knn_search")
+                                                 hnorm_max, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if want_dist else None,
+                                                 P(of[b0:b1]), P(ws), ws.numel(), S()), "knn_search")
             # queries the screen could not certify (rare: near-ties at the cut, or a sample-scaled threshold that was too
             # tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the device (no host round trip):
             # the step always returns exact results.  `missed` counts listed queries beyond the 8 one call handles
             # (checked after the timed region: must stay 0).
             native.check(lib.hwer_knn_exact_device(P(X), I, d, ldx, P(Q64[b0:b1]), P(V), ldv, P(anchors[b0:b1]), K, arith,
-                                                   1 if world == 1 else 0, None, id_base, P(o_idx[b0:b1]), P(o_score[b0:b1]),
-                                                   P(o_dist2[b0:b1]) if want_dist else None, P(o_flags[b0:b1]), P(ws), P(missed), P(ws_exact), ws_exact.numel(), S()),
+                                                   1 if world == 1 else 0, None, id_base, P(oi[b0:b1]), P(osc[b0:b1]),
+                                                   P(od[b0:b1]) if want_dist else None, P(of[b0:b1]), P(ws), P(missed), P(ws_exact), ws_exact.numel(), S()),
                          "knn_exact_device")
-        if world > 1:
-            # ONE exchange step: user-partitioned (every rank receives the local lists of ITS slice of the users from all
-            # ranks and merges those - 1/N of the all-gather's bytes per xGMI link), or the all-gather variant
-            g = exchange_by_query(o_idx, o_score, o_dist2) if exchange == "by_query" else all_gather_results(o_idx, o_score, o_dist2)
-            return merge_on_device(*g, True)
-        return o_idx, o_score, o_dist2
 
+    step_no = [0]
+
+    def step():
+        if world == 1:
+            search_into(sets[0])
+            return o_idx, o_score, o_dist2
+        # N > 1.  ONE exchange step per search: user-partitioned (every rank receives the local lists of ITS slice of the
+        # users from all ranks and merges those - 1/N of the all-gather's bytes per xGMI link), or the all-gather variant.
+        # The exchange + merge run on a side stream: while RCCL moves the lists of step i over xGMI, the compute stream is
+        # already searching step i + 1 into the other result set.  Every step's merge still completes inside the timed
+        # region (the closing barrier synchronises all streams).
+        s = step_no[0] & 1
+        step_no[0] += 1
+        o = sets[s]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev_merged[s])          # the exchange that read this result set two steps ago is done
+        search_into(o)
+        ev_searched[s].record(cur)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ev_searched[s])
+            g = exchange_by_query(o["idx"], o["score"], o["dist2"]) if exchange == "by_query" else all_gather_results(o["idx"], o["score"], o["dist2"])
+            merged[s] = merge_on_device(*g, True)
+            ev_merged[s].record(comm)
+        return merged[s]
+
+    comm = torch.cuda.Stream(device=dev) if world > 1 else None
+    ev_searched = [torch.cuda.Event() for _ in range(n_sets)]
+    ev_merged = [torch.cuda.Event() for _ in range(n_sets)]
+    merged = [None] * n_sets
     missed = torch.zeros(1, dtype=torch.int32, device=dev)
     exchange = os.environ.get("HWER_BENCH_EXCHANGE", "by_query")
     ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
@@ -208,10 +234,11 @@ def main():
     diag = bool(os.environ.get("HWER_BENCH_NOSYNC"))   # diagnosis runs (ablation switches) skip the result checks
     pos, neg, nan = audit_counts.tolist()[:3]
     assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
-    n_uncert = int((o_flags == 0).sum().item())
+    last = sets[(step_no[0] - 1) & 1] if world > 1 else sets[0]   # the result set of the last step
+    n_uncert = int((last["flags"] == 0).sum().item())
     assert diag or n_uncert == 0, "%d queries left without an exact result" % n_uncert
     assert diag or int(missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(missed.item())
-    n_exhaustive = int((o_flags == 2).sum().item())
+    n_exhaustive = int((last["flags"] == 2).sum().item())
     idx_h = res[0].cpu().numpy()
     score_h = res[1].cpu().numpy()
     parity_n = 0
@@ -228,6 +255,29 @@ def main():
         assert np.array_equal(idx_h[sel], oi + U), "GPU indices differ from the oracle"
         assert np.array_equal(score_h[sel], osc), "GPU scores differ from the oracle"
         parity_n = len(sel)
+    elif world > 1 and not diag and I * world <= 400000:
+        # N > 1: rank 0 collects every rank's item shard (rank order = global id order) and checks the merged lists of
+        # sampled users of ITS slice against the oracle's brute force over the whole catalogue
+        shard = V[U:, :d].contiguous()
+        if backend == "nccl":
+            allv = torch.empty((world * I, d), dtype=torch.float32, device=dev)
+            dist.all_gather_into_tensor(allv, shard)
+            items_h = allv.cpu().numpy()
+        else:
+            parts = [torch.empty((I, d), dtype=torch.float32) for _ in range(world)]
+            dist.all_gather(parts, shard.cpu())
+            items_h = torch.cat(parts).numpy()
+        if rank == 0:
+            from oracle import c_oracle
+            from oracle import hwer_oracle as orc
+            n_mine = idx_h.shape[0] if exchange != "by_query" else (U + world - 1) // world   # rank 0 owns users [0, ceil(U/N))
+            sel = np.unique(np.linspace(0, min(n_mine, U) - 1, 16).astype(np.int64))
+            V64 = V[:U, :d].cpu().numpy().astype(np.float64)
+            Qh = np.stack([orc.query_vector(V64, int(q)) for q in sel])
+            oi, osc, _ = c_oracle.find_closest_f64(items_h, Qh, V64[sel], K, threads=os.cpu_count())
+            assert np.array_equal(idx_h[sel], oi + U), "merged indices differ from the oracle (N = %d)" % world
+            assert np.array_equal(score_h[sel], osc), "merged scores differ from the oracle (N = %d)" % world
+            parity_n = len(sel)
 
     total_items = I * world
     pairs_per_step = float(U) * float(total_items)
@@ -252,7 +302,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "users": U, "items_per_gpu": I, "items_total": total_items, "d": d, "k": K,
-                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": ("items row-sharded x%d, %s + merge" % (world, "user-partitioned exchange" if exchange == "by_query" else "all-gather")) if world > 1 else "none"},
+                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": ("items row-sharded x%d, %s + merge, exchange of step i overlapped with the search of step i+1" % (world, "user-partitioned exchange" if exchange == "by_query" else "all-gather")) if world > 1 else "none"},
         "roofline": {"kernel": "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)", "bound": "mfma",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "avg_launch_ms": screen_ms, "launches_per_step": launches},

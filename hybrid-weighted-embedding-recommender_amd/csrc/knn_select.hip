@@ -21,7 +21,7 @@ __device__ __forceinline__ void bitonic_desc_u64(uint64_t* a, int n2) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
             for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
-                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                const int lo = 2 * t - (t & (stride - 1));   // = (t / stride) * 2 stride + t % stride, stride a power of two
                 const int hi = lo + stride;
                 const bool desc = (lo & size) == 0;
                 const uint64_t x = a[lo], y = a[hi];
@@ -45,7 +45,7 @@ __device__ __forceinline__ void bitonic_asc_ent(Ent* a, int n2) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
             for (int t = threadIdx.x; t < (n2 >> 1); t += blockDim.x) {
-                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                const int lo = 2 * t - (t & (stride - 1));   // = (t / stride) * 2 stride + t % stride, stride a power of two
                 const int hi = lo + stride;
                 const bool asc = (lo & size) == 0;
                 const Ent x = a[lo], y = a[hi];
@@ -885,51 +885,211 @@ struct MergeArgs {
     int64_t* out_idx;
     double* out_score;
     double* out_dist2;
+    int64_t list_stride;   // elements between list l and l + 1 of the same array (B * k when the lists are packed)
 };
 
-// entries: hi = orderable(dist2), lo = (position in the gathered array); ties broken by global id through a
-// second compare on equal hi (ids are fetched from `idx`).
+// Stable order of the k winners by score, descending, by ONE wave: win_key[r] = ~orderable(score of the winner of rank r).
+// Register bitonic sort on (32-bit approximation << 32 | rank) + exact fix-up of equal approximations; ord[p] = rank of the
+// winner that goes to output position p.
+template <int NE>
+__device__ __forceinline__ void merge_score_order(const uint64_t* win_key, int k, uint32_t* ord) {
+    const int lane = threadIdx.x & 63;
+    uint64_t key[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int r = NE * lane + j;
+        // padding has approximation 0xFFFFFFFF; real approximations are clamped below it (still monotone)
+        key[j] = r < k ? (uint64_t(min(uint32_t(win_key[r] >> 32), 0xFFFFFFFEu)) << 32) | uint64_t(uint32_t(r)) : ~0ull;
+    }
+    wave_sort_u64<NE>(key);
+    wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
+        const uint32_t rx = uint32_t(x), ry = uint32_t(y);
+        const uint64_t kx = win_key[rx], ky = win_key[ry];
+        return kx < ky || (kx == ky && rx < ry);
+    });
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int p = NE * lane + j;
+        if (p < k) ord[p] = uint32_t(key[j]);
+    }
+}
+
+// One workgroup per query.  Entries: hi = orderable(dist2), lo = global id << 22 | list << 9 | position in the list, sorted
+// ascending by (hi, lo) = (dist2, id) with the source position as the last resort (padding rows share id -1).
+//   1. T = max over the lists of their m-th entry, m = ceil(k / G): at least G m >= k entries are <= T, so nothing above T
+//      can be among the k smallest.  Lists are sorted, so the survivors of a list are a prefix: each wave scans its lists in
+//      64-entry pieces and stops at the first piece without a survivor (~k + 32 G entries read instead of G k).
+//   2. n_lists <= 16: every survivor finds its final rank directly - own position + one binary search per other list's
+//      survivor prefix (a sort of the survivors through LDS moves ~10x the bytes and was LDS-bandwidth-bound) - and, when
+//      the reference's order is wanted, one wave orders the k winners by score in registers.
+//      More lists: bitonic sort of the survivors in LDS, then of the k winners by score.
+constexpr int MERGE_POS_BITS = 22, MERGE_J_BITS = 9;   // k <= 512, n_lists * k <= 8192
+constexpr int MERGE_RANK_LISTS = 16;
+__host__ __device__ inline size_t merge_lds_bytes(int n_lists, int k) {
+    int n2 = 2;
+    while (n2 < n_lists * k) n2 <<= 1;
+    const size_t sort_path = size_t(n2 > 512 ? n2 : 512) * sizeof(Ent);
+    // rank path: entries at their list position | winners' score keys | their source positions | output order
+    const size_t rank_path = size_t(n_lists) * k * sizeof(Ent) + size_t(512) * (8 + 4 + 4);
+    return n_lists <= MERGE_RANK_LISTS ? rank_path : sort_path;
+}
 __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     Ent* ent = reinterpret_cast<Ent*>(smem_raw);
+    __shared__ Ent s_wave_max[4];
+    __shared__ int s_count;
     const int64_t b = blockIdx.x;
-    const int total = a.n_lists * a.k;
-    const int n2 = pow2ceil_i(max(total, 2));
-    // Two-level key: (dist2, global id).  Global ids are < 2^40 in practice; we need them in the key for the
-    // tie rule, so sort by (hi = dist2, lo = id) and carry the source position in a parallel pass afterwards.
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = a.k, G = a.n_lists;
+    const int64_t row = b * k;
+    auto load_ent = [&](int l, int j) {
+        const int64_t src = int64_t(l) * a.list_stride + row + j;
         Ent e;
-        if (i < total) {
-            const int l = i / a.k, j = i % a.k;
-            const int64_t src = (int64_t(l) * a.B + b) * a.k + j;
-            e.hi = f64_orderable(a.dist2[src]);
-            e.lo = (uint64_t(a.idx[src]) << 20) | uint64_t(uint32_t(i));  // id < 2^44, position < 2^20
-        } else {
-            e.hi = ~0ull;
-            e.lo = ~0ull;
-        }
-        ent[i] = e;
-    }
-    bitonic_asc_ent(ent, n2);
-    const int k = a.k;
-    const int k2 = pow2ceil_i(k);
-    auto src_of = [&](const Ent& e) {
-        const int i = int(e.lo & 0xFFFFFu);
-        return (int64_t(i / k) * a.B + b) * k + (i % k);
+        e.hi = f64_orderable(a.dist2[src]);
+        e.lo = (uint64_t(a.idx[src]) << MERGE_POS_BITS) | uint64_t(uint32_t((l << MERGE_J_BITS) | j));
+        return e;
     };
+    // ---- 1. bound T ---------------------------------------------------------------------------------------------------
+    const int m = (k + G - 1) / G;
+    Ent t{0ull, 0ull};
+    for (int l = tid; l < G; l += 256) {
+        const Ent e = load_ent(l, m - 1);
+        if (ent_less(t, e)) t = e;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        Ent o;
+        o.hi = __shfl_xor((unsigned long long)t.hi, off, kWave);
+        o.lo = __shfl_xor((unsigned long long)t.lo, off, kWave);
+        if (ent_less(t, o)) t = o;
+    }
+    if (tid == 0) s_count = 0;
+    if (lane == 0) s_wave_max[wave] = t;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+        if (ent_less(t, s_wave_max[w])) t = s_wave_max[w];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t pos_mask = (1u << MERGE_POS_BITS) - 1u;
+    auto src_of_pos = [&](uint32_t pos) {
+        return int64_t(pos >> MERGE_J_BITS) * a.list_stride + row + int64_t(pos & ((1u << MERGE_J_BITS) - 1u));
+    };
+    if (G <= MERGE_RANK_LISTS) {
+        __shared__ int s_cnt[MERGE_RANK_LISTS];
+        uint64_t* win_key = reinterpret_cast<uint64_t*>(ent + size_t(G) * k);
+        uint32_t* win_pos = reinterpret_cast<uint32_t*>(win_key + 512);
+        uint32_t* ord = win_pos + 512;
+        // ---- 2a. survivors stay at their list position; s_cnt[l] = length of list l's surviving prefix ---------------------
+        for (int l = wave; l < G; l += 4) {
+            int c = 0;
+            for (int j0 = 0; j0 < k; j0 += 64) {
+                const int j = j0 + lane;
+                bool keep = false;
+                Ent e{};
+                if (j < k) {
+                    e = load_ent(l, j);
+                    keep = !ent_less(t, e);
+                }
+                const uint64_t bal = __ballot(keep);
+                if (keep) ent[l * k + j] = e;
+                c += __builtin_popcountll(bal);
+                if (bal != ~0ull) break;   // sorted list: the survivors are a prefix, and it ended inside this piece
+            }
+            if (lane == 0) s_cnt[l] = c;
+        }
+        __syncthreads();
+        int n_s = 0;
+        for (int l = 0; l < G; ++l) n_s += s_cnt[l];
+        // ---- 2b. final rank of every survivor ---------------------------------------------------------------------------------
+        for (int i = tid; i < n_s; i += 256) {
+            int l = 0, j = i;
+            for (; l < G - 1; ++l) {
+                const int c = s_cnt[l];
+                if (j < c) break;
+                j -= c;
+            }
+            const Ent e = ent[l * k + j];
+            int rank = j;
+            for (int l2 = 0; l2 < G && rank < k; ++l2) {
+                if (l2 == l) continue;
+                const Ent* lst = ent + l2 * k;
+                int lo = 0, hi = s_cnt[l2];
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ent_less(lst[mid], e)) lo = mid + 1;
+                    else hi = mid;
+                }
+                rank += lo;
+            }
+            if (rank < k) {
+                const uint32_t pos = uint32_t(e.lo) & pos_mask;
+                const int64_t src = src_of_pos(pos);
+                if (a.sort_by_score) {
+                    win_key[rank] = ~f64_orderable(a.score[src]);
+                    win_pos[rank] = pos;
+                } else {
+                    a.out_idx[row + rank] = a.idx[src];
+                    a.out_score[row + rank] = a.score[src];
+                    a.out_dist2[row + rank] = a.dist2[src];
+                }
+            }
+        }
+        if (!a.sort_by_score) return;
+        __syncthreads();
+        // ---- 3a. the reference's final order: stable sort by score, descending (one wave, registers) -------------------------
+        if (wave == 0) {
+            if (k <= 128) merge_score_order<2>(win_key, k, ord);
+            else if (k <= 256) merge_score_order<4>(win_key, k, ord);
+            else merge_score_order<8>(win_key, k, ord);
+        }
+        __syncthreads();
+        for (int i = tid; i < k; i += 256) {
+            const int64_t src = src_of_pos(win_pos[ord[i]]);
+            a.out_idx[row + i] = a.idx[src];
+            a.out_score[row + i] = a.score[src];
+            a.out_dist2[row + i] = a.dist2[src];
+        }
+        return;
+    }
+    // ---- 2. survivors -> LDS ------------------------------------------------------------------------------------------
+    for (int l = wave; l < G; l += 4) {
+        for (int j0 = 0; j0 < k; j0 += 64) {
+            const int j = j0 + lane;
+            bool keep = false;
+            Ent e{};
+            if (j < k) {
+                e = load_ent(l, j);
+                keep = !ent_less(t, e);
+            }
+            const uint64_t bal = __ballot(keep);
+            if (bal == 0ull) break;   // sorted list: no later entry can be <= T
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&s_count, __builtin_popcountll(bal));
+            base = __shfl(base, 0, kWave);
+            if (keep) ent[base + __builtin_popcountll(bal & lt_mask)] = e;
+        }
+    }
+    __syncthreads();
+    const int n_s = s_count;                      // k <= n_s <= G k
+    const int n2 = pow2ceil_i(max(n_s, 2));
+    for (int i = n_s + tid; i < n2; i += 256) ent[i] = Ent{~0ull, ~0ull};
+    bitonic_asc_ent(ent, n2);
+    auto src_of = [&](const Ent& e) { return src_of_pos(uint32_t(e.lo) & pos_mask); };
+    // ---- 3. the reference's final order: stable sort by score, descending ---------------------------------------------------
     if (a.sort_by_score) {
+        const int k2 = pow2ceil_i(max(k, 2));
         auto make = [&](int i) {
             Ent e;
             if (i < k) {
                 e.hi = ~f64_orderable(a.score[src_of(ent[i])]);
-                e.lo = (uint64_t(uint32_t(i)) << 32) | (ent[i].lo & 0xFFFFFu);
+                e.lo = (uint64_t(uint32_t(i)) << 32) | (ent[i].lo & ((1ull << MERGE_POS_BITS) - 1ull));
             } else {
                 e.hi = ~0ull;
                 e.lo = ~0ull;
             }
             return e;
         };
-        const int i0 = threadIdx.x, i1 = threadIdx.x + 256;  // k2 <= 512, 256 threads
+        const int i0 = tid, i1 = tid + 256;  // k2 <= 512, 256 threads
         Ent e0{}, e1{};
         if (i0 < k2) e0 = make(i0);
         if (i1 < k2) e1 = make(i1);
@@ -938,11 +1098,11 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
         if (i1 < k2) ent[i1] = e1;
         bitonic_asc_ent(ent, k2);
     }
-    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    for (int i = tid; i < k; i += 256) {
         const int64_t src = src_of(ent[i]);
-        a.out_idx[b * k + i] = a.idx[src];
-        a.out_score[b * k + i] = a.score[src];
-        a.out_dist2[b * k + i] = a.dist2[src];
+        a.out_idx[row + i] = a.idx[src];
+        a.out_score[row + i] = a.score[src];
+        a.out_dist2[row + i] = a.dist2[src];
     }
 }
 
@@ -1344,17 +1504,22 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
 
 int hwer_merge_topk(const int64_t* idx, const double* score, const double* dist2, int n_lists, int64_t B, int k,
                     int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2, void* stream) {
+    return hwer_merge_topk_strided(idx, score, dist2, B * k, n_lists, B, k, sort_by_score, out_idx, out_score, out_dist2, stream);
+}
+
+int hwer_merge_topk_strided(const int64_t* idx, const double* score, const double* dist2, int64_t list_stride, int n_lists,
+                            int64_t B, int k, int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2,
+                            void* stream) {
     if (B == 0) return HWER_OK;
+    if (list_stride < B * k) return fail(HWER_EINVAL, "merge_topk: list_stride %lld < B * k", (long long)list_stride);
     if (!idx || !score || !dist2 || !out_idx || !out_score || !out_dist2) return fail(HWER_EINVAL, "merge_topk: null pointer");
     if (n_lists < 1 || k < 1 || k > 512) return fail(HWER_EINVAL, "merge_topk: need n_lists >= 1 and 1 <= k <= 512");
     const int64_t total = int64_t(n_lists) * k;
     if (total > 8192) return fail(HWER_EINVAL, "merge_topk: n_lists * k = %lld > 8192", (long long)total);
-    int n2 = 2;
-    while (n2 < total) n2 <<= 1;
-    const size_t lds = size_t(std::max(n2, 512)) * sizeof(Ent);
+    const size_t lds = merge_lds_bytes(n_lists, k);
     int rc;
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&merge_topk_kernel), lds, "merge_topk"))) return rc;
-    MergeArgs ma{idx, score, dist2, n_lists, B, k, sort_by_score, out_idx, out_score, out_dist2};
+    MergeArgs ma{idx, score, dist2, n_lists, B, k, sort_by_score, out_idx, out_score, out_dist2, list_stride};
     hipLaunchKernelGGL(merge_topk_kernel, dim3(unsigned(B)), dim3(256), lds, as_stream(stream), ma);
     return check_launch("merge_topk");
 }

@@ -679,6 +679,23 @@ int hwer_rank_filter_seen(const int64_t* ranked, int64_t B, int k, const int64_t
 
 int64_t hwer_unit_audit_ws_floats(int64_t N) { return ((N + 3) / 4) * 4 + (AUDIT_BLOCKS * 4 * 2) + 8; }
 
+// X1 pack of the user-partitioned exchange: send[g][c][j][:] = array c (0 idx, 1 score bits, 2 dist2 bits) of query
+// g * Bs + j, padding rows (query >= B) = (id -1, score 0, dist2 +inf).  One wave per 8-byte row of k elements.
+__global__ __launch_bounds__(256) void pack_exchange_kernel(const int64_t* __restrict__ idx, const int64_t* __restrict__ score,
+                                                            const int64_t* __restrict__ dist2, int64_t B, int k, int64_t Bs, int64_t n_rows,
+                                                            int64_t* __restrict__ send) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6); row < n_rows; row += int64_t(gridDim.x) * 4) {
+        const int64_t j = row % Bs, gc = row / Bs;
+        const int c = int(gc % 3);
+        const int64_t q = (gc / 3) * Bs + j;
+        const int64_t* src = (c == 0 ? idx : c == 1 ? score : dist2) + q * k;
+        const int64_t pad = c == 0 ? int64_t(-1) : c == 1 ? int64_t(0) : int64_t(0x7FF0000000000000ll);
+        int64_t* dst = send + row * k;
+        for (int e = lane; e < k; e += 64) dst[e] = q < B ? src[e] : pad;
+    }
+}
+
 // number of queries whose flag is 0 (uncertified) -> out[0]; lets the host decide on the exhaustive pass with one
 // 4-byte read instead of a device-wide nonzero()
 __global__ __launch_bounds__(256) void count_zero_flags_kernel(const int32_t* __restrict__ flags, int64_t B, int32_t* __restrict__ out) {
@@ -688,6 +705,18 @@ __global__ __launch_bounds__(256) void count_zero_flags_kernel(const int32_t* __
     for (int off = 1; off < kWave; off <<= 1) c += __shfl_xor(c, off, kWave);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);   // uncertified queries are rare: normally no atomic at all
 }
+int hwer_pack_exchange(const int64_t* idx, const double* score, const double* dist2, int64_t B, int k, int n_ranks,
+                       int64_t* send, void* stream) {
+    if (!idx || !score || !dist2 || !send) return fail(HWER_EINVAL, "pack_exchange: null pointer");
+    if (B < 1 || k < 1 || n_ranks < 1) return fail(HWER_EINVAL, "pack_exchange: need B, k, n_ranks >= 1");
+    const int64_t Bs = cdiv64(B, n_ranks);
+    const int64_t n_rows = int64_t(n_ranks) * 3 * Bs;
+    const int grid = int(std::min<int64_t>(cdiv64(n_rows, 4), 8192));
+    hipLaunchKernelGGL(pack_exchange_kernel, dim3(grid), dim3(256), 0, as_stream(stream), idx, reinterpret_cast<const int64_t*>(score),
+                       reinterpret_cast<const int64_t*>(dist2), B, k, Bs, n_rows, send);
+    return check_launch("pack_exchange");
+}
+
 int hwer_knn_count_uncertified(const int32_t* flags, int64_t B, int32_t* out_count, void* stream) {
     if (!flags || !out_count || B < 0) return fail(HWER_EINVAL, "count_uncertified: bad argument");
     if (hipMemsetAsync(out_count, 0, sizeof(int32_t), as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "count_uncertified: memset failed");

@@ -51,6 +51,37 @@ def query_slice(n_queries: int, world_size: int, rank: int) -> Tuple[int, int]:
     return shard_bounds(n_queries, world_size, rank)
 
 
+def pack_send_buffer(idx, score, dist2, G: int):
+    """(G, 3, Bs, k) int64 send buffer of the user-partitioned exchange, Bs = ceil(B / G): send[g] = (idx, score bits,
+    dist2 bits) of the queries of rank g's slice; rows past the batch are padding (id -1, score 0, dist2 +inf: they lose
+    every merge).  Device tensors: one hwer_pack_exchange launch."""
+    import torch
+    B, k = idx.shape
+    Bs = (B + G - 1) // G
+    send = torch.empty((G, 3, Bs, k), dtype=torch.int64, device=idx.device)
+    if idx.is_cuda:
+        from . import native
+        idx, score, dist2 = idx.contiguous(), score.contiguous(), dist2.contiguous()
+        native.check(native.lib().hwer_pack_exchange(native.ptr(idx), native.ptr(score), native.ptr(dist2), B, k, G,
+                                                     native.ptr(send), native.stream_ptr()), "pack_exchange")
+        return send
+    # CPU tensors (the gloo tests of the exchange logic)
+    full = B // Bs                      # slices that are completely inside the batch
+    rem = B - full * Bs                 # rows of the partial slice `full` (0 when there is none)
+    for c, t in enumerate((idx, score.view(torch.int64), dist2.view(torch.int64))):
+        if full:
+            send[:full, c].copy_(t[:full * Bs].view(full, Bs, k))
+        if rem:
+            send[full, c, :rem].copy_(t[full * Bs:])
+    if full < G:
+        inf_bits = int(np.array(np.inf, dtype=np.float64).view(np.int64))
+        for c, v in enumerate((-1, 0, inf_bits)):
+            send[full, c, rem:].fill_(v)
+            if full + 1 < G:
+                send[full + 1:, c].fill_(v)
+    return send
+
+
 def exchange_by_query(idx, score, dist2, group=None):
     """User-partitioned exchange (SURVEY.md §8e variant): rank r receives, from every rank g, g's local results for the
     queries of r's slice -> three (G, Bs, k) tensors, Bs = ceil(B/G) (rows beyond the slice are padding: ids -1,
@@ -62,16 +93,10 @@ def exchange_by_query(idx, score, dist2, group=None):
     G = dist.get_world_size(group)
     r = dist.get_rank(group)
     B, k = idx.shape
+    if B == 0:
+        return idx.new_empty((G, 0, k)), score.new_empty((G, 0, k)), dist2.new_empty((G, 0, k))
     Bs = (B + G - 1) // G
-    pad = Bs * G - B
-    packed = torch.stack([idx, score.view(torch.int64), dist2.view(torch.int64)], dim=0)   # (3, B, k) int64 bit patterns
-    if pad:
-        filler = torch.empty((3, pad, k), dtype=torch.int64, device=idx.device)
-        filler[0] = -1
-        filler[1] = 0
-        filler[2] = torch.full((pad, k), float("inf"), dtype=torch.float64, device=idx.device).view(torch.int64)
-        packed = torch.cat([packed, filler], dim=1)
-    send = packed.view(3, G, Bs, k).permute(1, 0, 2, 3).contiguous()   # (G, 3, Bs, k): slice g goes to rank g
+    send = pack_send_buffer(idx, score, dist2, G)
     staged = send.is_cuda and dist.get_backend(group) != "nccl"        # test harness only: ranks sharing a GPU over gloo
     if staged:
         send = send.cpu()
@@ -91,7 +116,8 @@ def exchange_by_query(idx, score, dist2, group=None):
                 w.wait()
     if staged:
         recv = recv.to(idx.device)
-    return recv[:, 0].contiguous(), recv[:, 1].contiguous().view(torch.float64), recv[:, 2].contiguous().view(torch.float64)
+    # strided views of the receive buffer (list stride 3 Bs k): merge_on_device reads them in place
+    return recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64)
 
 
 def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True):
@@ -100,12 +126,16 @@ def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True):
     from . import native
     lib = native.lib()
     G, B, k = g_idx.shape
+    strides = {t.stride() for t in (g_idx, g_score, g_dist2)}
+    if len(strides) != 1 or g_idx.stride()[1:] != (k, 1) or (G > 1 and g_idx.stride(0) < B * k):
+        g_idx, g_score, g_dist2 = g_idx.contiguous(), g_score.contiguous(), g_dist2.contiguous()
+    list_stride = g_idx.stride(0) if G > 1 else B * k
     o_idx = torch.empty((B, k), dtype=torch.int64, device=g_idx.device)
     o_score = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
     o_dist2 = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
-    native.check(lib.hwer_merge_topk(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), G, B, k,
-                                     1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
-                                     native.ptr(o_dist2), native.stream_ptr()), "merge_topk")
+    native.check(lib.hwer_merge_topk_strided(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), list_stride, G, B, k,
+                                             1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
+                                             native.ptr(o_dist2), native.stream_ptr()), "merge_topk")
     return o_idx, o_score, o_dist2
 
 

@@ -225,6 +225,18 @@ int hwer_rank_filter_seen(const int64_t* ranked, int64_t B, int k, const int64_t
  * ------------------------------------------------------------------------------------------------- */
 int hwer_merge_topk(const int64_t* idx, const double* score, const double* dist2, int n_lists, int64_t B, int k,
                     int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2, void* stream);
+/* Same merge over lists that are `list_stride` elements apart in each array (>= B * k): lets the receive buffer of the
+ * user-partitioned exchange, laid out (rank, array, B, k), be merged in place. */
+int hwer_merge_topk_strided(const int64_t* idx, const double* score, const double* dist2, int64_t list_stride, int n_lists,
+                            int64_t B, int k, int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2,
+                            void* stream);
+
+/* Send buffer of the user-partitioned exchange (hwer/distributed.py: exchange_by_query): with Bs = ceil(B / n_ranks),
+ * send[g][c][j][0..k) = array c (0 idx, 1 score, 2 dist2, as 8-byte patterns) of query g * Bs + j; rows of queries >= B are
+ * padding (id -1, score 0, dist2 +inf).  send: n_ranks * 3 * Bs * k int64.  One all_to_all_single with equal splits then
+ * hands rank g its slice from every rank, and hwer_merge_topk_strided (list_stride = 3 * Bs * k) merges it in place. */
+int hwer_pack_exchange(const int64_t* idx, const double* score, const double* dist2, int64_t B, int k, int n_ranks,
+                       int64_t* send, void* stream);
 
 #ifdef __cplusplus
 }

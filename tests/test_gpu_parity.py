@@ -628,6 +628,61 @@ def test_merge_topk_matches_single_shard(hw):
     g_idx = torch.stack([p[0] for p in parts]); g_s = torch.stack([p[1] for p in parts]); g_d = torch.stack([p[2] for p in parts])
     idx, score, dist2 = merge_on_device(g_idx, g_s, g_d, True)
     assert torch.equal(idx, ref[0]) and torch.equal(score, ref[1]) and torch.equal(dist2, ref[2])
+    # the receive-buffer layout of the user-partitioned exchange, (rank, array, B, k), merged in place (strided lists)
+    recv = torch.stack([g_idx, g_s.view(torch.int64), g_d.view(torch.int64)], dim=1).contiguous()
+    v_idx, v_s, v_d = recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64)
+    assert not v_idx.is_contiguous() and v_idx.stride(0) == 3 * B * k
+    idx2, score2, dist22 = merge_on_device(v_idx, v_s, v_d, True)
+    assert torch.equal(idx2, ref[0]) and torch.equal(score2, ref[1]) and torch.equal(dist22, ref[2])
+
+
+@pytest.mark.parametrize("G,k,B", [(1, 200, 7), (2, 200, 33), (3, 1, 5), (8, 200, 20), (16, 512, 3), (17, 100, 4), (40, 200, 3),
+                                   (4, 37, 9), (8192, 1, 2)])
+def test_merge_topk_shapes(hw, G, k, B):
+    """hwer_merge_topk against a lexsort merge: both kernel paths (rank merge for <= 16 lists, LDS sort beyond), exact
+    distance ties across lists, padded short lists (id -1, dist2 +inf), both output orders."""
+    import torch
+    from hwer.distributed import merge_on_device
+    rng = np.random.default_rng(1000 * G + k)
+    n = G * k
+    idx = np.empty((G, B, k), np.int64); d2 = np.empty((G, B, k)); sc = np.empty((G, B, k))
+    for b in range(B):
+        ids = rng.permutation(10 * n + 7)[:n].astype(np.int64) + 5
+        dist = np.round(rng.random(n), 2 if b % 2 else 12)          # 2 decimals: many exact ties between lists
+        score = np.round(rng.random(n), 1 if b % 3 == 0 else 9)     # and exact score ties
+        for g in range(G):
+            sl = slice(g * k, (g + 1) * k)
+            i_g, d_g, s_g = ids[sl].copy(), dist[sl].copy(), score[sl].copy()
+            n_pad = 0 if G == 1 else [0, 0, min(k - 1, 3), k // 2][(g + b) % 4]   # some shards are short (never the whole row: G*m >= k real entries not needed, pads just lose)
+            if n_pad:
+                i_g[k - n_pad:], d_g[k - n_pad:], s_g[k - n_pad:] = -1, np.inf, 0.0
+            o = np.lexsort((i_g, d_g))
+            idx[g, b], d2[g, b], sc[g, b] = i_g[o], d_g[o], s_g[o]
+    dev = torch.device("cuda")
+    t = [torch.from_numpy(x).to(dev) for x in (idx, sc, d2)]
+    for by_score in (False, True):
+        o_i, o_s, o_d = [x.cpu().numpy() for x in merge_on_device(*t, by_score)]
+        for b in range(B):
+            ii, dd, ss = idx[:, b].reshape(-1), d2[:, b].reshape(-1), sc[:, b].reshape(-1)
+            pos = np.arange(n)
+            order = np.lexsort((pos, ii, dd))[:k]
+            if by_score:
+                order = order[np.argsort(-ss[order], kind="stable")]
+            assert np.array_equal(o_i[b], ii[order]), (G, k, b, by_score)
+            assert np.array_equal(o_d[b], dd[order]) and np.array_equal(o_s[b], ss[order])
+
+
+@pytest.mark.parametrize("B,k,G", [(6040, 200, 8), (10, 7, 4), (5, 3, 8), (33, 200, 2), (1, 1, 1)])
+def test_pack_exchange_kernel_matches_host_packing(hw, B, k, G):
+    import torch
+    from hwer.distributed import pack_send_buffer
+    g = torch.Generator().manual_seed(B * 131 + G)
+    idx = torch.randint(0, 1 << 40, (B, k), generator=g)
+    score = torch.rand((B, k), generator=g, dtype=torch.float64)
+    dist2 = torch.rand((B, k), generator=g, dtype=torch.float64)
+    host = pack_send_buffer(idx, score, dist2, G)
+    dev = pack_send_buffer(idx.cuda(), score.cuda(), dist2.cuda(), G)
+    assert torch.equal(dev.cpu(), host)
 
 
 def test_blend_with_fused_audit(hw):
