@@ -225,13 +225,17 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                         const bool first = g8 == 0 || g8 == gA;
                         const int jj = 8 * g8;
                         if constexpr (mode == 0) {
-                            const double p0 = __dmul_rn(double(a32[jj + 0]), double(xv[8 * gg + 0])), p1 = __dmul_rn(double(a32[jj + 1]), double(xv[8 * gg + 1]));
-                            const double p2 = __dmul_rn(double(a32[jj + 2]), double(xv[8 * gg + 2])), p3 = __dmul_rn(double(a32[jj + 3]), double(xv[8 * gg + 3]));
-                            const double p4 = __dmul_rn(double(a32[jj + 4]), double(xv[8 * gg + 4])), p5 = __dmul_rn(double(a32[jj + 5]), double(xv[8 * gg + 5]));
-                            const double p6 = __dmul_rn(double(a32[jj + 6]), double(xv[8 * gg + 6])), p7 = __dmul_rn(double(a32[jj + 7]), double(xv[8 * gg + 7]));
-                            if (first) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; r5 = p5; r6 = p6; r7 = p7; }
-                            else { r0 = __dadd_rn(r0, p0); r1 = __dadd_rn(r1, p1); r2 = __dadd_rn(r2, p2); r3 = __dadd_rn(r3, p3);
-                                   r4 = __dadd_rn(r4, p4); r5 = __dadd_rn(r5, p5); r6 = __dadd_rn(r6, p6); r7 = __dadd_rn(r7, p7); }
+                            // a and x are float32 values, so a * x is EXACT in float64 (48 significant bits): fma(a, x, r) rounds
+                            // r + a x once, exactly like numpy's add of the (unrounded-because-exact) product - one instruction less
+                            // per element than mul + add, bit-identical results.
+                            const double a0 = double(a32[jj + 0]), a1 = double(a32[jj + 1]), a2 = double(a32[jj + 2]), a3 = double(a32[jj + 3]);
+                            const double a4 = double(a32[jj + 4]), a5 = double(a32[jj + 5]), a6 = double(a32[jj + 6]), a7 = double(a32[jj + 7]);
+                            const double x0 = double(xv[8 * gg + 0]), x1 = double(xv[8 * gg + 1]), x2 = double(xv[8 * gg + 2]), x3 = double(xv[8 * gg + 3]);
+                            const double x4 = double(xv[8 * gg + 4]), x5 = double(xv[8 * gg + 5]), x6 = double(xv[8 * gg + 6]), x7 = double(xv[8 * gg + 7]);
+                            if (first) { r0 = __dmul_rn(a0, x0); r1 = __dmul_rn(a1, x1); r2 = __dmul_rn(a2, x2); r3 = __dmul_rn(a3, x3);
+                                         r4 = __dmul_rn(a4, x4); r5 = __dmul_rn(a5, x5); r6 = __dmul_rn(a6, x6); r7 = __dmul_rn(a7, x7); }
+                            else { r0 = __fma_rn(a0, x0, r0); r1 = __fma_rn(a1, x1, r1); r2 = __fma_rn(a2, x2, r2); r3 = __fma_rn(a3, x3, r3);
+                                   r4 = __fma_rn(a4, x4, r4); r5 = __fma_rn(a5, x5, r5); r6 = __fma_rn(a6, x6, r6); r7 = __fma_rn(a7, x7, r7); }
                             if (g8 == gA - 1) sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
                         } else {
                             const float p0 = __fmul_rn((a32[jj + 0]), xv[8 * gg + 0]), p1 = __fmul_rn((a32[jj + 1]), xv[8 * gg + 1]);
