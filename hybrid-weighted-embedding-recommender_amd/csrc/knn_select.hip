@@ -1110,6 +1110,65 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// All float64 squared distances of a few queries (the k > K_MAX path of the host mirror: distances here, selection by
+// a device sort).  Grid (row blocks, queries); same data path as stage A of the exhaustive pass: rows gathered 64 B per
+// 4 lanes, transposed through wave-private LDS, every lane walks ITS row in scikit-learn's sequential order.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void all_dist2_kernel(const float* __restrict__ X, int64_t n_items, int d, int64_t ldx,
+                                                        const double* __restrict__ Q64, double* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float stage_all[4 * 64 * RR_RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* stage = stage_all + wave * (64 * RR_RS);
+    typedef const __attribute__((address_space(4))) double* cdouble_p;
+    const cdouble_p q64 = (cdouble_p)(Q64 + int64_t(blockIdx.y) * d);
+    double* orow = out + int64_t(blockIdx.y) * n_items;
+    const int n_steps = (d + RR_CW - 1) / RR_CW;
+    const int srow = lane >> 2, scol = 4 * (lane & 3);
+    const int64_t last = n_items - 1;
+    for (int64_t r0 = (int64_t(blockIdx.x) * 4 + wave) * 64; r0 < n_items; r0 += int64_t(gridDim.x) * 256) {
+        const float* src0 = X + min(r0 + 0 + srow, last) * ldx + scol;
+        const float* src1 = X + min(r0 + 16 + srow, last) * ldx + scol;
+        const float* src2 = X + min(r0 + 32 + srow, last) * ldx + scol;
+        const float* src3 = X + min(r0 + 48 + srow, last) * ldx + scol;
+        float* dst = stage + srow * RR_RS + scol;
+        float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
+        float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
+        double acc = 0.0;
+#pragma unroll 1
+        for (int c = 0; c < n_steps; ++c) {
+            *reinterpret_cast<float4*>(dst) = pre0;
+            *reinterpret_cast<float4*>(dst + 16 * RR_RS) = pre1;
+            *reinterpret_cast<float4*>(dst + 32 * RR_RS) = pre2;
+            *reinterpret_cast<float4*>(dst + 48 * RR_RS) = pre3;
+            if (c + 1 < n_steps) {
+                const int o = RR_CW * (c + 1);
+                pre0 = *reinterpret_cast<const float4*>(src0 + o);
+                pre1 = *reinterpret_cast<const float4*>(src1 + o);
+                pre2 = *reinterpret_cast<const float4*>(src2 + o);
+                pre3 = *reinterpret_cast<const float4*>(src3 + o);
+            }
+            wave_lds_sync();
+            float xv[RR_CW];
+#pragma unroll
+            for (int t = 0; t < RR_CW / 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
+                xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
+            }
+            wave_lds_sync();
+            const int j0 = RR_CW * c;
+#pragma unroll
+            for (int t = 0; t < RR_CW; ++t) {
+                if (j0 + t < d) {   // uniform
+                    const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
+                    acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                }
+            }
+        }
+        if (r0 + lane < n_items) orow[r0 + lane] = acc;
+    }
+}
+
 static int set_max_lds(const void* fn, size_t bytes, const char* what) {
     if (bytes <= 64 * 1024) return HWER_OK;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));
@@ -1252,6 +1311,17 @@ static int launch_select_rerank(const SelectArgs& sa, int d, int score_mode, hip
 extern "C" {
 
 int hwer_knn_max_k(void) { return K_MAX; }
+
+int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, int64_t nq, double* out,
+                           void* stream) {
+    if (nq == 0) return HWER_OK;
+    if (!X || !Q64 || !out) return fail(HWER_EINVAL, "knn_all_dist2: null pointer");
+    if (n_items < 1 || d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16 || nq < 0 || nq > 65535)
+        return fail(HWER_EINVAL, "knn_all_dist2: need n_items >= 1, 1 <= d <= 256, ldx >= roundup16(d), nq <= 65535");
+    const unsigned gx = unsigned(std::min<int64_t>(cdiv64(n_items, 256), 4096));
+    hipLaunchKernelGGL(all_dist2_kernel, dim3(gx, unsigned(nq)), dim3(256), 0, as_stream(stream), X, n_items, d, ldx, Q64, out);
+    return check_launch("knn_all_dist2");
+}
 
 int hwer_knn_f16_scale_exp(float hnorm_max) { return f16_scale_exp(hnorm_max); }
 

@@ -216,6 +216,9 @@ class DeviceIndex:
         dist2 = torch.empty((B, k), dtype=torch.float64, device=self.device) if want_dist else None
         flags = torch.empty(B, dtype=torch.int32, device=self.device)
         use_rows = id_base is None
+        if k > self.lib.hwer_knn_max_k():
+            self._search_large_k(tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, idx, score, dist2, flags)
+            return idx, score, dist2, flags
         for b0 in range(0, B, self.QUERY_CHUNK):
             b1 = min(B, b0 + self.QUERY_CHUNK)
             nb = b1 - b0
@@ -255,6 +258,49 @@ class DeviceIndex:
                 self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
                                      dist2, flags)
         return idx, score, dist2, flags
+
+    def _search_large_k(self, tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, idx, score, dist2, flags):
+        """k above the selection kernels' limit (hwer_knn_max_k; the reference takes any k <= N_t,
+        hwer/recommendation_base.py:79): all float64 distances (hwer_knn_all_dist2_f64, scikit-learn's summation order),
+        a stable device sort keeps the k nearest in (distance, row) order, hwer_pair_score re-scores them against the
+        anchors, a stable sort by score gives the reference's final order.  Same values and order as the regular path."""
+        torch = _torch()
+        if not use_rows:
+            raise ValueError("k > %d is only supported on an unsharded table" % self.lib.hwer_knn_max_k())
+        B, n = Q64.shape[0], tt.n
+        per = max(1, min(B, 65535, (1 << 30) // (8 * n)))   # <= 1 GiB of distances at a time
+        for b0 in range(0, B, per):
+            b1 = min(B, b0 + per)
+            nb = b1 - b0
+            D = torch.empty((nb, n), dtype=torch.float64, device=self.device)
+            native.check(self.lib.hwer_knn_all_dist2_f64(native.ptr(tt.X), n, self.d, self.ldx, native.ptr(Q64[b0:b1]), nb,
+                                                         native.ptr(D), native.stream_ptr()), "knn_all_dist2")
+            d_sorted, order = torch.sort(D, dim=1, stable=True)          # ties keep the row (= id) order
+            d2 = d_sorted[:, :k].contiguous()
+            ids = tt.rows_dev[order[:, :k]]                              # global rows
+            if score_mode == 2:
+                sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
+            else:
+                a = (anchors_dev[b0:b1] if anchors_dev is not None else
+                     torch.arange(b0, b1, device=self.device)).to(torch.int32)
+                src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
+                dst = ids.to(torch.int32).contiguous().view(-1)
+                if score_mode == 0:
+                    out = torch.empty(nb * k, dtype=torch.float64, device=self.device)
+                    fn = self.lib.hwer_pair_score_f64
+                else:
+                    out = torch.empty(nb * k, dtype=torch.float32, device=self.device)
+                    fn = self.lib.hwer_pair_score_f32
+                native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(src), native.ptr(dst), nb * k,
+                                native.ptr(out), native.stream_ptr()), "pair_score")
+                sc = out.view(nb, k).to(torch.float64)
+            if sort_by_score:
+                sc, o2 = torch.sort(sc, dim=1, descending=True, stable=True)
+                ids, d2 = ids.gather(1, o2), d2.gather(1, o2)
+            idx[b0:b1], score[b0:b1] = ids, sc
+            if dist2 is not None:
+                dist2[b0:b1] = d2
+        flags.fill_(2)
 
     #: more uncertified queries than this go through the exact-threshold retry first
     RETRY_MIN = 16

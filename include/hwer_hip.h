@@ -201,6 +201,12 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
                        double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* All float64 squared distances, out[q * n_items + i] = ||Q64[q] - X[i]||^2 in scikit-learn's summation order (the same
+ * values the re-rank computes).  The host mirror uses it for k > hwer_knn_max_k(): the reference accepts any k <= N_t
+ * (hwer/recommendation_base.py:79), there the k nearest come from a stable device sort of these rows.  nq <= 65535. */
+int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, int64_t nq, double* out,
+                           void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K12    seen-item filter + cuts of the Recall@K evaluation — replaces the per-user list comprehensions of
  *        validation.extraction_efficiency (hwer/validation.py:133-141):

@@ -685,6 +685,29 @@ def test_pack_exchange_kernel_matches_host_packing(hw, B, k, G):
     assert torch.equal(dev.cpu(), host)
 
 
+@pytest.mark.parametrize("k,flavour", [(393, "f64"), (600, "f64"), (1500, "f64"), (500, "f32"), (500, "gcn")])
+def test_large_k_path_matches_oracle(hw, k, flavour):
+    """k above the selection kernels' limit (392): all-distances kernel + stable device sorts; the reference takes any
+    k <= N_t (hwer/recommendation_base.py:79).  Same indices, scores and distances as the oracle, ties included."""
+    d, N, B = 48, 1500, 9
+    V32 = np.concatenate([unit_rows_f32(801, B, d), unit_rows_f32(802, N, d)])
+    V32[B + 7] = V32[B + 3]            # duplicate rows: an exact distance tie
+    V32[B + 900] = V32[B + 3]
+    V = V32.astype(np.float64) if flavour != "f32" else V32
+    ix = make_index(V, B, N)
+    if flavour == "gcn":
+        idx, sc, dist, fl = ix.search("item", np.arange(B), k=k, scoring="gcn")
+    else:
+        idx, sc, dist, fl = ix.search("item", np.arange(B), k=k)
+    assert (fl == 2).all()
+    for b in range(B):
+        o_idx, o_sc, o_dist = orc.find_closest(V, np.arange(B, B + N), b, k=k, scoring="gcn" if flavour == "gcn" else "base")
+        assert np.array_equal(idx[b], o_idx), (k, flavour, b)
+        assert np.array_equal(sc[b], o_sc) and np.array_equal(dist[b], o_dist)
+    with pytest.raises(ValueError):
+        ix.search("item", np.arange(B), k=N + 1)
+
+
 def test_blend_with_fused_audit(hw):
     """hwer_blend_normalize_audit_f32 == blend followed by the separate audit (counts exact)."""
     import torch
