@@ -549,16 +549,15 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     if (getenv("HWER_SCREEN_STAMPS")) {
         if (dbg) {   // print the previous launch's stamps
             std::vector<unsigned long long> h(size_t(dbg_grid) * 32);
-            hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double tiles = 0; int n = 0;
             for (int w = 0; w < dbg_grid * 4; ++w) { if (h[w * 8 + 5] == 0) continue; for (int c = 0; c < 8; ++c) sum[c] += double(h[w * 8 + c]); tiles += double(h[w * 8 + 5]); ++n; }
             fprintf(stderr, "[stamps] waves=%d tiles/wave=%.0f prologue=%.1f us; cycles/tile: mfma=%.0f epilogue=%.0f wait+barrier=%.0f post=%.0f; loop %.0f cycles in %.1f us -> in-kernel clock %.2f GHz\n", n, tiles / n,
                     sum[0] / n / 100.0, sum[1] / tiles, sum[2] / tiles, sum[3] / tiles, sum[4] / tiles, sum[6] / n, sum[7] / n / 100.0, sum[7] > 0 ? sum[6] / sum[7] * 0.1 : 0.0);
-            hipFree(dbg);
+            (void)hipFree(dbg);
         }
         dbg_grid = plan.n_qblocks * plan.n_splits;
-        hipMalloc(&dbg, size_t(dbg_grid) * 32 * 8);
-        hipMemset(dbg, 0, size_t(dbg_grid) * 32 * 8);
+        if (hipMalloc(&dbg, size_t(dbg_grid) * 32 * 8) != hipSuccess || hipMemset(dbg, 0, size_t(dbg_grid) * 32 * 8) != hipSuccess) dbg = nullptr;
     }
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? atoi(getenv("HWER_SCREEN_NOFILTER")) : 0,

@@ -1201,19 +1201,17 @@ struct ProfScope {
         if (!on) return;
         ProfSlot& p = g_prof[which];
         if (p.used == p.start.size()) {
-            hipEvent_t a, b;
-            hipEventCreate(&a);
-            hipEventCreate(&b);
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }   // no timing for this call
             p.start.push_back(a);
             p.stop.push_back(b);
         }
-        hipEventRecord(p.start[p.used], st);
+        if (hipEventRecord(p.start[p.used], st) != hipSuccess) on = false;
     }
     ~ProfScope() {
         if (!on) return;
         ProfSlot& p = g_prof[which];
-        hipEventRecord(p.stop[p.used], st);
-        ++p.used;
+        if (hipEventRecord(p.stop[p.used], st) == hipSuccess) ++p.used;
     }
 };
 }  // namespace
@@ -1230,14 +1228,15 @@ extern "C" int hwer_profile_read(int which, double* total_ms, int64_t* launches)
     if (which < 0 || which > 1 || !total_ms || !launches) return fail(HWER_EINVAL, "profile_read: bad argument");
     ProfSlot& p = g_prof[which];
     double sum = 0.0;
+    int64_t n = 0;
     for (size_t i = 0; i < p.used; ++i) {
-        hipEventSynchronize(p.stop[i]);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, p.start[i], p.stop[i]);
+        if (hipEventSynchronize(p.stop[i]) != hipSuccess || hipEventElapsedTime(&ms, p.start[i], p.stop[i]) != hipSuccess) continue;
         sum += ms;
+        ++n;
     }
     *total_ms = sum;
-    *launches = int64_t(p.used);
+    *launches = n;
     p.used = 0;
     return HWER_OK;
 }
