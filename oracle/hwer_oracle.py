@@ -191,6 +191,112 @@ def content_tail(E: np.ndarray, src: np.ndarray, dst: np.ndarray):
     return A, unit_length((E + A) / 2.0, axis=1)
 
 
+
+# --------------------------------------------------------------------------------------
+# fit-side table construction: hwer/content_recommender.py:24-76
+# --------------------------------------------------------------------------------------
+def pca_batches(n: int, batch_size: int, min_batch_size: int):
+    """sklearn.utils.gen_batches as IncrementalPCA.fit calls it (min_batch_size = n_components): a short last batch is
+    folded into the one before it."""
+    out, start = [], 0
+    for _ in range(int(n // batch_size)):
+        end = start + batch_size
+        if end + min_batch_size > n:
+            continue
+        out.append((start, end))
+        start = end
+    if start < n:
+        out.append((start, n))
+    return out
+
+
+def svd_flip_v(Vt: np.ndarray) -> np.ndarray:
+    """sklearn.utils.extmath.svd_flip(u_based_decision=False): the entry of largest magnitude of every row is positive."""
+    j = np.argmax(np.abs(Vt), axis=1)
+    return Vt * np.sign(Vt[np.arange(Vt.shape[0]), j])[:, None]
+
+
+def incremental_pca_fit_transform(X: np.ndarray, n_components: int, batch_size: int = 2 ** 16):
+    """`IncrementalPCA(n_components, batch_size).fit_transform(X)` (hwer/content_recommender.py:68-69) restated from
+    scikit-learn 1.7.2's published algorithm (sklearn/decomposition/_incremental_pca.py partial_fit, Ross et al. 2008):
+    batch 0: SVD of the centred batch; batch b > 0: SVD of [S * V ; batch - its mean ; sqrt(n_seen n_b / n_tot) (mean - batch
+    mean)], keeping n_components rows; transform = X V^T - mean V^T (sklearn/decomposition/_base.py _transform).
+    Returns (scores, components, mean, singular_values)."""
+    from scipy import linalg
+    X = np.asarray(X, dtype=np.float64)
+    n, w = X.shape
+    if not n_components <= w:
+        raise ValueError("n_components=%r invalid for n_features=%d, need more rows than columns for IncrementalPCA "
+                         "processing" % (n_components, w))
+    n_seen, mean, comps, sv = 0, np.zeros(w), None, None
+    for a, b in pca_batches(n, batch_size, n_components):
+        Xb = X[a:b].copy()
+        nb = b - a
+        if comps is None and n_components > nb:
+            raise ValueError("n_components=%d must be less or equal to the batch number of samples %d for the first "
+                             "partial_fit call." % (n_components, nb))
+        n_tot = n_seen + nb
+        col_mean = (mean * n_seen + Xb.sum(axis=0)) / n_tot       # _incremental_mean_and_var
+        if n_seen == 0:
+            Xb -= col_mean
+            stack = Xb
+        else:
+            bm = np.mean(Xb, axis=0)
+            Xb -= bm
+            corr = np.sqrt((n_seen / n_tot) * nb) * (mean - bm)
+            stack = np.vstack((sv.reshape((-1, 1)) * comps, Xb, corr))
+        _, S, Vt = linalg.svd(stack, full_matrices=False, check_finite=False)
+        Vt = svd_flip_v(Vt)
+        comps, sv, mean, n_seen = Vt[:n_components], S[:n_components], col_mean, n_tot
+    out = X @ comps.T
+    out -= mean.reshape(1, -1) @ comps.T
+    return out, comps, mean, sv
+
+
+def feature_table(blocks: Sequence[np.ndarray], type_id: np.ndarray) -> np.ndarray:
+    """The table IncrementalPCA sees (hwer/content_recommender.py:50-66): block-diagonal concat of the per-type blocks
+    (block t = unit rows of type t in `nodes` order), rows put back into `nodes` order, then the one-hot node type
+    (OneHotEncoder: categories sorted; here `type_id` already indexes the sorted type names).  Column order of the blocks =
+    order of `blocks`."""
+    type_id = np.asarray(type_id)
+    N = len(type_id)
+    T = len(blocks)
+    width = sum(b.shape[1] for b in blocks)
+    table = np.zeros((N, width + T))
+    c = 0
+    for t, b in enumerate(blocks):
+        rows = np.flatnonzero(type_id == t)
+        assert len(rows) == b.shape[0]
+        table[rows, c:c + b.shape[1]] = b
+        c += b.shape[1]
+    table[np.arange(N), width + type_id] = 1.0
+    return table
+
+
+def fit_feature_table(blocks: Sequence[np.ndarray], type_id: np.ndarray, n_dims, block_order: Optional[Sequence[int]] = None):
+    """hwer/content_recommender.py:50-76: feature table -> IncrementalPCA -> unit rows -> + one-hot type padded to a power
+    of two.  `block_order`: the order in which the reference visited the node types (its `set` iteration order; only the
+    column order of the table depends on it).  Returns (E, pca scores)."""
+    T = len(blocks)
+    order = list(range(T)) if block_order is None else list(block_order)
+    type_id = np.asarray(type_id)
+    width = sum(b.shape[1] for b in blocks)
+    table = np.zeros((len(type_id), width + T))
+    c = 0
+    for t in order:
+        rows = np.flatnonzero(type_id == t)
+        table[rows, c:c + blocks[t].shape[1]] = blocks[t]
+        c += blocks[t].shape[1]
+    table[np.arange(len(type_id)), width + type_id] = 1.0
+    if n_dims is None or np.isinf(n_dims):
+        n_dims = 2 ** int(np.log2(table.shape[1]))
+    scores, _, _, _ = incremental_pca_fit_transform(table, int(n_dims))
+    unit = unit_length(scores, axis=1)
+    ncol = 2 ** int(np.ceil(np.log2(T)))
+    ohe = np.zeros((len(type_id), ncol))
+    ohe[np.arange(len(type_id)), type_id] = 1.0
+    return np.concatenate((unit, ohe), axis=1), scores
+
 def blend_normalize(tables: Sequence[np.ndarray], row_idx: Sequence[Optional[np.ndarray]], alpha: np.ndarray):
     """Generalisation the build exposes: out[r] = unit(sum_t alpha[r,t] * T_t[i_t[r]]),
     accumulated left to right in float64.  With T=(E, A), alpha=(.5,.5) it equals

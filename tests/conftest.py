@@ -29,3 +29,28 @@ def unit_rows_f32(seed, n, d):
     x = np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32).astype(np.float64)
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     return x.astype(np.float32)
+
+
+def g12_scenario(g, tag):
+    """Inputs of a G12 scenario (tools/capture_goldens.py g12) regenerated from its recipe: per-type feature blocks in the
+    SORTED-type-name numbering, type ids, edges, the order in which the reference visited the types, n_dims."""
+    types = [str(t) for t in g[tag + "_types"]]
+    T = len(types)
+    rec = [int(x) for x in g[tag + "_recipe"]]
+    N, seed, n_edges, n_dims = rec[:4]
+    dims, with_data = rec[4:4 + T], [bool(b) for b in rec[4 + T:4 + 2 * T]]
+    type_of = {"small": lambda i: i % 3, "multi": lambda i: 0 if (i * 7) % 10 < 3 else 1}[tag]
+    rng = np.random.default_rng(seed)
+    tid = np.asarray([type_of(i) for i in range(N)], dtype=np.int32)
+    feats = [rng.standard_normal((int((tid == ti).sum()), dims[ti])) for ti in range(T)]
+    src = rng.integers(0, N, n_edges)
+    dst = rng.integers(0, N, n_edges)
+    srt = sorted(types)
+    remap = np.asarray([srt.index(t) for t in types], dtype=np.int32)
+    feats_sorted, data_sorted = [None] * T, [None] * T
+    for ti in range(T):
+        feats_sorted[remap[ti]] = feats[ti]
+        data_sorted[remap[ti]] = with_data[ti]
+    order = [srt.index(str(t)) for t in g[tag + "_type_order"]]
+    return dict(types=srt, type_id=remap[tid], feats=feats_sorted, with_data=data_sorted, src=src, dst=dst, order=order,
+                n_dims=n_dims, N=N)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import hwer_oracle as orc
-from conftest import unit_rows_f32
+from conftest import g12_scenario, unit_rows_f32
 
 
 def _flav(V32, f):
@@ -261,3 +261,43 @@ def test_reference_shaped_loop_agrees_with_oracle():
     for u in range(8):
         o_idx, o_sc, _ = orc.find_closest(V, rows, u, k=25)
         assert np.array_equal(idx[u], o_idx) and np.array_equal(sc[u], o_sc)
+
+
+@pytest.mark.parametrize("tag", ["small", "multi"])
+def test_g12_fit_feature_table(golden, tag):
+    """Fit-side table construction + IncrementalPCA restatement against the reference (one batch / two batches)."""
+    g = golden("g12_fit_pca")
+    sc = g12_scenario(g, tag)
+    blocks = [orc.unit_length(f, axis=1) if has else np.zeros((f.shape[0], 1)) for f, has in zip(sc["feats"], sc["with_data"])]
+    T = len(blocks)
+    width = sum(b.shape[1] for b in blocks)
+    # the table the reference handed to IncrementalPCA (block columns in the reference's set order)
+    table = np.zeros((sc["N"], width + T))
+    c = 0
+    for t in sc["order"]:
+        table[np.flatnonzero(sc["type_id"] == t), c:c + blocks[t].shape[1]] = blocks[t]
+        c += blocks[t].shape[1]
+    table[np.arange(sc["N"]), width + sc["type_id"]] = 1.0
+    assert hashlib.sha256(np.ascontiguousarray(table).tobytes()).hexdigest() == str(g[tag + "_table_sha"])
+    scores, comps, mean, sv = orc.incremental_pca_fit_transform(table, sc["n_dims"])
+    assert len(orc.pca_batches(sc["N"], 2 ** 16, sc["n_dims"])) == (1 if tag == "small" else 2)
+    assert np.abs(comps - g[tag + "_components"]).max() <= 1e-12
+    assert np.abs(mean - g[tag + "_mean"]).max() <= 1e-15
+    assert np.abs(sv - g[tag + "_singular_values"]).max() <= 1e-9
+    rows = g[tag + "_rows"]
+    assert np.abs(scores[rows] - g[tag + "_pca_out"]).max() <= 1e-12
+    E, _ = orc.fit_feature_table(blocks, sc["type_id"], sc["n_dims"], sc["order"])
+    assert np.abs(E[rows, :sc["n_dims"]] - g[tag + "_pca_unit"]).max() <= 1e-12
+    _, final = orc.content_tail(E, sc["src"], sc["dst"])
+    assert np.abs(final[rows] - g[tag + "_final"]).max() <= 1e-12
+    # the column order of the blocks (the reference's set order) only permutes the table: same scores up to rounding
+    E2, _ = orc.fit_feature_table(blocks, sc["type_id"], sc["n_dims"], None)
+    assert np.abs(E2 - E).max() <= 1e-9
+
+
+def test_g12_pca_errors():
+    X = np.random.default_rng(0).standard_normal((5, 4))
+    with pytest.raises(ValueError):
+        orc.incremental_pca_fit_transform(X, 5)          # more components than columns
+    with pytest.raises(ValueError):
+        orc.incremental_pca_fit_transform(X[:3], 4)      # more components than rows of the first batch

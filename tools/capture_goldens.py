@@ -396,6 +396,91 @@ def g11(pkg):
     np.savez_compressed(os.path.join(OUT, "g11_errors.npz"), **{k: np.asarray(v) for k, v in got.items()})
 
 
+def g12(pkg):
+    """Fit-side table construction (hwer/content_recommender.py:24-76): per-type embedder blocks -> block-diagonal table +
+    one-hot node type -> IncrementalPCA(batch_size=2**16) -> unit rows.  Recorders: the module-global unit_length of
+    hwer.content_recommender and a recording subclass installed as sklearn.decomposition.IncrementalPCA (the reference
+    imports it inside the function).  Scenario `small`: 3 node types, one of them WITHOUT node_data (zero block);
+    scenario `multi`: 70 000 nodes -> two IncrementalPCA batches (65 536 + 4 464).  `multi` stores its recipe (seeds) and a
+    row sample of the outputs; the test regenerates the inputs."""
+    import sklearn
+    import sklearn.decomposition as skd
+    cr = pkg.content_recommender
+    rb = pkg.recommendation_base
+    emb = pkg.embed_base
+    Node, Edge = rb.Node, rb.Edge
+    out = {"sklearn_version": np.asarray(sklearn.__version__)}
+
+    def run(tag, types, type_of, dims, with_data, n_dims, N, seed, n_edges, sample):
+        rng = np.random.default_rng(seed)
+        nodes = [Node(types[type_of(i)], i) for i in range(N)]
+        tid = np.asarray([type_of(i) for i in range(N)], dtype=np.int32)
+        feats = {t: rng.standard_normal((int((tid == ti).sum()), dims[ti])) for ti, t in enumerate(types)}
+        cursor = {t: 0 for t in types}
+        node_data = {}
+        for i, n in enumerate(nodes):
+            t = types[tid[i]]
+            if with_data[tid[i]]:
+                node_data[n] = {"f": feats[t][cursor[t]]}
+            cursor[t] += 1
+        src = rng.integers(0, N, n_edges)
+        dst = rng.integers(0, N, n_edges)
+        edges = [Edge(nodes[s], nodes[t], 1.0) for s, t in zip(src, dst)]
+        mapper = {t: {"f": emb.IdentityEmbedding(n_dims=dims[ti])} for ti, t in enumerate(types) if with_data[ti]}
+        rec_unit, rec_pca = [], []
+        orig_unit, orig_pca = cr.unit_length, skd.IncrementalPCA
+
+        def rec_unit_length(a, axis=0):
+            r = orig_unit(a, axis=axis)
+            rec_unit.append((np.array(a, copy=True), np.array(r, copy=True)))
+            return r
+
+        class RecPCA(orig_pca):
+            def fit_transform(self, X, y=None, **kw):
+                Xc = np.array(X, copy=True)
+                r = super().fit_transform(X, y, **kw)
+                rec_pca.append(dict(table=Xc, components=self.components_.copy(), mean=self.mean_.copy(),
+                                    singular_values=self.singular_values_.copy(), out=np.array(r, copy=True)))
+                return r
+
+        cr.unit_length = rec_unit_length
+        skd.IncrementalPCA = RecPCA
+        try:
+            model = cr.ContentRecommendation(embedding_mapper=mapper, node_types=set(types), n_dims=n_dims)
+            # the reference iterates `self.node_types` (a set): record that order, the block-diagonal column order follows it
+            type_order = list(model.node_types)
+            final = model.fit(nodes, edges, node_data)
+        finally:
+            cr.unit_length = orig_unit
+            skd.IncrementalPCA = orig_pca
+        assert len(rec_pca) == 1
+        pca = rec_pca[0]
+        pca_unit = rec_unit[-2][1]
+        assert np.array_equal(rec_unit[-2][0], pca["out"])
+        rows = np.arange(N) if sample is None else np.arange(0, N, sample)
+        out[tag + "_types"] = np.asarray(types)
+        out[tag + "_type_order"] = np.asarray(type_order)
+        out[tag + "_type_id"] = tid if sample is None else np.zeros(0, np.int32)
+        out[tag + "_recipe"] = np.asarray([N, seed, n_edges, n_dims] + list(dims) + [int(b) for b in with_data], dtype=np.int64)
+        if sample is None:
+            for ti, t in enumerate(types):
+                out[tag + "_feat_" + t] = feats[t]
+            out[tag + "_src"], out[tag + "_dst"] = src.astype(np.int32), dst.astype(np.int32)
+            out[tag + "_table"] = pca["table"]
+        out[tag + "_table_sha"] = np.asarray(sha(pca["table"]))
+        out[tag + "_components"] = pca["components"]
+        out[tag + "_mean"] = pca["mean"]
+        out[tag + "_singular_values"] = pca["singular_values"]
+        out[tag + "_rows"] = rows
+        out[tag + "_pca_out"] = pca["out"][rows]
+        out[tag + "_pca_unit"] = pca_unit[rows]
+        out[tag + "_final"] = final[rows]
+
+    run("small", ["user", "item", "tag"], lambda i: i % 3, [5, 7, 3], [True, True, False], 8, 300, 12, 1500, None)
+    run("multi", ["user", "item"], lambda i: 0 if (i * 7) % 10 < 3 else 1, [6, 5], [True, True], 8, 70000, 13, 100000, 137)
+    np.savez_compressed(os.path.join(OUT, "g12_fit_pca.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     pkg = ref_shims.install()
@@ -407,6 +492,7 @@ def main():
     g9(pkg)
     g10(pkg)
     g11(pkg)
+    g12(pkg)
     for f in sorted(os.listdir(OUT)):
         print("%-32s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))
 
