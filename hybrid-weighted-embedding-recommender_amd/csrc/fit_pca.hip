@@ -1,0 +1,254 @@
+// Fit-side table construction on the device: the data passes of
+//   IncrementalPCA(n_components, batch_size=2**16).fit_transform(table)          hwer/content_recommender.py:68-69
+//   unit_length(., axis=1) + the one-hot node-type columns                          hwer/content_recommender.py:70-74
+// over the reference's block-diagonal feature table (hwer/content_recommender.py:50-66) WITHOUT materialising it: a row
+// of node type t is non-zero only in the columns of block t and in one-hot column t, so
+//   * the Gram matrix of any row range is block diagonal over the types: one (D_t+1) x (D_t+1) Gram of [B_t | 1] per
+//     (batch, type) - `segment_gram_kernel`, float64 MFMA (v_mfma_f64_16x16x4_f64), deterministic two-stage reduction;
+//   * the projection of a row is B_t[l] . P_t + bias_t with P_t = the block's columns of the components -
+//     `pca_project_kernel`, float64 MFMA, fused with the row normalisation and the one-hot / padding columns.
+// The O(W^3) eigen-recurrence between the two (W = table width) runs on the host (hwer/fit_pca.py).
+#include "hwer_common.h"
+
+namespace hwer {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kGramRows = 8192;   // rows of one partial Gram (one workgroup): batches of 65 536 rows -> <= 8 partials
+constexpr int kGramTile = 64;     // output tile of a workgroup: 4 x 4 MFMA tiles per wave
+
+__host__ __device__ static inline int gram_padded(int D) { return (D + 1 + 15) & ~15; }
+
+// [B | 1 | 0...] element
+__device__ __forceinline__ double aug_load(const double* __restrict__ row, int col, int D, bool valid) {
+    if (!valid) return 0.0;
+    if (col < D) return row[col];
+    return col == D ? 1.0 : 0.0;
+}
+
+// grid: x = partial (chunk of kGramRows rows) inside the segment, y = segment, z = upper-triangle tile pair
+// ws[(seg * chunks_per_seg + chunk)][Dp][Dp]; only tiles (ti <= tj) are written
+__global__ __launch_bounds__(256) void segment_gram_kernel(const double* __restrict__ B, int64_t ldb, int D,
+                                                           const int64_t* __restrict__ seg_ptr, int chunks_per_seg,
+                                                           double* __restrict__ ws, int Dp, int ntile) {
+    __shared__ double tile[kGramTile * kGramTile];
+    const int seg = blockIdx.y, chunk = blockIdx.x;
+    const int64_t s0 = seg_ptr[seg], s1 = seg_ptr[seg + 1];
+    const int64_t r0 = s0 + int64_t(chunk) * kGramRows;
+    if (r0 >= s1) return;
+    const int64_t r1 = (r0 + kGramRows < s1) ? r0 + kGramRows : s1;
+    // tile pair
+    int ti = 0, z = blockIdx.z;
+    while (z >= ntile - ti) { z -= ntile - ti; ++ti; }
+    const int tj = ti + z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kr = lane >> 4, c = lane & 15;
+    const int na = min(4, (Dp - ti * kGramTile) / 16), nb = min(4, (Dp - tj * kGramTile) / 16);
+    const int ca = ti * kGramTile + c, cb = tj * kGramTile + c;
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = d4_t{0.0, 0.0, 0.0, 0.0};
+
+    double a[4], b[4], an[4], bn[4];
+    auto fetch = [&](int64_t row, double (&fa)[4], double (&fb)[4]) {
+        const int64_t r = row + kr;
+        const bool valid = r < r1;
+        const double* p = B + (valid ? r : r0) * ldb;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            fa[x] = x < na ? aug_load(p, ca + 16 * x, D, valid) : 0.0;
+            fb[x] = x < nb ? aug_load(p, cb + 16 * x, D, valid) : 0.0;
+        }
+    };
+    int64_t row = r0 + wave * 4;
+    if (row < r1) fetch(row, a, b);
+    for (; row < r1; row += 16) {
+        const bool more = row + 16 < r1;
+        if (more) fetch(row + 16, an, bn);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (x < na) {
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    if (y < nb) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { a[x] = an[x]; b[x] = bn[x]; }
+        }
+    }
+    // fixed-order reduction over the 4 waves through LDS (deterministic)
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = 16 * x + kr + 4 * r, j = 16 * y + c;   // f64 C/D map: col = lane & 15, row = (lane >> 4) + 4 reg
+                        if (w == 0) tile[i * kGramTile + j] = acc[x][y][r];
+                        else tile[i * kGramTile + j] += acc[x][y][r];
+                    }
+        }
+        __syncthreads();
+    }
+    double* out = ws + (int64_t(seg) * chunks_per_seg + chunk) * int64_t(Dp) * Dp;
+    for (int e = threadIdx.x; e < kGramTile * kGramTile; e += 256) {
+        const int i = e >> 6, j = e & 63, gi = ti * kGramTile + i, gj = tj * kGramTile + j;
+        if (gi < Dp && gj < Dp) out[int64_t(gi) * Dp + gj] = tile[e];
+    }
+}
+
+// G[seg][i][j] (Da x Da, Da = D + 1) = sum of the segment's partials in chunk order; lower-triangle tiles mirrored
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ ws, const int64_t* __restrict__ seg_ptr,
+                                                          int chunks_per_seg, int Dp, int Da, double* __restrict__ G) {
+    const int seg = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Da * Da) return;
+    const int i = e / Da, j = e % Da;
+    const int si = (i / kGramTile <= j / kGramTile) ? i : j, sj = (i / kGramTile <= j / kGramTile) ? j : i;
+    const int64_t rows = seg_ptr[seg + 1] - seg_ptr[seg];
+    const int nchunk = int((rows + kGramRows - 1) / kGramRows);
+    const double* p = ws + int64_t(seg) * chunks_per_seg * int64_t(Dp) * Dp + int64_t(si) * Dp + sj;
+    double s = 0.0;
+    for (int cidx = 0; cidx < nchunk; ++cidx) s += p[int64_t(cidx) * Dp * Dp];
+    G[int64_t(seg) * Da * Da + e] = s;
+}
+
+// One wave = 16 rows of the block x all (padded) components.  A = B rows (16 x 4 per step), B operand = P rows.
+template <int NT>
+__global__ __launch_bounds__(256) void pca_project_kernel(const double* __restrict__ B, int64_t ldb, int64_t n_rows, int D,
+                                                          const double* __restrict__ P, int64_t ldp,
+                                                          const double* __restrict__ bias, int n,
+                                                          const int64_t* __restrict__ out_rows, int onehot_col, int n_onehot,
+                                                          float* __restrict__ out32, int64_t ldo32,
+                                                          double* __restrict__ out64, int64_t ldo64) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kr = lane >> 4, c = lane & 15;
+    const int64_t R0 = (int64_t(blockIdx.x) * 4 + wave) * 16;
+    if (R0 >= n_rows) return;
+    d4_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = d4_t{0.0, 0.0, 0.0, 0.0};
+    const int64_t arow = R0 + c;
+    const bool avalid = arow < n_rows;
+    const double* ap = B + (avalid ? arow : R0) * ldb;
+    const int D4 = (D + 3) & ~3;
+    for (int c0 = 0; c0 < D4; c0 += 4) {
+        const int col = c0 + kr;
+        const double a = (avalid && col < D) ? ap[col] : 0.0;
+        const double* pp = P + int64_t(col) * ldp + c;     // P has D4 rows (zero padded) and 16 NT columns
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, pp[16 * t], acc[t], 0, 0, 0);
+    }
+    // lane holds rows kr + 4 r (r = 0..3), components 16 t + c
+    double nrm2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double bj = bias[16 * t + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[t][r] += bj;
+            nrm2[r] += acc[t][r] * acc[t][r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        for (int m = 1; m < 16; m <<= 1) nrm2[r] += __shfl_xor(nrm2[r], m, kWave);
+        nrm2[r] = sqrt(nrm2[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t lrow = R0 + kr + 4 * r;
+        if (lrow >= n_rows) continue;
+        const int64_t orow = out_rows ? out_rows[lrow] : lrow;
+        float* o32 = out32 + orow * ldo32;
+        double* o64 = out64 ? out64 + orow * ldo64 : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + c;
+            if (j < n) {
+                const double u = acc[t][r] / nrm2[r];      // 0/0 = NaN like numpy (hwer/utils.py:44 has no epsilon)
+                o32[j] = float(u);
+                if (o64) o64[j] = u;
+            }
+        }
+        for (int q = n + c; q < ldo32; q += 16) o32[q] = (q - n == onehot_col) ? 1.f : 0.f;
+        if (o64) for (int q = n + c; q < ldo64; q += 16) o64[q] = (q - n == onehot_col) ? 1.0 : 0.0;
+    }
+}
+
+}  // namespace hwer
+
+using namespace hwer;
+
+extern "C" {
+
+int hwer_gram_padded_dim(int D) { return D < 1 ? -1 : gram_padded(D); }
+
+static inline int gram_chunks(int64_t max_seg_rows) { return int((max_seg_rows + kGramRows - 1) / kGramRows); }
+
+size_t hwer_segment_gram_workspace_bytes(int D, int n_seg, int64_t max_seg_rows) {
+    if (D < 1 || n_seg < 1 || max_seg_rows < 1) return 0;
+    const size_t Dp = size_t(gram_padded(D));
+    return size_t(n_seg) * size_t(gram_chunks(max_seg_rows)) * Dp * Dp * sizeof(double);
+}
+
+int hwer_segment_gram_f64(const double* B, int64_t ldb, int D, const int64_t* seg_ptr, int n_seg, int64_t max_seg_rows,
+                          double* G, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n_seg == 0) return HWER_OK;
+    if (!B || !seg_ptr || !G || !workspace) return fail(HWER_EINVAL, "segment_gram: null pointer");
+    if (D < 1 || D > 4095 || ldb < D) return fail(HWER_EINVAL, "segment_gram: bad D=%d / ldb=%lld", D, (long long)ldb);
+    if (n_seg < 0 || n_seg > 65535 || max_seg_rows < 1) return fail(HWER_EINVAL, "segment_gram: bad n_seg=%d / max_seg_rows=%lld", n_seg, (long long)max_seg_rows);
+    const int chunks = gram_chunks(max_seg_rows);
+    if (chunks > 65535) return fail(HWER_EINVAL, "segment_gram: segment too long (%lld rows)", (long long)max_seg_rows);
+    if (workspace_bytes < hwer_segment_gram_workspace_bytes(D, n_seg, max_seg_rows)) return fail(HWER_EWORKSPACE, "segment_gram: workspace too small");
+    const int Dp = gram_padded(D), Da = D + 1;
+    const int ntile = (Dp + kGramTile - 1) / kGramTile;
+    const int npair = ntile * (ntile + 1) / 2;
+    hipLaunchKernelGGL(segment_gram_kernel, dim3(chunks, n_seg, npair), dim3(256), 0, as_stream(stream), B, ldb, D, seg_ptr, chunks,
+                       static_cast<double*>(workspace), Dp, ntile);
+    int rc = check_launch("segment_gram");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3((Da * Da + 255) / 256, n_seg), dim3(256), 0, as_stream(stream),
+                       static_cast<const double*>(workspace), seg_ptr, chunks, Dp, Da, G);
+    return check_launch("gram_reduce");
+}
+
+int hwer_pca_padded_components(int n) {
+    if (n < 1 || n > 256) return -1;
+    int nt = 1;
+    while (16 * nt < n) nt <<= 1;
+    return 16 * nt;
+}
+
+int hwer_pca_project_unit_f64(const double* B, int64_t ldb, int64_t n_rows, int D, const double* P, int64_t ldp,
+                              const double* bias, int n, const int64_t* out_rows, int onehot_col, int n_onehot, float* out32,
+                              int64_t ldo32, double* out64, int64_t ldo64, void* stream) {
+    if (n_rows == 0) return HWER_OK;
+    if (!B || !P || !bias || !out32) return fail(HWER_EINVAL, "pca_project: null pointer");
+    const int np = hwer_pca_padded_components(n);
+    if (np < 0) return fail(HWER_EINVAL, "pca_project: n_components=%d unsupported (1..256)", n);
+    if (D < 1 || ldb < D || ldp < np) return fail(HWER_EINVAL, "pca_project: bad D=%d ldb=%lld ldp=%lld (need ldp >= %d)", D, (long long)ldb, (long long)ldp, np);
+    if (n_onehot < 0 || onehot_col < -1 || onehot_col >= n_onehot) return fail(HWER_EINVAL, "pca_project: bad one-hot column %d of %d", onehot_col, n_onehot);
+    if (ldo32 < n + n_onehot || (out64 && ldo64 < n + n_onehot)) return fail(HWER_EINVAL, "pca_project: output rows too short");
+    if (n_rows < 0 || n_rows > (int64_t(1) << 36)) return fail(HWER_EINVAL, "pca_project: bad n_rows");
+    const unsigned grid = unsigned((n_rows + 63) / 64);
+#define HWER_LAUNCH_PROJ(NT)                                                                                                  \
+    hipLaunchKernelGGL(pca_project_kernel<NT>, dim3(grid), dim3(256), 0, as_stream(stream), B, ldb, n_rows, D, P, ldp, bias, n, \
+                       out_rows, onehot_col, n_onehot, out32, ldo32, out64, ldo64)
+    switch (np / 16) {
+        case 1: HWER_LAUNCH_PROJ(1); break;
+        case 2: HWER_LAUNCH_PROJ(2); break;
+        case 4: HWER_LAUNCH_PROJ(4); break;
+        case 8: HWER_LAUNCH_PROJ(8); break;
+        default: HWER_LAUNCH_PROJ(16); break;
+    }
+#undef HWER_LAUNCH_PROJ
+    return check_launch("pca_project");
+}
+
+}  // extern "C"

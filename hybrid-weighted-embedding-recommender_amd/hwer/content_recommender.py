@@ -3,8 +3,9 @@
 Hot path (device): the tail of __build_content_embeddings__ (reference lines 77-86) and the unit_length of fit
 (line 96) run as ONE fused HIP kernel (hwer_content_tail_f32: CSR neighbour mean -> (E + A)/2 -> L2 normalise),
 or as the general multi-table, per-row alpha blend (blend_tables / hwer_blend_normalize_f32).
-Fit-time table construction (reference lines 24-76: per-type embedders, block-diagonal concat, one-hot node type,
-IncrementalPCA) is not part of the accelerated path and stays on the host with scikit-learn.
+The table construction before it (reference lines 50-76: block-diagonal concat, one-hot node type, IncrementalPCA, unit
+rows) runs on the device too (hwer/fit_pca.py); only the per-type feature embedders (lines 24-49, out of
+scope) stay on the host.
 """
 from __future__ import annotations
 
@@ -44,13 +45,17 @@ def _dev_table(t, device, ld):
     return out
 
 
-def content_tail(E, src, dst, device=None, return_device=False):
-    """unit_rows((E + mean_adj(E)) / 2) on the GPU.  E: (N, D) array; src/dst: edge endpoints as row ids."""
+def content_tail(E, src, dst, device=None, return_device=False, d=None):
+    """unit_rows((E + mean_adj(E)) / 2) on the GPU.  E: (N, D) array; src/dst: edge endpoints as row ids.
+    d: logical width when E is a device table whose rows are already padded to a multiple of 4."""
     import torch
     from .device_index import _require_gpu, roundup
     lib = native.lib()
     dev = _require_gpu(device)
     N, D = E.shape
+    if d is not None:
+        assert roundup(d, 4) == D, "a pre-padded table must have roundup4(d) columns"
+        D = d
     ld = roundup(D, 4)
     Ed = _dev_table(E, dev, ld)
     indptr, indices = adjacency_csr(N, src, dst)
@@ -116,15 +121,20 @@ class ContentRecommendation(RecommendationBase):
         self.embedding_mapper = embedding_mapper
         self.log = getLogger(type(self).__name__)
 
-    # host, scikit-learn: reference hwer/content_recommender.py:24-76 (not on the accelerated path)
-    def __build_feature_table__(self, nodes: List[Node], node_data, n_dims) -> np.ndarray:
-        from sklearn.decomposition import IncrementalPCA
+    def __build_feature_blocks__(self, nodes: List[Node], node_data):
+        """Host part of the fit (reference hwer/content_recommender.py:24-49): run the per-type embedders (out of scope,
+        SURVEY.md §2) -> one float64 block of unit rows per node type, in SORTED type order (the OneHotEncoder's category
+        order), rows in `nodes` order; plus the order in which the types were visited (the column order of the
+        reference's block-diagonal table) and every node's type id."""
         from .utils import unit_length
-        blocks, order = [], []
+        cats = sorted({n.node_type for n in nodes})
+        cat_id = {t: i for i, t in enumerate(cats)}
+        blocks, visit = [None] * len(cats), []
         for nt in self.node_types:
             members = [n for n in nodes if n.node_type == nt]
             with_data = sum(1 for n in members if n in node_data)
             assert with_data in (0, len(members))
+            assert len(set(members)) == len(members)
             if with_data == 0:
                 block = np.zeros((len(members), 1))
             else:
@@ -138,35 +148,27 @@ class ContentRecommendation(RecommendationBase):
                     if block is None:
                         block = emb
                 block = unit_length(block, axis=1)
-            blocks.append(block)
-            order.extend(members)
-        width = sum(b.shape[1] for b in blocks)
-        table = np.zeros((len(order), width))
-        r = c = 0
-        for b in blocks:  # block diagonal
-            table[r:r + b.shape[0], c:c + b.shape[1]] = b
-            r, c = r + b.shape[0], c + b.shape[1]
-        pos = {n: i for i, n in enumerate(order)}
-        table = table[[pos[n] for n in nodes]]
-        cats = sorted({n.node_type for n in nodes})
-        ohe = np.zeros((len(nodes), len(cats)))
-        ohe[np.arange(len(nodes)), [cats.index(n.node_type) for n in nodes]] = 1.0
-        table = np.concatenate([table, ohe], axis=1)
-        if n_dims is None or np.isinf(n_dims):
-            n_dims = 2 ** int(np.log2(table.shape[1]))
-        table = unit_length(IncrementalPCA(n_components=n_dims, batch_size=2 ** 16).fit_transform(table), axis=1)
-        extra = 2 ** int(np.ceil(np.log2(ohe.shape[1]))) - ohe.shape[1]
-        if extra:
-            ohe = np.concatenate([ohe, np.zeros((ohe.shape[0], extra))], axis=1)
-        return np.concatenate([table, ohe], axis=1)
+            if nt in cat_id:
+                blocks[cat_id[nt]] = np.asarray(block, dtype=np.float64)
+                visit.append(cat_id[nt])
+        type_id = np.fromiter((cat_id[n.node_type] for n in nodes), dtype=np.int64, count=len(nodes))
+        return blocks, type_id, visit
+
+    def __build_feature_table__(self, nodes: List[Node], node_data, n_dims):
+        """Reference hwer/content_recommender.py:50-76 on the GPU (hwer/fit_pca.py): the block-diagonal table is never
+        built; IncrementalPCA's data passes, the row normalisation and the one-hot columns are HIP kernels.
+        -> (float32 device table (N, ld), its logical width)."""
+        from .fit_pca import device_feature_table
+        blocks, type_id, visit = self.__build_feature_blocks__(nodes, node_data)
+        return device_feature_table(blocks, type_id, n_dims, block_order=visit, device=self.device)
 
     def __build_content_embeddings__(self, nodes, edges, node_data, n_dims):
-        """-> unit-norm (N, D) float32 rows: feature table on the host, neighbour blend + normalise on the GPU."""
-        E = self.__build_feature_table__(nodes, node_data, n_dims)
+        """-> unit-norm (N, D) float32 rows: embedders on the host, PCA + neighbour blend + normalise on the GPU."""
+        E, D = self.__build_feature_table__(nodes, node_data, n_dims)
         get = self.nodes_to_idx.__getitem__
         src = np.fromiter((get(e.src) for e in edges), dtype=np.int64, count=len(edges))
         dst = np.fromiter((get(e.dst) for e in edges), dtype=np.int64, count=len(edges))
-        return content_tail(E, src, dst, device=self.device)
+        return content_tail(E, src, dst, device=self.device, d=D)
 
     def fit(self, nodes: List[Node], edges: List[Edge], node_data: Dict[Node, Dict[FeatureName, object]], **kwargs):
         super().fit(nodes, edges, node_data)

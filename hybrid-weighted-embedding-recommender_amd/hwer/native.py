@@ -51,6 +51,12 @@ PROTOTYPES = {
     "hwer_merge_topk": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "hwer_knn_all_dist2_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, _P]),
     "hwer_pack_exchange": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
+    "hwer_gram_padded_dim": (c_int, [c_int]),
+    "hwer_segment_gram_workspace_bytes": (c_size_t, [c_int, c_int, c_int64]),
+    "hwer_segment_gram_f64": (c_int, [_P, c_int64, c_int, _P, c_int, c_int64, _P, _P, c_size_t, _P]),
+    "hwer_pca_padded_components": (c_int, [c_int]),
+    "hwer_pca_project_unit_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int, _P, c_int, c_int, _P, c_int64,
+                                          _P, c_int64, _P]),
     "hwer_merge_topk_strided": (c_int, [_P, _P, _P, c_int64, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
 }
 

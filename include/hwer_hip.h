@@ -84,6 +84,32 @@ int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, co
                           int d, float* out, int64_t ldo, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * F1+F2  fit-side table construction — the data passes of
+ *          IncrementalPCA(n_components, batch_size=2**16).fit_transform(table)   hwer/content_recommender.py:68-69
+ *          unit_length(., axis=1) and the one-hot node-type columns               hwer/content_recommender.py:70-74
+ *        over the block-diagonal feature table of hwer/content_recommender.py:50-66, which is never materialised: a row
+ *        of node type t is non-zero only in block t's columns and in one-hot column t.  The host mirror (hwer/fit_pca.py)
+ *        runs IncrementalPCA's recurrence on the per-(batch, type) Gram matrices (eigen-decompositions of W x W matrices).
+ *
+ *   hwer_segment_gram_f64: for every segment s (rows seg_ptr[s] .. seg_ptr[s+1] of the float64 block B, row stride ldb),
+ *        G[s] = [B | 1]^T [B | 1], a dense (D+1) x (D+1) row-major matrix: G[i][j] = sum_r B[r][i] B[r][j],
+ *        G[i][D] = G[D][i] = column sums, G[D][D] = row count.  float64 MFMA; partial sums over 8 192-row chunks are reduced
+ *        in a fixed order (deterministic).  seg_ptr: device (n_seg + 1); max_seg_rows >= the longest segment.
+ *   hwer_pca_project_unit_f64: for every row l of B: y = B[l] . P + bias (n components), u = y / ||y||_2 (no epsilon),
+ *        out[out_rows ? out_rows[l] : l] = [u | one-hot(onehot_col) over n_onehot columns | zeros up to the row stride].
+ *        P: (roundup4(D), ldp) float64 row-major, rows >= D and columns >= n zero; ldp >= hwer_pca_padded_components(n);
+ *        bias: hwer_pca_padded_components(n) values, zero padded.  out32 (float32) required, out64 (float64) optional.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_gram_padded_dim(int D);
+size_t hwer_segment_gram_workspace_bytes(int D, int n_seg, int64_t max_seg_rows);
+int hwer_segment_gram_f64(const double* B, int64_t ldb, int D, const int64_t* seg_ptr, int n_seg, int64_t max_seg_rows,
+                          double* G, void* workspace, size_t workspace_bytes, void* stream);
+int hwer_pca_padded_components(int n); /* 16, 32, 64, 128 or 256; -1 if n is unsupported (n < 1 or n > 256) */
+int hwer_pca_project_unit_f64(const double* B, int64_t ldb, int64_t n_rows, int D, const double* P, int64_t ldp,
+                              const double* bias, int n, const int64_t* out_rows /*nullable*/, int onehot_col, int n_onehot,
+                              float* out32, int64_t ldo32, double* out64 /*nullable*/, int64_t ldo64, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K11    unit-norm audit — replaces utils.unit_length_violations (hwer/utils.py:51-57) as used by
  *        RecommendationBase.__build_knn__ (hwer/recommendation_base.py:106-107).
  *   out_counts[0..2] = rows with norm > 1+eps, rows with norm < 1-eps, rows with NaN norm

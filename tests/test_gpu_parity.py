@@ -764,3 +764,141 @@ def test_knn_tiny_catalogues(hw, knn_path, N, k):
         assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
     with pytest.raises(ValueError):
         ix.search("item", np.arange(U), k=N + 1)
+
+
+# ------------------------------------------------------------------------------------------------- fit-side table (§8f-3)
+def _gram_call(B, seg):
+    import torch
+    from hwer import native
+    lib = native.lib()
+    dev = torch.device("cuda:0")
+    n_seg, D = len(seg) - 1, B.shape[1]
+    Bd = torch.from_numpy(np.ascontiguousarray(B)).to(dev)
+    sd = torch.from_numpy(np.asarray(seg, dtype=np.int64)).to(dev)
+    mx = int(np.diff(seg).max())
+    G = torch.full((n_seg, D + 1, D + 1), np.nan, dtype=torch.float64, device=dev)
+    nb = lib.hwer_segment_gram_workspace_bytes(D, n_seg, mx)
+    ws = torch.empty(nb // 8, dtype=torch.float64, device=dev)
+    native.check(lib.hwer_segment_gram_f64(native.ptr(Bd), Bd.stride(0), D, native.ptr(sd), n_seg, mx, native.ptr(G),
+                                           native.ptr(ws), nb, native.stream_ptr()), "segment_gram")
+    return G.cpu().numpy()
+
+
+@pytest.mark.parametrize("D", [1, 5, 15, 16, 63, 64, 130, 257])
+def test_segment_gram_matches_numpy(hw, D):
+    """[B | 1]^T [B | 1] per row segment (float64 MFMA, two-stage deterministic reduction) vs numpy; tolerance: 1e-12 of
+    the entry scale (the sums run in a different order than BLAS)."""
+    rng = np.random.default_rng(D)
+    n = 21000
+    B = rng.standard_normal((n, D))
+    seg = np.asarray([0, 3, 3, 700, 700 + 8192, 700 + 8192 + 8193, n], dtype=np.int64)   # tiny, empty, exact chunk, chunk + 1
+    got = _gram_call(B, seg)
+    for s in range(len(seg) - 1):
+        A = np.concatenate([B[seg[s]:seg[s + 1]], np.ones((seg[s + 1] - seg[s], 1))], axis=1)
+        ref = A.T @ A
+        assert np.abs(got[s] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max()), (D, s)
+        assert np.array_equal(got[s], got[s].T)                     # mirrored tiles / symmetric by construction
+        assert got[s][D, D] == seg[s + 1] - seg[s]
+    assert np.array_equal(got, _gram_call(B, seg))                  # deterministic
+
+
+@pytest.mark.parametrize("D,n", [(1, 3), (5, 8), (13, 17), (64, 64), (130, 100), (200, 256)])
+def test_pca_project_unit_matches_numpy(hw, D, n):
+    import torch
+    from hwer import native
+    from hwer.device_index import roundup
+    lib = native.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(100 * D + n)
+    rows = 1000 + D
+    B = rng.standard_normal((rows, D))
+    C = rng.standard_normal((D, n))
+    bias = rng.standard_normal(n)
+    npad = lib.hwer_pca_padded_components(n)
+    P = np.zeros((roundup(D, 4), npad))
+    P[:D, :n] = C
+    bp = np.zeros(npad)
+    bp[:n] = bias
+    perm = rng.permutation(rows + 7)[:rows].astype(np.int64)         # scatter into a larger table
+    n_onehot, col = 4, 2
+    ld = roundup(n + n_onehot, 4) + 4
+    o32 = torch.full((rows + 7, ld), 7.0, dtype=torch.float32, device=dev)
+    o64 = torch.full((rows + 7, ld), 7.0, dtype=torch.float64, device=dev)
+    Bd, Pd, bd, pd = (torch.from_numpy(x).to(dev) for x in (B, P, bp, perm))
+    native.check(lib.hwer_pca_project_unit_f64(native.ptr(Bd), D, rows, D, native.ptr(Pd), npad, native.ptr(bd), n, native.ptr(pd),
+                                               col, n_onehot, native.ptr(o32), ld, native.ptr(o64), ld, native.stream_ptr()), "proj")
+    y = B @ C + bias
+    u = y / np.linalg.norm(y, axis=1, keepdims=True)
+    ref = np.zeros((rows, ld))
+    ref[:, :n] = u
+    ref[:, n + col] = 1.0
+    g64, g32 = o64.cpu().numpy(), o32.cpu().numpy()
+    assert np.abs(g64[perm] - ref).max() <= 1e-13                     # float64 MFMA vs BLAS: rounding only
+    assert np.abs(g32[perm] - ref).max() <= 6e-8                      # float32 rounding of unit rows
+    untouched = np.setdiff1d(np.arange(rows + 7), perm)
+    assert np.all(g32[untouched] == 7.0) and np.all(g64[untouched] == 7.0)
+
+
+def _sign_ties(ref_components):
+    """Components whose sign in the reference is a coin toss: svd_flip makes the entry of largest magnitude positive, and
+    with two node types the two one-hot entries of a component are exact negatives of each other - when they are the
+    largest, rounding noise picked the reference's sign."""
+    a = np.sort(np.abs(ref_components), axis=1)
+    return (a[:, -1] - a[:, -2]) <= 1e-9
+
+
+@pytest.mark.parametrize("tag", ["small", "multi"])
+def test_fit_feature_table_g12(golden, hw, tag):
+    """hwer/content_recommender.py:50-76 on the device vs the reference (G12: one IncrementalPCA batch / two batches) and
+    vs the oracle's SVD restatement.  Tolerance 1e-9 on the float64 rows (Gram + eigh instead of SVD), 1e-6 on the float32
+    rows the path hands on."""
+    from conftest import g12_scenario
+    from hwer.content_recommender import content_tail
+    from hwer.fit_pca import device_feature_table
+    g = golden("g12_fit_pca")
+    sc = g12_scenario(g, tag)
+    blocks = [orc.unit_length(f, axis=1) if has else np.zeros((f.shape[0], 1)) for f, has in zip(sc["feats"], sc["with_data"])]
+    det = {}
+    E32, E64, D = device_feature_table(blocks, sc["type_id"], sc["n_dims"], block_order=sc["order"], want_f64=True, details=det)
+    n = sc["n_dims"]
+    assert D == n + (4 if tag == "small" else 2) and len(det["batches"]) == (1 if tag == "small" else 2)
+    tie = _sign_ties(g[tag + "_components"])
+    sign = np.sign((det["components"] * g[tag + "_components"]).sum(1))
+    assert np.all(sign[~tie] == 1.0)                                   # flips only where the reference's sign is a tie
+    assert np.abs(det["components"] * sign[:, None] - g[tag + "_components"]).max() <= 1e-9
+    assert np.abs(det["mean"] - g[tag + "_mean"]).max() <= 1e-12
+    assert np.abs(det["singular_values"] - g[tag + "_singular_values"]).max() <= 1e-8
+    rows = g[tag + "_rows"]
+    e64, e32 = E64.cpu().numpy(), E32.cpu().numpy()
+    assert np.abs(e64[rows, :n] * sign - g[tag + "_pca_unit"]).max() <= 1e-9
+    assert np.abs(e32[rows, :n] * sign - g[tag + "_pca_unit"]).max() <= 1e-6
+    Eo, _ = orc.fit_feature_table(blocks, sc["type_id"], n, sc["order"])
+    full_sign = np.concatenate([sign, np.ones(D - n)])
+    assert np.abs(e64[:, :D] * full_sign - Eo).max() <= 1e-9            # every row, incl. the one-hot columns
+    assert np.all(e32[:, D:] == 0)
+    # the tail on top of it (neighbour mean + blend + unit rows) vs the reference's final vectors
+    final = content_tail(E32, sc["src"], sc["dst"], d=D)
+    assert np.abs(final[rows] * full_sign - g[tag + "_final"]).max() <= 1e-6
+
+
+def test_content_recommendation_fit_g12_small(golden, hw):
+    """ContentRecommendation.fit end to end (embedders on the host, everything after them on the device), including a node
+    type without node_data."""
+    from conftest import g12_scenario
+    from hwer import ContentRecommendation, Edge, IdentityEmbedding, Node
+    g = golden("g12_fit_pca")
+    sc = g12_scenario(g, "small")
+    types = sc["types"]
+    nodes = [Node(types[t], i) for i, t in enumerate(sc["type_id"])]
+    cursor = [0] * len(types)
+    node_data = {}
+    for nd, t in zip(nodes, sc["type_id"]):
+        if sc["with_data"][t]:
+            node_data[nd] = {"f": sc["feats"][t][cursor[t]]}
+        cursor[t] += 1
+    edges = [Edge(nodes[s], nodes[t], 1.0) for s, t in zip(sc["src"], sc["dst"])]
+    mapper = {types[t]: {"f": IdentityEmbedding(n_dims=sc["feats"][t].shape[1])} for t in range(len(types)) if sc["with_data"][t]}
+    model = ContentRecommendation(mapper, set(types), n_dims=sc["n_dims"])
+    final = model.fit(nodes, edges, node_data)
+    assert final.shape == g["small_final"].shape
+    assert np.abs(final - g["small_final"]).max() <= 1e-6

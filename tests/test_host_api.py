@@ -110,3 +110,51 @@ def test_persisted_index_format_roundtrip(tmp_path):
     np.savez(open(path, "wb"), format=np.array("something-else"))
     with pytest.raises(ValueError):
         persist.load_index(path)
+
+
+@pytest.mark.parametrize("tag", ["small", "multi"])
+def test_pca_recurrence_on_grams_matches_reference(golden, tag):
+    """Host half of the device PCA (hwer/fit_pca.py: IncrementalPCA's recurrence on per-(batch, type) Gram matrices), fed
+    with numpy Grams, against the reference's components / mean / singular values (G12)."""
+    from conftest import g12_scenario
+    from hwer import fit_pca
+    g = golden("g12_fit_pca")
+    sc = g12_scenario(g, tag)
+    blocks = [orc.unit_length(f, axis=1) if has else np.zeros((f.shape[0], 1)) for f, has in zip(sc["feats"], sc["with_data"])]
+    T, n = len(blocks), sc["n_dims"]
+    dims = [b.shape[1] for b in blocks]
+    width = sum(dims)
+    batches = fit_pca.pca_batches(sc["N"], fit_pca.BATCH_SIZE, n)
+    assert batches == orc.pca_batches(sc["N"], 2 ** 16, n)
+    bounds = np.asarray([a for a, _ in batches] + [batches[-1][1]])
+    col_of, c = [None] * T, 0
+    for t in sc["order"]:
+        col_of[t] = np.arange(c, c + dims[t])
+        c += dims[t]
+    grams = []
+    for t in range(T):
+        seg = np.searchsorted(np.flatnonzero(sc["type_id"] == t), bounds)
+        G = np.zeros((len(batches), dims[t] + 1, dims[t] + 1))
+        for b in range(len(batches)):
+            A = np.concatenate([blocks[t][seg[b]:seg[b + 1]], np.ones((seg[b + 1] - seg[b], 1))], axis=1)
+            G[b] = A.T @ A
+        grams.append(G)
+    comps, mean, sv = fit_pca.pca_from_grams(grams, col_of, [width + t for t in range(T)], width + T, n)
+    ref = g[tag + "_components"]
+    a = np.sort(np.abs(ref), axis=1)
+    tie = (a[:, -1] - a[:, -2]) <= 1e-9          # the reference's own sign is rounding noise there (see test_gpu_parity)
+    sign = np.sign((comps * ref).sum(1))
+    assert np.all(sign[~tie] == 1.0)
+    assert np.abs(comps * sign[:, None] - ref).max() <= 1e-9
+    assert np.abs(mean - g[tag + "_mean"]).max() <= 1e-12
+    assert np.abs(sv - g[tag + "_singular_values"]).max() <= 1e-8
+    with pytest.raises(ValueError):
+        fit_pca.pca_from_grams(grams, col_of, [width + t for t in range(T)], width + T, width + T + 1)
+
+
+def test_pca_batches_like_gen_batches():
+    from hwer.fit_pca import pca_batches
+    assert pca_batches(7, 3, 0) == [(0, 3), (3, 6), (6, 7)]
+    assert pca_batches(7, 3, 2) == [(0, 3), (3, 7)]
+    assert pca_batches(6, 3, 2) == [(0, 3), (3, 6)]
+    assert pca_batches(2, 3, 1) == [(0, 2)]
