@@ -509,6 +509,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
         const int64_t n_tiles = cdiv64(n_items, 32);
         // one full round of workgroups: 256 CUs x 2 resident = 512 slots
         int64_t sp = std::min<int64_t>(n_tiles, std::max<int64_t>(1, 512 / p.n_qblocks));
+        if (const char* e = getenv("HWER_DENSE_SPLITS")) sp = std::min<int64_t>(n_tiles, std::max(1, atoi(e)));   // tuning override
         int64_t per_d = cdiv64(n_tiles, sp) * 32;
         p.n_splits = int(cdiv64(n_items, per_d));
         p.split_items = per_d;

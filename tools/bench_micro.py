@@ -2,7 +2,7 @@
 """Micro-benchmarks of the secondary metrics of SURVEY.md §8(d): pair_score / blend_normalize / segment_mean throughput
 against the HBM roofline, and per-batch retrieval latency on a C4 shard for B in {1, 8, 64, 512, 4096}.
 
-    python tools/bench_micro.py [--what rowops,latency] [--items 1250000] [--d 128]
+    python tools/bench_micro.py [--what rowops,latency,fit] [--items 1250000] [--d 128]
 
 Prints one JSON object per measurement.  Inputs are resident in HBM; timing with HIP events on the launch stream.
 """
@@ -102,6 +102,44 @@ def main():
                           "roofline": {"bound": "hbm (gathered rows)", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": byts / ms / 1e6 / HBM_PEAK_GBS}}))
         del E, indices, indptr, out
+
+
+    if "fit" in what:
+        # ---- fit-side table construction: segmented Gram + projection, float64 MFMA -----------------
+        # one node type, N rows of D features, 2**16-row batches (IncrementalPCA's), n components.  Roofline: float64 MFMA
+        # (v_mfma_f64_16x16x4_f64; 78.6 TF is AMD's MI355X data-sheet FP64 matrix figure - the guide has no f64 row).
+        F64_PEAK_TF = 78.6
+        for (N, D, n) in [(1 << 20, 64, 32), (1 << 22, 128, 64), (1 << 21, 256, 128)]:
+            g = torch.Generator(device=dev).manual_seed(N % 1000 + D)
+            B = torch.randn((N, D), generator=g, device=dev, dtype=torch.float64)
+            B = B / B.norm(dim=1, keepdim=True)
+            nseg = N >> 16
+            seg = torch.arange(0, nseg + 1, dtype=torch.int64, device=dev) * 65536
+            G = torch.empty((nseg, D + 1, D + 1), dtype=torch.float64, device=dev)
+            wsb = lib.hwer_segment_gram_workspace_bytes(D, nseg, 65536)
+            ws = torch.empty(wsb // 8, dtype=torch.float64, device=dev)
+            fn = lambda: native.check(lib.hwer_segment_gram_f64(P(B), D, D, P(seg), nseg, 65536, P(G), P(ws), wsb, S()), "gram")  # noqa: E731
+            ms = timeit(torch, fn, iters=5, warmup=1)
+            Da = D + 1
+            flops = 2.0 * N * Da * Da            # algorithmic: the full (D+1)^2 Gram of every row
+            nt = (lib.hwer_gram_padded_dim(D) + 63) // 64
+            issued = 2.0 * N * (nt * (nt + 1) // 2) * 64 * 64
+            print(json.dumps({"kernel": "segment_gram_f64 + reduce", "case": "%d rows x %d features, %d segments" % (N, D, nseg), "ms": ms,
+                              "TFs_algorithmic": flops / ms / 1e9, "frac_f64_mfma": flops / ms / 1e9 / F64_PEAK_TF,
+                              "TFs_issued_upper_tiles": issued / ms / 1e9, "hbm_GBs": 8.0 * N * D / ms / 1e6, "workspace_MB": wsb / 1e6}))
+            npad = lib.hwer_pca_padded_components(n)
+            Pm = torch.zeros((D, npad), dtype=torch.float64, device=dev)
+            Pm[:, :n] = torch.randn((D, n), generator=g, device=dev, dtype=torch.float64)
+            bias = torch.zeros(npad, dtype=torch.float64, device=dev)
+            ld = n + 4
+            out = torch.empty((N, ld), dtype=torch.float32, device=dev)
+            fn = lambda: native.check(lib.hwer_pca_project_unit_f64(P(B), D, N, D, P(Pm), npad, P(bias), n, None, 1, 4, P(out), ld, None, 0, S()), "proj")  # noqa: E731
+            ms = timeit(torch, fn, iters=5, warmup=1)
+            byt = 8.0 * N * D + 4.0 * N * ld
+            print(json.dumps({"kernel": "pca_project_unit_f64", "case": "%d rows x %d features -> %d components + 4 one-hot" % (N, D, n), "ms": ms,
+                              "TFs": 2.0 * N * D * n / ms / 1e9, "frac_f64_mfma": 2.0 * N * D * n / ms / 1e9 / F64_PEAK_TF,
+                              "hbm_GBs": byt / ms / 1e6, "hbm_frac": byt / ms / 1e6 / HBM_PEAK_GBS}))
+            del B, G, ws, out
 
     if "latency" in what:
         I, d, K = args.items, args.d, args.k
