@@ -8,76 +8,78 @@
 //   * the projection of a row is B_t[l] . P_t + bias_t with P_t = the block's columns of the components -
 //     `pca_project_kernel`, float64 MFMA, fused with the row normalisation and the one-hot / padding columns.
 // The O(W^3) eigen-recurrence between the two (W = table width) runs on the host (hwer/fit_pca.py).
+#include <algorithm>
+
 #include "hwer_common.h"
 
 namespace hwer {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kGramRows = 8192;   // rows of one partial Gram (one workgroup): batches of 65 536 rows -> <= 8 partials
 constexpr int kGramTile = 64;     // output tile of a workgroup: 4 x 4 MFMA tiles per wave
+constexpr int kGramPF = 3;        // row steps in flight per wave (register ring of 4 operand sets)
 
-__host__ __device__ static inline int gram_padded(int D) { return (D + 1 + 15) & ~15; }
+__host__ __device__ static inline int gram_padded(int D) { return (D + 15) & ~15; }
 
-// [B | 1 | 0...] element
-__device__ __forceinline__ double aug_load(const double* __restrict__ row, int col, int D, bool valid) {
-    if (!valid) return 0.0;
-    if (col < D) return row[col];
-    return col == D ? 1.0 : 0.0;
+// rows of one partial Gram (one workgroup): 8 192 (a 65 536-row batch -> 8 partials), fewer on small inputs so that the
+// launch still has ~1 000 workgroups
+static inline int gram_chunk_rows(int D, int n_seg, int64_t max_seg_rows) {
+    const int nt = (gram_padded(D) + kGramTile - 1) / kGramTile;
+    const int64_t npair = int64_t(nt) * (nt + 1) / 2;
+    int rows = 8192;
+    while (rows > 1024 && int64_t(n_seg) * ((max_seg_rows + rows - 1) / rows) * npair < 1024) rows >>= 1;
+    return rows;
 }
 
-// grid: x = partial (chunk of kGramRows rows) inside the segment, y = segment, z = upper-triangle tile pair
-// ws[(seg * chunks_per_seg + chunk)][Dp][Dp]; only tiles (ti <= tj) are written
-__global__ __launch_bounds__(256) void segment_gram_kernel(const double* __restrict__ B, int64_t ldb, int D,
-                                                           const int64_t* __restrict__ seg_ptr, int chunks_per_seg,
-                                                           double* __restrict__ ws, int Dp, int ntile) {
-    __shared__ double tile[kGramTile * kGramTile];
-    const int seg = blockIdx.y, chunk = blockIdx.x;
-    const int64_t s0 = seg_ptr[seg], s1 = seg_ptr[seg + 1];
-    const int64_t r0 = s0 + int64_t(chunk) * kGramRows;
-    if (r0 >= s1) return;
-    const int64_t r1 = (r0 + kGramRows < s1) ? r0 + kGramRows : s1;
-    // tile pair
-    int ti = 0, z = blockIdx.z;
-    while (z >= ntile - ti) { z -= ntile - ti; ++ti; }
-    const int tj = ti + z;
+// Partial layout per (segment, chunk): Dp x Dp Gram (upper-triangle elements of the tile pairs ti <= tj), then Dp column sums.
+// grid: x = chunk inside the segment, y = segment, z = upper-triangle tile pair.  DIAG (ti == tj): one operand set, only the
+// sub-tiles x <= y, and the column sums of the tile's columns (VALU adds next to the MFMAs).
+template <bool DIAG>
+__device__ __forceinline__ void gram_tile(const double* __restrict__ B, int64_t ldb, int D, int64_t r0, int64_t r1, int ti, int tj,
+                                          int Dp, double* __restrict__ out, double* tile) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, kr = lane >> 4, c = lane & 15;
     const int na = min(4, (Dp - ti * kGramTile) / 16), nb = min(4, (Dp - tj * kGramTile) / 16);
     const int ca = ti * kGramTile + c, cb = tj * kGramTile + c;
-
     d4_t acc[4][4];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = d4_t{0.0, 0.0, 0.0, 0.0};
-
-    double a[4], b[4], an[4], bn[4];
-    auto fetch = [&](int64_t row, double (&fa)[4], double (&fb)[4]) {
-        const int64_t r = row + kr;
+    double csum[4] = {0.0, 0.0, 0.0, 0.0};
+    double fa[4][4], fb[DIAG ? 1 : 4][4];
+    const int64_t first = r0 + wave * 4;
+    const int nsteps = first < r1 ? int((r1 - first + 15) / 16) : 0;
+    auto fetch = [&](int step, double (&va)[4], double (&vb)[4]) {
+        const int64_t r = first + int64_t(step) * 16 + kr;
         const bool valid = r < r1;
         const double* p = B + (valid ? r : r0) * ldb;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-            fa[x] = x < na ? aug_load(p, ca + 16 * x, D, valid) : 0.0;
-            fb[x] = x < nb ? aug_load(p, cb + 16 * x, D, valid) : 0.0;
+            va[x] = (valid && x < na && ca + 16 * x < D) ? p[ca + 16 * x] : 0.0;
+            if (!DIAG) vb[x] = (valid && x < nb && cb + 16 * x < D) ? p[cb + 16 * x] : 0.0;
         }
     };
-    int64_t row = r0 + wave * 4;
-    if (row < r1) fetch(row, a, b);
-    for (; row < r1; row += 16) {
-        const bool more = row + 16 < r1;
-        if (more) fetch(row + 16, an, bn);
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            if (x < na) {
+    for (int u = 0; u < kGramPF; ++u)
+        if (u < nsteps) fetch(u, fa[u], fb[DIAG ? 0 : u]);
+    for (int base = 0; base < nsteps; base += 4) {
 #pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    if (y < nb) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            const int step = base + u;
+            if (step < nsteps) {   // wave-uniform
+                if (step + kGramPF < nsteps) fetch(step + kGramPF, fa[(u + kGramPF) & 3], fb[DIAG ? 0 : ((u + kGramPF) & 3)]);
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    if (x < na) {
+                        if (DIAG) csum[x] += fa[u][x];
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) {
+                            if (y < nb && (!DIAG || x <= y))
+                                acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[u][x], DIAG ? fa[u][y] : fb[DIAG ? 0 : u][y], acc[x][y], 0, 0, 0);
+                        }
+                    }
+                }
             }
-        }
-        if (more) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) { a[x] = an[x]; b[x] = bn[x]; }
         }
     }
     // fixed-order reduction over the 4 waves through LDS (deterministic)
@@ -93,29 +95,69 @@ __global__ __launch_bounds__(256) void segment_gram_kernel(const double* __restr
                         if (w == 0) tile[i * kGramTile + j] = acc[x][y][r];
                         else tile[i * kGramTile + j] += acc[x][y][r];
                     }
+            if (DIAG) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    double v = csum[x];                  // rows kr, kr + 4, ... of this wave: add the 4 row groups in lane order
+                    const double v1 = __shfl(v, c + 16, kWave), v2 = __shfl(v, c + 32, kWave), v3 = __shfl(v, c + 48, kWave);
+                    v = ((__shfl(v, c, kWave) + v1) + v2) + v3;
+                    if (kr == 0) {
+                        double* sl = tile + kGramTile * kGramTile + 16 * x + c;
+                        if (w == 0) *sl = v; else *sl += v;
+                    }
+                }
+            }
         }
         __syncthreads();
     }
-    double* out = ws + (int64_t(seg) * chunks_per_seg + chunk) * int64_t(Dp) * Dp;
     for (int e = threadIdx.x; e < kGramTile * kGramTile; e += 256) {
         const int i = e >> 6, j = e & 63, gi = ti * kGramTile + i, gj = tj * kGramTile + j;
-        if (gi < Dp && gj < Dp) out[int64_t(gi) * Dp + gj] = tile[e];
+        if (gi < Dp && gj < Dp && (!DIAG || (i >> 4) <= (j >> 4))) out[int64_t(gi) * Dp + gj] = tile[e];
     }
+    if (DIAG && threadIdx.x < kGramTile && ti * kGramTile + threadIdx.x < Dp)
+        out[int64_t(Dp) * Dp + ti * kGramTile + threadIdx.x] = tile[kGramTile * kGramTile + threadIdx.x];
 }
 
-// G[seg][i][j] (Da x Da, Da = D + 1) = sum of the segment's partials in chunk order; lower-triangle tiles mirrored
+// grid: x = tile pair (fastest: the workgroups that read the same rows are dispatched together, so all but the first read
+// of a row chunk are served by the L2 / Infinity Cache), y = chunk inside the segment, z = segment
+__global__ __launch_bounds__(256, 2) void segment_gram_kernel(const double* __restrict__ B, int64_t ldb, int D,
+                                                              const int64_t* __restrict__ seg_ptr, int chunks_per_seg, int chunk_rows,
+                                                              double* __restrict__ ws, int Dp, int ntile) {
+    __shared__ double tile[kGramTile * kGramTile + kGramTile];
+    const int seg = blockIdx.z, chunk = blockIdx.y;
+    const int64_t s1 = seg_ptr[seg + 1];
+    const int64_t r0 = seg_ptr[seg] + int64_t(chunk) * chunk_rows;
+    if (r0 >= s1) return;
+    const int64_t r1 = (r0 + chunk_rows < s1) ? r0 + chunk_rows : s1;
+    int ti = 0, z = blockIdx.x;
+    while (z >= ntile - ti) { z -= ntile - ti; ++ti; }
+    const int tj = ti + z;
+    double* out = ws + (int64_t(seg) * chunks_per_seg + chunk) * (int64_t(Dp) * Dp + Dp);
+    if (ti == tj) gram_tile<true>(B, ldb, D, r0, r1, ti, tj, Dp, out, tile);
+    else gram_tile<false>(B, ldb, D, r0, r1, ti, tj, Dp, out, tile);
+}
+
+// G[seg] (Da x Da, Da = D + 1): Gram entries = sum of the segment's partials in chunk order (upper-triangle element mirrored),
+// row / column D = the column sums, G[D][D] = the row count
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ ws, const int64_t* __restrict__ seg_ptr,
-                                                          int chunks_per_seg, int Dp, int Da, double* __restrict__ G) {
+                                                          int chunks_per_seg, int chunk_rows, int Dp, int Da, double* __restrict__ G) {
     const int seg = blockIdx.y;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= Da * Da) return;
+    const int D = Da - 1;
     const int i = e / Da, j = e % Da;
-    const int si = (i / kGramTile <= j / kGramTile) ? i : j, sj = (i / kGramTile <= j / kGramTile) ? j : i;
     const int64_t rows = seg_ptr[seg + 1] - seg_ptr[seg];
-    const int nchunk = int((rows + kGramRows - 1) / kGramRows);
-    const double* p = ws + int64_t(seg) * chunks_per_seg * int64_t(Dp) * Dp + int64_t(si) * Dp + sj;
-    double s = 0.0;
-    for (int cidx = 0; cidx < nchunk; ++cidx) s += p[int64_t(cidx) * Dp * Dp];
+    double s;
+    if (i == D && j == D) {
+        s = double(rows);
+    } else {
+        const int nchunk = int((rows + chunk_rows - 1) / chunk_rows);
+        const int64_t stride = int64_t(Dp) * Dp + Dp;
+        const int lo = min(i, j), hi = max(i, j);
+        const double* p = ws + int64_t(seg) * chunks_per_seg * stride + (hi == D ? int64_t(Dp) * Dp + lo : int64_t(lo) * Dp + hi);
+        s = 0.0;
+        for (int cidx = 0; cidx < nchunk; ++cidx) s += p[int64_t(cidx) * stride];
+    }
     G[int64_t(seg) * Da * Da + e] = s;
 }
 
@@ -189,12 +231,11 @@ extern "C" {
 
 int hwer_gram_padded_dim(int D) { return D < 1 ? -1 : gram_padded(D); }
 
-static inline int gram_chunks(int64_t max_seg_rows) { return int((max_seg_rows + kGramRows - 1) / kGramRows); }
-
 size_t hwer_segment_gram_workspace_bytes(int D, int n_seg, int64_t max_seg_rows) {
     if (D < 1 || n_seg < 1 || max_seg_rows < 1) return 0;
     const size_t Dp = size_t(gram_padded(D));
-    return size_t(n_seg) * size_t(gram_chunks(max_seg_rows)) * Dp * Dp * sizeof(double);
+    const int rows = gram_chunk_rows(D, n_seg, max_seg_rows);
+    return size_t(n_seg) * size_t((max_seg_rows + rows - 1) / rows) * (Dp * Dp + Dp) * sizeof(double);
 }
 
 int hwer_segment_gram_f64(const double* B, int64_t ldb, int D, const int64_t* seg_ptr, int n_seg, int64_t max_seg_rows,
@@ -203,18 +244,18 @@ int hwer_segment_gram_f64(const double* B, int64_t ldb, int D, const int64_t* se
     if (!B || !seg_ptr || !G || !workspace) return fail(HWER_EINVAL, "segment_gram: null pointer");
     if (D < 1 || D > 4095 || ldb < D) return fail(HWER_EINVAL, "segment_gram: bad D=%d / ldb=%lld", D, (long long)ldb);
     if (n_seg < 0 || n_seg > 65535 || max_seg_rows < 1) return fail(HWER_EINVAL, "segment_gram: bad n_seg=%d / max_seg_rows=%lld", n_seg, (long long)max_seg_rows);
-    const int chunks = gram_chunks(max_seg_rows);
+    const int chunk_rows = gram_chunk_rows(D, n_seg, max_seg_rows);
+    const int chunks = int(std::min<int64_t>((max_seg_rows + chunk_rows - 1) / chunk_rows, 1 << 20));
     if (chunks > 65535) return fail(HWER_EINVAL, "segment_gram: segment too long (%lld rows)", (long long)max_seg_rows);
     if (workspace_bytes < hwer_segment_gram_workspace_bytes(D, n_seg, max_seg_rows)) return fail(HWER_EWORKSPACE, "segment_gram: workspace too small");
     const int Dp = gram_padded(D), Da = D + 1;
     const int ntile = (Dp + kGramTile - 1) / kGramTile;
-    const int npair = ntile * (ntile + 1) / 2;
-    hipLaunchKernelGGL(segment_gram_kernel, dim3(chunks, n_seg, npair), dim3(256), 0, as_stream(stream), B, ldb, D, seg_ptr, chunks,
-                       static_cast<double*>(workspace), Dp, ntile);
+    hipLaunchKernelGGL(segment_gram_kernel, dim3(ntile * (ntile + 1) / 2, chunks, n_seg), dim3(256), 0, as_stream(stream), B, ldb, D, seg_ptr,
+                       chunks, chunk_rows, static_cast<double*>(workspace), Dp, ntile);
     int rc = check_launch("segment_gram");
     if (rc) return rc;
     hipLaunchKernelGGL(gram_reduce_kernel, dim3((Da * Da + 255) / 256, n_seg), dim3(256), 0, as_stream(stream),
-                       static_cast<const double*>(workspace), seg_ptr, chunks, Dp, Da, G);
+                       static_cast<const double*>(workspace), seg_ptr, chunks, chunk_rows, Dp, Da, G);
     return check_launch("gram_reduce");
 }
 

@@ -120,13 +120,21 @@ def main():
             ws = torch.empty(wsb // 8, dtype=torch.float64, device=dev)
             fn = lambda: native.check(lib.hwer_segment_gram_f64(P(B), D, D, P(seg), nseg, 65536, P(G), P(ws), wsb, S()), "gram")  # noqa: E731
             ms = timeit(torch, fn, iters=5, warmup=1)
-            Da = D + 1
-            flops = 2.0 * N * Da * Da            # algorithmic: the full (D+1)^2 Gram of every row
-            nt = (lib.hwer_gram_padded_dim(D) + 63) // 64
-            issued = 2.0 * N * (nt * (nt + 1) // 2) * 64 * 64
+            # algorithmic work: a symmetric Gram of [B | 1] needs (D+1)(D+2)/2 multiply-adds per row; the kernel issues whole
+            # 16 x 16 MFMA sub-tiles of the upper triangle (diagonal 64-tiles: 10 of 16, off-diagonal: 16) and re-reads the
+            # rows once per 64-column tile pair
+            flops = 1.0 * N * (D + 1) * (D + 2)
+            dp = lib.hwer_gram_padded_dim(D)
+            nt = (dp + 63) // 64
+            sub = [min(4, (dp - 64 * t) // 16) for t in range(nt)]
+            issued_sub = sum(x * (x + 1) // 2 for x in sub) + sum(sub[i] * sub[j] for i in range(nt) for j in range(i + 1, nt))
+            issued = 2.0 * N * issued_sub * 256
+            cols_read = sum(16 * x for x in sub) + sum(16 * (sub[i] + sub[j]) for i in range(nt) for j in range(i + 1, nt))
             print(json.dumps({"kernel": "segment_gram_f64 + reduce", "case": "%d rows x %d features, %d segments" % (N, D, nseg), "ms": ms,
                               "TFs_algorithmic": flops / ms / 1e9, "frac_f64_mfma": flops / ms / 1e9 / F64_PEAK_TF,
-                              "TFs_issued_upper_tiles": issued / ms / 1e9, "hbm_GBs": 8.0 * N * D / ms / 1e6, "workspace_MB": wsb / 1e6}))
+                              "TFs_issued": issued / ms / 1e9, "frac_issued": issued / ms / 1e9 / F64_PEAK_TF,
+                              "hbm_GBs_algorithmic": 8.0 * N * D / ms / 1e6, "read_GBs_incl_rereads": 8.0 * N * cols_read / ms / 1e6,
+                              "workspace_MB": wsb / 1e6}))
             npad = lib.hwer_pca_padded_components(n)
             Pm = torch.zeros((D, npad), dtype=torch.float64, device=dev)
             Pm[:, :n] = torch.randn((D, n), generator=g, device=dev, dtype=torch.float64)
