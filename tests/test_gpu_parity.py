@@ -902,3 +902,57 @@ def test_content_recommendation_fit_g12_small(golden, hw):
     final = model.fit(nodes, edges, node_data)
     assert final.shape == g["small_final"].shape
     assert np.abs(final - g["small_final"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=500, dims=[9], n=4, seed=1),                              # one node type (constant one-hot column)
+    dict(N=3000, dims=[3, 1, 17, 6], n=None, seed=2, zero=[1]),      # four types, one without features, n_dims = inf
+    dict(N=65536 + 5, dims=[4, 5], n=8, seed=3),                     # short last batch folded into the first (one batch)
+    dict(N=65536 + 8, dims=[4, 5], n=8, seed=4),                     # ... and the smallest second batch (8 rows)
+    dict(N=140000, dims=[20, 12, 7], n=16, seed=5),                  # three batches
+    dict(N=20000, dims=[70, 40], n=64, seed=6),                      # wide blocks: two 64-column tiles, 4 MFMA column tiles
+])
+def test_fit_feature_table_vs_oracle_shapes(hw, case):
+    """Device fit-side path vs the oracle's SVD restatement (itself pinned by G12) over table shapes / batch structures.
+    Tolerance 1e-8 on the float64 rows, components compared up to the sign where the oracle's own sign is a near-tie."""
+    from hwer.fit_pca import device_feature_table
+    rng = np.random.default_rng(case["seed"])
+    N, dims = case["N"], case["dims"]
+    T = len(dims)
+    tid = rng.integers(0, T, N)
+    blocks = []
+    for t in range(T):
+        nt = int((tid == t).sum())
+        if t in case.get("zero", []):
+            blocks.append(np.zeros((nt, 1)))
+        else:
+            # anisotropic features: well-separated principal directions (isotropic noise has no preferred basis to compare)
+            f = rng.standard_normal((nt, dims[t])) * (1.0 + np.arange(dims[t]))[None, :] ** -0.5
+            blocks.append(orc.unit_length(f, axis=1))
+    order = list(rng.permutation(T))
+    det = {}
+    E32, E64, D = device_feature_table(blocks, tid, case["n"], block_order=order, want_f64=True, details=det)
+    W = sum(b.shape[1] for b in blocks) + T
+    n = case["n"] if case["n"] is not None else 2 ** int(np.log2(W))
+    table = np.zeros((N, W))
+    c = 0
+    for t in order:
+        table[np.flatnonzero(tid == t), c:c + blocks[t].shape[1]] = blocks[t]
+        c += blocks[t].shape[1]
+    table[np.arange(N), W - T + tid] = 1.0
+    scores, comps, mean, sv = orc.incremental_pca_fit_transform(table, n)
+    assert det["batches"] == orc.pca_batches(N, 2 ** 16, n)
+    keep = sv > 1e-6 * sv[0]                                          # directions with variance (a null direction has no defined basis)
+    sign = np.sign((det["components"] * comps).sum(1))
+    sign[sign == 0] = 1.0
+    assert np.all(sign[keep & ~_sign_ties(comps)] == 1.0)
+    assert np.abs(det["singular_values"] - sv).max() <= 1e-7 * sv[0]
+    assert np.abs((det["components"] * sign[:, None] - comps)[keep]).max() <= 1e-8
+    Eo, _ = orc.fit_feature_table(blocks, tid, n, order)
+    e64 = E64.cpu().numpy()
+    if keep.all():
+        assert np.abs(e64[:, :n] * sign - Eo[:, :n]).max() <= 1e-8
+    ncol = 2 ** int(np.ceil(np.log2(T)))
+    assert D == n + ncol
+    assert np.array_equal(e64[:, n:D], Eo[:, n:])                     # one-hot columns
+    assert np.abs(E32.cpu().numpy()[:, :D] - e64[:, :D]).max() <= 6e-8
