@@ -167,9 +167,6 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     for (int b = 0; b < TQ; ++b) {
         const int64_t q = qw0 + 32 * b + r;
         const bool live = q < a.B;
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            qf[b][g] = reinterpret_cast<const float4*>(a.Q)[((qw0 / 32 + b) * NG + g) * 64 + lane];   // fragment order: 1 KiB per instruction
         tau[b] = (live && !a.debug_nofilter) ? a.debug_tau0 : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
         first[b] = true;
@@ -228,7 +225,16 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     int p_cur = 0;                       // perm(t)
     int p_dma = perm_next(0);            // perm(t + 1), then perm(t + 2) while tile t is computed
     if (n_tiles > 0) tile_dma(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The query fragments are requested AFTER the first tile: vmcnt retires in issue order, so waiting for "all but the
+    // TQ * NG fragment loads" means the tile has landed, and the first tile's MFMAs start as soon as their own fragments
+    // arrive (the compiler's per-register waits) instead of after the whole 32-KiB-per-wave prologue.
+    static_assert(TQ * NG <= 63, "vmcnt immediate");
+#pragma unroll
+    for (int b = 0; b < TQ; ++b)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            qf[b][g] = reinterpret_cast<const float4*>(a.Q)[((qw0 / 32 + b) * NG + g) * 64 + lane];   // fragment order: 1 KiB per instruction
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TQ * NG) : "memory");
     __syncthreads();   // tile 0 has landed for every wave
     if (n_tiles > 1) tile_dma(1, p_dma);
     p_dma = perm_next(p_dma);
