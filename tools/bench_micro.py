@@ -107,8 +107,10 @@ def main():
     if "fit" in what:
         # ---- fit-side table construction: segmented Gram + projection, float64 MFMA -----------------
         # one node type, N rows of D features, 2**16-row batches (IncrementalPCA's), n components.  Roofline: float64 MFMA
-        # (v_mfma_f64_16x16x4_f64; 78.6 TF is AMD's MI355X data-sheet FP64 matrix figure - the guide has no f64 row).
-        F64_PEAK_TF = 78.6
+        # (v_mfma_f64_16x16x4_f64).  The guide has no float64 MFMA row; tools/ubench/mfma_f64_rate.hip measures back-to-back
+        # issue at ~128 cycles per MFMA per SIMD (profiles/r1_ubench_mfma_f64_rate.txt: 34-45 TFLOP/s over the chip), i.e.
+        # 16 flop / clk / SIMD = 39.3 TF at 2.4 GHz - half of the 78.6 TF data-sheet figure.  39.3 TF is the peak used here.
+        F64_PEAK_TF = 39.3
         for (N, D, n) in [(1 << 20, 64, 32), (1 << 22, 128, 64), (1 << 21, 256, 128)]:
             g = torch.Generator(device=dev).manual_seed(N % 1000 + D)
             B = torch.randn((N, D), generator=g, device=dev, dtype=torch.float64)
