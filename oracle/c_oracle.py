@@ -58,3 +58,21 @@ def pair_score_f64(V32, src, dst, threads=1):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def effective_cpus():
+    """Threads worth starting: min(os.cpu_count(), affinity mask, cgroup CPU quota).  A GPU box shows all 256 host CPUs but
+    caps the container at 16: OpenMP with 256 threads then runs several times SLOWER than with 16."""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n

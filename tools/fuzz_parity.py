@@ -35,7 +35,7 @@ def main():
     Ns = [1, 5, 31, 32, 33, 1000, 4095, 8191, 8192, 8193, 8300, 12000, 20000, 40000, 70000]
     ds = [1, 3, 8, 17, 31, 32, 33, 64, 66, 100, 128, 129, 200, 256]
     ks = [1, 2, 10, 64, 100, 200, 256, 392]
-    cores = os.cpu_count() or 1
+    cores = c_oracle.effective_cpus()
     bad = 0
     for case in range(args.cases):
         while True:

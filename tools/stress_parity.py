@@ -48,7 +48,7 @@ def main():
     ]
     if args.quick:
         cases = cases[:2] + cases[4:6]
-    cores = os.cpu_count() or 1
+    cores = c_oracle.effective_cpus()
     bad = 0
     for name, B, N, d, k, clustered in cases:
         users = unit_rows(1, B, d)
