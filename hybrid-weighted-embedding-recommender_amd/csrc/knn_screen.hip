@@ -484,9 +484,10 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     p.kprime = ((k + SLACK + 63) / 64) * 64;
     // queries per wave: TQ = 2 subtiles (64 queries, 256 per workgroup) while the B fragments fit the register budget
     // (NG * TQ float4 <= 32 float4) AND the query blocks alone fill the 512 workgroup slots.  Below that (B <= 65 536) the
-    // launch is split over the items anyway, and TQ = 1 is the better trade: half the fragment registers -> 3 instead of 2
-    // workgroups per CU (more of the filter / DMA phases hidden under another wave's MFMAs), half the item splits -> half the
-    // candidate lists the select stage reduces (C4, 4 096 x 1.25 M: screen 12.5 -> 11.9 ms, select 1.0 -> 0.56 ms).
+    // launch is split over the items anyway, and TQ = 1 is the better trade: twice the query blocks -> half the item splits
+    // -> half the candidate lists the select stage reduces, and shorter per-wave filter / DMA phases between the MFMA
+    // phases (measured, C4 4 096 x 1.25 M: screen 12.5 -> 11.9 ms, select 1.0 -> 0.56 ms; a third resident workgroup per
+    // CU - 168 VGPRs - was measured too and does not help).
     p.tq = (p.ng <= 16 && B > 65536) ? 2 : 1;
     if (const char* e = getenv("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : p.tq;   // tuning override
     const int qpw = 32 * p.tq;
