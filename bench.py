@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep-only", action="store_true",
+                    help="profiling runs: skip the one-anchor latency and pair-score measurements after the timed region, so that every "
+                         "launch of a kernel in a rocprofv3 summary is a launch of the timed sweep")
     ap.add_argument("--cpu-sample", type=int, default=0, help="users in the CPU-baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -343,7 +346,7 @@ def main():
     }
 
     # ---------------- per-query latency: one anchor against this rank's catalogue, outside the timed region ----
-    if world == 1:
+    if world == 1 and not args.sweep_only:
         ws1 = torch.empty(lib.hwer_knn_workspace_bytes(1, I, d, K), dtype=torch.uint8, device=dev)
 
         def one_query():

@@ -12,13 +12,13 @@ for c in ["c1", "c2", "c3", "c4", "c5"]:
     shutil.copy(f"{src}/bench_{c}.json", f"profiles/r1_bench_{c}_{ver}.json")
 for c in ["c2", "c3"]:
     j = json.load(open(f"{src}/stats_{c}_bench.json"))
-    hdr = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --config {c} --no-cpu-baseline   (MI355X, round 1, final kernels; tools/profile_round.sh)",
-           "# (calls beyond 55 per kernel - 5 warm-up + 50 timed steps - come from the one-anchor latency and pair-score loops after the timed region)",
+    hdr = [f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --config {c} --no-cpu-baseline --sweep-only   (MI355X, round 1, final kernels; tools/profile_round.sh)",
+           "# (55 calls per kernel = 5 warm-up + 50 timed steps; --sweep-only skips the one-anchor latency and pair-score loops after the timed region)",
            "# bench line under the profiler: ms_per_step=%.3f roofline=%s" % (j["ms_per_step"], json.dumps(j["roofline"]))]
     open(f"profiles/r1_rocprof_stats_{c}.txt", "w").write(
         "\n".join(hdr) + "\n" + open(f"{src}/stats_{c}.txt").read() +
         "\n# per-step timeline (tools/trace_timeline.py): mean start offset / duration of every kernel of a step\n" + open(f"{src}/timeline_{c}.txt").read())
-    hdr = (f"# rocprofv3 --pmc <counter> -- python3 bench.py --config {c} --no-cpu-baseline --steps 3 --warmup 1  (one pass per counter; "
+    hdr = (f"# rocprofv3 --pmc <counter> -- python3 bench.py --config {c} --no-cpu-baseline --sweep-only --steps 3 --warmup 1  (one pass per counter; "
            "averages per launch; FETCH/WRITE_SIZE in KiB; final kernels)\n")
     open(f"profiles/r1_rocprof_pmc_{c}.txt", "w").write(hdr + open(f"{src}/pmc_{c}.txt").read())
 shutil.copy(f"{src}/micro.jsonl", "profiles/r1_micro_rowops_latency.jsonl")
