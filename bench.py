@@ -285,7 +285,7 @@ def main():
         # oracle query = unit(anchor) in numpy's own arithmetic
         from oracle import hwer_oracle as orc
         Qh = np.stack([orc.query_vector(V64, int(s)) for s in sel])
-        oi, osc, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=os.cpu_count())
+        oi, osc, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=effective_cpus()[0])
         assert np.array_equal(idx_h[sel], oi + U), "GPU indices differ from the oracle"
         assert np.array_equal(score_h[sel], osc), "GPU scores differ from the oracle"
         parity_n = len(sel)
@@ -308,7 +308,7 @@ def main():
             sel = np.unique(np.linspace(0, min(n_mine, U) - 1, 16).astype(np.int64))
             V64 = V[:U, :d].cpu().numpy().astype(np.float64)
             Qh = np.stack([orc.query_vector(V64, int(q)) for q in sel])
-            oi, osc, _ = c_oracle.find_closest_f64(items_h, Qh, V64[sel], K, threads=os.cpu_count())
+            oi, osc, _ = c_oracle.find_closest_f64(items_h, Qh, V64[sel], K, threads=effective_cpus()[0])
             assert np.array_equal(idx_h[sel], oi + U), "merged indices differ from the oracle (N = %d)" % world
             assert np.array_equal(score_h[sel], osc), "merged scores differ from the oracle (N = %d)" % world
             parity_n = len(sel)
