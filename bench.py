@@ -42,6 +42,7 @@ CONFIGS = {
 K = 200
 PROFILE_EVERY = 5
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PF dense BF16 / F16 (only priced against with --f16-screen)
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E 8 TB/s spec
 
 
@@ -88,6 +89,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f16-screen", action="store_true",
+                    help="HWER_KNN_F16_SCREEN: the streaming screen (catalogues above 8 192 rows) runs on a float16 copy of the table "
+                         "(rebuilt every step like the float32 one); results are unchanged.  Not the default: see DESIGN.md")
     ap.add_argument("--sweep-only", action="store_true",
                     help="profiling runs: skip the one-anchor latency and pair-score measurements after the timed region, so that every "
                          "launch of a kernel in a rocprofv3 summary is a launch of the timed sweep")
@@ -159,6 +163,8 @@ def main():
     I_pad = lib.hwer_knn_padded_rows(I)
     X = torch.empty((I_pad, ldx), dtype=torch.float32, device=dev)
     hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
+    f16_screen = bool(args.f16_screen) and I > 8192
+    X16 = torch.empty((I_pad, ldx), dtype=torch.float16, device=dev) if f16_screen else None
     Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
     Q32 = torch.empty((U, ldx), dtype=torch.float32, device=dev)
     # N > 1: two result sets, so that the exchange + merge of step i (side stream) overlaps the search of step i + 1
@@ -173,6 +179,7 @@ def main():
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     # rows passed the 1e-4 unit-norm audit (checked after the timed region) => 0.5||x||^2 <= 0.5 (1 + 1e-4)^2
     hnorm_max = 0.5 * (1.0 + 1e-4) ** 2
+    x16_exp = int(lib.hwer_knn_f16_scale_exp(hnorm_max)) if f16_screen else 0
     id_base = U + rank * I          # global row id of this rank's first item (users first, then shards in rank order)
     arith = 0                       # float64 score arithmetic (ContentRecommendation flavour)
     # find_closest_neighbours returns (node, score): distances are an output only where the shards' results are merged
@@ -183,15 +190,18 @@ def main():
         native.check(lib.hwer_blend_normalize_audit_f32(P(tab_ptrs), d, None, P(alpha), 1 if cfg["per_row"] else 0, T, N, d,
                                                         P(V), ldv, 1e-4, P(audit_counts), P(audit_dev), S()), "blend+audit")
         native.check(lib.hwer_pack_rows_f32(P(V), N, d, ldv, P(item_rows), I, P(X), ldx, P(hnorm), S()), "pack")
+        if f16_screen:
+            native.check(lib.hwer_pack_rows_f16(P(X), I_pad, ldx, x16_exp, P(X16), S()), "pack16")
         native.check(lib.hwer_query_mix(P(V), N, d, ldv, P(anchors), None, None, None, None, U, arith, P(Q64), P(Q32),
                                         ldx, S()), "query_mix")
         oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
         for b0 in range(0, U, CH):
             b1 = min(U, b0 + CH)
-            native.check(lib.hwer_knn_search_f32(P(X), P(hnorm), I, d, ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(V), ldv,
-                                                 P(anchors[b0:b1]), b1 - b0, K, arith, 1 if world == 1 else 0, None, id_base,
-                                                 hnorm_max, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if want_dist else None,
-                                                 P(of[b0:b1]), P(ws), ws.numel(), S()), "knn_search")
+            native.check(lib.hwer_knn_search_opts_f32(P(X), P(hnorm), I, d, ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(V), ldv,
+                                                      P(anchors[b0:b1]), b1 - b0, K, arith, 1 if world == 1 else 0, None, id_base,
+                                                      hnorm_max, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if want_dist else None,
+                                                      P(of[b0:b1]), P(ws), ws.numel(), 2 if f16_screen else 0,
+                                                      P(X16) if f16_screen else None, x16_exp, S()), "knn_search")
             # queries the screen could not certify (rare: near-ties at the cut, or a sample-scaled threshold that was too
             # tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the device (no host round trip):
             # the step always returns exact results.  `missed` counts listed queries beyond the 8 one call handles
@@ -334,11 +344,13 @@ def main():
         "metric": "user-item pairs/sec scored (blend + L2-normalise + exact top-%d retrieval)" % K,
         "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f16" if f16_screen else "f32", "data": "synthetic",
         "config": {"workload": cfg["name"], "users": U, "items_per_gpu": I, "items_total": total_items, "d": d, "k": K,
-                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "sharding": ("items row-sharded x%d, %s + merge, exchange of step i overlapped with the search of step i+1" % (world, "user-partitioned exchange" if exchange == "by_query" else "all-gather")) if world > 1 else "none"},
-        "roofline": {"kernel": "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)", "bound": "mfma",
-                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "f16_screen": f16_screen, "sharding": ("items row-sharded x%d, %s + merge, exchange of step i overlapped with the search of step i+1" % (world, "user-partitioned exchange" if exchange == "by_query" else "all-gather")) if world > 1 else "none"},
+        "roofline": {"kernel": ("knn_screen (v_mfma_f32_32x32x8_f16 on a float16 copy of the table + streaming top-K' filter; exact float64 re-rank)"
+                                if f16_screen else "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)"), "bound": "mfma",
+                     "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS if f16_screen else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / (MFMA_F16_PEAK_TFLOPS if f16_screen else MFMA_F32_PEAK_TFLOPS),
                      "traffic": traffic, "avg_launch_ms": screen_ms, "launches_per_step": launches},
         "kernels_ms": {"knn_screen": screen_ms, "knn_select_rerank": select_ms},
         "recall_latency_ms": ms_per_step, "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive,

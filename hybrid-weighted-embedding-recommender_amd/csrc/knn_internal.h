@@ -56,8 +56,19 @@ __device__ __forceinline__ void hdr_reset(WsHeader* hdr, int tid, int n_threads)
 static_assert(sizeof(WsHeader) <= WS_HEADER_BYTES, "header must fit its slot");
 constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
 
+// float16 screen inputs (HWER_KNN_F16_SCREEN): the float16 table, the float16 query fragments and their per-query exponents
+struct ScreenF16 {
+    const void* X16;
+    const void* Qf16;
+    const int32_t* qexp;
+    int x_exp;
+};
+bool screen_f16_supported(const ScreenPlan& plan);   // streaming mode, padded dim >= 64
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
-                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream);
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream,
+                  const ScreenF16* f16 = nullptr);
+// queries -> float16 MFMA fragments + per-query scale exponents (knn_small.hip); Qf16: bq * ng * 16 bytes, qexp: bq ints
+int repack_queries16(const float* Q32, int64_t B, int64_t bq, int ldx, void* Qf16, int32_t* qexp, hipStream_t stream);
 
 // LDS-DMA (global -> LDS without a register destination) issued through inline asm: hipcc counts a builtin
 // global_load_lds as a pending LDS write and drains vmcnt(0) before the NEXT ds_read, which would serialise the

@@ -17,6 +17,7 @@
 // HBM (streaming X once per query block) below that.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "knn_internal.h"
@@ -24,6 +25,7 @@
 namespace hwer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 
 struct ScreenArgs {
     const float* X;
@@ -46,6 +48,12 @@ struct ScreenArgs {
     float debug_tau0;    // ablation only (HWER_SCREEN_TAU0=x): thresholds start at x instead of -inf
     unsigned long long* debug_stamps;   // diagnostic build only (HWER_SCREEN_STAMPS=1): per-wave phase cycle sums
     WsHeader* hdr;       // workspace header: the uncertified-query list of this search starts empty
+    // float16 screen (F16 kernels; HWER_KNN_F16_SCREEN): the table scaled by 2^x_exp and rounded to float16, the queries in
+    // fragment order scaled per query by 2^qexp[q] (knn_small.hip: repack_queries16), see small_screen16_kernel
+    const void* X16;
+    const void* Qf16;
+    const int32_t* qexp;
+    int x_exp;
 };
 
 // sc1 load: served by L2, never by a stale L1 line
@@ -132,10 +140,15 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 #define STAMP(var) if (DIAG_STAMPS) { var = stamp(); }
 
-template <int NG, int TQ, bool DENSE>
+// F16: the item tiles come from the float16 copy of the table and the tile product runs on v_mfma_f32_32x32x8_f16 (float32
+// accumulation, a quarter of the MFMA cycles): keys are computed in per-query scaled units (thresholds too) and unscaled
+// when appended; the select stage widens its error bound by the float16 rounding (key_rel_err), re-ranks from the float32
+// rows in float64 as always, so the results are unchanged.  Streaming mode only.
+template <int NG, int TQ, bool DENSE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
+    static_assert(!(F16 && DENSE), "the float16 screen is a streaming-mode variant");
     constexpr int IB = 32;                         // item rows per tile = one 32-row MFMA subtile
-    constexpr int CH = 2 * NG;                     // 16-byte chunks per row
+    constexpr int CH = F16 ? NG : 2 * NG;          // 16-byte chunks per row
     constexpr int TILE_CHUNKS = IB * CH;
     constexpr int DMA_PER_WAVE = TILE_CHUNKS / 256 > 0 ? TILE_CHUNKS / 256 : 1;   // 1-KiB LDS-DMA pieces per wave and tile
     static_assert(TILE_CHUNKS % 64 == 0, "tile must be a whole number of 1-KiB pieces");
@@ -157,7 +170,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     float* keypark = keypark_all + wave * (64 * 16 * TQ);
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
-    float4 qf[TQ][NG];
+    using QF = typename std::conditional<F16, half4_t, float4>::type;
+    QF qf[TQ][NG];
+    int e_tot[TQ];       // F16: key scale of this lane's query (2^e_tot)
     float tau[TQ];
     int cnt[TQ];
     bool first[TQ], scaled[TQ];
@@ -168,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         const int64_t q = qw0 + 32 * b + r;
         const bool live = q < a.B;
         tau[b] = (live && !a.debug_nofilter) ? a.debug_tau0 : INFINITY;  // strict '>' filter: dead queries never append
+        e_tot[b] = F16 ? a.x_exp + a.qexp[q] : 0;                        // qexp has bq entries
         cnt[b] = 0;
         first[b] = true;
         scaled[b] = false;
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // Per-lane byte offset of this lane's chunk inside a tile (piece 0); piece i adds i * PIECE_ROWS rows.
     constexpr int PIECE_ROWS = 64 / CH > 0 ? 64 / CH : 1;        // rows covered by one 1-KiB piece (CH <= 64)
     static_assert(CH <= 64, "one LDS-DMA piece must hold at least one whole row");
-    const uint32_t row_bytes = uint32_t(a.ldx) * 4u;
+    const uint32_t row_bytes = uint32_t(a.ldx) * (F16 ? 2u : 4u);
     // Piece p = wave + 4 i covers rows p * PIECE_ROWS + lane / CH.  For CH >= 16 the swizzle is row & 15 and
     // PIECE_ROWS * 4 is a multiple of ... handled generically: the offset of piece i is recomputed from two lane
     // constants with 32-bit integer ops only (v_mad_u32_u24-class: row < 32, row_bytes <= 1024).
@@ -202,7 +218,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     static_assert(TILE_CHUNKS % 256 == 0, "every wave issues the same number of pieces");
     const uint32_t xs_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(xs)) + uint32_t(wave) * 1024u;
     const uint32_t hn_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(hn));
-    const char* const x_split = reinterpret_cast<const char*>(a.X + i_begin * a.ldx);
+    const char* const x_split = F16 ? reinterpret_cast<const char*>(a.X16) + i_begin * a.ldx * 2
+                                    : reinterpret_cast<const char*>(a.X + i_begin * a.ldx);
     const float* const hn_split = a.hnorm + i_begin;
     const uint32_t tile_bytes = uint32_t(IB) * row_bytes;
     auto tile_dma = [&](int t, int ptile) {
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     for (int b = 0; b < TQ; ++b)
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-            qf[b][g] = reinterpret_cast<const float4*>(a.Q)[((qw0 / 32 + b) * NG + g) * 64 + lane];   // fragment order: 1 KiB per instruction
+            qf[b][g] = reinterpret_cast<const QF*>(F16 ? a.Qf16 : static_cast<const void*>(a.Q))[((qw0 / 32 + b) * NG + g) * 64 + lane];   // fragment order: 1 KiB (float16: 512 B) per instruction
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TQ * NG) : "memory");
     __syncthreads();   // tile 0 has landed for every wave
     if (n_tiles > 1) tile_dma(1, p_dma);
@@ -256,12 +273,36 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
+                    if constexpr (F16) {   // scaled units: exact (powers of two)
+                        acc[b][4 * rg + 0] = -ldexpf(hv.x, e_tot[b]);
+                        acc[b][4 * rg + 1] = -ldexpf(hv.y, e_tot[b]);
+                        acc[b][4 * rg + 2] = -ldexpf(hv.z, e_tot[b]);
+                        acc[b][4 * rg + 3] = -ldexpf(hv.w, e_tot[b]);
+                    } else {
                     acc[b][4 * rg + 0] = -hv.x;
                     acc[b][4 * rg + 1] = -hv.y;
                     acc[b][4 * rg + 2] = -hv.z;
                     acc[b][4 * rg + 3] = -hv.w;
+                    }
                 }
             }
+            if constexpr (F16) {
+                // A fragment of k-group g: the 8 bytes of half h of logical chunk g of row r, stored at chunk g ^ swz(r)
+                int sw = swz<CH>(r);
+                asm volatile("" : "+v"(sw));
+                const unsigned char* abase = reinterpret_cast<const unsigned char*>(xb) + r * (NG * 16) + 8 * h;
+                auto a_ptr = [&](int g) { return abase + 16 * (g ^ sw); };
+                half4_t av_next = *reinterpret_cast<const half4_t*>(a_ptr(0));
+                __builtin_amdgcn_s_setprio(0);
+                STAMP(t1);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const half4_t av = av_next;
+                    if (g + 1 < NG) av_next = *reinterpret_cast<const half4_t*>(a_ptr(g + 1));
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x8f16(av, qf[b][g], acc[b], 0, 0, 0);
+                }
+            } else {
             // A fragment of k-group g: logical chunk 2g + h of row r, stored at chunk (2g + h) ^ swz(r).
             // (2g + h) ^ sw = 2 (g ^ (sw >> 1)) + (h ^ (sw & 1)), and XOR-ing g with a 3-bit value only touches g's low
             // three bits: the address is lane_base + 32 B * ((g & 7) ^ swh) + 256 B * (g >> 3).  `swh` is made opaque to
@@ -290,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, qf[b][g].z, acc[b], 0, 0, 0);
                     acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qf[b][g].w, acc[b], 0, 0, 0);
                 }
+            }
             }
             __builtin_amdgcn_s_setprio(3);
             if (DIAG_STAMPS) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
@@ -340,7 +382,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                         const int bit = __builtin_ctz(mask);
                         mask &= mask - 1u;
                         const int q = 15 - (bit & 15);
-                        const uint64_t key = pack_key(park[((bit & 16) + q) * 64], item0 + (q & 3) + 8 * (q >> 2));
+                        float kval = park[((bit & 16) + q) * 64];
+                        if constexpr (F16) kval = ldexpf(kval, -((TQ == 2 && (bit & 16)) ? e_tot[TQ - 1] : e_tot[0]));   // back to real units (exact)
+                        const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
                         if constexpr (TQ == 1) {
                             wg_cand[soff[0] + uint32_t(cnt[0])] = key;
                             ++cnt[0];
@@ -410,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 // in-loop compactions may keep up to 32 keys more than asked (a stream then holds <= K' + 32 <= CAPH - 32)
                 compact_query(s0, s0 + CAPH, c0, c1, rank, rank == a.kprime ? COMPACT_SLACK : min(COMPACT_SLACK, rank / 4 + 1), T, n0, n1);
                 if (r == jj) {
-                    tau[b] = T;
+                    tau[b] = F16 ? ldexpf(T, e_tot[b]) : T;   // the filter compares in the query's scaled units
                     cnt[b] = h == 0 ? n0 : n1;
                     scaled[b] = scaled[b] || (rank != a.kprime);
                     first[b] = false;
@@ -530,6 +574,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     return p;
 }
 
+bool screen_f16_supported(const ScreenPlan& plan) { return !plan.dense && plan.ng >= 8; }
+
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | key park 4 x 64 x 16 TQ
@@ -550,9 +596,25 @@ template <int NG, int TQ>
 static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     return plan.dense ? launch_screen_t2<NG, TQ, true>(plan, a, stream) : launch_screen_t2<NG, TQ, false>(plan, a, stream);
 }
+// float16 screen (streaming mode): tiles of 32 rows x NG 16-byte chunks
+template <int NG, int TQ>
+static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
+    const size_t lds = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done = true;
+    }
+    const int grid = plan.n_qblocks * plan.n_splits;
+    hipLaunchKernelGGL((screen_kernel<NG, TQ, false, true>), dim3(grid), dim3(256), lds, stream, a);
+    return check_launch("knn_screen16");
+}
 
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
-                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream) {
+                  const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream,
+                  const ScreenF16* f16) {
     static unsigned long long* dbg = nullptr;
     static int dbg_grid = 0;
 #ifndef HWER_DIAG_STAMPS
@@ -573,8 +635,20 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     }
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? atoi(getenv("HWER_SCREEN_NOFILTER")) : 0,
-                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY, getenv("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr};
+                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY, getenv("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
+                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0};
     const int key = plan.ng * 10 + plan.tq;
+    if (f16) {
+        if (plan.dense) return fail(HWER_EINVAL, "knn_screen16: streaming mode only");
+        switch (key) {
+            case 81: return launch_screen16_t<8, 1>(plan, a, stream);
+            case 82: return launch_screen16_t<8, 2>(plan, a, stream);
+            case 161: return launch_screen16_t<16, 1>(plan, a, stream);
+            case 162: return launch_screen16_t<16, 2>(plan, a, stream);
+            case 321: return launch_screen16_t<32, 1>(plan, a, stream);
+            default: return fail(HWER_EINVAL, "knn_screen16: unsupported padded dim %d / tq %d", plan.ng * 8, plan.tq);
+        }
+    }
     switch (key) {
         case 41: return launch_screen_t<4, 1>(plan, a, stream);
         case 42: return launch_screen_t<4, 2>(plan, a, stream);

@@ -415,6 +415,7 @@ struct SelectArgs {
     int kprime;
     int kcap;     // LDS capacity of the re-rank tables (= K')
     float hnorm_max;
+    float key_rel_err;   // extra |key error| / (||q|| ||x||max) of the screen that produced the keys (float16 screen: ~2^-10)
     EmitArgs emit;
 };
 
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256, 4) void select_rerank_kernel(const SelectArgs 
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
     }
-    const float e32 = e32_bound(d, Q2, a.hnorm_max);
+    const float e32 = e32_bound(d, Q2, a.hnorm_max) + a.key_rel_err * float(sqrt(Q2)) * sqrtf(2.0f * a.hnorm_max) * 1.0001f;
     const float thr = t_k - 2.0f * e32;
     // provable members ("sure"): key32 >= s with count(key32 >= s - 2 E32) < k - such an item cannot be beaten by k others
     const float s_sure = lazy_ok ? t_hi + 2.0f * e32 : INFINITY;
@@ -1412,10 +1413,19 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     int rc;
     prof_next_call();
     float* qf = reinterpret_cast<float*>(ws + w.qf);
-    if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) return rc;
+    // float16 screen (option, streaming mode): float16 query fragments in the first half of the fragment area, the per-query
+    // exponents in the second half (bq ints <= bq * ng * 16 bytes)
+    const bool f16_screen = (options & HWER_KNN_F16_SCREEN) != 0 && X16 != nullptr && screen_f16_supported(plan);
+    ScreenF16 f16{X16, qf, reinterpret_cast<const int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), x16_exp};
+    if (f16_screen) {
+        if ((rc = repack_queries16(Q32, B, plan.bq, int(ldx), qf, reinterpret_cast<int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), st))) return rc;
+    } else if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) {
+        return rc;
+    }
     {
         ProfScope ps(0, st);
-        rc = launch_screen(plan, X, hnorm, n_items, ldx, qf, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st);
+        rc = launch_screen(plan, X, hnorm, n_items, ldx, qf, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st,
+                           f16_screen ? &f16 : nullptr);
     }
     if (rc) return rc;
     ProfScope ps_select(1, st);
@@ -1473,6 +1483,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     sa.kprime = plan.kprime;
     sa.kcap = plan.kprime;   // the screen's final compaction is exact: a list holds at most K' keys
     sa.hnorm_max = hnorm_max;
+    sa.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;   // two float16 roundings per product (2^-11 each), as in the small-batch path
     sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, hdr};
     return launch_select_rerank(sa, d, score_mode, st);

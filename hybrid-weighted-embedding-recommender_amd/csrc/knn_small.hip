@@ -546,6 +546,12 @@ static int launch_small_screen16(const SmallPlan& p, const Small16Args& a, hipSt
     return check_launch("knn_small(screen16)");
 }
 
+int repack_queries16(const float* Q32, int64_t B, int64_t bq, int ldx, void* Qf16, int32_t* qexp, hipStream_t stream) {
+    hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(bq / 32)), dim3(256), 0, stream, Q32, B, ldx, ldx / 8,
+                       reinterpret_cast<half4_t*>(Qf16), qexp);
+    return check_launch("knn_repack_queries16");
+}
+
 int f16_scale_exp(float hnorm_max) {
     // largest power of two that keeps every element of a row (|x_i| <= ||x|| <= sqrt(2 hnorm_max)) below 2^14 after scaling
     const float xmax = sqrtf(2.0f * hnorm_max) * 1.0001f;

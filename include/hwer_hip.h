@@ -185,6 +185,11 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
  * uncertified on genuine near-ties: the retry tier for catalogues whose row order defeats the sampling (e.g. sorted by
  * cluster), before the exhaustive pass.  Workspace size: hwer_knn_workspace_bytes_opts with the same options. */
 #define HWER_KNN_EXACT_THRESHOLDS 1u
+/* HWER_KNN_F16_SCREEN (needs X16): the streaming screen (large catalogues, more than 1 024 queries) also runs on the float16
+ * copy of the table - v_mfma_f32_32x32x8_f16, a quarter of the MFMA cycles - instead of only the small-batch path.  The select
+ * stage widens its error bound by the float16 rounding and re-ranks from the float32 rows, so the results are identical;
+ * a few more queries may come back uncertified (flag 0) on near-ties and take the exhaustive pass.  Off by default. */
+#define HWER_KNN_F16_SCREEN 2u
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
 int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,

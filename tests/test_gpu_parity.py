@@ -956,3 +956,42 @@ def test_fit_feature_table_vs_oracle_shapes(hw, case):
     assert D == n + ncol
     assert np.array_equal(e64[:, n:D], Eo[:, n:])                     # one-hot columns
     assert np.abs(E32.cpu().numpy()[:, :D] - e64[:, :D]).max() <= 6e-8
+
+
+# ------------------------------------------------------------------------------------------------- float16 streaming screen
+@pytest.mark.parametrize("d,N,B,k,splits", [
+    (128, 30000, 2100, 200, "item splits, TQ = 1"),
+    (64, 20000, 3000, 50, "d = 64"),
+    (256, 16000, 1500, 100, "d = 256"),
+    (100, 12000, 1100, 10, "padded dim"),
+    (128, 9000, 70000, 200, "one list, TQ = 2"),
+])
+def test_knn_f16_streaming_screen_is_invisible(hw, monkeypatch, d, N, B, k, splits):
+    """HWER_KNN_F16_SCREEN: the streaming screen on the float16 copy of the table (v_mfma_f32_32x32x8_f16) must return the
+    same ids / scores / distances as the float32 screen and the oracle - bit for bit; non-unit row norms included.
+    (HWER_NO_SMALL keeps these modest shapes on the streaming path: by default launches that cannot fill the machine are
+    routed through the dense-key small-batch path.)"""
+    from hwer.device_index import DeviceIndex
+    monkeypatch.setenv("HWER_NO_SMALL", "1")
+    X = unit_rows_f32(135 + d, N, d)
+    X[::7] *= np.float32(1.00004)                      # row norms off 1 by up to 4e-5 (inside the audit's 1e-4)
+    users = unit_rows_f32(136 + d, B, d)
+    V = np.concatenate([users, X]).astype(np.float64)
+    type_rows = {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}
+    res = []
+    for f16 in (True, False):
+        ix = DeviceIndex(V, type_rows, arith=0)
+        ix.f16_screen = f16
+        res.append(ix.search("item", np.arange(B), k=k))
+        assert (ix.tables["item"].X16 is not None) == f16
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b)
+    assert (res[0][3] > 0).all()                       # certified (1) or recomputed exhaustively (2): always exact
+    assert (res[0][3] == 1).mean() > 0.98
+    from oracle import c_oracle
+    Q = V[:B] / np.linalg.norm(V[:B], axis=1, keepdims=True)
+    sel = np.arange(0, B, max(1, B // 64))
+    Qs = np.stack([orc.query_vector(V, int(u)) for u in sel])
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(X, Qs, V[sel], k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(res[0][0][sel], o_idx + B) and np.array_equal(res[0][1][sel], o_sc)
+    assert np.array_equal(res[0][2][sel] ** 2, o_d2) or np.allclose(res[0][2][sel], np.sqrt(o_d2), rtol=0, atol=0)
