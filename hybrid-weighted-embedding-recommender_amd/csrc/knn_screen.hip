@@ -533,7 +533,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     // phases (measured, C4 4 096 x 1.25 M: screen 12.5 -> 11.9 ms, select 1.0 -> 0.56 ms; a third resident workgroup per
     // CU - 168 VGPRs - was measured too and does not help).
     p.tq = (p.ng <= 16 && B > 65536) ? 2 : 1;
-    if (const char* e = getenv("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : p.tq;   // tuning override
+    if (const char* e = getenv("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : ((atoi(e) == 2 && p.ng <= 16 && B > 32) ? 2 : p.tq);   // tuning override
     const int qpw = 32 * p.tq;
     p.wq = B > 2 * qpw ? 4 : (B > qpw ? 2 : 1);
     p.qb = p.wq * qpw;
