@@ -366,8 +366,9 @@ def main():
         ws1 = torch.empty(lib.hwer_knn_workspace_bytes(1, I, d, K), dtype=torch.uint8, device=dev)
 
         def one_query():
-            native.check(lib.hwer_knn_search_f32(P(X), P(hnorm), I, d, ldx, P(Q32), P(Q64), P(V), ldv, P(anchors), 1, K, arith, 1, None,
-                                                 id_base, hnorm_max, P(o_idx), P(o_score), None, P(o_flags), P(ws1), ws1.numel(), S()), "knn_search(B=1)")
+            native.check(lib.hwer_knn_search_opts_f32(P(X), P(hnorm), I, d, ldx, P(Q32), P(Q64), P(V), ldv, P(anchors), 1, K, arith, 1, None,
+                                                      id_base, hnorm_max, P(o_idx), P(o_score), None, P(o_flags), P(ws1), ws1.numel(), 0,
+                                                      P(X16) if f16_screen else None, x16_exp, S()), "knn_search(B=1)")
         for _ in range(3):
             one_query()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -376,7 +377,7 @@ def main():
             one_query()
         e1.record()
         torch.cuda.synchronize()
-        out["query_latency_ms"] = {"batch": 1, "value": e0.elapsed_time(e1) / 20.0, "note": "one anchor, exact top-%d, catalogue resident" % K}
+        out["query_latency_ms"] = {"batch": 1, "value": e0.elapsed_time(e1) / 20.0, "note": "one anchor, exact top-%d, catalogue resident%s" % (K, ", float16 storage" if f16_screen else "")}
 
         # ---------------- pair scoring (P / t), outside the timed region: P random (user, item) pairs of this table ----
         n_pairs = 1000209 if args.config in ("c1", "c2") else 16000000

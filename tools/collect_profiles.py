@@ -38,8 +38,8 @@ t = json.load(open("profiles/r1_pmc_traffic.json"))
 # c2: the dense screen kernel of the full sweep (the largest-traffic screen_kernel<..., true> entry)
 f2, w2 = grab("c2", "screen_kernel<16, ", "FETCH_SIZE"), grab("c2", "screen_kernel<16, ", "WRITE_SIZE")
 t["c2"].update(knn_screen_bytes_per_launch=int((2 * f2 + w2) * 1024), fetch_size_kb=f2, write_size_kb=w2)
-fs, ws = grab("c3", "hwer::screen_kernel<16, 2, false>", "FETCH_SIZE"), grab("c3", "hwer::screen_kernel<16, 2, false>", "WRITE_SIZE")
-fd, wd = grab("c3", "small_screen_kernel<16, 2", "FETCH_SIZE"), grab("c3", "small_screen_kernel<16, 2", "WRITE_SIZE")
+fs, ws = grab("c3", "hwer::screen_kernel<16, 2, false", "FETCH_SIZE"), grab("c3", "hwer::screen_kernel<16, 2, false", "WRITE_SIZE")
+fd, wd = grab("c3", "hwer::small_screen", "FETCH_SIZE"), grab("c3", "hwer::small_screen", "WRITE_SIZE")
 t["c3"]["streaming_launch"].update(fetch_size_kb=fs, write_size_kb=ws, bytes=int((2 * fs + ws) * 1024))
 t["c3"]["dense_key_launch"].update(fetch_size_kb=fd, write_size_kb=wd, bytes=int((2 * fd + wd) * 1024))
 t["c3"]["knn_screen_bytes_per_launch"] = int(((2 * fs + ws) + (2 * fd + wd)) * 1024 / 2)
