@@ -158,3 +158,16 @@ def test_pca_batches_like_gen_batches():
     assert pca_batches(7, 3, 2) == [(0, 3), (3, 7)]
     assert pca_batches(6, 3, 2) == [(0, 3), (3, 6)]
     assert pca_batches(2, 3, 1) == [(0, 2)]
+
+
+def test_effective_cpus_respects_quota():
+    """bench.py / oracle.c_oracle: the CPU-baseline thread count follows the container's CPU quota, not the host's CPU count."""
+    import importlib.util
+    import os
+    from oracle import c_oracle
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n, note = bench.effective_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1) and "os.cpu_count()" in note
+    assert c_oracle.effective_cpus() == n
