@@ -93,6 +93,9 @@ def main():
                     help="switch HWER_KNN_F16_SCREEN off.  By default the streaming screen (catalogues above 8 192 rows: c3, c4, c5) runs "
                          "on a float16 copy of the table, rebuilt every step like the float32 one (results unchanged, exact float64 "
                          "re-rank); the dense path of the default configuration (c2) and c1 always screen in float32")
+    ap.add_argument("--f16-dense", action="store_true",
+                    help="experiment: also run the DENSE screen (catalogues up to 8 192 rows: c1, c2) on a float16 copy of the table; "
+                         "not the default (DESIGN.md 4.2b)")
     ap.add_argument("--sweep-only", action="store_true",
                     help="profiling runs: skip the one-anchor latency and pair-score measurements after the timed region, so that every "
                          "launch of a kernel in a rocprofv3 summary is a launch of the timed sweep")
@@ -164,7 +167,7 @@ def main():
     I_pad = lib.hwer_knn_padded_rows(I)
     X = torch.empty((I_pad, ldx), dtype=torch.float32, device=dev)
     hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
-    f16_screen = (not args.f32_screen) and I > 8192
+    f16_screen = ((not args.f32_screen) and I > 8192) or (args.f16_dense and I <= 8192)
     X16 = torch.empty((I_pad, ldx), dtype=torch.float16, device=dev) if f16_screen else None
     Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
     Q32 = torch.empty((U, ldx), dtype=torch.float32, device=dev)

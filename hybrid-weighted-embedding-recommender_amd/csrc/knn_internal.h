@@ -63,7 +63,7 @@ struct ScreenF16 {
     const int32_t* qexp;
     int x_exp;
 };
-bool screen_f16_supported(const ScreenPlan& plan);   // streaming mode, padded dim >= 64
+bool screen_f16_supported(const ScreenPlan& plan);   // padded dim >= 64
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream,
                   const ScreenF16* f16 = nullptr);

@@ -143,10 +143,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 // F16: the item tiles come from the float16 copy of the table and the tile product runs on v_mfma_f32_32x32x8_f16 (float32
 // accumulation, a quarter of the MFMA cycles): keys are computed in per-query scaled units (thresholds too) and unscaled
 // when appended; the select stage widens its error bound by the float16 rounding (key_rel_err), re-ranks from the float32
-// rows in float64 as always, so the results are unchanged.  Streaming mode only.
+// rows in float64 as always, so the results are unchanged.  Default for the streaming mode above 8 192 rows; opt-in for the
+// dense mode (its keys are unscaled when they are stored).
 template <int NG, int TQ, bool DENSE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
-    static_assert(!(F16 && DENSE), "the float16 screen is a streaming-mode variant");
     constexpr int IB = 32;                         // item rows per tile = one 32-row MFMA subtile
     constexpr int CH = F16 ? NG : 2 * NG;          // 16-byte chunks per row
     constexpr int TILE_CHUNKS = IB * CH;
@@ -348,8 +348,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     const int64_t q = qw0 + 32 * b + r;
                     float* row = a.dense + q * a.ld_dense + i0 + 4 * h;
 #pragma unroll
-                    for (int rg = 0; rg < 4; ++rg)
-                        *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
+                    for (int rg = 0; rg < 4; ++rg) {
+                        if constexpr (F16)   // back to real units (exact)
+                            *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(ldexpf(acc[b][4 * rg], -e_tot[b]), ldexpf(acc[b][4 * rg + 1], -e_tot[b]),
+                                                                                  ldexpf(acc[b][4 * rg + 2], -e_tot[b]), ldexpf(acc[b][4 * rg + 3], -e_tot[b]));
+                        else
+                            *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
+                    }
                 }
             } else {
             // ---- streaming filter ---------------------------------------------------------------------------------
@@ -574,7 +579,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     return p;
 }
 
-bool screen_f16_supported(const ScreenPlan& plan) { return !plan.dense && plan.ng >= 8; }
+bool screen_f16_supported(const ScreenPlan& plan) { return plan.ng >= 8; }
 
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
@@ -608,6 +613,17 @@ static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStr
         attr_done = true;
     }
     const int grid = plan.n_qblocks * plan.n_splits;
+    if (plan.dense) {
+        static bool attr_done_d = false;
+        if (!attr_done_d) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, true, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+            if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16(dense): hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_done_d = true;
+        }
+        hipLaunchKernelGGL((screen_kernel<NG, TQ, true, true>), dim3(grid), dim3(256), lds, stream, a);
+        return check_launch("knn_screen16(dense)");
+    }
     hipLaunchKernelGGL((screen_kernel<NG, TQ, false, true>), dim3(grid), dim3(256), lds, stream, a);
     return check_launch("knn_screen16");
 }
@@ -639,7 +655,6 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
                  f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
-        if (plan.dense) return fail(HWER_EINVAL, "knn_screen16: streaming mode only");
         switch (key) {
             case 81: return launch_screen16_t<8, 1>(plan, a, stream);
             case 82: return launch_screen16_t<8, 2>(plan, a, stream);

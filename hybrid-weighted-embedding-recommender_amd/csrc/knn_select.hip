@@ -1436,6 +1436,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.B = B;
         da.kp = plan.kprime;
         da.hnorm_max = hnorm_max;
+        da.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;
         da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                            out_idx, out_score, out_dist2, out_flags, hdr};
         const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
