@@ -995,3 +995,27 @@ def test_knn_f16_streaming_screen_is_invisible(hw, monkeypatch, d, N, B, k, spli
     o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(X, Qs, V[sel], k, threads=c_oracle.effective_cpus())
     assert np.array_equal(res[0][0][sel], o_idx + B) and np.array_equal(res[0][1][sel], o_sc)
     assert np.array_equal(res[0][2][sel] ** 2, o_d2) or np.allclose(res[0][2][sel], np.sqrt(o_d2), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("d,N,B,k", [(128, 3706, 700, 200), (64, 1682, 943, 200), (200, 8000, 300, 50)])
+def test_knn_f16_dense_screen_opt_in_is_invisible(hw, d, N, B, k):
+    """Opt-in: the DENSE screen (catalogues up to 8 192 rows) on a float16 copy of the table.  Same ids / scores / distances
+    as the float32 screen (the default there) and the oracle."""
+    from hwer.device_index import DeviceIndex
+    X = unit_rows_f32(235 + d, N, d)
+    users = unit_rows_f32(236 + d, B, d)
+    V = np.concatenate([users, X]).astype(np.float64)
+    type_rows = {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}
+    res = []
+    for f16 in (True, False):
+        ix = DeviceIndex(V, type_rows, arith=0)
+        ix.f16_screen = f16
+        ix.F16_MIN_ROWS = 0 if f16 else DeviceIndex.F16_MIN_ROWS      # hand the dense path a float16 copy as well
+        res.append(ix.search("item", np.arange(B), k=k))
+        assert (ix.tables["item"].X16 is not None) == f16
+    for a, b in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b)
+    assert (res[0][3] > 0).all()
+    for u in range(0, B, max(1, B // 8)):
+        o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(res[0][0][u], o_idx) and np.array_equal(res[0][1][u], o_score) and np.array_equal(res[0][2][u], o_dist)
