@@ -45,6 +45,11 @@ def main():
         ("small path, clustered catalogue", 200, 200000, 64, 100, True),
         ("streaming, clustered catalogue", 9000, 200000, 64, 100, True),
         ("dense", 5000, 8000, 128, 200, False),
+        # shapes aimed at the float16 streaming screen (the default above 8 192 rows)
+        ("streaming f16, k = 392, 16 splits", 8192, 500000, 128, 392, False),
+        ("streaming f16, d=256, clustered", 20000, 60000, 256, 200, True),
+        ("streaming, d=32 (float32 screen: no float16 variant)", 70000, 40000, 32, 100, False),
+        ("streaming f16, TQ = 2, one list", 140000, 9000, 128, 200, False),
     ]
     if args.quick:
         cases = cases[:2] + cases[4:6]
