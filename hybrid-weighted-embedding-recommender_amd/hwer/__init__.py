@@ -22,16 +22,16 @@ class VectorIndex(RecommendationBase):
 
 
 def prepare_for_knn(collaborative_vectors, n_dims, device=None):
-    """GcnNCF.prepare_for_knn (reference: hwer/gcn_ncf.py:447-456): PCA to `n_dims` only if the vectors are wider
-    (host, scikit-learn, as in the reference), ValueError if they are narrower, then unit-length rows — the
-    normalisation runs on the GPU (blend kernel with one table and alpha = 1).  Returns float32 rows, the dtype the
+    """GcnNCF.prepare_for_knn (reference: hwer/gcn_ncf.py:447-456): PCA to `n_dims` only if the vectors are wider,
+    ValueError if they are narrower, then unit-length rows - all on the GPU (PCA: hwer/fit_pca.py device_pca_unit, float64 Gram
+    + projection kernels; otherwise the blend kernel with one table and alpha = 1).  Returns float32 rows, the dtype the
     reference's GcnNCF hands to __build_knn__."""
     import numpy as np
     from .content_recommender import blend_tables
     v = np.asarray(collaborative_vectors)
     if v.shape[1] > n_dims:
-        from sklearn.decomposition import PCA
-        v = PCA(n_components=n_dims).fit_transform(v)
+        from .fit_pca import device_pca_unit
+        return device_pca_unit(v, n_dims, device=device)
     elif v.shape[1] < n_dims:
         raise ValueError()
     return blend_tables([v.astype(np.float32)], np.array([1.0], dtype=np.float32), device=device)

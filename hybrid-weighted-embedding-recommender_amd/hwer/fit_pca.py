@@ -177,3 +177,48 @@ def device_feature_table(blocks: Sequence[np.ndarray], type_id: np.ndarray, n_di
                                                    native.ptr(E64), ld, stream), "pca_project")
     torch.cuda.current_stream().synchronize()                   # P / bias / rows_d go out of scope
     return (E32, E64, D_out) if want_f64 else (E32, D_out)
+
+
+def device_pca_unit(vectors: np.ndarray, n_components: int, device=None) -> np.ndarray:
+    """unit_length(PCA(n_components).fit_transform(vectors), axis=1) on the GPU - the PCA-if-wider step of
+    GcnNCF.prepare_for_knn (reference hwer/gcn_ncf.py:447-456).  Exact PCA through the same two kernels as the fit-side table:
+    one Gram matrix of [V | 1] over all rows (float64 MFMA), eigen-decomposition of the d x d covariance on the host, signs like
+    scikit-learn's svd_flip(u_based_decision=False), fused projection + row normalisation.  scikit-learn's `full` and
+    `covariance_eigh` solvers compute the same thing (in the input's precision: float32 vectors there carry ~1e-6 of rounding
+    noise, the device path works in float64); its `randomized` solver (wide or short inputs) is an approximation of it.
+    Returns float32 rows (N, n_components)."""
+    import torch
+    from .device_index import _require_gpu, roundup
+    lib = native.lib()
+    dev = _require_gpu(device)
+    V = np.ascontiguousarray(vectors, dtype=np.float64)
+    N, d = V.shape
+    n = int(n_components)
+    if not 1 <= n <= min(N, d):
+        raise ValueError("n_components=%r must be between 1 and min(n_samples, n_features)=%r" % (n, min(N, d)))
+    npad = lib.hwer_pca_padded_components(n)
+    if npad < 0:
+        raise native.HwerNativeError("device PCA supports 1..256 components, got %d" % n)
+    stream = native.stream_ptr()
+    Bd = torch.from_numpy(V).to(dev)
+    seg = torch.tensor([0, N], dtype=torch.int64, device=dev)
+    G = torch.zeros((1, d + 1, d + 1), dtype=torch.float64, device=dev)
+    ws_bytes = lib.hwer_segment_gram_workspace_bytes(d, 1, N)
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=dev)
+    native.check(lib.hwer_segment_gram_f64(native.ptr(Bd), Bd.stride(0), d, native.ptr(seg), 1, N, native.ptr(G), native.ptr(ws),
+                                           ws_bytes, stream), "segment_gram")
+    g = G[0].cpu().numpy()
+    mean = g[:d, d] / N
+    C = g[:d, :d] - N * np.outer(mean, mean)
+    lam, vec = np.linalg.eigh(0.5 * (C + C.T))
+    comps = _flip_rows(vec[:, np.argsort(-lam, kind="stable")[:n]].T)
+    P = np.zeros((roundup(d, 4), npad))
+    P[:d, :n] = comps.T
+    bias = np.zeros(npad)
+    bias[:n] = -(comps @ mean)
+    Pd, bd = torch.from_numpy(P).to(dev), torch.from_numpy(bias).to(dev)
+    ld = roundup(n, 4)
+    out = torch.empty((N, ld), dtype=torch.float32, device=dev)
+    native.check(lib.hwer_pca_project_unit_f64(native.ptr(Bd), Bd.stride(0), N, d, native.ptr(Pd), npad, native.ptr(bd), n, None, -1, 0,
+                                               native.ptr(out), ld, None, 0, stream), "pca_project")
+    return out[:, :n].cpu().numpy()

@@ -1019,3 +1019,25 @@ def test_knn_f16_dense_screen_opt_in_is_invisible(hw, d, N, B, k):
     for u in range(0, B, max(1, B // 8)):
         o_idx, o_score, o_dist = orc.find_closest(V, np.arange(B, B + N), u, k=k)
         assert np.array_equal(res[0][0][u], o_idx) and np.array_equal(res[0][1][u], o_score) and np.array_equal(res[0][2][u], o_dist)
+
+
+@pytest.mark.parametrize("N,d,n", [(5000, 40, 16), (70000, 96, 64), (300, 130, 32)])
+def test_prepare_for_knn_pca_if_wider(hw, N, d, n):
+    """GcnNCF.prepare_for_knn (hwer/gcn_ncf.py:447-456): PCA to n_dims when the vectors are wider, then unit rows - on the device.
+    Against scikit-learn's exact PCA on the float64 input (1e-6: float32 output rows) and on the float32 input the reference
+    would hand it (5e-5: scikit-learn then works in float32)."""
+    from sklearn.decomposition import PCA
+    from hwer import prepare_for_knn
+    rng = np.random.default_rng(N + d)
+    X = (rng.standard_normal((N, d)) * np.linspace(3.0, 0.2, d)).astype(np.float32)
+    got = prepare_for_knn(X, n)
+    assert got.dtype == np.float32 and got.shape == (N, n)
+    unit = lambda a: a / np.linalg.norm(a, axis=1, keepdims=True)   # noqa: E731
+    ref64 = unit(PCA(n_components=n, svd_solver="full").fit_transform(X.astype(np.float64)))
+    assert np.abs(got - ref64).max() <= 1e-6
+    ref32 = unit(PCA(n_components=n, svd_solver="full").fit_transform(X))
+    assert np.abs(got - ref32).max() <= 5e-5
+    with pytest.raises(ValueError):
+        prepare_for_knn(X[:, :n - 1], n)
+    same = prepare_for_knn(X[:, :n], n)                               # equal width: unit rows only
+    assert np.abs(same - unit(X[:, :n].astype(np.float64))).max() <= 1e-6
