@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <math.h>
 
 #include "hwer_hip.h"
@@ -15,6 +16,22 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
+
+// Tuning / ablation switches read from the environment exist only in diagnostic builds (HIPCC_EXTRA=-DHWER_DIAG_STAMPS):
+// the production library never calls getenv() on the search path, and no stray variable can change its results.
+#ifdef HWER_DIAG_STAMPS
+static inline const char* diag_env(const char* name) { return getenv(name); }
+#else
+static inline const char* diag_env(const char*) { return nullptr; }
+#endif
+
+// hipFuncSetAttribute applies to the CURRENT device only: a "done" cache must be kept per device (bit = device id)
+static inline bool attr_pending(uint64_t mask, int* dev_out) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    *dev_out = dev & 63;
+    return ((mask >> (dev & 63)) & 1ull) == 0ull;
+}
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 

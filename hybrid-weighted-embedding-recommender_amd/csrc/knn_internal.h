@@ -33,7 +33,7 @@ struct ScreenPlan {
     int64_t ld_dense;
 };
 
-ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k);
+ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options = 0);
 
 // Header at the start of the k-NN workspace: the queries the last search could not certify (flag 0), appended by the
 // select kernels, consumed by the on-device exhaustive pass (hwer_knn_exact_device) without a host round trip.
@@ -119,7 +119,7 @@ struct SmallPlan {
     int kprime;
 };
 SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k);
-bool use_small_path(int64_t B, int64_t n_items);
+bool use_small_path(int64_t B, int64_t n_items, uint32_t options = 0);
 size_t small_ws_bytes(const SmallPlan& p);   // without the header
 // keys -> per-query candidate lists: list_out (B, SMALL_LIST_CAP) packed keys, cnt_out (B) appended counts
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,

@@ -527,7 +527,7 @@ int repack_queries(const float* Q32, int64_t B, int64_t B_padded, int ldx, float
 // =====================================================================================================
 // host side: plan + launch
 // =====================================================================================================
-ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
+ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options) {
     ScreenPlan p{};
     p.ng = ldx / 8;
     p.kprime = ((k + SLACK + 63) / 64) * 64;
@@ -538,7 +538,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     // phases (measured, C4 4 096 x 1.25 M: screen 12.5 -> 11.9 ms, select 1.0 -> 0.56 ms; a third resident workgroup per
     // CU - 168 VGPRs - was measured too and does not help).
     p.tq = (p.ng <= 16 && B > 65536) ? 2 : 1;
-    if (const char* e = getenv("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : ((atoi(e) == 2 && p.ng <= 16 && B > 32) ? 2 : p.tq);   // tuning override
+    if (const char* e = diag_env("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : ((atoi(e) == 2 && p.ng <= 16 && B > 32) ? 2 : p.tq);   // tuning override
     const int qpw = 32 * p.tq;
     p.wq = B > 2 * qpw ? 4 : (B > qpw ? 2 : 1);
     p.qb = p.wq * qpw;
@@ -551,8 +551,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     const int64_t slots = 512;
     int64_t splits = std::max<int64_t>(1, slots / p.n_qblocks);
     int64_t min_list = 4096;
-    if (const char* e = getenv("HWER_SCREEN_SPLITS")) splits = std::max(1, atoi(e));  // tuning / ablation overrides
-    if (const char* e = getenv("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
+    if (const char* e = diag_env("HWER_SCREEN_SPLITS")) splits = std::max(1, atoi(e));  // tuning / ablation overrides
+    if (const char* e = diag_env("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
     const int64_t max_splits = std::max<int64_t>(1, n_items / (min_list * wi));
     splits = std::min(splits, max_splits);
     const int ib = 32;
@@ -564,12 +564,12 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k) {
     p.scaled_first = 1;
     // Small catalogues: materialise every key (8 B of HBM traffic per pair) instead of streaming selection, whose
     // warm-up (~4 K' appends + a compaction per query and list) dominates when N is only a few K'.
-    p.dense = n_items <= DENSE_MAX_ITEMS && !getenv("HWER_NO_DENSE");
+    p.dense = n_items <= DENSE_MAX_ITEMS && !(options & HWER_KNN_NO_DENSE);
     if (p.dense) {
         const int64_t n_tiles = cdiv64(n_items, 32);
         // one full round of workgroups: 256 CUs x 2 resident = 512 slots
         int64_t sp = std::min<int64_t>(n_tiles, std::max<int64_t>(1, 512 / p.n_qblocks));
-        if (const char* e = getenv("HWER_DENSE_SPLITS")) sp = std::min<int64_t>(n_tiles, std::max(1, atoi(e)));   // tuning override
+        if (const char* e = diag_env("HWER_DENSE_SPLITS")) sp = std::min<int64_t>(n_tiles, std::max(1, atoi(e)));   // tuning override
         int64_t per_d = cdiv64(n_tiles, sp) * 32;
         p.n_splits = int(cdiv64(n_items, per_d));
         p.split_items = per_d;
@@ -585,13 +585,14 @@ template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | key park 4 x 64 x 16 TQ
     size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
-    if (const char* e = getenv("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
-    static bool attr_done = false;
-    if (!attr_done || getenv("HWER_SCREEN_LDS_PAD_KB")) {
+    if (const char* e = diag_env("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
+    static uint64_t attr_done = 0;   // per device
+    int dev;
+    if (attr_pending(attr_done, &dev) || diag_env("HWER_SCREEN_LDS_PAD_KB")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, DENSE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done |= 1ull << dev;
     }
     const int grid = plan.n_qblocks * plan.n_splits;
     hipLaunchKernelGGL((screen_kernel<NG, TQ, DENSE>), dim3(grid), dim3(256), lds, stream, a);
@@ -605,21 +606,21 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 template <int NG, int TQ>
 static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     const size_t lds = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static uint64_t attr_done = 0, attr_done_d = 0;   // per device
+    int dev;
+    if (attr_pending(attr_done, &dev)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done = true;
+        attr_done |= 1ull << dev;
     }
     const int grid = plan.n_qblocks * plan.n_splits;
     if (plan.dense) {
-        static bool attr_done_d = false;
-        if (!attr_done_d) {
+        if (attr_pending(attr_done_d, &dev)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, true, true>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
             if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16(dense): hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_done_d = true;
+            attr_done_d |= 1ull << dev;
         }
         hipLaunchKernelGGL((screen_kernel<NG, TQ, true, true>), dim3(grid), dim3(256), lds, stream, a);
         return check_launch("knn_screen16(dense)");
@@ -634,9 +635,9 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     static unsigned long long* dbg = nullptr;
     static int dbg_grid = 0;
 #ifndef HWER_DIAG_STAMPS
-    if (getenv("HWER_SCREEN_STAMPS")) fprintf(stderr, "[stamps] this library was built without -DHWER_DIAG_STAMPS (HIPCC_EXTRA=-DHWER_DIAG_STAMPS python csrc/build.py --force)\n");
+    if (diag_env("HWER_SCREEN_STAMPS")) fprintf(stderr, "[stamps] this library was built without -DHWER_DIAG_STAMPS (HIPCC_EXTRA=-DHWER_DIAG_STAMPS python csrc/build.py --force)\n");
 #endif
-    if (getenv("HWER_SCREEN_STAMPS")) {
+    if (diag_env("HWER_SCREEN_STAMPS")) {
         if (dbg) {   // print the previous launch's stamps
             std::vector<unsigned long long> h(size_t(dbg_grid) * 32);
             (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
@@ -650,8 +651,8 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
         if (hipMalloc(&dbg, size_t(dbg_grid) * 32 * 8) != hipSuccess || hipMemset(dbg, 0, size_t(dbg_grid) * 32 * 8) != hipSuccess) dbg = nullptr;
     }
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
-                 plan.kprime, (plan.scaled_first && !getenv("HWER_SCREEN_EXACT")) ? 1 : 0, getenv("HWER_SCREEN_NOFILTER") ? atoi(getenv("HWER_SCREEN_NOFILTER")) : 0,
-                 getenv("HWER_SCREEN_TAU0") ? float(atof(getenv("HWER_SCREEN_TAU0"))) : -INFINITY, getenv("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
+                 plan.kprime, (plan.scaled_first && !diag_env("HWER_SCREEN_EXACT")) ? 1 : 0, diag_env("HWER_SCREEN_NOFILTER") ? atoi(diag_env("HWER_SCREEN_NOFILTER")) : 0,
+                 diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
                  f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {

@@ -1311,13 +1311,14 @@ static int launch_select_rerank(const SelectArgs& sa, int d, int score_mode, hip
 extern "C" {
 
 int hwer_knn_max_k(void) { return K_MAX; }
+int hwer_knn_max_dim(void) { return 256; }
 
 int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, int64_t nq, double* out,
                            void* stream) {
     if (nq == 0) return HWER_OK;
     if (!X || !Q64 || !out) return fail(HWER_EINVAL, "knn_all_dist2: null pointer");
-    if (n_items < 1 || d < 1 || d > 256 || ldx < ((d + 15) / 16) * 16 || nq < 0 || nq > 65535)
-        return fail(HWER_EINVAL, "knn_all_dist2: need n_items >= 1, 1 <= d <= 256, ldx >= roundup16(d), nq <= 65535");
+    if (n_items < 1 || d < 1 || d > 1024 || ldx < ((d + 15) / 16) * 16 || nq < 0 || nq > 65535)
+        return fail(HWER_EINVAL, "knn_all_dist2: need n_items >= 1, 1 <= d <= 1024, ldx >= roundup16(d), nq <= 65535");
     const unsigned gx = unsigned(std::min<int64_t>(cdiv64(n_items, 256), 4096));
     hipLaunchKernelGGL(all_dist2_kernel, dim3(gx, unsigned(nq)), dim3(256), 0, as_stream(stream), X, n_items, d, ldx, Q64, out);
     return check_launch("knn_all_dist2");
@@ -1336,8 +1337,8 @@ size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, u
     const int ldx = hwer_knn_padded_dim(d);
     if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
     const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
-    if (!conservative && use_small_path(B, n_items)) return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k));
-    return ws_layout(make_screen_plan(B, n_items, ldx, k), B).total;
+    if (!conservative && use_small_path(B, n_items, options)) return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k));
+    return ws_layout(make_screen_plan(B, n_items, ldx, k, options), B).total;
 }
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) { return hwer_knn_workspace_bytes_opts(B, n_items, d, k, 0); }
 
@@ -1374,7 +1375,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         return fail(HWER_EINVAL, "knn_search: X/Q32 must be 16-byte and workspace 256-byte aligned");
     hipStream_t st = as_stream(stream);
     unsigned char* ws = static_cast<unsigned char*>(workspace);
-    if (!conservative && use_small_path(B, n_items)) {   // a handful of queries over a large catalogue: HBM-bound path (knn_small.hip)
+    if (!conservative && use_small_path(B, n_items, options)) {   // a handful of queries over a large catalogue: HBM-bound path (knn_small.hip)
         const SmallPlan sp = make_small_plan(B, n_items, int(ldx), k);
         const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp);
         if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, need);
@@ -1403,7 +1404,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.key_rel_err = X16 ? 1.02f * 0.0009765625f : 0.f;
         return launch_select_list(da, d, score_mode, st);
     }
-    ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k);
+    ScreenPlan plan = make_screen_plan(B, n_items, int(ldx), k, options);
     if (conservative) plan.scaled_first = 0;   // every threshold is an exact K'-th key: a list can only fail on genuine ties
     const WsLayout w = ws_layout(plan, B);
     if (workspace_bytes < w.total) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, w.total);
@@ -1437,7 +1438,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.kp = plan.kprime;
         da.hnorm_max = hnorm_max;
         da.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;
-        da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
+        da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, diag_env("HWER_SELECT_SKIP") ? atoi(diag_env("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                            out_idx, out_score, out_dist2, out_flags, hdr};
         const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
         static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
@@ -1485,7 +1486,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     sa.kcap = plan.kprime;   // the screen's final compaction is exact: a list holds at most K' keys
     sa.hnorm_max = hnorm_max;
     sa.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;   // two float16 roundings per product (2^-11 each), as in the small-batch path
-    sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, getenv("HWER_SELECT_SKIP") ? atoi(getenv("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
+    sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, diag_env("HWER_SELECT_SKIP") ? atoi(diag_env("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                        out_idx, out_score, out_dist2, out_flags, hdr};
     return launch_select_rerank(sa, d, score_mode, st);
 }

@@ -482,10 +482,10 @@ __global__ __launch_bounds__(256) void small_collect_kernel(const SmallSelectArg
 // =====================================================================================================
 static size_t al256(size_t x) { return (x + 255) & ~size_t(255); }
 
-bool use_small_path(int64_t B, int64_t n_items) {
-    if (getenv("HWER_NO_SMALL")) return false;
+bool use_small_path(int64_t B, int64_t n_items, uint32_t options) {
+    if (options & HWER_KNN_NO_SMALL) return false;
     if (n_items <= DENSE_MAX_ITEMS || B * n_items * 4 > SMALL_MAX_KEY_BYTES) return false;
-    if (const char* e = getenv("HWER_SMALL_MAXQ")) return B <= atoi(e);   // tuning override
+    if (const char* e = diag_env("HWER_SMALL_MAXQ")) return B <= atoi(e);   // tuning override
     if (B <= SMALL_MAX_QUERIES) return true;
     // Beyond that the streaming screen wins once its launch can fill the machine: 512 workgroup slots, one workgroup per
     // 256 queries and item split, lists of at least 4096 items.  A launch that cannot (e.g. the last 7 421 of C3's users

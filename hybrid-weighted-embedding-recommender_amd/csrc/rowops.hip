@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
     const int c0 = lane % L;
 
     const int64_t n_batches = cdiv64(P, 8);
-    const int64_t wave_global = int64_t(blockIdx.x) * 4 + wave;
-    const int64_t wave_stride = int64_t(gridDim.x) * 4;
+    const int nw = int(blockDim.x) >> 6;   // 4 waves, fewer when a wave's slab is large (wide float64 rows)
+    const int64_t wave_global = int64_t(blockIdx.x) * nw + wave;
+    const int64_t wave_stride = int64_t(gridDim.x) * nw;
 
     for (int64_t b = wave_global; b < n_batches; b += wave_stride) {
         const int64_t p0 = b * 8;
@@ -117,10 +118,20 @@ static int launch_pair_score(const float* V, int64_t N, int d, int64_t ldv, cons
     const int d4 = int((d + 3) / 4);
     int stride = 4 * d4;
     while (stride % 32 != 8) ++stride;  // chain reads of 4 pairs x 8 chains hit 32 distinct banks
-    const size_t lds = size_t(4) * 8 * stride * sizeof(T);
+    // one slab of 8 product rows per wave; 4 waves per workgroup while they fit the CU's 160 KB of LDS (d = 1024 in
+    // float64: 66 KB per wave -> 2 waves)
+    const size_t slab = size_t(8) * stride * sizeof(T);
+    int nw = 4;
+    while (nw > 1 && size_t(nw) * slab > size_t(160) * 1024) nw >>= 1;
+    const size_t lds = size_t(nw) * slab;
+    if (lds > size_t(160) * 1024) return fail(HWER_EINVAL, "pair_score: d=%d needs %zu bytes of LDS per wave", d, slab);
+    if (lds > size_t(64) * 1024) {   // per device, cheap: the runtime caches the attribute
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_score_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(HWER_ELAUNCH, "pair_score: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
+    }
     const int64_t n_batches = cdiv64(P, 8);
-    const int grid = int(std::min<int64_t>(cdiv64(n_batches, 4), kMaxStreamBlocks * 2));
-    hipLaunchKernelGGL(pair_score_kernel<T>, dim3(grid), dim3(256), lds, as_stream(stream), V, d, d4, ldv, src, dst,
+    const int grid = int(std::min<int64_t>(cdiv64(n_batches, nw), kMaxStreamBlocks * 2));
+    hipLaunchKernelGGL(pair_score_kernel<T>, dim3(grid), dim3(64 * nw), lds, as_stream(stream), V, d, d4, ldv, src, dst,
                        P, out, stride);
     return check_launch("pair_score");
 }

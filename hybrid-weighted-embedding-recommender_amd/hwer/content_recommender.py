@@ -45,6 +45,7 @@ def _dev_table(t, device, ld):
     return out
 
 
+@native.on_device_kw
 def content_tail(E, src, dst, device=None, return_device=False, d=None):
     """unit_rows((E + mean_adj(E)) / 2) on the GPU.  E: (N, D) array; src/dst: edge endpoints as row ids.
     d: logical width when E is a device table whose rows are already padded to a multiple of 4."""
@@ -67,6 +68,7 @@ def content_tail(E, src, dst, device=None, return_device=False, d=None):
     return out if return_device else out[:, :D].cpu().numpy()
 
 
+@native.on_device_kw
 def segment_mean(E, indptr, indices, device=None):
     """A[n] = mean of E rows listed in CSR row n (reference: hwer/content_recommender.py:83)."""
     import torch
@@ -84,6 +86,7 @@ def segment_mean(E, indptr, indices, device=None):
     return out[:, :D].cpu().numpy()
 
 
+@native.on_device_kw
 def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, device=None, return_device=False,
                  return_norm=False):
     """out[r] = unit(sum_t alpha[r, t] * tables[t][row_idx[t][r]]) — the weighted blend of content and

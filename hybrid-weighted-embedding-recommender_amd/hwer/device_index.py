@@ -38,6 +38,18 @@ def roundup(x, m):
     return (x + m - 1) // m * m
 
 
+def _on_device(fn):
+    """Run a DeviceIndex method with the index's device current (native launches go to the CURRENT HIP device and to its
+    current torch stream - an index on cuda:1 used while cuda:0 is current would otherwise launch on the wrong GPU)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        with native.device_guard(self.device):
+            return fn(self, *a, **kw)
+    return wrapped
+
+
 class _TypeTable:
     __slots__ = ("rows", "rows_dev", "X", "hnorm", "hnorm_max", "n", "id_base", "X16", "x16_exp")
 
@@ -67,6 +79,11 @@ class DeviceIndex:
         torch = _torch()
         self.lib = native.lib()
         self.device = _require_gpu(device)
+        with native.device_guard(self.device):
+            self._init(vectors, type_rows, arith, audit)
+
+    def _init(self, vectors, type_rows, arith, audit):
+        torch = _torch()
         if isinstance(vectors, np.ndarray):
             if arith is None:
                 arith = 0 if vectors.dtype == np.float64 else 1
@@ -85,7 +102,12 @@ class DeviceIndex:
         else:
             self.V = torch.zeros((self.N, self.ldv), dtype=torch.float32, device=self.device)
             self.V[:, :self.d] = src
-        self.ldx = self.lib.hwer_knn_padded_dim(self.d)
+        # d <= 256: the MFMA screen's padded widths.  Wider tables (the reference has no width limit,
+        # hwer/recommendation_base.py:74) keep rows padded to 16 columns and take the exhaustive float64 path.
+        self.wide = self.d > self.lib.hwer_knn_max_dim()
+        if self.d > 1024:
+            raise native.HwerNativeError("k-NN index supports 1 <= d <= 1024 (got d=%d)" % self.d)
+        self.ldx = roundup(self.d, 16) if self.wide else self.lib.hwer_knn_padded_dim(self.d)
         self.audit_result = self.unit_audit() if audit else None
         self.tables: Dict[str, _TypeTable] = {}
         for t, rows in type_rows.items():
@@ -93,6 +115,7 @@ class DeviceIndex:
         self._ws = None
 
     # ------------------------------------------------------------------------------------------------
+    @_on_device
     def unit_audit(self, eps: float = 1e-4):
         """(violations, mean |len - 1|, positive, negative, nan_rows) — utils.unit_length_violations on device."""
         torch = _torch()
@@ -100,14 +123,13 @@ class DeviceIndex:
         counts = torch.zeros(3, dtype=torch.int64, device=self.device)
         dev = torch.zeros(1, dtype=torch.float64, device=self.device)
         native.check(self.lib.hwer_unit_audit_f32(native.ptr(self.V), self.N, self.d, self.ldv, eps, native.ptr(ws),
-                                                  native.ptr(counts), native.ptr(dev), native.stream_ptr()), "unit_audit")
+                                                  native.ptr(counts), native.ptr(dev), native.stream_ptr(self.device)), "unit_audit")
         pos, neg, nan = (int(x) for x in counts.tolist())
         return pos + neg, float(dev.item()) / self.N, pos, neg, nan
 
+    @_on_device
     def add_type(self, node_type: str, rows: np.ndarray):
         torch = _torch()
-        if self.ldx < 0:
-            raise native.HwerNativeError("k-NN index supports 1 <= d <= 256 (got d=%d)" % self.d)
         tt = _TypeTable()
         tt.rows = np.ascontiguousarray(rows, dtype=np.int64)
         tt.n = len(tt.rows)
@@ -116,13 +138,14 @@ class DeviceIndex:
         tt.X = torch.empty((n_pad, self.ldx), dtype=torch.float32, device=self.device)
         tt.hnorm = torch.empty(n_pad, dtype=torch.float32, device=self.device)
         native.check(self.lib.hwer_pack_rows_f32(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(tt.rows_dev), tt.n,
-                                                 native.ptr(tt.X), self.ldx, native.ptr(tt.hnorm), native.stream_ptr()),
+                                                 native.ptr(tt.X), self.ldx, native.ptr(tt.hnorm), native.stream_ptr(self.device)),
                      "pack_rows")
         tt.hnorm_max = float(tt.hnorm[:tt.n].max().item()) if tt.n else 0.0
         self.tables[node_type] = tt
         return tt
 
     # ------------------------------------------------------------------------------------------------
+    @_on_device
     def pair_score(self, src: np.ndarray, dst: np.ndarray, arith: Optional[int] = None) -> np.ndarray:
         """RecommendationBase.predict on resolved indices (-1 = unknown node)."""
         torch = _torch()
@@ -137,10 +160,11 @@ class DeviceIndex:
             out = torch.empty(P, dtype=torch.float32, device=self.device)
             fn = self.lib.hwer_pair_score_f32
         native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(s), native.ptr(t), P, native.ptr(out),
-                        native.stream_ptr()), "pair_score")
+                        native.stream_ptr(self.device)), "pair_score")
         return out.cpu().numpy()
 
     # ------------------------------------------------------------------------------------------------
+    @_on_device
     def build_queries(self, anchors: np.ndarray, positive: Optional[Sequence[Sequence[int]]] = None,
                       negative: Optional[Sequence[Sequence[int]]] = None):
         """-> (Q64 (B, d) float64, Q32 (B, ldx) float32, anchors_dev int32) on the device."""
@@ -168,7 +192,7 @@ class DeviceIndex:
         Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=self.device)
         native.check(self.lib.hwer_query_mix(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(a), native.ptr(pp),
                                              native.ptr(pi), native.ptr(np_), native.ptr(ni), B, self.arith,
-                                             native.ptr(Q64), native.ptr(Q32), self.ldx, native.stream_ptr()), "query_mix")
+                                             native.ptr(Q64), native.ptr(Q32), self.ldx, native.stream_ptr(self.device)), "query_mix")
         return Q64, Q32, a
 
     #: catalogues above this many rows keep a float16 copy of their table for small query batches
@@ -189,7 +213,7 @@ class DeviceIndex:
             tt.x16_exp = int(self.lib.hwer_knn_f16_scale_exp(float(tt.hnorm_max)))
             tt.X16 = torch.empty(tt.X.shape, dtype=torch.float16, device=self.device)
             native.check(self.lib.hwer_pack_rows_f16(native.ptr(tt.X), tt.X.shape[0], self.ldx, tt.x16_exp, native.ptr(tt.X16),
-                                                     native.stream_ptr()), "pack_rows_f16")
+                                                     native.stream_ptr(self.device)), "pack_rows_f16")
         return tt.X16, tt.x16_exp
 
     def _workspace(self, nbytes):
@@ -204,6 +228,13 @@ class DeviceIndex:
             self._ws_exact = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws_exact
 
+    @staticmethod
+    def _path_options():
+        """Path-forcing switches for tests (results are identical on every path): HWER_NO_DENSE / HWER_NO_SMALL in the
+        environment of the HOST mirror map to the library's HWER_KNN_NO_DENSE / HWER_KNN_NO_SMALL options."""
+        return (4 if os.environ.get("HWER_NO_DENSE") else 0) | (8 if os.environ.get("HWER_NO_SMALL") else 0)
+
+    @_on_device
     def search_queries(self, node_type: str, Q64, Q32, k: int, anchors_dev=None, score_mode: Optional[int] = None,
                        sort_by_score: bool = True, id_base: Optional[int] = None, want_dist: bool = True):
         """Exact k nearest rows of `node_type` for B query vectors already on the device.
@@ -223,13 +254,18 @@ class DeviceIndex:
         dist2 = torch.empty((B, k), dtype=torch.float64, device=self.device) if want_dist else None
         flags = torch.empty(B, dtype=torch.int32, device=self.device)
         use_rows = id_base is None
-        if k > self.lib.hwer_knn_max_k():
-            self._search_large_k(tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, idx, score, dist2, flags)
+        if anchors_dev is None and score_mode != 2:
+            # anchor row of query b defaults to row b of the table - materialised ONCE, so that every chunk and every
+            # fallback tier scores query b against V[b] (a NULL a_idx means "chunk-local index" inside the library)
+            anchors_dev = torch.arange(B, dtype=torch.int32, device=self.device)
+        if k > self.lib.hwer_knn_max_k() or self.wide:
+            self._search_exhaustive(tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags)
             return idx, score, dist2, flags
+        path_opt = self._path_options()
         for b0 in range(0, B, self.QUERY_CHUNK):
             b1 = min(B, b0 + self.QUERY_CHUNK)
             nb = b1 - b0
-            wsb = self.lib.hwer_knn_workspace_bytes(nb, tt.n, self.d, k)
+            wsb = self.lib.hwer_knn_workspace_bytes_opts(nb, tt.n, self.d, k, path_opt)
             if wsb == 0:
                 raise native.HwerNativeError("knn: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" %
                                              (nb, tt.n, self.d, k, self.lib.hwer_knn_max_k()))
@@ -237,13 +273,13 @@ class DeviceIndex:
             a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
             # the small-batch screen always reads the float16 copy; the streaming screen only with f16_screen
             x16, x16_exp = self._x16(tt) if (nb <= 1024 or self.f16_screen) else (None, 0)
-            opt = self.KNN_F16_SCREEN if (self.f16_screen and x16 is not None) else 0
+            opt = (self.KNN_F16_SCREEN if (self.f16_screen and x16 is not None) else 0) | path_opt
             native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,
                 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
                 tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None,
-                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), opt, native.ptr(x16), x16_exp, native.stream_ptr()), "knn_search")
+                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), opt, native.ptr(x16), x16_exp, native.stream_ptr(self.device)), "knn_search")
             # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
             # to 8 per call; anything beyond that is picked up by the host-driven pass below
             wse = self._exact_workspace(self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
@@ -252,9 +288,9 @@ class DeviceIndex:
                 self.ldv, native.ptr(a_sub), k, score_mode, 1 if sort_by_score else 0,
                 native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), native.ptr(idx[b0:b1]),
                 native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None, native.ptr(flags[b0:b1]), native.ptr(ws), None,
-                native.ptr(wse), wse.numel(), native.stream_ptr()), "knn_exact_device")
+                native.ptr(wse), wse.numel(), native.stream_ptr(self.device)), "knn_exact_device")
         n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
-        native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr()), "count_uncertified")
+        native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr(self.device)), "count_uncertified")
         if int(n_bad.item()):
             bad = torch.nonzero(flags == 0).flatten()
             if bad.numel() > self.RETRY_MIN:
@@ -268,32 +304,33 @@ class DeviceIndex:
                                      dist2, flags)
         return idx, score, dist2, flags
 
-    def _search_large_k(self, tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, idx, score, dist2, flags):
-        """k above the selection kernels' limit (hwer_knn_max_k; the reference takes any k <= N_t,
-        hwer/recommendation_base.py:79): all float64 distances (hwer_knn_all_dist2_f64, scikit-learn's summation order),
-        a stable device sort keeps the k nearest in (distance, row) order, hwer_pair_score re-scores them against the
-        anchors, a stable sort by score gives the reference's final order.  Same values and order as the regular path."""
+    def _search_exhaustive(self, tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
+        """Shapes outside the selection kernels' limits - k above hwer_knn_max_k() or d above hwer_knn_max_dim(); the reference
+        takes any k <= N_t and any width (hwer/recommendation_base.py:74,79): all float64 distances (hwer_knn_all_dist2_f64,
+        scikit-learn's summation order), a stable device sort keeps the k nearest in (distance, row) order, hwer_pair_score
+        re-scores them against the anchors, a stable sort by score gives the reference's final order.  Same values and order
+        as the regular path; works on a shard too (ids = id_base + local row)."""
         torch = _torch()
-        if not use_rows:
-            raise ValueError("k > %d is only supported on an unsharded table" % self.lib.hwer_knn_max_k())
         B, n = Q64.shape[0], tt.n
         per = max(1, min(B, 65535, (1 << 30) // (8 * n)))   # <= 1 GiB of distances at a time
+        stream = native.stream_ptr(self.device)
         for b0 in range(0, B, per):
             b1 = min(B, b0 + per)
             nb = b1 - b0
             D = torch.empty((nb, n), dtype=torch.float64, device=self.device)
             native.check(self.lib.hwer_knn_all_dist2_f64(native.ptr(tt.X), n, self.d, self.ldx, native.ptr(Q64[b0:b1]), nb,
-                                                         native.ptr(D), native.stream_ptr()), "knn_all_dist2")
+                                                         native.ptr(D), stream), "knn_all_dist2")
             d_sorted, order = torch.sort(D, dim=1, stable=True)          # ties keep the row (= id) order
             d2 = d_sorted[:, :k].contiguous()
-            ids = tt.rows_dev[order[:, :k]]                              # global rows
+            local = order[:, :k]
+            rows = tt.rows_dev[local]                                    # rows of the vector table (pair scoring)
+            ids = rows if use_rows else local + int(id_base)             # reported ids
             if score_mode == 2:
                 sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
             else:
-                a = (anchors_dev[b0:b1] if anchors_dev is not None else
-                     torch.arange(b0, b1, device=self.device)).to(torch.int32)
+                a = anchors_dev[b0:b1].to(torch.int32)
                 src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
-                dst = ids.to(torch.int32).contiguous().view(-1)
+                dst = rows.to(torch.int32).contiguous().view(-1)
                 if score_mode == 0:
                     out = torch.empty(nb * k, dtype=torch.float64, device=self.device)
                     fn = self.lib.hwer_pair_score_f64
@@ -301,7 +338,7 @@ class DeviceIndex:
                     out = torch.empty(nb * k, dtype=torch.float32, device=self.device)
                     fn = self.lib.hwer_pair_score_f32
                 native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(src), native.ptr(dst), nb * k,
-                                native.ptr(out), native.stream_ptr()), "pair_score")
+                                native.ptr(out), stream), "pair_score")
                 sc = out.view(nb, k).to(torch.float64)
             if sort_by_score:
                 sc, o2 = torch.sort(sc, dim=1, descending=True, stable=True)
@@ -320,8 +357,6 @@ class DeviceIndex:
         nb = int(bad.numel())
         q64, q32 = Q64.index_select(0, bad).contiguous(), Q32.index_select(0, bad).contiguous()
         a_sub = anchors_dev.index_select(0, bad).contiguous() if anchors_dev is not None else None
-        if a_sub is None and score_mode != 2:
-            a_sub = bad.to(torch.int32)   # anchor row of query b defaults to row b of the table
         r_idx = torch.empty((nb, k), dtype=torch.int64, device=self.device)
         r_score = torch.empty((nb, k), dtype=torch.float64, device=self.device)
         r_dist2 = torch.empty((nb, k), dtype=torch.float64, device=self.device) if dist2 is not None else None
@@ -337,7 +372,7 @@ class DeviceIndex:
                 b1 - b0, k, score_mode, 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None,
                 0 if use_rows else int(id_base), tt.hnorm_max, native.ptr(r_idx[b0:b1]), native.ptr(r_score[b0:b1]),
                 native.ptr(r_dist2[b0:b1]) if r_dist2 is not None else None, native.ptr(r_flags[b0:b1]), native.ptr(ws), ws.numel(),
-                opt, None, 0, native.stream_ptr()), "knn_search(exact thresholds)")
+                opt, None, 0, native.stream_ptr(self.device)), "knn_search(exact thresholds)")
         good = torch.nonzero(r_flags > 0).flatten()
         rows = bad.index_select(0, good)
         idx.index_copy_(0, rows, r_idx.index_select(0, good))
@@ -358,8 +393,9 @@ class DeviceIndex:
             self.ldv, native.ptr(anchors_dev), qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), k, score_mode,
             1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
             native.ptr(idx), native.ptr(score), native.ptr(dist2) if dist2 is not None else None, native.ptr(flags), native.ptr(ws), ws.numel(),
-            native.stream_ptr()), "knn_exact")
+            native.stream_ptr(self.device)), "knn_exact")
 
+    @_on_device
     def search(self, node_type: str, anchors: np.ndarray, k: int = 200, positive=None, negative=None,
                scoring: str = "base", sort_by_score: bool = True, want_dist: bool = True):
         """Batched find_closest_neighbours on resolved indices.

@@ -23,27 +23,28 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
 
 
 def all_gather_results(idx, score, dist2, group=None):
-    """all_gather_into_tensor of the three (B, k) result tensors -> three (G, B, k) tensors.
-    The payload is packed into ONE byte buffer per rank so that a batch costs a single collective."""
+    """ONE all_gather_into_tensor of the three (B, k) result arrays -> three (G, B, k) views of the receive buffer.
+    Every rank packs (idx | score bits | dist2 bits) into one (3, B, k) int64 buffer (device tensors: one hwer_pack_exchange
+    launch), the collective writes rank g's buffer to recv[g], and the returned tensors are STRIDED VIEWS of recv (list
+    stride 3 B k): hwer_merge_topk_strided merges them in place - no unpack copies.
+    24 bytes per entry: the exact float64 distance orders the merge, the id names the row, and the score has to travel
+    with them - it is computed from the item's row, which only the owning rank holds."""
     import torch
     import torch.distributed as dist
     G = dist.get_world_size(group)
     B, k = idx.shape
-    packed = torch.cat([idx.reshape(-1).view(torch.uint8), score.reshape(-1).view(torch.uint8),
-                        dist2.reshape(-1).view(torch.uint8)])
-    if packed.is_cuda and dist.get_backend(group) != "nccl":
+    if B == 0:
+        return idx.new_empty((G, 0, k)), score.new_empty((G, 0, k)), dist2.new_empty((G, 0, k))
+    send = pack_send_buffer(idx, score, dist2, 1)[0]                      # (3, B, k) int64
+    if send.is_cuda and dist.get_backend(group) != "nccl":
         # test harness only (e.g. two ranks sharing one GPU over gloo): stage the payload through host memory
-        host = torch.empty((G, packed.numel()), dtype=torch.uint8)
-        dist.all_gather_into_tensor(host.view(-1), packed.cpu(), group=group)
-        out = host.to(packed.device)
+        host = torch.empty((G,) + tuple(send.shape), dtype=torch.int64)
+        dist.all_gather_into_tensor(host.view(-1), send.cpu().view(-1), group=group)
+        recv = host.to(send.device)
     else:
-        out = torch.empty((G, packed.numel()), dtype=torch.uint8, device=packed.device)
-        dist.all_gather_into_tensor(out.view(-1), packed, group=group)
-    n = B * k * 8
-    g_idx = out[:, 0:n].contiguous().view(torch.int64).view(G, B, k)
-    g_score = out[:, n:2 * n].contiguous().view(torch.float64).view(G, B, k)
-    g_dist2 = out[:, 2 * n:3 * n].contiguous().view(torch.float64).view(G, B, k)
-    return g_idx, g_score, g_dist2
+        recv = torch.empty((G,) + tuple(send.shape), dtype=torch.int64, device=send.device)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
+    return recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64)
 
 
 def query_slice(n_queries: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -62,8 +63,9 @@ def pack_send_buffer(idx, score, dist2, G: int):
     if idx.is_cuda:
         from . import native
         idx, score, dist2 = idx.contiguous(), score.contiguous(), dist2.contiguous()
-        native.check(native.lib().hwer_pack_exchange(native.ptr(idx), native.ptr(score), native.ptr(dist2), B, k, G,
-                                                     native.ptr(send), native.stream_ptr()), "pack_exchange")
+        with native.device_guard(idx.device):
+            native.check(native.lib().hwer_pack_exchange(native.ptr(idx), native.ptr(score), native.ptr(dist2), B, k, G,
+                                                         native.ptr(send), native.stream_ptr(idx.device)), "pack_exchange")
         return send
     # CPU tensors (the gloo tests of the exchange logic)
     full = B // Bs                      # slices that are completely inside the batch
@@ -133,9 +135,10 @@ def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True):
     o_idx = torch.empty((B, k), dtype=torch.int64, device=g_idx.device)
     o_score = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
     o_dist2 = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
-    native.check(lib.hwer_merge_topk_strided(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), list_stride, G, B, k,
-                                             1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
-                                             native.ptr(o_dist2), native.stream_ptr()), "merge_topk")
+    with native.device_guard(g_idx.device):
+        native.check(lib.hwer_merge_topk_strided(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), list_stride, G, B, k,
+                                                 1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
+                                                 native.ptr(o_dist2), native.stream_ptr(g_idx.device)), "merge_topk")
     return o_idx, o_score, o_dist2
 
 

@@ -90,12 +90,23 @@ def pca_from_grams(grams: Sequence[np.ndarray], col_of: Sequence[np.ndarray], on
         M = 0.5 * (M + M.T)
         lam, vec = np.linalg.eigh(M)
         top = np.argsort(-lam, kind="stable")[:n_components]
+        # Rank-deficient tables (e.g. a zero block for a type without features): components beyond the numerical rank span
+        # the null space, where ANY orthonormal basis is a valid answer - scikit-learn's SVD returns rounding noise there
+        # too, so neither side defines those columns; the unit-row normalisation then amplifies ~1e-8 coordinates of rows
+        # whose projection is (nearly) zero.  Parity with the reference only holds up to the numerical rank: say so.
+        rank = int(np.sum(lam > lam.max() * W * np.finfo(np.float64).eps * 16.0)) if lam.max() > 0 else 0
+        if n_components > rank:
+            import warnings
+            warnings.warn("device PCA: n_components=%d exceeds the numerical rank %d of the feature table (batch %d); the "
+                          "trailing components are an arbitrary null-space basis, as in scikit-learn's IncrementalPCA"
+                          % (n_components, rank, b), RuntimeWarning, stacklevel=2)
         comps = _flip_rows(vec[:, top].T)
         sv = np.sqrt(np.maximum(lam[top], 0.0))
         mean, n_seen = col_mean, n_tot
     return comps, mean, sv
 
 
+@native.on_device_kw
 def device_feature_table(blocks: Sequence[np.ndarray], type_id: np.ndarray, n_dims, block_order: Optional[Sequence[int]] = None,
                          device=None, want_f64: bool = False, details: Optional[dict] = None):
     """hwer/content_recommender.py:50-76 on the GPU.
@@ -110,6 +121,8 @@ def device_feature_table(blocks: Sequence[np.ndarray], type_id: np.ndarray, n_di
     dev = _require_gpu(device)
     type_id = np.ascontiguousarray(type_id, dtype=np.int64)
     N, T = len(type_id), len(blocks)
+    if N == 0 or T == 0:
+        raise ValueError("device_feature_table: empty table (N=%d rows, %d node types)" % (N, T))
     order = list(range(T)) if block_order is None else list(block_order)
     dims = [int(b.shape[1]) for b in blocks]
     width = sum(dims)
@@ -179,6 +192,7 @@ def device_feature_table(blocks: Sequence[np.ndarray], type_id: np.ndarray, n_di
     return (E32, E64, D_out) if want_f64 else (E32, D_out)
 
 
+@native.on_device_kw
 def device_pca_unit(vectors: np.ndarray, n_components: int, device=None) -> np.ndarray:
     """unit_length(PCA(n_components).fit_transform(vectors), axis=1) on the GPU - the PCA-if-wider step of
     GcnNCF.prepare_for_knn (reference hwer/gcn_ncf.py:447-456).  Exact PCA through the same two kernels as the fit-side table:

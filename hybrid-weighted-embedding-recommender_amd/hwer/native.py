@@ -33,6 +33,7 @@ PROTOTYPES = {
     "hwer_pack_rows_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P]),
     "hwer_query_mix": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "hwer_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "hwer_knn_max_dim": (c_int, []),
     "hwer_knn_max_k": (c_int, []),
     "hwer_knn_search_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                     c_int, _P, c_int64, c_float, _P, _P, _P, _P, _P, c_size_t, _P]),
@@ -105,6 +106,32 @@ def ptr(t):
     return None if t is None else c_void_p(t.data_ptr())
 
 
-def stream_ptr():
+def stream_ptr(device=None):
+    """Current torch stream of `device` (default: the current device).  Native calls launch on the CURRENT HIP device, so
+    callers that were handed an explicit device wrap their calls in `device_guard(device)`."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def device_guard(device):
+    """Context manager: make `device` the current HIP device for the native calls inside (kernels launch on the current
+    device; a tensor on cuda:1 handed to a launch on cuda:0 faults or silently relies on peer access)."""
+    import torch
+    return torch.cuda.device(device)
+
+
+def on_device_kw(fn):
+    """Decorator for host-mirror functions with a `device=None` keyword: resolve it once and run the body with that device
+    current, so that every allocation, launch and stream query inside refers to the same GPU."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, device=None, **kw):
+        import torch
+        if not torch.cuda.is_available():
+            raise HwerNativeError("hwer (MI355X build) needs a ROCm GPU: torch.cuda.is_available() is False; "
+                                  "there is no CPU fallback for this path")
+        dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        with torch.cuda.device(dev):
+            return fn(*a, device=dev, **kw)
+    return wrapped

@@ -10,6 +10,7 @@ import operator
 import random
 import time
 from collections import defaultdict
+from collections.abc import Mapping
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -23,15 +24,40 @@ def model_get_topk_arrays(model, anchors: List[Node], node_type: NodeType, k: in
     return model.find_closest_neighbours_batch(node_type, anchors, k=k)
 
 
+class LazyRows(Mapping):
+    """Read-only {key: list} whose lists are built from array rows on first access (and cached).  The retrieval sweep returns
+    U x 200 neighbours; as eager Python objects that is millions of tuples built after a sub-millisecond search - most
+    callers only look at some users, or only iterate once.  Supports the dict read API (`[]`, `in`, `len`, iteration,
+    keys / values / items, get) - what the reference's callers use on the dict they get (hwer/validation.py:133-141)."""
+
+    def __init__(self, keys, build_row):
+        self._pos = {k: j for j, k in enumerate(keys)}
+        self._build = build_row
+        self._cache = {}
+
+    def __getitem__(self, key):
+        got = self._cache.get(key)
+        if got is None:
+            got = self._cache[key] = self._build(self._pos[key])   # KeyError for an unknown key, like a dict
+        return got
+
+    def __iter__(self):
+        return iter(self._pos)
+
+    def __len__(self):
+        return len(self._pos)
+
+    def __contains__(self, key):
+        return key in self._pos
+
+
 def model_get_topk_knn(model, anchors: List[Node], node_type: NodeType) -> Dict[Node, List[Tuple[Node, float]]]:
-    """{anchor: [(Node, score)] * 200} ordered by score desc (reference: hwer/validation.py:30-35)."""
+    """{anchor: [(Node, score)] * 200} ordered by score desc (reference: hwer/validation.py:30-35).  ONE batched search;
+    the per-anchor lists of (Node, score) tuples are materialised lazily (LazyRows)."""
     anchors = list(anchors)
     idx, score = model_get_topk_arrays(model, anchors, node_type)
     table = model.knn.idx_to_node()
-    out = defaultdict(list)
-    for u, row, sc in zip(anchors, idx.tolist(), score.tolist()):
-        out[u] = [(table[i], s) for i, s in zip(row, sc)]
-    return out
+    return LazyRows(anchors, lambda j: [(table[i], s) for i, s in zip(idx[j].tolist(), score[j].tolist())])
 
 
 model_get_topk = model_get_topk_knn
@@ -100,6 +126,40 @@ def _csr_rows(lists):
 _CUTS = (10, 20, 50, 100)
 
 
+def _unpack_hit_bits(words: np.ndarray, n_bits: int) -> np.ndarray:
+    """(V, W) uint64 words -> (V, n_bits) int64 0/1, bit p of the row = bit p % 64 of word p // 64."""
+    bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), axis=1, bitorder="little")   # little-endian words
+    return bits[:, :n_bits].astype(np.int64)
+
+
+def recall_rows(hitbits, n_pred, n_true, c):
+    """mean over users of utils.recall(truth, pred[:c]) from hit marks (reference: hwer/utils.py:118-121)."""
+    if len(n_pred) == 0:
+        return np.mean([])
+    lp = np.minimum(n_pred, c)
+    h = (hitbits[:, :c] * (np.arange(c)[None, :] < lp[:, None])).sum(1)
+    return np.mean(h / np.maximum(np.minimum(lp, n_true), 1.0))
+
+
+def binary_ndcg_rows(hitbits, n_pred, n_true, c):
+    """mean over users of utils.binary_ndcg(truth, pred[:c]) from hit marks (reference: hwer/utils.py:101-111)."""
+    V = len(n_pred)
+    if V == 0:
+        return np.mean([])
+    lp = np.minimum(n_pred, c).astype(np.int64)
+    vals = np.empty(V, dtype=np.float64)
+    ideal_len = np.minimum(n_true, lp)
+    idcg_of = np.asarray([np.sum((np.power(2, [1] * m) - 1) / np.log2(np.arange(m) + 2)) for m in range(c + 1)])
+    for length in np.unique(lp):          # a handful of distinct lengths (nearly every user has c survivors)
+        rows = np.flatnonzero(lp == length)
+        length = int(length)
+        gains = np.ascontiguousarray(hitbits[rows, :length])
+        discounts = np.log2(np.arange(length) + 2)
+        dcg = np.sum((np.power(2, gains) - 1) / discounts, axis=1) if length else np.zeros(len(rows))
+        vals[rows] = dcg / (idcg_of[ideal_len[rows]] + 1e-8)
+    return np.mean(vals)
+
+
 def _extraction_efficiency_device(model, train_edges, validation_edges, node_type, k: int = 200):
     import torch
     from . import native
@@ -153,45 +213,34 @@ def _extraction_efficiency_device(model, train_edges, validation_edges, node_typ
     ulen = torch.empty(B, dtype=torch.int32, device=dev)
     hits = torch.empty((B, (cmax + 63) // 64), dtype=torch.int64, device=dev)
     cover = torch.zeros((cover_n + 31) // 32, dtype=torch.int32, device=dev)
-    native.check(lib.hwer_rank_filter_seen(native.ptr(idx_dev), B, k, native.ptr(d_sp), native.ptr(d_si), native.ptr(d_tp), native.ptr(d_ti),
-                                           cmax, native.ptr(unseen), native.ptr(ulen), native.ptr(hits), native.ptr(cover), cover_base,
-                                           cover_n, native.stream_ptr()), "rank_filter_seen")
+    with native.device_guard(dev):
+        native.check(lib.hwer_rank_filter_seen(native.ptr(idx_dev), B, k, native.ptr(d_sp), native.ptr(d_si), native.ptr(d_tp), native.ptr(d_ti),
+                                               cmax, native.ptr(unseen), native.ptr(ulen), native.ptr(hits), native.ptr(cover), cover_base,
+                                               cover_n, native.stream_ptr(dev)), "rank_filter_seen")
     unseen_h, ulen_h = unseen.cpu().numpy(), ulen.cpu().numpy().astype(np.int64)
     hits_h = hits.cpu().numpy().view(np.uint64)
     n_covered = int(np.unpackbits(cover.cpu().numpy().view(np.uint8)).sum())
     idx_h = idx_dev[:, :100].cpu().numpy()
 
-    # ---- float metrics from the integers, with the reference's own numpy expressions (utils.py:101-121) -------------------------
+    # ---- float metrics from the integers, with the reference's own numpy expressions (utils.py:101-121), vectorised over the
+    # users: element-wise operations are identical to the per-user ones, and every per-user np.sum is reproduced by a row sum
+    # over a contiguous slice of exactly that user's length (users grouped by length; numpy reduces each contiguous row with
+    # the same pairwise summation as a 1-D np.sum, tests/test_host_api.py::test_vectorised_metrics_match_reference_loops)
     pos_of = {u: j for j, u in enumerate(all_users)}
     vrow = np.asarray([pos_of[u] for u in validation_users], dtype=np.int64)
-    hitbits = np.zeros((len(vrow), cmax), dtype=np.int64)   # hitbits[v, p] = the p-th survivor of user v is truth
-    for w in range(hits_h.shape[1]):
-        word = hits_h[vrow, w]
-        for bit in range(min(64, cmax - 64 * w)):
-            hitbits[:, 64 * w + bit] = (word >> np.uint64(bit)) & np.uint64(1)
+    hitbits = _unpack_hit_bits(hits_h[vrow], cmax)            # hitbits[v, p] = the p-th survivor of user v is truth
     n_true = np.asarray([len(val_scores.get(u, ())) for u in validation_users], dtype=np.int64)
     n_pred = ulen_h[vrow]
 
     def recall_at(c):
-        lp = np.minimum(n_pred, c)
-        h = (hitbits[:, :c] * (np.arange(c)[None, :] < lp[:, None])).sum(1)
-        return np.mean([hh / max(min(int(l), int(t)), 1.0) for hh, l, t in zip(h.tolist(), lp.tolist(), n_true.tolist())])
+        return recall_rows(hitbits, n_pred, n_true, c)
 
     def binary_ndcg_at(c):
-        vals = []
-        for v in range(len(vrow)):
-            lp = int(min(n_pred[v], c))
-            gains = hitbits[v, :lp]
-            discounts = np.log2(np.arange(lp) + 2)
-            ideal = [1] * min(int(n_true[v]), lp)
-            idcg = np.sum((np.power(2, ideal) - 1) / np.log2(np.arange(len(ideal)) + 2))
-            dcg = np.sum((np.power(2, gains) - 1) / discounts)
-            vals.append(dcg / (idcg + 1e-8))
-        return np.mean(vals)
+        return binary_ndcg_rows(hitbits, n_pred, n_true, c)
 
     table = model.knn.idx_to_node()
-    cuts100 = {u: [table[i] for i in unseen_h[j, :ulen_h[j]].tolist()] for j, u in enumerate(all_users)}
-    train_predictions = {u: [table[i] for i in idx_h[j].tolist()] for j, u in enumerate(all_users)}
+    cuts100 = LazyRows(all_users, lambda j: [table[i] for i in unseen_h[j, :ulen_h[j]].tolist()])
+    train_predictions = LazyRows(all_users, lambda j: [table[i] for i in idx_h[j].tolist()])
     train_actuals = {u: [i for i, _ in sorted(d.items(), key=operator.itemgetter(1), reverse=True)]
                      for u, d in train_scores.items()}
 

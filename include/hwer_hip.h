@@ -173,6 +173,7 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
  * ------------------------------------------------------------------------------------------------- */
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k);
 int hwer_knn_max_k(void);
+int hwer_knn_max_dim(void); /* widest d the MFMA screen takes (256); wider tables (d <= 1024) go through hwer_knn_all_dist2_f64 */
 int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                         const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
                         int score_mode,
@@ -190,6 +191,11 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
  * stage widens its error bound by the float16 rounding and re-ranks from the float32 rows, so the results are identical;
  * a few more queries may come back uncertified (flag 0) on near-ties and take the exhaustive pass.  Off by default. */
 #define HWER_KNN_F16_SCREEN 2u
+/* Path selection (results are identical on every path; tests use these to hold each path to the same goldens):
+ * HWER_KNN_NO_DENSE: catalogues of up to 8 192 rows also take the streaming screen;  HWER_KNN_NO_SMALL: small query batches
+ * over large catalogues take the streaming screen instead of the HBM-bound small-batch path. */
+#define HWER_KNN_NO_DENSE 4u
+#define HWER_KNN_NO_SMALL 8u
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
 int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
@@ -233,8 +239,9 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
                        void* stream);
 
 /* All float64 squared distances, out[q * n_items + i] = ||Q64[q] - X[i]||^2 in scikit-learn's summation order (the same
- * values the re-rank computes).  The host mirror uses it for k > hwer_knn_max_k(): the reference accepts any k <= N_t
- * (hwer/recommendation_base.py:79), there the k nearest come from a stable device sort of these rows.  nq <= 65535. */
+ * values the re-rank computes).  The host mirror uses it for k > hwer_knn_max_k() and for d > hwer_knn_max_dim(): the reference
+ * accepts any k <= N_t and any width (hwer/recommendation_base.py:74,79), there the k nearest come from a stable device sort of
+ * these rows.  1 <= d <= 1024, ldx >= roundup16(d) (X from hwer_pack_rows_f32 with that stride), nq <= 65535. */
 int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, int64_t nq, double* out,
                            void* stream);
 

@@ -171,3 +171,56 @@ def test_effective_cpus_respects_quota():
     n, note = bench.effective_cpus()
     assert 1 <= n <= (os.cpu_count() or 1) and "os.cpu_count()" in note
     assert c_oracle.effective_cpus() == n
+
+
+def test_vectorised_metrics_match_reference_loops():
+    """validation.recall_rows / binary_ndcg_rows (the vectorised float metrics of the device evaluation path) against the
+    reference's per-user expressions (hwer/utils.py:101-121) on ragged inputs: EXACT equality, including the summation order."""
+    from hwer import validation
+    from hwer.utils import binary_ndcg, recall
+    rng = np.random.default_rng(5)
+    V, cmax = 257, 100
+    n_pred = rng.integers(0, cmax + 1, V)
+    n_pred[:40] = cmax                                   # the usual case: a full list
+    n_true = rng.integers(0, 30, V)
+    hit = (rng.random((V, cmax)) < 0.15).astype(np.int64)
+    hit *= (np.arange(cmax)[None, :] < n_pred[:, None])  # no hit marks beyond a user's survivors
+    words = np.zeros((V, 2), dtype=np.uint64)
+    for p in range(cmax):
+        words[:, p // 64] |= hit[:, p].astype(np.uint64) << np.uint64(p % 64)
+    bits = validation._unpack_hit_bits(words, cmax)
+    assert np.array_equal(bits, hit)
+    for c in (10, 20, 100):
+        rec, nd = [], []
+        for v in range(V):
+            lp = int(min(n_pred[v], c))
+            pred = list(range(lp))                                       # item ids 0..lp-1, truth = the marked positions
+            # truth: the marked positions within the cut + enough unreachable ids to make |truth| = n_true
+            marked = [p for p in pred if hit[v, p]]
+            truth = {p: 1.0 for p in marked}
+            extra = 10_000
+            while len(truth) < n_true[v]:
+                truth[extra] = 1.0
+                extra += 1
+            nt = len(truth)
+            rec.append(recall(truth, pred))
+            nd.append(binary_ndcg(truth, pred))
+            n_true[v] = nt                                               # (marks may exceed the drawn count)
+        assert validation.recall_rows(bits, n_pred, n_true, c) == np.mean(rec)
+        assert validation.binary_ndcg_rows(bits, n_pred, n_true, c) == np.mean(nd)
+
+
+def test_lazy_rows_mapping_api():
+    from hwer.validation import LazyRows
+    built = []
+
+    def build(j):
+        built.append(j)
+        return [j, j + 1]
+    m = LazyRows(["a", "b", "c"], build)
+    assert len(m) == 3 and list(m) == ["a", "b", "c"] and "b" in m and "z" not in m
+    assert m["b"] == [1, 2] and m["b"] is m["b"] and built == [1]      # built once, on demand
+    assert dict(m.items()) == {"a": [0, 1], "b": [1, 2], "c": [2, 3]}
+    assert m.get("z") is None
+    with pytest.raises(KeyError):
+        m["z"]

@@ -265,12 +265,22 @@ def g7(pkg):
             edges.append(Edge(Node("user", user), Node("item", item_ids[j]), 1))
             e_src.append(i)
             e_dst.append(3 + j)
-    mapper = {"item": {"numeric": NumericEmbed(n_dims=8)}}
+    embedded = []
+
+    class RecordingNumericEmbed(NumericEmbed):   # records the embedder's output (the embedders are out of scope of the build:
+        def fit_transform(self, feature, **kw):  # the GPU test feeds this table to the device fit through an identity embedder)
+            out = super().fit_transform(feature, **kw)
+            embedded.append(np.array(out, dtype=np.float64))
+            return out
+    mapper = {"item": {"numeric": RecordingNumericEmbed(n_dims=8)}}
     node_data = {node: {"numeric": i1_15[idx]} for idx, node in enumerate(item_nodes)}
     recsys = cr.ContentRecommendation(embedding_mapper=mapper, n_dims=4, node_types={"user", "item"})
     final = recsys.fit(user_nodes + item_nodes, edges, node_data)
     res = recsys.find_closest_neighbours("item", user_nodes[0], k=3)
-    np.savez_compressed(os.path.join(OUT, "g7_content_fit_e2e.npz"), item_features=i1_15,
+    res10 = recsys.find_closest_neighbours("item", user_nodes[1], k=10)
+    np.savez_compressed(os.path.join(OUT, "g7_content_fit_e2e.npz"), item_features=i1_15, item_embed=embedded[0],
+                        knn10_idx=np.asarray([recsys.nodes_to_idx[n] for n, _ in res10], dtype=np.int32),
+                        knn10_score=np.asarray([s for _, s in res10]),
                         e_src=np.asarray(e_src, np.int32), e_dst=np.asarray(e_dst, np.int32), final=final,
                         knn_idx=np.asarray([recsys.nodes_to_idx[n] for n, _ in res], dtype=np.int32),
                         knn_score=np.asarray([s for _, s in res]), sklearn_version=sklearn.__version__)
@@ -481,9 +491,55 @@ def g12(pkg):
     np.savez_compressed(os.path.join(OUT, "g12_fit_pca.npz"), **out)
 
 
+def g13(pkg):
+    """ncf_eval and link_prediction_accuracy (hwer/validation.py:41-97) on the G9 scenario.  ncf_eval draws its 100 negatives
+    with random.sample(set difference): the order of a set of Nodes depends on the process's string-hash seed, so a seed alone
+    does not pin the draw - the draws themselves are recorded (a recording proxy installed as the module global
+    `hwer.validation.random`; the reference file is untouched) and the test replays them."""
+    import types
+    val, rb = pkg.validation, pkg.recommendation_base
+    g9f = np.load(os.path.join(OUT, "g9_metrics.npz"))
+    V32, U, I = g9f["ee_V32"], int(g9f["ee_n_users"]), int(g9f["ee_n_items"])
+    m, unodes, inodes = make_model(pkg, V32.astype(np.float64), U, I)
+    nodes = unodes + inodes
+    mk = lambda arr: [rb.Edge(nodes[int(a)], nodes[int(b)], float(r)) for a, b, r in arr]   # noqa: E731
+    train, valid = mk(g9f["ee_train"]), mk(g9f["ee_valid"])
+    drawn = []
+    real = val.random
+
+    def rec_sample(population, k):
+        res = real.sample(list(population), k)      # Python >= 3.11 refuses a set; the draw is recorded either way
+        drawn.append([m.nodes_to_idx[n] for n in res])
+        return res
+    proxy = types.SimpleNamespace(sample=rec_sample, choices=real.choices, seed=real.seed)
+    val.random = proxy
+    try:
+        real.seed(13)
+        res = val.ncf_eval(m, train, valid, inodes)
+        real.seed(13)
+        lp = val.link_prediction_accuracy(m, nodes, train, valid)
+        # the float32 flavour of the same model (GcnNCF-like dtype): predict runs in float32
+        m32, _, _ = make_model(pkg, V32, U, I)
+        nodes32 = list(m32.nodes_to_idx.keys())
+        real.seed(13)
+        lp32 = val.link_prediction_accuracy(m32, nodes32, [rb.Edge(nodes32[int(a)], nodes32[int(b)], float(r)) for a, b, r in g9f["ee_train"]],
+                                            [rb.Edge(nodes32[int(a)], nodes32[int(b)], float(r)) for a, b, r in g9f["ee_valid"]])
+    finally:
+        val.random = real
+    out = dict(ncf_draws=np.asarray(drawn, dtype=np.int32), ncf_hr=res["ncf_hr"], ncf_ndcg=res["ncf_ndcg"], seed=13)
+    out.update({k: v for k, v in lp.items()})
+    out.update({k + "_f32": v for k, v in lp32.items()})
+    np.savez_compressed(os.path.join(OUT, "g13_eval_callers.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     pkg = ref_shims.install()
+    only = [a for a in sys.argv[1:] if a.startswith("g")]
+    if only:   # e.g. `python tools/capture_goldens.py g7 g13`: rewrite just those fixtures
+        for name in only:
+            globals()[name](pkg)
+        return
     g1_g5(pkg)
     g2(pkg)
     g6(pkg)
@@ -493,6 +549,7 @@ def main():
     g10(pkg)
     g11(pkg)
     g12(pkg)
+    g13(pkg)
     for f in sorted(os.listdir(OUT)):
         print("%-32s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))
 
