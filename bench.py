@@ -1,26 +1,36 @@
 #!/usr/bin/env python3
 """Benchmark of the hwer retrieval hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c1|c2|c3|c4|c5|c4full]
 
 One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
   blend of the content + collaborative tables with alpha weights -> L2-normalise -> unit-norm audit ->
-  per-type item table (+ half norms) -> query construction for every user -> exact top-K retrieval
-  (float32 MFMA screen + float64 re-rank + re-score + sort), K = 200.
+  per-type item table (+ half norms, + float16 copy above 8 192 rows) -> query construction for every user ->
+  exact top-K retrieval (MFMA screen + float64 re-rank + re-score + sort; on-device exhaustive pass for any query the
+  screen could not certify), K = 200.
 `value` = user-item pairs scored per second = users * items / step time (whole job, all GPUs).
 
-Default (N = 1): BASELINE.json configs[1] — ML-1M-shaped synthetic, 6040 users x 3706 items, d = 128, two tables,
-alpha = 0.5.  N > 1 (launched by torch.distributed.run, one rank per GPU): the item catalogue is row-sharded, every
-rank holds a shard of the SAME size as the N = 1 catalogue (weak scaling), queries are replicated, and the local
-top-K are exchanged in ONE step over RCCL - user-partitioned: every rank receives the lists of its slice of the users
-from all ranks (all_to_all_single) and merges those; HWER_BENCH_EXCHANGE=all_gather selects the replicated variant.
+N = 1, no --config (what the driver runs): ONE JSON line whose top level is BASELINE.json's metric on the shape it is quoted
+on - ML-100K-shaped synthetic (943 x 1682, d = 64) - with `cpu_baseline`, `roofline` (every kernel >= 10 % of the step),
+`api_latency_ms` (the same sweep through the drop-in Python classes, results on the host), and a `configs` object holding the
+same measurements for c2 (ML-1M shape), c3 (ML-20M shape: the roofline configuration), c4 (one 1.25 M-item shard, B in
+{1, 64, 4096}) and c4full (the whole 10 M-item catalogue on this GPU: the 1-GPU anchor of the scaling curve below).
 
-Prints ONE JSON line (rank 0).  See DESIGN.md §6 for the roofline arithmetic.
+N > 1: STRONG scaling of one fixed 10 M-item catalogue (BASELINE.json configs[3]; d = 128, 4 096 queries per step): the
+catalogue is row-sharded over the ranks (same rows for every N: generated per 65 536-row block from the block's seed),
+queries are replicated, each rank searches its shard and the local top-K are exchanged in ONE step over RCCL - an all-gather
+(north_star; every rank ends with the full result) - then merged by hwer_merge_topk_strided.  The user-partitioned
+all-to-all variant is timed after it and reported under `variants`.  Launch: `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE from the environment), or plain
+`python bench.py --gpus N`, which starts the N ranks itself as child processes (before anything touches a GPU).
+
+Prints ONE JSON line (rank 0).  DESIGN.md §6 explains every field and the roofline arithmetic.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -32,26 +42,27 @@ for p in (ROOT, os.path.join(ROOT, "hybrid-weighted-embedding-recommender_amd"))
 import numpy as np  # noqa: E402
 
 CONFIGS = {
-    # name: users, items per GPU, d, tables, per-row alpha, queries per step (None = all users), description
-    "c1": dict(U=943, I=1682, d=64, T=2, per_row=False, B=None, name="ML-100K-shaped synthetic (943x1682, d=64)"),
-    "c2": dict(U=6040, I=3706, d=128, T=2, per_row=False, B=None, name="ML-1M-shaped synthetic (6040x3706, d=128, alpha=0.5)"),
-    "c3": dict(U=138493, I=26744, d=128, T=2, per_row=False, B=None, name="ML-20M-shaped synthetic (138493x26744, d=128)"),
-    "c4": dict(U=4096, I=1250000, d=128, T=2, per_row=False, B=None, name="10M-item catalogue shard (4096 queries x 1.25M items/GPU, d=128)"),
-    "c5": dict(U=4096, I=1250000, d=256, T=4, per_row=True, B=None, name="multi-alpha hybrid (3 content + 1 collaborative, per-row alpha, d=256)"),
+    # users (queries per step), items, d, tables, per-row alpha
+    "c1": dict(U=943, I=1682, d=64, T=2, per_row=False, name="ML-100K-shaped synthetic (943x1682, d=64, alpha=0.5)"),
+    "c2": dict(U=6040, I=3706, d=128, T=2, per_row=False, name="ML-1M-shaped synthetic (6040x3706, d=128, alpha=0.5)"),
+    "c3": dict(U=138493, I=26744, d=128, T=2, per_row=False, name="ML-20M-shaped synthetic (138493x26744, d=128)"),
+    "c4": dict(U=4096, I=1250000, d=128, T=2, per_row=False, name="one shard of the 10M-item catalogue (4096 queries x 1.25M items, d=128)"),
+    "c5": dict(U=4096, I=1250000, d=256, T=4, per_row=True, name="multi-alpha hybrid shard (3 content + 1 collaborative, per-row alpha, d=256, 4096 x 1.25M)"),
+    "c4full": dict(U=4096, I=10000000, d=128, T=2, per_row=False, name="10M-item catalogue (4096 queries x 10M items, d=128)"),
 }
 K = 200
 PROFILE_EVERY = 5
+GEN_BLOCK = 65536              # rows per generation block: row r of a table depends only on (table seed, r // GEN_BLOCK, r % GEN_BLOCK)
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_32x32x2_f32)
-MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PF dense BF16 / F16 (only priced against with --f16-screen)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PF dense BF16 / F16
+VALU_F64_PEAK_TFLOPS = 78.6    # MI355X data sheet: FP64 vector (the re-rank's float64 chains run on the VALU)
 HBM_PEAK_GBS = 8000.0          # same guide: HBM3E 8 TB/s spec
+METRIC = "user-item pairs/sec scored (blend + L2-normalise + exact top-%d retrieval)" % K
 
 
-def unit_rows(torch, gen, n, d, device):
-    x = torch.randn((n, d), generator=gen, device=device, dtype=torch.float32)
-    return x / x.norm(dim=1, keepdim=True)
-
-
-
+# ====================================================================================================================
+# host facts
+# ====================================================================================================================
 def effective_cpus():
     """CPU threads this process can actually keep busy: the smallest of os.cpu_count(), the affinity mask and the cgroup CPU
     quota (a GPU box exposes all host CPUs but caps the container: more runnable threads than the quota get throttled and
@@ -62,16 +73,15 @@ def effective_cpus():
         n = min(n, len(os.sched_getaffinity(0)))
     except (AttributeError, OSError):
         pass
-    for path in ("/sys/fs/cgroup/cpu.max",):
-        try:
-            quota, period = open(path).read().split()[:2]
-            if quota != "max":
-                q = max(1, int(float(quota) / float(period) + 0.5))
-                if q < n:
-                    note += ", cgroup cpu.max=%s/%s -> %d" % (quota, period, q)
-                    n = q
-        except (OSError, ValueError):
-            pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(float(quota) / float(period) + 0.5))
+            if q < n:
+                note += ", cgroup cpu.max=%s/%s -> %d" % (quota, period, q)
+                n = q
+    except (OSError, ValueError):
+        pass
     try:
         q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
         per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
@@ -82,418 +92,832 @@ def effective_cpus():
         pass
     return n, note
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--f32-screen", action="store_true",
-                    help="switch HWER_KNN_F16_SCREEN off.  By default the streaming screen (catalogues above 8 192 rows: c3, c4, c5) runs "
-                         "on a float16 copy of the table, rebuilt every step like the float32 one (results unchanged, exact float64 "
-                         "re-rank); the dense path of the default configuration (c2) and c1 always screen in float32")
-    ap.add_argument("--f16-dense", action="store_true",
-                    help="experiment: also run the DENSE screen (catalogues up to 8 192 rows: c1, c2) on a float16 copy of the table; "
-                         "not the default (DESIGN.md 4.2b)")
-    ap.add_argument("--sweep-only", action="store_true",
-                    help="profiling runs: skip the one-anchor latency and pair-score measurements after the timed region, so that every "
-                         "launch of a kernel in a rocprofv3 summary is a launch of the timed sweep")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="users in the CPU-baseline sample (0 = auto)")
-    args = ap.parse_args()
 
+def host_description():
+    """CPU model, sockets / threads, numpy BLAS build ("host description to report")."""
+    out = {}
+    try:
+        models, phys = set(), set()
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                models.add(line.split(":", 1)[1].strip())
+            elif line.startswith("physical id"):
+                phys.add(line.split(":", 1)[1].strip())
+        out["cpu_model"] = sorted(models)[0] if models else None
+        out["sockets"] = len(phys) or None
+    except OSError:
+        pass
+    out["logical_cpus"] = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        out["blas"] = [{"api": x.get("internal_api"), "version": x.get("version"), "threads": x.get("num_threads"),
+                        "arch": x.get("architecture")} for x in threadpool_info() if x.get("user_api") == "blas"]
+    except Exception:
+        pass
+    out["numpy"] = np.__version__
+    try:
+        import sklearn
+        out["sklearn"] = sklearn.__version__
+    except ImportError:
+        pass
+    return out
+
+
+# ====================================================================================================================
+# self-launch (N > 1 without a launcher): start the ranks as child processes BEFORE anything touches a GPU
+# ====================================================================================================================
+def self_launch(args, argv):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+# ====================================================================================================================
+# synthetic inputs: unit rows, row r of a table depends only on (seed, r): any shard of the catalogue can be generated
+# ====================================================================================================================
+def gen_unit_rows(torch, seed, lo, hi, d, dev):
+    out = torch.empty((hi - lo, d), dtype=torch.float32, device=dev)
+    gen = torch.Generator(device=dev)
+    for blk in range(lo // GEN_BLOCK, (hi + GEN_BLOCK - 1) // GEN_BLOCK):
+        gen.manual_seed(seed * 1000003 + blk)
+        x = torch.randn((GEN_BLOCK, d), generator=gen, device=dev, dtype=torch.float32)
+        a, b = max(lo, blk * GEN_BLOCK), min(hi, (blk + 1) * GEN_BLOCK)
+        x = x[a - blk * GEN_BLOCK:b - blk * GEN_BLOCK]
+        out[a - lo:b - lo] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+class Workload:
+    """The resident tensors of one configuration on one GPU and the step over them.  `lo:hi` = the item rows this GPU holds
+    (the whole catalogue at N = 1); ids reported by the search are global: users 0..U-1, then the items."""
+
+    def __init__(self, torch, lib, cfg, dev, lo=None, hi=None, f32_screen=False, f16_dense=False, want_dist=False, local_order=False,
+                 n_sets=1):
+        from hwer import native
+        from hwer.device_index import roundup
+        self.torch, self.lib, self.cfg, self.dev, self.native = torch, lib, cfg, dev, native
+        U, I_total, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
+        lo = 0 if lo is None else lo
+        hi = I_total if hi is None else hi
+        I = hi - lo
+        self.U, self.I, self.d, self.T, self.lo, self.hi = U, I, d, T, lo, hi
+        self.N = N = U + I
+        self.ldv = roundup(d, 4)
+        assert self.ldv == d, "bench tables are passed with row stride d"
+        self.ldx = lib.hwer_knn_padded_dim(d)
+        self.tables = []
+        for t in range(T):
+            tab = torch.empty((N, d), dtype=torch.float32, device=dev)
+            tab[:U] = gen_unit_rows(torch, 3000 + 20 * t, 0, U, d, dev)          # users: identical on every rank
+            tab[U:] = gen_unit_rows(torch, 3001 + 20 * t, lo, hi, d, dev)        # items: rows lo..hi of the catalogue
+            self.tables.append(tab)
+        if cfg["per_row"]:
+            # Dirichlet(1, .., 1) = normalised unit exponentials; 20 % cold-start rows (alpha_collab = 0, renormalised).
+            # Row-wise deterministic like the tables: generated per global row block.
+            al = torch.empty((N, T), dtype=torch.float32, device=dev)
+            al[:U] = self._alpha_rows(5005, 0, U)
+            al[U:] = self._alpha_rows(5006, lo, hi)
+            self.alpha = al.contiguous()
+        else:
+            self.alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
+        self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
+        self.item_rows = torch.arange(U, N, dtype=torch.int64, device=dev)
+        self.anchors = torch.arange(0, U, dtype=torch.int32, device=dev)
+        self.V = torch.zeros((N, self.ldv), dtype=torch.float32, device=dev)
+        self.audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)     # counts[4] | sum |norm-1| (f64) | pad
+        self.audit_counts = self.audit_buf[:4]
+        self.audit_dev = self.audit_buf[4:5].view(torch.float64)
+        I_pad = lib.hwer_knn_padded_rows(I)
+        self.I_pad = I_pad
+        self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
+        self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
+        self.f16_screen = ((not f32_screen) and I > 8192) or (f16_dense and I <= 8192)
+        self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
+        self.Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
+        self.Q32 = torch.empty((U, self.ldx), dtype=torch.float32, device=dev)
+        self.want_dist = want_dist
+        self.sort_by_score = 0 if local_order else 1
+        self.sets = [dict(idx=torch.empty((U, K), dtype=torch.int64, device=dev), score=torch.empty((U, K), dtype=torch.float64, device=dev),
+                          dist2=torch.empty((U, K), dtype=torch.float64, device=dev) if want_dist else None,
+                          flags=torch.empty(U, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
+        self.CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
+        self.opts = 2 if self.f16_screen else 0
+        ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(U, self.CH), I, d, K, self.opts),
+                       lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(U, 64), I, d, K, 0))
+        assert ws_bytes > 0
+        self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
+        self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
+        # rows passed the 1e-4 unit-norm audit (checked after the timed region) => 0.5||x||^2 <= 0.5 (1 + 1e-4)^2
+        self.hnorm_max = 0.5 * (1.0 + 1e-4) ** 2
+        self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
+        self.id_base = U + lo
+        self.arith = 0                  # float64 score arithmetic (ContentRecommendation flavour)
+
+    def _alpha_rows(self, seed, lo, hi):
+        torch = self.torch
+        T = self.T
+        out = torch.empty((hi - lo, T), dtype=torch.float32, device=self.dev)
+        gen = torch.Generator(device=self.dev)
+        for blk in range(lo // GEN_BLOCK, (hi + GEN_BLOCK - 1) // GEN_BLOCK):
+            gen.manual_seed(seed * 1000003 + blk)
+            e = -torch.log(torch.rand((GEN_BLOCK, T), generator=gen, device=self.dev, dtype=torch.float64).clamp_min(1e-300))
+            cold = torch.rand((GEN_BLOCK,), generator=gen, device=self.dev) < 0.2
+            e[cold, T - 1] = 0.0
+            e = (e / e.sum(1, keepdim=True)).to(torch.float32)
+            a, b = max(lo, blk * GEN_BLOCK), min(hi, (blk + 1) * GEN_BLOCK)
+            out[a - lo:b - lo] = e[a - blk * GEN_BLOCK:b - blk * GEN_BLOCK]
+        return out
+
+    # ---- stages of a step (each a closure over the resident tensors; S() = the current torch stream) -----------------------
+    def S(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def stage_blend(self):
+        P, lib, c = self.native.ptr, self.lib, self.cfg
+        self.native.check(lib.hwer_blend_normalize_audit_f32(P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if c["per_row"] else 0, self.T, self.N,
+                                                             self.d, P(self.V), self.ldv, 1e-4, P(self.audit_counts), P(self.audit_dev), self.S()), "blend+audit")
+
+    def stage_pack(self):
+        P, lib = self.native.ptr, self.lib
+        self.native.check(lib.hwer_pack_rows_f32(P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
+                                                 self.S()), "pack")
+        if self.f16_screen:
+            self.native.check(lib.hwer_pack_rows_f16(P(self.X), self.I_pad, self.ldx, self.x16_exp, P(self.X16), self.S()), "pack16")
+
+    def stage_queries(self):
+        P, lib = self.native.ptr, self.lib
+        self.native.check(lib.hwer_query_mix(P(self.V), self.N, self.d, self.ldv, P(self.anchors), None, None, None, None, self.U, self.arith,
+                                             P(self.Q64), P(self.Q32), self.ldx, self.S()), "query_mix")
+
+    def stage_search(self, o, B=None, opts=None):
+        """exact top-K of queries 0..B-1 (default: all) into result set `o`; uncertified queries (rare: near-ties at the cut,
+        or a sample-scaled threshold that was too tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the
+        device (no host round trip): the step always returns exact results."""
+        P, lib = self.native.ptr, self.lib
+        U = self.U if B is None else B
+        opts = self.opts if opts is None else opts
+        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
+        for b0 in range(0, U, self.CH):
+            b1 = min(U, b0 + self.CH)
+            self.native.check(lib.hwer_knn_search_opts_f32(
+                P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.V), self.ldv,
+                P(self.anchors[b0:b1]), b1 - b0, K, self.arith, self.sort_by_score, None, self.id_base, self.hnorm_max, P(oi[b0:b1]),
+                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(), opts,
+                P(self.X16) if self.f16_screen else None, self.x16_exp, self.S()), "knn_search")
+            self.native.check(lib.hwer_knn_exact_device(
+                P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
+                self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
+                P(self.ws), P(self.missed), P(self.ws_exact), self.ws_exact.numel(), self.S()), "knn_exact_device")
+
+    def step(self, o=None):
+        o = self.sets[0] if o is None else o
+        self.stage_blend()
+        self.stage_pack()
+        self.stage_queries()
+        self.stage_search(o)
+        return o
+
+    # ---- algorithmic work (SURVEY.md §8d) -----------------------------------------------------------------------------------
+    def stage_bytes(self):
+        d, T, N, U, I = self.d, self.T, self.N, self.U, self.I
+        per_row = self.cfg["per_row"]
+        return {
+            "blend_normalize_audit": N * (4.0 * d * (T + 1) + (4.0 * T if per_row else 0.0)),       # T rows in, one out (+ per-row alpha)
+            "pack_rows": I * (4.0 * d + 4.0 * self.ldx + 4.0 + 8.0) + (I * (4.0 + 2.0) * self.ldx if self.f16_screen else 0.0),
+            "query_mix": U * (4.0 * d + 8.0 * d + 4.0 * self.ldx + 4.0),
+        }
+
+    def checks(self, o):
+        pos, neg, nan = self.audit_counts.tolist()[:3]
+        assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
+        n_uncert = int((o["flags"] == 0).sum().item())
+        assert n_uncert == 0, "%d queries left without an exact result" % n_uncert
+        assert int(self.missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(self.missed.item())
+        return int((o["flags"] == 2).sum().item())
+
+
+def cuda_time(torch, fn, reps, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def read_profile(lib):
+    tot, cnt = ctypes.c_double(), ctypes.c_int64()
+    lib.hwer_profile_read(0, ctypes.byref(tot), ctypes.byref(cnt))
+    screen_ms, n0 = tot.value / max(cnt.value, 1), cnt.value
+    lib.hwer_profile_read(1, ctypes.byref(tot), ctypes.byref(cnt))
+    return screen_ms, tot.value / max(cnt.value, 1), n0
+
+
+def load_traffic(config):
+    """HBM-side bytes of the screen stage per launch from the committed rocprofv3 PMC passes of THIS command
+    ((2 * FETCH_SIZE + WRITE_SIZE) * 1024; gfx950 counts wide reads at half their bytes - MI355X_MICROARCH.md §HBM).  The
+    counters cannot be read from inside the run: the value is labelled with the file it comes from."""
+    for fn in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as fh:
+                ent = json.load(fh).get(config)
+            if ent and ent.get("knn_screen_bytes_per_launch"):
+                return ent["knn_screen_bytes_per_launch"], "profiles/" + fn
+        except OSError:
+            pass
+    return None, None
+
+
+# ====================================================================================================================
+# one configuration on one GPU
+# ====================================================================================================================
+def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api=False, latencies=(), stage_reps=20, f32_beside=False):
+    from hwer import native
+    cfg = CONFIGS[name]
+    w = Workload(torch, lib, cfg, dev, f32_screen=args.f32_screen, f16_dense=args.f16_dense)
+    U, I, d = w.U, w.I, w.d
+    # Small catalogues: a step is ~8 launches of a few microseconds each, so issuing them from Python costs as much as running
+    # them.  The step is captured ONCE into a hipGraph (every buffer is preallocated, nothing in the step synchronises or
+    # allocates) and the timed region replays it.
+    graph = None
+    if I <= 8192 and not args.no_graph:
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    w.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                w.step()
+            graph = g
+        except Exception as e:   # capture refused: measure the eager step and say so
+            graph = None
+            torch.cuda.synchronize()
+            sys.stderr.write("[bench] hipGraph capture failed (%s): timing the eager step\n" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
+    run_step = graph.replay if graph is not None else w.step
+    for _ in range(warmup):
+        run_step()
+    torch.cuda.synchronize()
+    if graph is None:
+        lib.hwer_profile_enable(PROFILE_EVERY)   # HIP events around every PROFILE_EVERY-th search (a pair costs ~10 us of stream time)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.hwer_profile_enable(0)
+    if graph is not None:    # kernel durations: an eager pass with event brackets after the timed region
+        lib.hwer_profile_enable(1)
+        for _ in range(10):
+            w.step()
+        torch.cuda.synchronize()
+        lib.hwer_profile_enable(0)
+    screen_ms, select_ms, _ = read_profile(lib)
+    o = w.sets[0]
+    n_exhaustive = w.checks(o)
+    ms_per_step = elapsed / steps * 1e3
+    value = float(U) * float(I) / (elapsed / steps)
+    idx_h, score_h = o["idx"].cpu().numpy(), o["score"].cpu().numpy()
+
+    # ---- parity of the timed step's result: sampled users against the oracle's C brute force on the same float32 rows -------
+    from oracle import c_oracle
+    from oracle import hwer_oracle as orc
+    cores, cores_note = effective_cpus()
+    Vh = w.V[:, :d].cpu().numpy()
+    n_par = 16 if I <= 2000000 else 8
+    sel = np.unique(np.linspace(0, U - 1, n_par).astype(np.int64))
+    V64u = Vh[:U].astype(np.float64)
+    Qh = np.stack([orc.query_vector(V64u, int(s)) for s in sel])
+    oi, osc, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64u[sel], K, threads=cores)
+    assert np.array_equal(idx_h[sel], oi + U), "GPU indices differ from the oracle (%s)" % name
+    assert np.array_equal(score_h[sel], osc), "GPU scores differ from the oracle (%s)" % name
+
+    # ---- per-stage times (outside the timed region), per-kernel rooflines ----------------------------------------------------
+    searches_per_step = (U + w.CH - 1) // w.CH
+    stages = {"blend_normalize_audit": cuda_time(torch, w.stage_blend, stage_reps), "pack_rows": cuda_time(torch, w.stage_pack, stage_reps),
+              "query_mix": cuda_time(torch, w.stage_queries, stage_reps)}
+    stages["knn_search"] = cuda_time(torch, lambda: w.stage_search(o), max(3, stage_reps // 2), warm=1)
+    sbytes = w.stage_bytes()
+    f16 = w.f16_screen
+    flops = 2.0 * U * I * d
+    mfma_peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
+    screen_step_ms, select_step_ms = screen_ms * searches_per_step, select_ms * searches_per_step
+    kernels = []
+    for sname in ("blend_normalize_audit", "pack_rows", "query_mix"):
+        ms = stages[sname]
+        kernels.append({"kernel": sname, "ms_per_step": ms, "share": ms / ms_per_step, "bound": "hbm", "achieved": sbytes[sname] / ms / 1e6,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sbytes[sname] / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": sbytes[sname]})
+    traffic, traffic_src = load_traffic(name)
+    kernels.append({"kernel": "knn_screen (%s)" % ("v_mfma_f32_32x32x16_f16 on the float16 copy + streaming top-K' filter" if f16 else "v_mfma_f32_32x32x2_f32 + fused top-K' filter"),
+                    "ms_per_step": screen_step_ms, "share": screen_step_ms / ms_per_step, "bound": "mfma", "achieved": flops / (screen_step_ms * 1e-3) / 1e12 if screen_step_ms > 0 else 0.0,
+                    "peak": mfma_peak, "unit": "TFLOP/s", "frac": (flops / (screen_step_ms * 1e-3) / 1e12 / mfma_peak) if screen_step_ms > 0 else 0.0,
+                    "vs_fp32_mfma_peak": (flops / (screen_step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if screen_step_ms > 0 else 0.0,
+                    "launches_per_step": searches_per_step, "avg_launch_ms": screen_ms, "algorithmic_flops": flops,
+                    "traffic": traffic, "traffic_source": traffic_src})
+    # re-rank: per query ~ (k + boundary) candidates x d x 3 float64 operations for the score chain (+ 4 d per boundary candidate)
+    rr_flops = float(U) * (K + 16) * d * 3.0
+    kernels.append({"kernel": "knn_select_rerank (float64 re-rank + certificate + sort)", "ms_per_step": select_step_ms, "share": select_step_ms / ms_per_step,
+                    "bound": "valu_f64", "achieved": rr_flops / (select_step_ms * 1e-3) / 1e12 if select_step_ms > 0 else 0.0, "peak": VALU_F64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": (rr_flops / (select_step_ms * 1e-3) / 1e12 / VALU_F64_PEAK_TFLOPS) if select_step_ms > 0 else 0.0,
+                    "note": "instruction-count-bound selection + gather code around the float64 chains; its useful work is tiny next to the screen's"})
+    dominant = max(kernels, key=lambda kk: kk["ms_per_step"])
+    stage_tf = flops / ((screen_step_ms + select_step_ms) * 1e-3) / 1e12 if screen_step_ms + select_step_ms > 0 else 0.0
+    res = {
+        "workload": cfg["name"], "users": U, "items": I, "d": d, "k": K, "tables": w.T, "alpha": "per-row" if cfg["per_row"] else "scalar",
+        "f16_screen": f16, "dtype": "f16" if f16 else "f32", "steps": steps, "warmup": warmup, "hip_graph": graph is not None,
+        "value": value, "unit": "pairs/s", "ms_per_step": ms_per_step,
+        "roofline": {k_: dominant[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
+        "stage_frac": stage_tf / MFMA_F32_PEAK_TFLOPS,
+        "stage_frac_note": "2*B*N*d / (screen + select time) / 157.3 TF: the cosine_topk unit of SURVEY.md 8d against the float32-MFMA peak",
+        "kernels": [kk for kk in kernels if kk["share"] >= 0.10 or kk["kernel"].startswith("knn_")],
+        "stages_ms": stages,
+        "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive, "parity_checked_queries": int(len(sel)),
+    }
+    res["roofline"]["traffic"] = traffic
+    res["roofline"]["traffic_source"] = traffic_src
+    res["roofline"]["share_of_step"] = dominant["share"]
+
+    # ---- the same step with the float32 screen, beside the float16 number (streaming configurations) -------------------------
+    if f32_beside and f16:
+        def step32():
+            w.stage_blend(); w.stage_pack(); w.stage_queries(); w.stage_search(o, opts=0)   # noqa: E702
+        lib.hwer_profile_enable(1)
+        ms32 = cuda_time(torch, step32, max(3, min(steps, 5)), warm=1)
+        lib.hwer_profile_enable(0)
+        s32, sel32, _ = read_profile(lib)
+        res["f32_screen"] = {"ms_per_step": ms32, "value": float(U) * I / ms32 * 1e3, "knn_screen_ms": s32 * searches_per_step,
+                             "knn_screen_frac_of_fp32_mfma_peak": flops / (s32 * searches_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS if s32 > 0 else None,
+                             "knn_select_rerank_ms": sel32 * searches_per_step}
+        w.stage_search(o)   # leave the default path's result in place
+
+    # ---- query-batch latencies against this catalogue (SURVEY.md §8d C4: B in {1, 64, 4096}) ---------------------------------
+    for B in latencies:
+        if B > U:
+            continue
+        ob = dict(idx=o["idx"][:B], score=o["score"][:B], dist2=None, flags=o["flags"][:B])
+        opts_b = w.opts if B > 1024 else 0       # small batches take the HBM-bound path, which reads the float16 copy when there is one
+        ms = cuda_time(torch, lambda: w.stage_search(ob, B=B, opts=opts_b), 20 if B <= 64 else 5, warm=2)
+        row_bytes = (2.0 if w.X16 is not None else 4.0) * w.ldx
+        ent = {"batch": B, "ms": ms, "pairs_per_s": float(B) * I / ms * 1e3}
+        if B <= 64:
+            ent["hbm_frac_of_6.3TBs"] = (I * row_bytes / (ms * 1e-3)) / 6.3e12
+        res.setdefault("query_latency_ms", []).append(ent)
+
+    # ---- pair scoring (SURVEY.md §8d-i: P / t): random (user, item) pairs of this table -------------------------------------
+    if not args.sweep_only:
+        n_pairs = 1000209 if I < 100000 else 16000000
+        gp = torch.Generator(device=dev).manual_seed(4001)
+        p_src = torch.randint(0, U, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
+        p_dst = torch.randint(U, w.N, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
+        p_out = torch.empty(n_pairs, dtype=torch.float64, device=dev)
+        P = native.ptr
+        ps_ms = cuda_time(torch, lambda: native.check(lib.hwer_pair_score_f64(P(w.V), w.N, d, w.ldv, P(p_src), P(p_dst), n_pairs, P(p_out), w.S()), "pair_score"), 20, warm=3)
+        ps_bytes = n_pairs * (8.0 * d + 8 + 8)     # two rows + two int32 ids + one float64 result per pair
+        table_mb = w.N * d * 4 / 1e6
+        res["pair_score"] = {"pairs": n_pairs, "value": n_pairs / ps_ms * 1e3, "unit": "pairs/s", "ms": ps_ms, "dtype": "f64", "table_MB": table_mb,
+                             "roofline": {"bound": "hbm", "achieved": ps_bytes / ps_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": ps_bytes / ps_ms / 1e6 / HBM_PEAK_GBS,
+                                          "note": "table resident in L2 / Infinity Cache: not an HBM measurement" if table_mb < 256 else "gathered rows from HBM"}}
+
+    # ---- CPU baseline on the host cores: the oracle's C restatement (kind "port"), the vectorised float32 formulation, the
+    # reference-shaped per-anchor loop (scikit-learn KD-tree + Python, one thread) ---------------------------------------------
+    if cpu_budget_s > 0:
+        res["cpu_baseline"] = cpu_baseline(w, Vh, idx_h, cpu_budget_s, cores, cores_note)
+        res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
+        if "reference_shaped" in res["cpu_baseline"]:
+            res["speedup_vs_reference_shaped_loop"] = value / res["cpu_baseline"]["reference_shaped"]["value"]
+
+    # ---- API-level latency: the same sweep through the drop-in Python classes, results on the host -----------------------------
+    if api:
+        res["api_latency_ms"] = api_latency(torch, Vh, U, I, d, arrays_only=(api == "arrays"))
+    del w
+    torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline(w, Vh, idx_h, budget_s, cores, cores_note):
+    from oracle import c_oracle
+    from oracle import hwer_oracle as orc
+    U, I, d = w.U, w.I, w.d
+    V64 = Vh[:U].astype(np.float64)
+    n_s = int(min(U, max(64, 0.7e9 * budget_s * cores / (float(I) * d * 8))))
+    sel = np.linspace(0, U - 1, n_s).astype(np.int64)
+    Qh = V64[sel] / np.linalg.norm(V64[sel], axis=1, keepdims=True)
+    c_oracle.find_closest_f64(Vh[U:U + min(I, 2048)], Qh[:8], V64[sel[:8]], min(K, 64), threads=cores)  # warm up the thread pool
+    passes, t_all = 0, 0.0
+    while passes < 1 or (t_all < budget_s and passes < 64):
+        t1 = time.perf_counter()
+        c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=cores)
+        t_all += time.perf_counter() - t1
+        passes += 1
+    t_pass = t_all / passes
+    n_1 = max(8, n_s // (4 * cores))
+    t1 = time.perf_counter()
+    c_oracle.find_closest_f64(Vh[U:], Qh[:n_1], V64[sel[:n_1]], K, threads=1)
+    t_one = time.perf_counter() - t1
+    out = {"value": n_s * float(I) / t_pass, "unit": "pairs/s", "cores": cores, "kind": "port",
+           "sample": "%d of %d users x %d items, %d passes (%.1f s of CPU work), exact float64 brute force + re-score + sort (oracle/hwer_oracle.c, OpenMP)" % (n_s, U, I, passes, t_all),
+           "seconds_per_pass": t_pass, "single_thread_value": n_1 * float(I) / t_one, "cores_note": cores_note, "host": host_description()}
+    # best-effort VECTORISED CPU path (SURVEY.md §8d (2)): batched float32 Q @ X^T (BLAS, all cores) + argpartition + sort +
+    # exact float64 re-score of the k kept per user.  Not the reference's algorithm (its KD-tree is exact in float64).
+    try:
+        n_v = int(min(U, 4096, max(64, 2.0e9 / (4.0 * I))))     # key matrix of the sample <= 2 GB
+        v_sel = np.linspace(0, U - 1, n_v).astype(np.int64)
+        Xh = np.ascontiguousarray(Vh[U:U + I])
+        X64 = None
+        hn = 0.5 * (Xh.astype(np.float64) ** 2).sum(1).astype(np.float32)
+
+        def vectorised():
+            Qv = np.ascontiguousarray(Vh[v_sel])
+            keys = Qv @ Xh.T
+            keys -= hn[None, :]
+            part = np.argpartition(-keys, K - 1, axis=1)[:, :K]
+            ks = np.take_along_axis(keys, part, axis=1)
+            order = np.argsort(-ks, axis=1, kind="stable")
+            top = np.take_along_axis(part, order, axis=1)
+            sc = (np.einsum("bkd,bd->bk", Xh[top].astype(np.float64), V64[v_sel]) + 1.0) / 2.0
+            return top, sc
+        try:
+            from threadpoolctl import threadpool_limits
+            limiter = threadpool_limits(limits=cores, user_api="blas")
+        except Exception:
+            limiter = None
+        n_runs = 3 if I <= 50000 else 1
+        if n_runs > 1:
+            vectorised()
+        ts = []
+        for _ in range(n_runs):
+            t1 = time.perf_counter()
+            v_top, _ = vectorised()
+            ts.append(time.perf_counter() - t1)
+        t_v = float(np.median(ts))
+        if limiter is not None:
+            limiter.restore_original_limits()
+        agree = float(np.mean([len(np.intersect1d(v_top[i], idx_h[v_sel[i]] - U)) / float(K) for i in range(0, n_v, max(1, n_v // 256))]))
+        out["vectorised_f32"] = {"value": n_v * float(I) / t_v, "unit": "pairs/s", "cores": cores,
+                                 "sample": "%d users x %d items, median of %d" % (n_v, I, n_runs), "seconds": t_v,
+                                 "note": "float32 BLAS screen + argpartition + float64 re-score of k: approximate at the cut",
+                                 "neighbour_overlap_with_gpu": agree}
+        del X64
+    except MemoryError:
+        pass
+    # the reference-SHAPED loop (scikit-learn KD-tree + per-anchor Python loop, one thread: SURVEY.md §8d (1), BASELINE.md §3 A)
+    if I <= 50000:
+        try:
+            n_ref = 48
+            ref_sel = np.linspace(0, U - 1, n_ref).astype(np.int64)
+            Vall = Vh.astype(np.float64)
+            t1 = time.perf_counter()
+            r_idx, _ = orc.reference_shaped_sweep(Vall, np.arange(U, U + I), ref_sel.tolist(), K)
+            t_ref = time.perf_counter() - t1
+            out["reference_shaped"] = {"value": n_ref * float(I) / t_ref, "unit": "pairs/s", "cores": 1, "ms_per_anchor": t_ref / n_ref * 1e3,
+                                       "includes": "KD-tree build + %d anchors" % n_ref,
+                                       "same_neighbours_as_gpu": bool(np.array_equal(r_idx, idx_h[ref_sel]))}
+        except ImportError:
+            pass
+    return out
+
+
+def api_latency(torch, Vh, U, I, d, arrays_only=False):
+    """Wall time of the retrieval sweep THROUGH the drop-in Python API (reference: `retrieval_time` = the wall clock of
+    get_topk for all anchors, hwer/validation.py:110-113, :30-35), results on the host: query construction, search, D2H copy
+    and Python object construction included."""
+    from hwer import Edge, Node, VectorIndex, validation
+    out = {}
+    users = [Node("user", i) for i in range(U)]
+    items = [Node("item", i) for i in range(I)]
+    t1 = time.perf_counter()
+    m = VectorIndex(node_types={"user", "item"}, n_dims=d)
+    m.fit(users + items, Vh.astype(np.float64))
+    torch.cuda.synchronize()
+    out["index_build_ms"] = (time.perf_counter() - t1) * 1e3
+
+    def med(fn, n=5):
+        fn()
+        ts = []
+        for _ in range(n):
+            t = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts)) * 1e3
+    out["find_closest_neighbours_batch"] = med(lambda: m.find_closest_neighbours_batch("item", users, k=K), 5 if U < 50000 else 2)
+    out["find_closest_neighbours_batch_note"] = "all %d anchors -> (idx, score) numpy arrays on the host" % U
+    if arrays_only:
+        return out
+    out["model_get_topk"] = med(lambda: validation.model_get_topk(m, users, "item"))
+    out["model_get_topk_note"] = "the reference's retrieval_time call: {anchor: [(Node, score)] * 200}; lists are materialised on access"
+
+    def materialise():
+        r = validation.model_get_topk(m, users, "item")
+        for u in users:
+            r[u]
+    out["model_get_topk_all_lists_materialised"] = med(materialise, 3)
+    n_loop = min(U, 64)
+    t1 = time.perf_counter()
+    for u in users[:n_loop]:
+        m.find_closest_neighbours("item", u, k=K)
+    out["find_closest_neighbours_per_anchor"] = (time.perf_counter() - t1) / n_loop * 1e3
+    out["find_closest_neighbours_per_anchor_note"] = "the reference-shaped loop (one call per anchor) through the drop-in class, ms per anchor"
+    # extraction_efficiency end to end on synthetic edges: per user 20 train items + 1 validation item
+    rng = np.random.default_rng(4001)
+    train, valid = [], []
+    for ui, u in enumerate(users):
+        its = rng.choice(I, 21, replace=False)
+        for j in its[:20]:
+            train.append(Edge(u, items[int(j)], float(1 + (ui + int(j)) % 5)))
+        valid.append(Edge(u, items[int(its[20])], 5.0))
+    import random
+    random.seed(0)
+    t1 = time.perf_counter()
+    res = validation.extraction_efficiency(m, train, valid, validation.model_get_topk, "item")
+    t_ee = time.perf_counter() - t1
+    random.seed(0)
+    t1 = time.perf_counter()
+    validation.ncf_eval(m, train, valid, items)
+    t_ncf = time.perf_counter() - t1
+    out["extraction_efficiency"] = t_ee * 1e3
+    out["extraction_efficiency_parts"] = {"retrieval_time": res["metrics"]["retrieval_time"] * 1e3, "ncf_eval (host sampling, reference semantics)": t_ncf * 1e3}
+    return out
+
+
+# ====================================================================================================================
+# N = 1
+# ====================================================================================================================
+def run_single(args):
+    import torch
+    from hwer import native
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    lib = native.lib()
+    base = {"metric": METRIC, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    if args.config:      # one configuration only (profiling runs)
+        r = run_config(torch, lib, args.config, dev, args.steps, args.warmup, args, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0,
+                       latencies=() if args.sweep_only else ((1,) if args.config != "c4" else (1, 64, 4096)), f32_beside=not args.sweep_only)
+        return finish_line(base, r)
+    t_start = time.perf_counter()
+    top = run_config(torch, lib, "c1", dev, args.steps, args.warmup, args, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0, api=True, latencies=(1,))
+    configs = {}
+    configs["c2"] = run_config(torch, lib, "c2", dev, args.steps, args.warmup, args, cpu_budget_s=0.0 if args.no_cpu_baseline else 5.0, api=True, latencies=(1,))
+    configs["c3"] = run_config(torch, lib, "c3", dev, min(args.steps, 20), min(args.warmup, 3), args, cpu_budget_s=0.0 if args.no_cpu_baseline else 4.0,
+                               api="arrays", stage_reps=5, f32_beside=True)
+    configs["c4"] = run_config(torch, lib, "c4", dev, min(args.steps, 10), min(args.warmup, 2), args, latencies=(1, 64, 4096), stage_reps=5, f32_beside=True)
+    configs["c4full"] = run_config(torch, lib, "c4full", dev, min(args.steps, 5), min(args.warmup, 2), args, stage_reps=3)
+    configs["c4full"]["note"] = ("the whole 10M-item catalogue on ONE GPU: the 1-GPU value of the workload that `bench.py --gpus N` (N > 1) strong-scales; "
+                                 "use this value as the N = 1 point of the scaling curve")
+    out = finish_line(base, top)
+    out["configs"] = configs
+    out["bench_wall_s"] = time.perf_counter() - t_start
+    return out
+
+
+def finish_line(base, r):
+    out = dict(base)
+    out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "steps": r["steps"], "warmup": r["warmup"],
+                "config": {"workload": r["workload"], "users": r["users"], "items_per_gpu": r["items"], "items_total": r["items"], "d": r["d"],
+                           "k": r["k"], "tables": r["tables"], "alpha": r["alpha"], "f16_screen": r["f16_screen"], "sharding": "none"}})
+    for k_ in ("roofline", "stage_frac", "stage_frac_note", "kernels", "stages_ms", "certified_queries", "exhaustive_fallback_queries",
+               "parity_checked_queries", "hip_graph", "f32_screen", "query_latency_ms", "pair_score", "cpu_baseline", "speedup_vs_cpu",
+               "speedup_vs_reference_shaped_loop", "api_latency_ms"):
+        if k_ in r:
+            out[k_] = r[k_]
+    if "api_latency_ms" in r and "model_get_topk" in r["api_latency_ms"]:
+        out["recall_latency_ms"] = r["api_latency_ms"]["model_get_topk"]
+        out["recall_latency_note"] = "wall time of model_get_topk for all anchors through the drop-in API (the reference's retrieval_time), results on the host"
+    return out
+
+
+# ====================================================================================================================
+# N > 1: strong scaling of the 10 M-item catalogue
+# ====================================================================================================================
+def run_sharded(args, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     from hwer import native
-    from hwer.device_index import roundup
-    from hwer.distributed import all_gather_results, exchange_by_query, merge_on_device
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    from hwer.distributed import all_gather_results, exchange_by_query, merge_on_device, shard_bounds
     backend = os.environ.get("HWER_BENCH_BACKEND", "nccl")     # "gloo" only to exercise the N > 1 code path on a 1-GPU box
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
-
-    lib = native.lib()
-    cfg = CONFIGS[args.config]
-    U, I, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
-    N = U + I                      # rows held by this rank: replicated users + the local item shard
-    ldv = roundup(d, 4)
-    ldx = lib.hwer_knn_padded_dim(d)
-    S = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
-    P = native.ptr
-
-    # ---------------- synthetic inputs, resident in HBM ------------------------------------------------------
-    gen = torch.Generator(device=dev)
-    tables = []
-    for t in range(T):
-        gen.manual_seed(3000 + 10 * 2 + t)                       # users: identical on every rank
-        users = unit_rows(torch, gen, U, d, dev)
-        gen.manual_seed(100003 * (rank + 1) + 3000 + t)          # items: this rank's shard
-        items = unit_rows(torch, gen, I, d, dev)
-        tables.append(torch.cat([users, items]).contiguous())
-    if cfg["per_row"]:
-        g = torch.Generator(device="cpu").manual_seed(5005)
-        # Dirichlet(1, .., 1) = normalised unit exponentials, drawn from the seeded generator (torch.distributions has no generator argument)
-        alpha = -torch.log(torch.rand((N, T), generator=g, dtype=torch.float64).clamp_min(1e-300))
-        alpha = (alpha / alpha.sum(1, keepdim=True)).to(torch.float32)
-        cold = torch.rand(N, generator=g) < 0.2
-        alpha[cold, T - 1] = 0.0
-        alpha = (alpha / alpha.sum(1, keepdim=True)).to(dev).contiguous()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
-        alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
-    tab_ptrs = torch.tensor([t.data_ptr() for t in tables], dtype=torch.int64, device=dev)
-    item_rows = torch.arange(U, N, dtype=torch.int64, device=dev)
-    anchors = torch.arange(0, U, dtype=torch.int32, device=dev)
-
-    # ---------------- preallocated outputs / workspace ----------------------------------------------------------
-    V = torch.zeros((N, ldv), dtype=torch.float32, device=dev)
-    norm_ws = torch.empty(lib.hwer_unit_audit_ws_floats(N), dtype=torch.float32, device=dev)
-    audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)      # counts[4] | sum |norm-1| (f64) | pad: one 48-byte memset
-    audit_counts = audit_buf[:4]
-    audit_dev = audit_buf[4:5].view(torch.float64)
-    I_pad = lib.hwer_knn_padded_rows(I)
-    X = torch.empty((I_pad, ldx), dtype=torch.float32, device=dev)
-    hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
-    f16_screen = ((not args.f32_screen) and I > 8192) or (args.f16_dense and I <= 8192)
-    X16 = torch.empty((I_pad, ldx), dtype=torch.float16, device=dev) if f16_screen else None
-    Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
-    Q32 = torch.empty((U, ldx), dtype=torch.float32, device=dev)
-    # N > 1: two result sets, so that the exchange + merge of step i (side stream) overlaps the search of step i + 1
-    n_sets = 2 if world > 1 else 1
-    sets = [dict(idx=torch.empty((U, K), dtype=torch.int64, device=dev), score=torch.empty((U, K), dtype=torch.float64, device=dev),
-                 dist2=torch.empty((U, K), dtype=torch.float64, device=dev), flags=torch.empty(U, dtype=torch.int32, device=dev))
-            for _ in range(n_sets)]
-    o_idx, o_score, o_dist2, o_flags = sets[0]["idx"], sets[0]["score"], sets[0]["dist2"], sets[0]["flags"]
-    CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
-    ws_bytes = lib.hwer_knn_workspace_bytes(min(U, CH), I, d, K)
-    assert ws_bytes > 0
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    # rows passed the 1e-4 unit-norm audit (checked after the timed region) => 0.5||x||^2 <= 0.5 (1 + 1e-4)^2
-    hnorm_max = 0.5 * (1.0 + 1e-4) ** 2
-    x16_exp = int(lib.hwer_knn_f16_scale_exp(hnorm_max)) if f16_screen else 0
-    id_base = U + rank * I          # global row id of this rank's first item (users first, then shards in rank order)
-    arith = 0                       # float64 score arithmetic (ContentRecommendation flavour)
-    # find_closest_neighbours returns (node, score): distances are an output only where the shards' results are merged
-    want_dist = world > 1
-
-    def search_into(o):
-        # blend + L2-normalise with the unit-norm audit of the output rows fused into the same pass
-        native.check(lib.hwer_blend_normalize_audit_f32(P(tab_ptrs), d, None, P(alpha), 1 if cfg["per_row"] else 0, T, N, d,
-                                                        P(V), ldv, 1e-4, P(audit_counts), P(audit_dev), S()), "blend+audit")
-        native.check(lib.hwer_pack_rows_f32(P(V), N, d, ldv, P(item_rows), I, P(X), ldx, P(hnorm), S()), "pack")
-        if f16_screen:
-            native.check(lib.hwer_pack_rows_f16(P(X), I_pad, ldx, x16_exp, P(X16), S()), "pack16")
-        native.check(lib.hwer_query_mix(P(V), N, d, ldv, P(anchors), None, None, None, None, U, arith, P(Q64), P(Q32),
-                                        ldx, S()), "query_mix")
-        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
-        for b0 in range(0, U, CH):
-            b1 = min(U, b0 + CH)
-            native.check(lib.hwer_knn_search_opts_f32(P(X), P(hnorm), I, d, ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(V), ldv,
-                                                      P(anchors[b0:b1]), b1 - b0, K, arith, 1 if world == 1 else 0, None, id_base,
-                                                      hnorm_max, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if want_dist else None,
-                                                      P(of[b0:b1]), P(ws), ws.numel(), 2 if f16_screen else 0,
-                                                      P(X16) if f16_screen else None, x16_exp, S()), "knn_search")
-            # queries the screen could not certify (rare: near-ties at the cut, or a sample-scaled threshold that was too
-            # tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the device (no host round trip):
-            # the step always returns exact results.  `missed` counts listed queries beyond the 8 one call handles
-            # (checked after the timed region: must stay 0).
-            native.check(lib.hwer_knn_exact_device(P(X), I, d, ldx, P(Q64[b0:b1]), P(V), ldv, P(anchors[b0:b1]), K, arith,
-                                                   1 if world == 1 else 0, None, id_base, P(oi[b0:b1]), P(osc[b0:b1]),
-                                                   P(od[b0:b1]) if want_dist else None, P(of[b0:b1]), P(ws), P(missed), P(ws_exact), ws_exact.numel(), S()),
-                         "knn_exact_device")
-
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    lib = native.lib()
+    name = args.config or "c4full"
+    cfg = dict(CONFIGS[name])
+    if os.environ.get("HWER_BENCH_ITEMS"):       # rehearsals on small boxes: a smaller catalogue, same code path
+        cfg["I"] = int(os.environ["HWER_BENCH_ITEMS"])
+        cfg["name"] += " [catalogue cut to %d items]" % cfg["I"]
+    I_total, U, d = cfg["I"], cfg["U"], cfg["d"]
+    lo, hi = shard_bounds(I_total, world, rank)
+    w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2)
+    comm = torch.cuda.Stream(device=dev)
+    ev_searched = [torch.cuda.Event() for _ in range(2)]
+    ev_merged = [torch.cuda.Event() for _ in range(2)]
+    merged = [None, None]
     step_no = [0]
+    ev_log = []      # (start, collective done, merge done) events of every step, read after the closing barrier
 
-    def step():
-        if world == 1:
-            search_into(sets[0])
-            return o_idx, o_score, o_dist2
-        # N > 1.  ONE exchange step per search: user-partitioned (every rank receives the local lists of ITS slice of the
-        # users from all ranks and merges those - 1/N of the all-gather's bytes per xGMI link), or the all-gather variant.
-        # The exchange + merge run on a side stream: while RCCL moves the lists of step i over xGMI, the compute stream is
-        # already searching step i + 1 into the other result set.  Every step's merge still completes inside the timed
-        # region (the closing barrier synchronises all streams).
-        s = step_no[0] & 1
-        step_no[0] += 1
-        o = sets[s]
-        cur = torch.cuda.current_stream()
-        cur.wait_event(ev_merged[s])          # the exchange that read this result set two steps ago is done
-        search_into(o)
-        ev_searched[s].record(cur)
-        with torch.cuda.stream(comm):
-            comm.wait_event(ev_searched[s])
-            g = exchange_by_query(o["idx"], o["score"], o["dist2"]) if exchange == "by_query" else all_gather_results(o["idx"], o["score"], o["dist2"])
-            merged[s] = merge_on_device(*g, True)
-            ev_merged[s].record(comm)
-        return merged[s]
-
-    comm = torch.cuda.Stream(device=dev) if world > 1 else None
-    ev_searched = [torch.cuda.Event() for _ in range(n_sets)]
-    ev_merged = [torch.cuda.Event() for _ in range(n_sets)]
-    merged = [None] * n_sets
-    missed = torch.zeros(1, dtype=torch.int32, device=dev)
-    exchange = os.environ.get("HWER_BENCH_EXCHANGE", "by_query")
-    ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
+    def make_step(exchange):
+        def step():
+            # ONE exchange step per search.  The exchange + merge run on a side stream: while RCCL moves the lists of step i over
+            # xGMI, the compute stream is already searching step i + 1 into the other result set.  Every step's merge still
+            # completes inside the timed region (the closing barrier synchronises all streams).
+            s = step_no[0] & 1
+            step_no[0] += 1
+            o = w.sets[s]
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev_merged[s])          # the exchange that read this result set two steps ago is done
+            w.step(o)
+            ev_searched[s].record(cur)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_searched[s])
+                e0.record(comm)
+                g = exchange_by_query(o["idx"], o["score"], o["dist2"]) if exchange == "by_query" else all_gather_results(o["idx"], o["score"], o["dist2"])
+                e1.record(comm)
+                merged[s] = merge_on_device(*g, True)
+                e2.record(comm)
+                ev_merged[s].record(comm)
+            ev_log.append((e0, e1, e2))
+            return merged[s]
+        return step
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dist.barrier()
         torch.cuda.synchronize()
 
-    assert d == ldv, "bench tables are passed with row stride d"
-    for _ in range(args.warmup):
-        res = step()
-    barrier()
-    lib.hwer_profile_enable(PROFILE_EVERY)   # HIP events around every PROFILE_EVERY-th search (each pair costs ~10 us of stream time)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    lib.hwer_profile_enable(0)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    def timed(step, steps, warmup, profile=False):
+        for _ in range(warmup):
+            res = step()
+        barrier()
+        ev_log.clear()
+        if profile:
+            lib.hwer_profile_enable(PROFILE_EVERY)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            res = step()
+        barrier()
+        el = time.perf_counter() - t0
+        if profile:
+            lib.hwer_profile_enable(0)
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    tot = ctypes.c_double()
-    cnt = ctypes.c_int64()
-    lib.hwer_profile_read(0, ctypes.byref(tot), ctypes.byref(cnt))
-    screen_ms = tot.value / max(cnt.value, 1)
-    searches_per_step = (U + CH - 1) // CH
-    screen_launches_per_step = float(searches_per_step)
-    lib.hwer_profile_read(1, ctypes.byref(tot), ctypes.byref(cnt))
-    select_ms = tot.value / max(cnt.value, 1)
+        xs = [(a.elapsed_time(b), b.elapsed_time(c)) for a, b, c in ev_log]
+        return float(tt.item()), res, xs
 
-    # ---------------- post-hoc checks (outside the timed region) ------------------------------------------------
-    diag = bool(os.environ.get("HWER_BENCH_NOSYNC"))   # diagnosis runs (ablation switches) skip the result checks
-    pos, neg, nan = audit_counts.tolist()[:3]
-    assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
-    last = sets[(step_no[0] - 1) & 1] if world > 1 else sets[0]   # the result set of the last step
-    n_uncert = int((last["flags"] == 0).sum().item())
-    assert diag or n_uncert == 0, "%d queries left without an exact result" % n_uncert
-    assert diag or int(missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(missed.item())
-    n_exhaustive = int((last["flags"] == 2).sum().item())
-    idx_h = res[0].cpu().numpy()
-    score_h = res[1].cpu().numpy()
-    parity_n = 0
-    if world == 1 and not diag:
+    main_exchange = os.environ.get("HWER_BENCH_EXCHANGE", "all_gather")
+    elapsed, res, xs = timed(make_step(main_exchange), args.steps, args.warmup, profile=True)
+    screen_ms, select_ms, _ = read_profile(lib)
+    last = w.sets[(step_no[0] - 1) & 1]
+    n_exhaustive = w.checks(last)
+    idx_h, score_h = res[0].cpu().numpy(), res[1].cpu().numpy()
+    other = "by_query" if main_exchange == "all_gather" else "all_gather"
+    el2, _, xs2 = timed(make_step(other), args.steps, min(args.warmup, 2))
+
+    # ---- parity: rank 0 collects every rank's blended item rows (rank order = global id order) and checks the merged lists of
+    # sampled users against the oracle's brute force over the WHOLE catalogue ----------------------------------------------
+    per = (I_total + world - 1) // world
+    shard = torch.zeros((per, d), dtype=torch.float32, device=dev)
+    shard[:hi - lo] = w.V[U:, :d]
+    parity_n, result_sha = 0, None
+    if backend == "nccl":
+        allv = torch.empty((world * per, d), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(allv, shard)
+        items_h = allv[:I_total].cpu().numpy() if rank == 0 else None
+        del allv
+    else:
+        parts = [torch.empty((per, d), dtype=torch.float32) for _ in range(world)]
+        dist.all_gather(parts, shard.cpu())
+        items_h = torch.cat(parts)[:I_total].numpy() if rank == 0 else None
+    if rank == 0:
+        import hashlib
         from oracle import c_oracle
-        Vh = V[:, :d].cpu().numpy()
-        sel = np.unique(np.linspace(0, U - 1, 16).astype(np.int64))
-        V64 = Vh.astype(np.float64)
-        Qh = V64[sel] / np.sqrt(np.stack([(V64[s] * V64[s]).sum() for s in sel]))[:, None]
-        # oracle query = unit(anchor) in numpy's own arithmetic
         from oracle import hwer_oracle as orc
-        Qh = np.stack([orc.query_vector(V64, int(s)) for s in sel])
-        oi, osc, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=effective_cpus()[0])
-        assert np.array_equal(idx_h[sel], oi + U), "GPU indices differ from the oracle"
-        assert np.array_equal(score_h[sel], osc), "GPU scores differ from the oracle"
+        cores, _ = effective_cpus()
+        n_mine = idx_h.shape[0]      # all-gather: every query; by_query: rank 0 owns users [0, ceil(U/N))
+        sel = np.unique(np.linspace(0, n_mine - 1, 16 if I_total <= 2000000 else 8).astype(np.int64))
+        V64 = w.V[:U, :d].cpu().numpy().astype(np.float64)
+        Qh = np.stack([orc.query_vector(V64, int(q)) for q in sel])
+        oi, osc, _ = c_oracle.find_closest_f64(items_h, Qh, V64[sel], K, threads=cores)
+        assert np.array_equal(idx_h[sel], oi + U), "merged indices differ from the oracle (N = %d)" % world
+        assert np.array_equal(score_h[sel], osc), "merged scores differ from the oracle (N = %d)" % world
         parity_n = len(sel)
-    elif world > 1 and not diag and I * world <= 400000:
-        # N > 1: rank 0 collects every rank's item shard (rank order = global id order) and checks the merged lists of
-        # sampled users of ITS slice against the oracle's brute force over the whole catalogue
-        shard = V[U:, :d].contiguous()
-        if backend == "nccl":
-            allv = torch.empty((world * I, d), dtype=torch.float32, device=dev)
-            dist.all_gather_into_tensor(allv, shard)
-            items_h = allv.cpu().numpy()
-        else:
-            parts = [torch.empty((I, d), dtype=torch.float32) for _ in range(world)]
-            dist.all_gather(parts, shard.cpu())
-            items_h = torch.cat(parts).numpy()
-        if rank == 0:
-            from oracle import c_oracle
-            from oracle import hwer_oracle as orc
-            n_mine = idx_h.shape[0] if exchange != "by_query" else (U + world - 1) // world   # rank 0 owns users [0, ceil(U/N))
-            sel = np.unique(np.linspace(0, min(n_mine, U) - 1, 16).astype(np.int64))
-            V64 = V[:U, :d].cpu().numpy().astype(np.float64)
-            Qh = np.stack([orc.query_vector(V64, int(q)) for q in sel])
-            oi, osc, _ = c_oracle.find_closest_f64(items_h, Qh, V64[sel], K, threads=effective_cpus()[0])
-            assert np.array_equal(idx_h[sel], oi + U), "merged indices differ from the oracle (N = %d)" % world
-            assert np.array_equal(score_h[sel], osc), "merged scores differ from the oracle (N = %d)" % world
-            parity_n = len(sel)
+        result_sha = hashlib.sha256(np.ascontiguousarray(idx_h[:64]).tobytes()).hexdigest()[:16]
+        del items_h
 
-    total_items = I * world
-    pairs_per_step = float(U) * float(total_items)
+    # ---- the same workload on ONE GPU, measured in this job by rank 0 (the denominator of the strong-scaling speedup) --------
+    n1 = None
+    del w
+    torch.cuda.empty_cache()
+    if rank == 0 and not os.environ.get("HWER_BENCH_NO_ANCHOR"):
+        w1 = Workload(torch, lib, cfg, dev, f32_screen=args.f32_screen)
+        for _ in range(2):
+            w1.step()
+        torch.cuda.synchronize()
+        n1_steps = max(3, min(args.steps, 5))
+        t0 = time.perf_counter()
+        for _ in range(n1_steps):
+            w1.step()
+        torch.cuda.synchronize()
+        t1 = (time.perf_counter() - t0) / n1_steps
+        w1.checks(w1.sets[0])
+        same = bool(np.array_equal(w1.sets[0]["idx"].cpu().numpy(), idx_h)) if main_exchange == "all_gather" else None
+        n1 = {"ms_per_step": t1 * 1e3, "value": float(U) * I_total / t1, "steps": n1_steps, "same_result_as_sharded": same,
+              "note": "the whole catalogue on rank 0's GPU alone, same step, measured after the timed region of this job"}
+        del w1
+    barrier()
+
+    value = float(U) * float(I_total) / (elapsed / args.steps)
     ms_per_step = elapsed / args.steps * 1e3
-    value = pairs_per_step / (elapsed / args.steps)
-    # dominant kernel: the float32 MFMA screen.  Algorithmic work per launch = 2 * B * N_t * d flops
-    launches = max(1.0, screen_launches_per_step)
-    flops_per_launch = 2.0 * U * I * d / launches
-    achieved = flops_per_launch / (screen_ms * 1e-3) / 1e12 if screen_ms > 0 else 0.0
-    # HBM traffic of the screen kernel per launch, measured with rocprofv3 PMC passes for the SAME command and kept in
-    # profiles/r1_pmc_traffic.json: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes (FETCH_SIZE reads half the bytes of wide
-    # loads on gfx950 - MI355X_MICROARCH.md §HBM).  None when no profile exists for this config / GPU count.
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as fh:
-            traffic = json.load(fh).get(args.config if world == 1 else "", {}).get("knn_screen_bytes_per_launch")
-    except OSError:
-        pass
+    f16 = (not args.f32_screen) and (hi - lo) > 8192
+    flops_local = 2.0 * U * (hi - lo) * d
+    achieved = flops_local / (screen_ms * 1e-3) / 1e12 if screen_ms > 0 else 0.0
+    peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
+    xa = np.asarray(xs) if xs else np.zeros((0, 2))
+    xb = np.asarray(xs2) if xs2 else np.zeros((0, 2))
     out = {
-        "metric": "user-item pairs/sec scored (blend + L2-normalise + exact top-%d retrieval)" % K,
-        "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if f16_screen else "f32", "data": "synthetic",
-        "config": {"workload": cfg["name"], "users": U, "items_per_gpu": I, "items_total": total_items, "d": d, "k": K,
-                   "tables": T, "alpha": "per-row" if cfg["per_row"] else "scalar", "f16_screen": f16_screen, "sharding": ("items row-sharded x%d, %s + merge, exchange of step i overlapped with the search of step i+1" % (world, "user-partitioned exchange" if exchange == "by_query" else "all-gather")) if world > 1 else "none"},
-        "roofline": {"kernel": ("knn_screen (v_mfma_f32_32x32x8_f16 on a float16 copy of the table + streaming top-K' filter; exact float64 re-rank)"
-                                if f16_screen else "knn_screen (v_mfma_f32_32x32x2_f32 + streaming top-K' filter)"), "bound": "mfma",
-                     "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS if f16_screen else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / (MFMA_F16_PEAK_TFLOPS if f16_screen else MFMA_F32_PEAK_TFLOPS),
-                     **({"vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
-                         "note": "float16 screen: the kernel is bound by its filter / LDS-DMA phases, not by the float16 MFMA pipe; "
-                                 "vs_fp32_mfma_peak > 1 = faster than any float32-MFMA screen could be"} if f16_screen else {}),
-                     "traffic": traffic, "avg_launch_ms": screen_ms, "launches_per_step": launches},
+        "metric": METRIC, "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
+        "config": {"workload": cfg["name"] + ", strong scaling: the SAME catalogue for every N", "users": U, "items_per_gpu": hi - lo, "items_total": I_total,
+                   "d": d, "k": K, "tables": cfg["T"], "alpha": "per-row" if cfg["per_row"] else "scalar", "f16_screen": f16,
+                   "sharding": "items row-sharded x%d, queries replicated, ONE %s of the local top-%d per step + hwer_merge_topk_strided; the exchange of step i "
+                               "overlaps the search of step i+1" % (world, "RCCL all-gather" if main_exchange == "all_gather" else "user-partitioned all-to-all", K),
+                   "backend": backend, "rccl_ranks": dist.get_world_size()},
+        "roofline": {"kernel": "knn_screen on this rank's shard", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": screen_ms},
         "kernels_ms": {"knn_screen": screen_ms, "knn_select_rerank": select_ms},
-        "recall_latency_ms": ms_per_step, "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive,
-        "parity_checked_queries": parity_n,
+        "exchange": {"kind": main_exchange, "bytes_sent_per_rank_per_step": 24 * U * K if main_exchange == "all_gather" else 24 * U * K * (world - 1) // world,
+                     "collective_ms": float(xa[:, 0].mean()) if len(xa) else None, "merge_ms": float(xa[:, 1].mean()) if len(xa) else None,
+                     "note": "side-stream times (HIP events around the collective and around the merge kernel), overlapped with the next step's search"},
+        "variants": {other: {"ms_per_step": el2 / args.steps * 1e3, "value": float(U) * I_total / (el2 / args.steps),
+                             "collective_ms": float(xb[:, 0].mean()) if len(xb) else None, "merge_ms": float(xb[:, 1].mean()) if len(xb) else None}},
+        "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive, "parity_checked_queries": parity_n,
+        "result_sha16_first64_queries": result_sha,
+        "one_gpu_same_workload": n1, "speedup_vs_one_gpu": (value / n1["value"]) if n1 else None,
+        "scaling_note": "N = 1 point of this curve: `configs.c4full` of the `--gpus 1` line, or one_gpu_same_workload here",
     }
-
-    # ---------------- per-query latency: one anchor against this rank's catalogue, outside the timed region ----
-    if world == 1 and not args.sweep_only:
-        ws1 = torch.empty(lib.hwer_knn_workspace_bytes(1, I, d, K), dtype=torch.uint8, device=dev)
-
-        def one_query():
-            native.check(lib.hwer_knn_search_opts_f32(P(X), P(hnorm), I, d, ldx, P(Q32), P(Q64), P(V), ldv, P(anchors), 1, K, arith, 1, None,
-                                                      id_base, hnorm_max, P(o_idx), P(o_score), None, P(o_flags), P(ws1), ws1.numel(), 0,
-                                                      P(X16) if f16_screen else None, x16_exp, S()), "knn_search(B=1)")
-        for _ in range(3):
-            one_query()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            one_query()
-        e1.record()
-        torch.cuda.synchronize()
-        out["query_latency_ms"] = {"batch": 1, "value": e0.elapsed_time(e1) / 20.0, "note": "one anchor, exact top-%d, catalogue resident%s" % (K, ", float16 storage" if f16_screen else "")}
-
-        # ---------------- pair scoring (P / t), outside the timed region: P random (user, item) pairs of this table ----
-        n_pairs = 1000209 if args.config in ("c1", "c2") else 16000000
-        gp = torch.Generator(device=dev).manual_seed(4001)
-        p_src = torch.randint(0, U, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
-        p_dst = torch.randint(U, N, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
-        p_out = torch.empty(n_pairs, dtype=torch.float64, device=dev)
-
-        def score_pairs():
-            native.check(lib.hwer_pair_score_f64(P(V), N, d, ldv, P(p_src), P(p_dst), n_pairs, P(p_out), S()), "pair_score")
-        for _ in range(3):
-            score_pairs()
-        e0.record()
-        for _ in range(20):
-            score_pairs()
-        e1.record()
-        torch.cuda.synchronize()
-        ps_ms = e0.elapsed_time(e1) / 20.0
-        ps_bytes = n_pairs * (8.0 * d + 8 + 8)     # two rows + two int32 ids + one float64 result per pair
-        out["pair_score"] = {"pairs": n_pairs, "value": n_pairs / ps_ms * 1e3, "unit": "pairs/s", "ms": ps_ms, "dtype": "f64",
-                             "roofline": {"bound": "hbm", "achieved": ps_bytes / ps_ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": ps_bytes / ps_ms / 1e6 / HBM_PEAK_GBS}}
-
-    # ---------------- CPU baseline: the oracle's C restatement on the host cores (rank 0, N = 1 only) -------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import c_oracle
-        from oracle import hwer_oracle as orc
-        Vh = V[:, :d].cpu().numpy()
-        V64 = Vh.astype(np.float64)
-        cores, cores_note = effective_cpus()
-        n_s = args.cpu_sample or int(min(U, max(64, 6.0e9 * cores / (float(I) * d * 8))))  # ~10-20 s of CPU work
-        sel = np.linspace(0, U - 1, n_s).astype(np.int64)
-        Qh = V64[sel] / np.linalg.norm(V64[sel], axis=1, keepdims=True)
-        c_oracle.find_closest_f64(Vh[U:U + min(I, 2048)], Qh[:8], V64[sel[:8]], min(K, 64), threads=cores)  # warm up the thread pool
-        # bounded sample of the same workload, repeated until ~8 s of CPU work have been timed (at least one full pass)
-        passes, t_all = 0, 0.0
-        while passes < 1 or (t_all < 8.0 and passes < 64):
-            t1 = time.perf_counter()
-            c_oracle.find_closest_f64(Vh[U:], Qh, V64[sel], K, threads=cores)
-            t_all += time.perf_counter() - t1
-            passes += 1
-        t_all /= passes
-        n_1 = max(8, n_s // (4 * cores))
-        t1 = time.perf_counter()
-        c_oracle.find_closest_f64(Vh[U:], Qh[:n_1], V64[sel[:n_1]], K, threads=1)
-        t_one = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": n_s * float(I) / t_all, "unit": "pairs/s", "cores": cores, "kind": "port",
-                               "sample": "%d of %d users x %d items, %d passes, exact float64 brute force + re-score + sort (oracle/hwer_oracle.c, OpenMP)" % (n_s, U, I, passes),
-                               "seconds": t_all, "single_thread_value": n_1 * float(I) / t_one, "cores_note": cores_note}
-        out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
-        # best-effort VECTORISED CPU path: batched float32 Q @ X^T (BLAS, all cores) + argpartition + sort
-        # + exact float64 re-score of the k kept per user.  Not the reference's algorithm (its KD-tree is exact in float64):
-        # reported so that the GPU/CPU ratio can also be read against the strongest CPU formulation of the same sweep.
-        try:
-            n_v = int(min(U, 4096, max(64, 2.0e9 / (4.0 * I))))     # key matrix of the sample <= 2 GB
-            v_sel = np.linspace(0, U - 1, n_v).astype(np.int64)
-            Xh = np.ascontiguousarray(Vh[U:U + I])
-            hn = 0.5 * (Xh.astype(np.float64) ** 2).sum(1).astype(np.float32)
-
-            def vectorised():
-                Qv = np.ascontiguousarray(Vh[v_sel])
-                keys = Qv @ Xh.T
-                keys -= hn[None, :]
-                part = np.argpartition(-keys, K - 1, axis=1)[:, :K]
-                ks = np.take_along_axis(keys, part, axis=1)
-                order = np.argsort(-ks, axis=1, kind="stable")
-                top = np.take_along_axis(part, order, axis=1)
-                sc = (np.einsum("bkd,bd->bk", V64[U + top], V64[v_sel]) + 1.0) / 2.0
-                return top, sc
-            try:
-                from threadpoolctl import threadpool_info, threadpool_limits
-                limiter = threadpool_limits(limits=cores, user_api="blas")
-            except Exception:
-                threadpool_info = limiter = None
-            n_runs = 5 if I <= 50000 else 2      # a pass over a 1.25 M-item shard takes seconds
-            if n_runs == 5:
-                vectorised()
-            ts = []
-            for _ in range(n_runs):
-                t1 = time.perf_counter()
-                v_top, _ = vectorised()
-                ts.append(time.perf_counter() - t1)
-            t_v = float(np.median(ts))
-            blas = None
-            if threadpool_info is not None:
-                blas = [{"api": x.get("internal_api"), "threads": x.get("num_threads")} for x in threadpool_info() if x.get("user_api") == "blas"]
-                limiter.restore_original_limits()
-            agree = float(np.mean([len(np.intersect1d(v_top[i], idx_h[v_sel[i]] - U)) / float(K) for i in range(0, n_v, max(1, n_v // 256))]))
-            out["cpu_baseline"]["vectorised_f32"] = {"value": n_v * float(I) / t_v, "unit": "pairs/s", "cores": cores, "blas": blas,
-                                                     "sample": "%d users x %d items, median of %d" % (n_v, I, n_runs), "seconds": t_v,
-                                                     "note": "float32 BLAS screen + argpartition + float64 re-score of k: approximate at the cut",
-                                                     "neighbour_overlap_with_gpu": agree}
-            out["speedup_vs_cpu_vectorised_f32"] = value / out["cpu_baseline"]["vectorised_f32"]["value"]
-        except MemoryError:
-            pass
-        # the reference-SHAPED loop (scikit-learn KD-tree + per-anchor Python loop, one thread: SURVEY.md §8d), on a small sample
-        if I <= 50000:
-            try:
-                n_ref = 48
-                ref_sel = np.linspace(0, U - 1, n_ref).astype(np.int64)
-                t1 = time.perf_counter()
-                r_idx, r_sc = orc.reference_shaped_sweep(V64, np.arange(U, U + I), ref_sel.tolist(), K)
-                t_ref = time.perf_counter() - t1
-                same = bool(np.array_equal(r_idx, idx_h[ref_sel])) if world == 1 else None
-                out["cpu_baseline"]["reference_shaped"] = {"value": n_ref * float(I) / t_ref, "unit": "pairs/s", "cores": 1,
-                                                           "ms_per_anchor": t_ref / n_ref * 1e3, "includes": "KD-tree build + %d anchors" % n_ref,
-                                                           "same_neighbours_as_gpu": same}
-            except ImportError:
-                pass
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
+                    help="N = 1: run only this configuration (profiling); default = c1 at the top level + c2, c3, c4, c4full under `configs`.  "
+                         "N > 1: the catalogue to strong-scale (default c4full)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--f32-screen", action="store_true",
+                    help="switch HWER_KNN_F16_SCREEN off.  By default the streaming screen (catalogues above 8 192 rows: c3, c4, c5) runs "
+                         "on a float16 copy of the table, rebuilt every step like the float32 one (results unchanged, exact float64 "
+                         "re-rank); the dense path (c1, c2) always screens in float32")
+    ap.add_argument("--f16-dense", action="store_true", help="experiment: also run the small-catalogue screen (c1, c2) on a float16 copy of the table")
+    ap.add_argument("--no-graph", action="store_true", help="time the eager step of the small configurations instead of a hipGraph replay of it")
+    ap.add_argument("--sweep-only", action="store_true",
+                    help="profiling runs: skip the latency / pair-score / float32-screen measurements after the timed region, so that "
+                         "the launches in a rocprofv3 summary are (almost only) those of the timed sweep")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        if world != 1:
+            raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
+        sys.exit(self_launch(args, sys.argv[1:]))      # nothing has touched a GPU in this process
     if world > 1:
-        dist.destroy_process_group()
+        run_sharded(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world)
+        return
+    print(json.dumps(run_single(args)))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,80 @@
+"""Worker of the two-process exchange tests (tests/test_gpu_round2.py): one rank of a row-sharded search that runs the REAL
+HIP local search -> the real exchange (all-gather and user-partitioned) -> the real merge kernel, and checks the merged result
+against the oracle's brute force over the WHOLE catalogue.
+
+    python tests/dist_worker.py <backend: nccl|gloo> <rank> <world> <port> <out_dir> [n_items] [d] [B] [k]
+
+backend nccl: one GPU per rank (RCCL).  backend gloo: every rank uses cuda:0 and the payload is staged through host memory
+(hwer.distributed does that for non-nccl backends) - the kernels, layouts and the merge are the same as under RCCL.
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "hybrid-weighted-embedding-recommender_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def unit_rows_f32(seed, n, d):
+    x = np.random.default_rng(seed).standard_normal((n, d), dtype=np.float32).astype(np.float64)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+def main():
+    backend, rank, world, port, out_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    n_items, d, B, k = (int(x) for x in (sys.argv[6:10] + ["20011", "64", "97", "200"][len(sys.argv) - 6:]))
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hwer.device_index import DeviceIndex
+    from hwer.distributed import ShardedSearch, query_slice, shard_bounds, sharded_index_search
+    from oracle import c_oracle
+    from oracle import hwer_oracle as orc
+
+    U = B
+    users, items = unit_rows_f32(101, U, d), unit_rows_f32(202, n_items, d)
+    lo, hi = shard_bounds(n_items, world, rank)
+    # this rank's table: the (replicated) users followed by ITS item rows; reported ids are global (id_base = lo)
+    V_local = np.concatenate([users, items[lo:hi]]).astype(np.float64)
+    ix = DeviceIndex(V_local, {"user": np.arange(U), "item": np.arange(U, U + hi - lo)}, device=dev)
+    Q64, Q32, a_dev = ix.build_queries(np.arange(U))
+    V64 = np.concatenate([users, items]).astype(np.float64)
+    Qh = np.stack([orc.query_vector(V64, u) for u in range(U)])
+    o_idx, o_score, o_d2 = c_oracle.find_closest_f64(items, Qh, V64[:U], k, threads=4)
+
+    results = {}
+    for exchange in ("all_gather", "by_query"):
+        sh = ShardedSearch(n_items, None, exchange=exchange)
+        assert (sh.lo, sh.hi) == (lo, hi)
+        idx, score, dist2 = sharded_index_search(ix, "item", sh, Q64, Q32, k, anchors_dev=a_dev)
+        torch.cuda.synchronize()
+        q_lo, q_hi = (0, U) if exchange == "all_gather" else query_slice(U, world, rank)
+        assert idx.shape == (q_hi - q_lo, k)
+        got_idx, got_score, got_d2 = idx.cpu().numpy(), score.cpu().numpy(), dist2.cpu().numpy()
+        assert np.array_equal(got_idx, o_idx[q_lo:q_hi]), (exchange, rank)          # ids are item-local here: id_base = lo
+        assert np.array_equal(got_score, o_score[q_lo:q_hi]), (exchange, rank)
+        assert np.array_equal(got_d2, o_d2[q_lo:q_hi]), (exchange, rank)
+        results[exchange] = got_idx
+    # the distance-ordered variant (MultiKNN.query order) through the same exchange
+    sh = ShardedSearch(n_items, None, exchange="all_gather")
+    idx, score, dist2 = sharded_index_search(ix, "item", sh, Q64, Q32, k, anchors_dev=a_dev, sort_by_score=False)
+    r_idx, _, r_d2 = c_oracle.find_closest_f64(items, Qh, V64[:U], k, sort_by_score=False, threads=4)
+    assert np.array_equal(idx.cpu().numpy(), r_idx) and np.array_equal(dist2.cpu().numpy(), r_d2)
+    with open(os.path.join(out_dir, "ok%d" % rank), "w") as fh:
+        fh.write("%s world=%d shard=[%d,%d)\n" % (backend, world, lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
