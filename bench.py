@@ -216,7 +216,8 @@ class Workload:
                           dist2=torch.empty((U, K), dtype=torch.float64, device=dev) if want_dist else None,
                           flags=torch.empty(U, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
         self.CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
-        self.opts = 2 if self.f16_screen else 0
+        # HWER_KNN_F16_SCREEN (2) above 8 192 rows; HWER_BENCH_OPTS ORs in further option bits for A/B runs (e.g. 16 = HWER_KNN_NO_SEED)
+        self.opts = (2 if self.f16_screen else 0) | int(os.environ.get("HWER_BENCH_OPTS", "0"))
         ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(U, self.CH), I, d, K, self.opts),
                        lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(U, 64), I, d, K, 0))
         assert ws_bytes > 0

@@ -31,6 +31,14 @@ struct ScreenPlan {
     int scaled_first;  // use the sample-scaled first threshold (verified; UNDERFULL lists are flagged)
     int dense;         // small catalogue: write every key to a (B, ld_dense) float matrix, select from it
     int64_t ld_dense;
+    // Seeded thresholds (streaming mode): a pre-pass computes the keys of `seed_tiles` sample tiles (every seed_stride-th
+    // 32-row tile of the catalogue) for every query into a dense (bq, seed_ld) matrix, the seed_rank-th largest sample key of
+    // a query becomes its initial threshold tau0 - about seed_c K' of the catalogue's keys clear it - and every list of the
+    // query starts filtering with it instead of collecting its first ~1 000 keys unconditionally.
+    int seed;
+    int seed_tiles, seed_stride, seed_splits;
+    int64_t seed_ld;       // = seed_tiles * 32
+    double seed_frac;      // expected fraction of the catalogue's keys above tau0 (= seed_c * K' / n_items)
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options = 0);
@@ -54,7 +62,10 @@ __device__ __forceinline__ void hdr_reset(WsHeader* hdr, int tid, int n_threads)
     for (int i = tid; i < HDR_RESET_INTS; i += n_threads) reinterpret_cast<int32_t*>(hdr)[i] = 0;
 }
 static_assert(sizeof(WsHeader) <= WS_HEADER_BYTES, "header must fit its slot");
-constexpr int CNT_UNDERFULL = 1 << 30;  // flag bit in cand_cnt
+constexpr int CNT_UNDERFULL = 1 << 30;     // flag bit in cand_cnt: the list's (sample-scaled) threshold dropped keys it should not have
+constexpr int CNT_SEEDED_SHORT = 1 << 29;  // flag bit: the list kept only the keys above the query's SEEDED threshold and they are fewer than K';
+                                           // fine as long as the UNION of the query's lists holds >= K' keys (all of them > tau0 >= anything dropped)
+constexpr int CNT_FLAGS = CNT_UNDERFULL | CNT_SEEDED_SHORT;
 
 // float16 screen inputs (HWER_KNN_F16_SCREEN): the float16 table, the float16 query fragments and their per-query exponents
 struct ScreenF16 {
@@ -66,7 +77,13 @@ struct ScreenF16 {
 bool screen_f16_supported(const ScreenPlan& plan);   // padded dim >= 64
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream,
-                  const ScreenF16* f16 = nullptr);
+                  const ScreenF16* f16 = nullptr, const float* tau0 = nullptr);
+// seed pre-pass: keys of the plan's sample tiles for every query -> seed_keys (bq, plan.seed_ld); same query fragments as the main pass
+int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Qf, int64_t B,
+                       float* seed_keys, WsHeader* hdr, hipStream_t stream, const ScreenF16* f16 = nullptr);
+// per query: tau0[b] = the (want_frac * sample size)-th largest key of its row of `keys` (B, ld), n valid keys per row (knn_small.hip)
+int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, double want_frac, float* tau0, int32_t* count_scratch,
+                          hipStream_t stream);
 // queries -> float16 MFMA fragments + per-query scale exponents (knn_small.hip); Qf16: bq * ng * 16 bytes, qexp: bq ints
 int repack_queries16(const float* Q32, int64_t B, int64_t bq, int ldx, void* Qf16, int32_t* qexp, hipStream_t stream);
 

@@ -26,6 +26,7 @@ namespace hwer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_32x32x16_f16
 
 struct ScreenArgs {
     const float* X;
@@ -54,6 +55,8 @@ struct ScreenArgs {
     const void* Qf16;
     const int32_t* qexp;
     int x_exp;
+    const float* tau0;   // streaming mode: per-query initial threshold from the seed pre-pass (NULL: open thresholds)
+    int tile_stride;     // 1; the seed pre-pass visits every tile_stride-th tile of the catalogue (its items are sample-local)
 };
 
 // sc1 load: served by L2, never by a stale L1 line
@@ -140,7 +143,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 #define STAMP(var) if (DIAG_STAMPS) { var = stamp(); }
 
-// F16: the item tiles come from the float16 copy of the table and the tile product runs on v_mfma_f32_32x32x8_f16 (float32
+// F16: the item tiles come from the float16 copy of the table and the tile product runs on v_mfma_f32_32x32x16_f16 (float32
 // accumulation, a quarter of the MFMA cycles): keys are computed in per-query scaled units (thresholds too) and unscaled
 // when appended; the select stage widens its error bound by the float16 rounding (key_rel_err), re-ranks from the float32
 // rows in float64 as always, so the results are unchanged.  Default for the streaming mode above 8 192 rows; opt-in for the
@@ -170,20 +173,24 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     float* keypark = keypark_all + wave * (64 * 16 * TQ);
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
-    using QF = typename std::conditional<F16, half4_t, float4>::type;
-    QF qf[TQ][NG];
+    // float32: NG k-groups of 8 columns (float4 per lane half); float16: NG / 2 k-steps of 16 columns (half8 per lane half)
+    using QF = typename std::conditional<F16, half8_t, float4>::type;
+    constexpr int NQF = F16 ? NG / 2 : NG;
+    QF qf[TQ][NQF];
     int e_tot[TQ];       // F16: key scale of this lane's query (2^e_tot)
     float tau[TQ];
     int cnt[TQ];
-    bool first[TQ], scaled[TQ];
+    bool first[TQ], scaled[TQ], seeded[TQ];
     uint32_t soff[TQ];   // this lane's stream = wg_cand[soff .. soff + CAPH)
     uint64_t* const wg_cand = a.cand + ((int64_t(list) * a.bq + qw0) * 2) * CAPH;   // wave-uniform base
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
         const int64_t q = qw0 + 32 * b + r;
         const bool live = q < a.B;
-        tau[b] = (live && !a.debug_nofilter) ? a.debug_tau0 : INFINITY;  // strict '>' filter: dead queries never append
         e_tot[b] = F16 ? a.x_exp + a.qexp[q] : 0;                        // qexp has bq entries
+        const float t0 = (a.tau0 && live) ? a.tau0[q] : a.debug_tau0;    // seeded threshold of this query (real units), or open
+        seeded[b] = a.tau0 != nullptr && live && t0 > -INFINITY;
+        tau[b] = (live && !a.debug_nofilter) ? (F16 ? ldexpf(t0, e_tot[b]) : t0) : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
         first[b] = true;
         scaled[b] = false;
@@ -218,10 +225,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     static_assert(TILE_CHUNKS % 256 == 0, "every wave issues the same number of pieces");
     const uint32_t xs_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(xs)) + uint32_t(wave) * 1024u;
     const uint32_t hn_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(hn));
-    const char* const x_split = F16 ? reinterpret_cast<const char*>(a.X16) + i_begin * a.ldx * 2
-                                    : reinterpret_cast<const char*>(a.X + i_begin * a.ldx);
-    const float* const hn_split = a.hnorm + i_begin;
-    const uint32_t tile_bytes = uint32_t(IB) * row_bytes;
+    // (seed pre-pass: sample tile p is catalogue tile p * tile_stride; everything else works in sample-local item numbers)
+    const char* const x_split = F16 ? reinterpret_cast<const char*>(a.X16) + i_begin * a.ldx * 2 * a.tile_stride
+                                    : reinterpret_cast<const char*>(a.X + i_begin * a.ldx * a.tile_stride);
+    const float* const hn_split = a.hnorm + i_begin * a.tile_stride;
+    const uint32_t tile_bytes = uint32_t(IB) * row_bytes * uint32_t(a.tile_stride);
+    const uint32_t hn_tile = uint32_t(IB) * uint32_t(a.tile_stride);
     auto tile_dma = [&](int t, int ptile) {
         const uint32_t xb_addr = xs_addr0 + uint32_t(t & 1) * uint32_t(IB * CH * 16);
         const char* tile_ptr = x_split + uint64_t(uint32_t(ptile)) * tile_bytes;    // wave-uniform
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             lds_dma16(tile_ptr, off, xb_addr + uint32_t(i) * 4096u);
         }
         if (wave == 0 && lane < IB)   // half norms of the tile rows: one 4-byte piece, lanes 0..31
-            lds_dma4(hn_split + int64_t(ptile) * IB, uint32_t(lane) * 4u, hn_addr0 + uint32_t(t & 1) * uint32_t(IB * 4));
+            lds_dma4(hn_split + int64_t(ptile) * hn_tile, uint32_t(lane) * 4u, hn_addr0 + uint32_t(t & 1) * uint32_t(IB * 4));
     };
 
     __builtin_amdgcn_s_setprio(3);
@@ -245,13 +254,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // The query fragments are requested AFTER the first tile: vmcnt retires in issue order, so waiting for "all but the
     // TQ * NG fragment loads" means the tile has landed, and the first tile's MFMAs start as soon as their own fragments
     // arrive (the compiler's per-register waits) instead of after the whole 32-KiB-per-wave prologue.
-    static_assert(TQ * NG <= 63, "vmcnt immediate");
+    static_assert(TQ * NQF <= 63, "vmcnt immediate");
 #pragma unroll
     for (int b = 0; b < TQ; ++b)
 #pragma unroll
-        for (int g = 0; g < NG; ++g)
-            qf[b][g] = reinterpret_cast<const QF*>(F16 ? a.Qf16 : static_cast<const void*>(a.Q))[((qw0 / 32 + b) * NG + g) * 64 + lane];   // fragment order: 1 KiB (float16: 512 B) per instruction
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TQ * NG) : "memory");
+        for (int g = 0; g < NQF; ++g)
+            qf[b][g] = reinterpret_cast<const QF*>(F16 ? a.Qf16 : static_cast<const void*>(a.Q))[((qw0 / 32 + b) * NQF + g) * 64 + lane];   // fragment order: 1 KiB per instruction
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TQ * NQF) : "memory");
     __syncthreads();   // tile 0 has landed for every wave
     if (n_tiles > 1) tile_dma(1, p_dma);
     p_dma = perm_next(p_dma);
@@ -287,20 +296,21 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 }
             }
             if constexpr (F16) {
-                // A fragment of k-group g: the 8 bytes of half h of logical chunk g of row r, stored at chunk g ^ swz(r)
+                // A fragment of k-step g (columns 16 g .. 16 g + 15): logical chunk 2 g + h of row r, stored at chunk (2 g + h) ^ swz(r):
+                // one conflict-free ds_read_b128 per v_mfma_f32_32x32x16_f16 (gfx950: twice the K of the 32x32x8 form per issue)
                 int sw = swz<CH>(r);
                 asm volatile("" : "+v"(sw));
-                const unsigned char* abase = reinterpret_cast<const unsigned char*>(xb) + r * (NG * 16) + 8 * h;
-                auto a_ptr = [&](int g) { return abase + 16 * (g ^ sw); };
-                half4_t av_next = *reinterpret_cast<const half4_t*>(a_ptr(0));
+                const unsigned char* abase = reinterpret_cast<const unsigned char*>(xb) + r * (NG * 16);
+                auto a_ptr = [&](int g) { return abase + 16 * ((2 * g + h) ^ sw); };
+                half8_t av_next = *reinterpret_cast<const half8_t*>(a_ptr(0));
                 __builtin_amdgcn_s_setprio(0);
                 STAMP(t1);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    const half4_t av = av_next;
-                    if (g + 1 < NG) av_next = *reinterpret_cast<const half4_t*>(a_ptr(g + 1));
+                for (int g = 0; g < NQF; ++g) {
+                    const half8_t av = av_next;
+                    if (g + 1 < NQF) av_next = *reinterpret_cast<const half8_t*>(a_ptr(g + 1));
 #pragma unroll
-                    for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x8f16(av, qf[b][g], acc[b], 0, 0, 0);
+                    for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, qf[b][g], acc[b], 0, 0, 0);
                 }
             } else {
             // A fragment of k-group g: logical chunk 2g + h of row r, stored at chunk (2g + h) ^ swz(r).
@@ -486,6 +496,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         const int partner = __shfl_xor(cnt[b], 32, kWave);
         const int total = cnt[b] + partner;
         const bool underfull = scaled[b] && total < a.kprime;   // the scaled threshold dropped keys it should not have
+        // seeded threshold, never compacted, fewer than K' keys above it: complete only together with the query's other lists
+        const bool seeded_short = seeded[b] && first[b] && total < a.kprime;
         uint64_t need = __ballot(total > a.kprime) & 0xFFFFFFFFull;
         while (need != 0ull) {
             const int jj = __builtin_ctzll(need);
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             need &= ~(1ull << jj);
         }
         const int64_t q = qw0 + 32 * b + r;
-        a.cand_cnt[(int64_t(list) * a.bq + q) * 2 + h] = cnt[b] | (underfull ? (1 << 30) : 0);
+        a.cand_cnt[(int64_t(list) * a.bq + q) * 2 + h] = cnt[b] | (underfull ? CNT_UNDERFULL : 0) | (seeded_short ? CNT_SEEDED_SHORT : 0);
     }
 }
 
@@ -562,6 +574,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     p.split_items = per;
     p.n_lists = p.n_splits * wi;
     p.scaled_first = 1;
+    p.seed = 0;
     // Small catalogues: materialise every key (8 B of HBM traffic per pair) instead of streaming selection, whose
     // warm-up (~4 K' appends + a compaction per query and list) dominates when N is only a few K'.
     p.dense = n_items <= DENSE_MAX_ITEMS && !(options & HWER_KNN_NO_DENSE);
@@ -575,6 +588,27 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         p.split_items = per_d;
         p.n_lists = 0;
         p.ld_dense = n_tiles * 32;
+    }
+    // Seeded thresholds (streaming mode).  The sample: ~4.5 % of the catalogue's 32-row tiles at a regular stride (1 024 to
+    // 65 536 items); tau0 = the sample key whose rank corresponds to c K' keys of the whole catalogue, c >= 4 and large enough
+    // for a sample rank of >= 44: with the rank's relative spread 1 / sqrt(rank) the catalogue then holds fewer than K' keys
+    // above tau0 with probability < 1e-6 per query - and such a query is flagged (CNT_SEEDED_SHORT -> uncertified), never wrong.
+    if (!p.dense && !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS)) && !diag_env("HWER_SCREEN_NOSEED")) {
+        const int64_t n_tiles = cdiv64(n_items, 32);
+        int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t(0.045 * double(n_items)), 32)));
+        ns = std::min(ns, n_tiles);
+        const double S = double(ns) * 32.0;
+        const double c = std::max(4.0, 44.0 * double(n_items) / (double(p.kprime) * S));
+        const double frac = c * double(p.kprime) / double(n_items);
+        if (frac <= 0.25) {   // (a catalogue of a few K' rows forced onto this path: nothing to gain)
+            p.seed = 1;
+            p.seed_tiles = int(ns);
+            p.seed_stride = int(n_tiles / ns);
+            p.seed_ld = ns * 32;
+            p.seed_frac = frac;
+            p.seed_splits = int(std::min<int64_t>(ns, std::max<int64_t>(1, 512 / p.n_qblocks)));
+            p.scaled_first = 0;   // every in-loop compaction selects the exact K'-th key: lists are either exact or seeded
+        }
     }
     return p;
 }
@@ -629,9 +663,47 @@ static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStr
     return check_launch("knn_screen16");
 }
 
+int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Qf, int64_t B,
+                       float* seed_keys, WsHeader* hdr, hipStream_t stream, const ScreenF16* f16) {
+    (void)n_items;
+    // the DENSE mode of the screen kernel over the sample: same query blocks / fragments as the main pass, the sample's tiles
+    // split over seed_splits workgroups per query block, every key stored to seed_keys[q][sample-local item]
+    ScreenPlan sp = plan;
+    sp.dense = 1;
+    sp.ld_dense = plan.seed_ld;
+    const int64_t per = cdiv64(plan.seed_tiles, plan.seed_splits) * 32;
+    sp.split_items = per;
+    sp.n_splits = int(cdiv64(plan.seed_ld, per));
+    sp.n_lists = 0;
+    ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
+                 plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride};
+    const int key = plan.ng * 10 + plan.tq;
+    if (f16) {
+        switch (key) {
+            case 81: return launch_screen16_t<8, 1>(sp, a, stream);
+            case 82: return launch_screen16_t<8, 2>(sp, a, stream);
+            case 161: return launch_screen16_t<16, 1>(sp, a, stream);
+            case 162: return launch_screen16_t<16, 2>(sp, a, stream);
+            case 321: return launch_screen16_t<32, 1>(sp, a, stream);
+            default: return fail(HWER_EINVAL, "knn_seed16: unsupported padded dim %d / tq %d", plan.ng * 8, plan.tq);
+        }
+    }
+    switch (key) {
+        case 41: return launch_screen_t<4, 1>(sp, a, stream);
+        case 42: return launch_screen_t<4, 2>(sp, a, stream);
+        case 81: return launch_screen_t<8, 1>(sp, a, stream);
+        case 82: return launch_screen_t<8, 2>(sp, a, stream);
+        case 161: return launch_screen_t<16, 1>(sp, a, stream);
+        case 162: return launch_screen_t<16, 2>(sp, a, stream);
+        case 321: return launch_screen_t<32, 1>(sp, a, stream);
+        default: return fail(HWER_EINVAL, "knn_seed: unsupported padded dim %d / tq %d", plan.ng * 8, plan.tq);
+    }
+}
+
 int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx,
                   const float* Q32, int64_t B, uint64_t* cand, int32_t* cand_cnt, float* dense, WsHeader* hdr, hipStream_t stream,
-                  const ScreenF16* f16) {
+                  const ScreenF16* f16, const float* tau0) {
     static unsigned long long* dbg = nullptr;
     static int dbg_grid = 0;
 #ifndef HWER_DIAG_STAMPS
@@ -653,7 +725,7 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !diag_env("HWER_SCREEN_EXACT")) ? 1 : 0, diag_env("HWER_SCREEN_NOFILTER") ? atoi(diag_env("HWER_SCREEN_NOFILTER")) : 0,
                  diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
-                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0};
+                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

@@ -431,9 +431,12 @@ __global__ __launch_bounds__(256, 4) void select_rerank_kernel(const SelectArgs 
     uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);   // = `cand` of wave_rerank_emit
 
     const int c0r = a.cand_cnt[b * 2], c1r = a.cand_cnt[b * 2 + 1];
-    const bool underfull = ((c0r | c1r) & CNT_UNDERFULL) != 0;
-    const int c0 = c0r & ~CNT_UNDERFULL, c1 = c1r & ~CNT_UNDERFULL;
+    const int c0 = c0r & ~CNT_FLAGS, c1 = c1r & ~CNT_FLAGS;
     const int M = c0 + c1;                                             // <= K' (final compaction of the screen)
+    // a list that kept only the keys above the query's seeded threshold is complete as long as the query's lists together
+    // hold K' keys (every one of them above the threshold, hence above everything that was dropped)
+    const bool seeded_short = ((c0r | c1r) & CNT_SEEDED_SHORT) != 0;
+    const bool underfull = ((c0r | c1r) & CNT_UNDERFULL) != 0 || (seeded_short && M < a.kprime);
     const uint64_t* s0 = a.cand + (b * 2) * CAPH;
     const uint64_t* s1 = s0 + CAPH;
     uint64_t key[RR_MAXR];
@@ -681,8 +684,8 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
         for (int s = 0; s < n_streams; ++s) {
             s_off[s] = off;
             const int c = a.cnt_in[(int64_t(l0 + (s >> 1)) * a.bq + b) * 2 + (s & 1)];
-            under |= c & CNT_UNDERFULL;
-            off += c & ~CNT_UNDERFULL;
+            under |= c & CNT_FLAGS;
+            off += c & ~CNT_FLAGS;
         }
         s_off[n_streams] = off;
         s_off[25] = under;
@@ -1246,7 +1249,7 @@ extern "C" int hwer_profile_read(int which, double* total_ms, int64_t* launches)
 static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct WsLayout {
-    size_t qf, cand_a, cnt_a, cand_b, cnt_b, total;
+    size_t qf, cand_a, cnt_a, cand_b, cnt_b, seed_keys, seed_tau, seed_cnt, total;
 };
 static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     WsLayout w{};
@@ -1267,6 +1270,14 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     off += align256(size_t(groups) * p.bq * 2 * CAPH * 8);
     w.cnt_b = off;
     off += align256(size_t(groups) * p.bq * 2 * 4);
+    if (p.seed) {   // seed pre-pass: sample keys (bq, seed_ld), thresholds, a scratch counter row
+        w.seed_keys = off;
+        off += align256(size_t(p.bq) * size_t(p.seed_ld) * 4);
+        w.seed_tau = off;
+        off += align256(size_t(p.bq) * 4);
+        w.seed_cnt = off;
+        off += align256(size_t(p.bq) * 4);
+    }
     w.total = off;
     return w;
 }
@@ -1425,8 +1436,16 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     }
     {
         ProfScope ps(0, st);
+        const float* tau0 = nullptr;
+        if (plan.seed) {   // sample pre-pass -> per-query initial thresholds
+            float* seed_keys = reinterpret_cast<float*>(ws + w.seed_keys);
+            float* tau = reinterpret_cast<float*>(ws + w.seed_tau);
+            if ((rc = launch_seed_screen(plan, X, hnorm, n_items, ldx, qf, B, seed_keys, hdr, st, f16_screen ? &f16 : nullptr))) return rc;
+            if ((rc = launch_seed_threshold(seed_keys, plan.seed_ld, plan.seed_ld, B, plan.seed_frac, tau, reinterpret_cast<int32_t*>(ws + w.seed_cnt), st))) return rc;
+            tau0 = tau;
+        }
         rc = launch_screen(plan, X, hnorm, n_items, ldx, qf, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st,
-                           f16_screen ? &f16 : nullptr);
+                           f16_screen ? &f16 : nullptr, tau0);
     }
     if (rc) return rc;
     ProfScope ps_select(1, st);

@@ -145,13 +145,14 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
 // ---------------------------------------------------------------------------------------------------------------------
 // float16 storage variant of the screen: the same wave-private streaming, but the item rows come from a
 // float16 copy of the table (half the HBM bytes, the bound of this path) and the tile product runs on
-// v_mfma_f32_32x32x8_f16 (float32 accumulation).  Rows and queries are scaled by powers of two before the rounding
+// v_mfma_f32_32x32x16_f16 (float32 accumulation).  Rows and queries are scaled by powers of two before the rounding
 // (sx for the table, 2^qexp[b] per query) so that no element falls into float16's subnormal range; the accumulator is
 // seeded with -hnorm * scale and rescaled at the end (exact).  The keys then differ from the float32 keys by at most
 // ~2^-10 ||q|| ||x|| (two float16 roundings per product): the select stage widens its error bound accordingly, re-ranks
 // from the float32 rows in float64 as always, and the results stay bit-identical.
 // ---------------------------------------------------------------------------------------------------------------------
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_32x32x16_f16: lane (r, h) holds k = 8 h + 0..7 of a 16-wide k-step
 
 template <int NG>
 __device__ __forceinline__ int swz16(int row) {   // 16-byte chunk swizzle of a row of NG chunks (2 NG bytes x 8)
@@ -164,7 +165,7 @@ struct Small16Args {
     const _Float16* X16;   // (Np, ldx) float16, scaled by 2^x_exp
     const float* hnorm;
     int64_t ldx;
-    const half4_t* Qf16;   // query fragments, scaled per query by 2^qexp[q]
+    const half8_t* Qf16;   // query fragments (k-steps of 16 columns), scaled per query by 2^qexp[q]
     const int32_t* qexp;   // (bq)
     int x_exp;
     int64_t B;
@@ -190,12 +191,13 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
     float* hn = reinterpret_cast<float*>(ring + NSLOT * TILE_BYTES);                       // [NSLOT][IB] half norms
     const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
 
-    half4_t qf[TQ][NG];
+    constexpr int KS = NG / 2;   // k-steps of 16 columns (one 16-byte chunk per lane half)
+    half8_t qf[TQ][KS];
     int e_tot[TQ];
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) qf[b][g] = a.Qf16[((q0 / 32 + b) * NG + g) * 64 + lane];
+        for (int g = 0; g < KS; ++g) qf[b][g] = a.Qf16[((q0 / 32 + b) * KS + g) * 64 + lane];
         e_tot[b] = a.x_exp + a.qexp[q0 + 32 * b + r];
     }
     const int n_waves = gridDim.x * NW;
@@ -244,18 +246,18 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
                 acc[b][4 * rg + 3] = -ldexpf(hv.w, e_tot[b]);
             }
         }
-        // A fragment of k-group g: the 8 bytes of half h of logical chunk g of row r, stored at chunk g ^ swz16(r)
+        // A fragment of k-step g (columns 16 g .. 16 g + 15): logical chunk 2 g + h of row r, stored at chunk (2 g + h) ^ swz16(r)
         int sw = swz16<NG>(r);
         asm volatile("" : "+v"(sw));
-        const unsigned char* abase = xb + r * (NG * 16) + 8 * h;
-        auto a_ptr = [&](int g) { return abase + 16 * (g ^ sw); };
-        half4_t av_next = *reinterpret_cast<const half4_t*>(a_ptr(0));
+        const unsigned char* abase = xb + r * (NG * 16);
+        auto a_ptr = [&](int g) { return abase + 16 * ((2 * g + h) ^ sw); };
+        half8_t av_next = *reinterpret_cast<const half8_t*>(a_ptr(0));
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const half4_t av = av_next;
-            if (g + 1 < NG) av_next = *reinterpret_cast<const half4_t*>(a_ptr(g + 1));
+        for (int g = 0; g < KS; ++g) {
+            const half8_t av = av_next;
+            if (g + 1 < KS) av_next = *reinterpret_cast<const half8_t*>(a_ptr(g + 1));
 #pragma unroll
-            for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x8f16(av, qf[b][g], acc[b], 0, 0, 0);
+            for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, qf[b][g], acc[b], 0, 0, 0);
         }
 #pragma unroll
         for (int b = 0; b < TQ; ++b) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
 
 // queries -> float16 MFMA fragments, each query scaled by the power of two that puts its largest element in
 // [2^13, 2^14).  One 256-thread block per 32-query subtile: 8 threads scan a query row for its maximum.
-__global__ __launch_bounds__(256) void repack_queries16_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, half4_t* __restrict__ Qf16,
+__global__ __launch_bounds__(256) void repack_queries16_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, half8_t* __restrict__ Qf16,
                                                               int32_t* __restrict__ qexp) {
     __shared__ int s_exp[32];
     const int64_t s = blockIdx.x;
@@ -293,16 +295,22 @@ __global__ __launch_bounds__(256) void repack_queries16_kernel(const float* __re
         qexp[q] = e;               // qexp has bq >= 32 * gridDim.x entries
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < ng * 64; o += 256) {
+    // fragment order of v_mfma_f32_32x32x16_f16: Qf16[(s * KS + g) * 64 + lane] = Q[32 s + (lane & 31)][16 g + 8 (lane >> 5) .. + 7]
+    const int ks = ng / 2;
+    for (int o = threadIdx.x; o < ks * 64; o += 256) {
         const int g = o >> 6, lane = o & 63;
         const int64_t qq = s * 32 + (lane & 31);
-        half4_t v = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        half8_t v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (_Float16)0.f;
         if (qq < B) {
-            const float4 x = *reinterpret_cast<const float4*>(Q + qq * ldx + 8 * g + 4 * (lane >> 5));
+            const float* src = Q + qq * ldx + 16 * g + 8 * (lane >> 5);
+            const float4 x = *reinterpret_cast<const float4*>(src), y = *reinterpret_cast<const float4*>(src + 4);
             const int e = s_exp[lane & 31];
             v[0] = (_Float16)ldexpf(x.x, e); v[1] = (_Float16)ldexpf(x.y, e); v[2] = (_Float16)ldexpf(x.z, e); v[3] = (_Float16)ldexpf(x.w, e);
+            v[4] = (_Float16)ldexpf(y.x, e); v[5] = (_Float16)ldexpf(y.y, e); v[6] = (_Float16)ldexpf(y.z, e); v[7] = (_Float16)ldexpf(y.w, e);
         }
-        Qf16[(s * ng + g) * 64 + lane] = v;
+        Qf16[(s * ks + g) * 64 + lane] = v;
     }
 }
 
@@ -325,19 +333,21 @@ struct SmallSelectArgs {
     float* thr;         // (B)
     int32_t* count;     // (B) list lengths (may exceed the capacity: overflow)
     uint64_t* list;     // (B, SMALL_LIST_CAP) packed keys
+    double want_frac;   // > 0: the threshold's rank in the sample = want_frac * sample size (seed pre-pass of the streaming screen);
+                        // 0: about 4.75 K' keys of the ROW clear the threshold (small-batch path)
 };
 
 // threshold of one query from a strided sample of its key row: the r-th largest sample key, r chosen so that about
 // 4.75 K' keys of the row clear it (never fewer than 16 sample keys: the row count then has a relative spread <= 25 %)
+template <int PER>   // samples per thread: 16 (16 384-key sample), 32 or 64 (65 536): a probe is PER compares + one block reduction
 __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelectArgs a) {
     constexpr int NT = 1024, NWV = NT / 64;
-    constexpr int PER = SMALL_SAMPLE / NT;   // samples per thread (16): a probe is 16 compares + one block reduction
     __shared__ int s_cnt[NWV];
     __shared__ float s_mm[2 * NWV];
     const int64_t b = blockIdx.x;
     const float* row = a.keys + b * a.ld;
     const int64_t n = a.n_items;
-    const int64_t S = n < SMALL_SAMPLE ? n : SMALL_SAMPLE;
+    const int64_t S = n < int64_t(NT) * PER ? n : int64_t(NT) * PER;
     const double step = double(n) / double(S);
     const int wave = threadIdx.x >> 6;
     float v[PER];
@@ -378,7 +388,7 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
         return tot;
     };
     // sample rank: expected row count 4.75 K' (>= K' with overwhelming probability, <= the list capacity)
-    const double want = 4.75 * double(a.kprime) * double(S) / double(n);
+    const double want = a.want_frac > 0.0 ? a.want_frac * double(S) : 4.75 * double(a.kprime) * double(S) / double(n);
     int rank = int(want + 0.5);
     if (rank < 16) rank = 16;
     if (rank > S) rank = int(S);
@@ -416,7 +426,7 @@ __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSe
         n_sample += 16;
     }
     const double S = double(64 * PER);   // segments may overlap on rows shorter than the sample: the rank only gets safer
-    const double want = 4.75 * double(a.kprime) * S / double(n > 64 * PER ? n : 64 * PER);
+    const double want = a.want_frac > 0.0 ? a.want_frac * S : 4.75 * double(a.kprime) * S / double(n > 64 * PER ? n : 64 * PER);
     int rank = int(want + 0.5);
     if (rank < 16) rank = 16;
     if (rank > 64 * PER) rank = 64 * PER;
@@ -548,7 +558,7 @@ static int launch_small_screen16(const SmallPlan& p, const Small16Args& a, hipSt
 
 int repack_queries16(const float* Q32, int64_t B, int64_t bq, int ldx, void* Qf16, int32_t* qexp, hipStream_t stream) {
     hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(bq / 32)), dim3(256), 0, stream, Q32, B, ldx, ldx / 8,
-                       reinterpret_cast<half4_t*>(Qf16), qexp);
+                       reinterpret_cast<half8_t*>(Qf16), qexp);
     return check_launch("knn_repack_queries16");
 }
 
@@ -570,12 +580,23 @@ int pack_rows16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, v
     return check_launch("pack_rows16");
 }
 
+int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, double want_frac, float* tau0, int32_t* count_scratch,
+                          hipStream_t stream) {
+    SmallSelectArgs sa{keys, ld, n, B, 0, tau0, count_scratch, nullptr, want_frac};
+    if (n <= 1024) hipLaunchKernelGGL(small_threshold_wave_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 4096) hipLaunchKernelGGL(small_threshold_wave_kernel<64>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 16384) hipLaunchKernelGGL(small_threshold_kernel<16>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    else if (n <= 32768) hipLaunchKernelGGL(small_threshold_kernel<32>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    else hipLaunchKernelGGL(small_threshold_kernel<64>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    return check_launch("knn_seed(threshold)");
+}
+
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
                  unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16, int x_exp, hipStream_t stream) {
     const SmallLayout w = small_layout(p);
     int rc;
     if (X16) {   // float16 storage: half the HBM bytes for the catalogue stream
-        half4_t* qf16 = reinterpret_cast<half4_t*>(ws + w.qf);
+        half8_t* qf16 = reinterpret_cast<half8_t*>(ws + w.qf);
         int32_t* qexp = reinterpret_cast<int32_t*>(ws + w.qexp);
         hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(p.bq / 32)), dim3(256), 0, stream, Q32, B, int(ldx), p.ng, qf16, qexp);
         if ((rc = check_launch("knn_small(repack16)"))) return rc;
@@ -610,14 +631,14 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
     if (rc) return rc;
     }
     SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, reinterpret_cast<float*>(ws + w.thr),
-                       reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list)};
+                       reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list), 0.0};
     // sample rank = 4.75 K' S / N must stay >= 16 (kept >= 32 here): one wave per query with a 1024- or 4096-key sample
     if (double(n_items) * 32.0 <= 1024.0 * 4.75 * double(p.kprime))
         hipLaunchKernelGGL(small_threshold_wave_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
     else if (double(n_items) * 32.0 <= 4096.0 * 4.75 * double(p.kprime))
         hipLaunchKernelGGL(small_threshold_wave_kernel<64>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
     else
-        hipLaunchKernelGGL(small_threshold_kernel, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+        hipLaunchKernelGGL(small_threshold_kernel<SMALL_SAMPLE / 1024>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     if ((rc = check_launch("knn_small(threshold)"))) return rc;
     hipLaunchKernelGGL(small_collect_kernel, dim3(unsigned(cdiv64(p.ld / 4, 256 * 16)), unsigned(B)), dim3(256), 0, stream, sa);
     if ((rc = check_launch("knn_small(collect)"))) return rc;

@@ -196,6 +196,9 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
  * over large catalogues take the streaming screen instead of the HBM-bound small-batch path. */
 #define HWER_KNN_NO_DENSE 4u
 #define HWER_KNN_NO_SMALL 8u
+/* HWER_KNN_NO_SEED: the streaming screen starts every candidate list with an open threshold (collect, then select) instead of the
+ * per-query threshold seeded from a sample pre-pass.  Same results; kept for A/B measurements and path coverage in the tests. */
+#define HWER_KNN_NO_SEED 16u
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
 int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
