@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <math.h>
+#include <type_traits>
 
 #include "hwer_hip.h"
 
@@ -98,6 +99,49 @@ __device__ __forceinline__ T np_pairwise(const T* p, int n, int k) {
 }
 constexpr int kPairwiseDepth = 3;  // d <= 1024
 
+// ---- lane exchanges without the LDS crossbar -----------------------------------------------------------------------
+// lane_xor32<LM>(v): the value of lane (lane ^ LM).  __shfl_xor compiles to ds_bpermute_b32 (an LDS-pipe round trip, ~100
+// cycles of latency per dependent step); these are one or two VALU moves: DPP quad permutes / row mirrors inside a row of 16
+// lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows.  Sort networks and wave reductions are chains of such
+// exchanges, so their latency - what a wave-per-query kernel waits for - drops several-fold.
+template <int LM>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v) {
+    static_assert(LM == 1 || LM == 2 || LM == 4 || LM == 8 || LM == 16 || LM == 32, "power-of-two lane mask");
+    const int x = int(v);
+    if constexpr (LM == 1) {
+        return uint32_t(__builtin_amdgcn_update_dpp(x, x, 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    } else if constexpr (LM == 2) {
+        return uint32_t(__builtin_amdgcn_update_dpp(x, x, 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    } else if constexpr (LM == 4) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xF, 0xF, true);      // row_half_mirror: i -> 7 - i
+        return uint32_t(__builtin_amdgcn_update_dpp(t, t, 0x1B, 0xF, 0xF, true));    // quad_perm [3,2,1,0]: (7 - i) -> i ^ 4
+    } else if constexpr (LM == 8) {
+        const int t = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xF, 0xF, true);      // row_mirror: i -> 15 - i
+        return uint32_t(__builtin_amdgcn_update_dpp(t, t, 0x141, 0xF, 0xF, true));   // row_half_mirror: (15 - i) -> i ^ 8
+    } else if constexpr (LM == 16) {
+        // [0]: odd rows replaced by the even rows' data, [1]: even rows replaced by the odd rows' data
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (threadIdx.x & 16) ? r[0] : r[1];
+    } else {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);          // [0]: both halves = lanes 0..31, [1]: = lanes 32..63
+        return (threadIdx.x & 32) ? r[0] : r[1];
+    }
+}
+template <int LM>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v) {
+    return (uint64_t(lane_xor32<LM>(uint32_t(v >> 32))) << 32) | uint64_t(lane_xor32<LM>(uint32_t(v)));
+}
+// sum over the wave, result in every lane
+__device__ __forceinline__ int wave_sum_i32(int v) {
+    v += int(lane_xor32<1>(uint32_t(v)));
+    v += int(lane_xor32<2>(uint32_t(v)));
+    v += int(lane_xor32<4>(uint32_t(v)));
+    v += int(lane_xor32<8>(uint32_t(v)));
+    v += int(lane_xor32<16>(uint32_t(v)));
+    v += int(lane_xor32<32>(uint32_t(v)));
+    return v;
+}
+
 // ---- wave-level selection on register-resident floats ------------------------------------------------------------
 // v[0..NV) per lane (entries that do not exist hold -inf).  wave_find_rank returns `lo` with
 //   rank <= count(v >= lo) <= rank + slack
@@ -176,6 +220,9 @@ __device__ __forceinline__ void wave_sort_u64(uint64_t (&key)[NE]) {
         for (int stride = size >> 1; stride >= NE; stride >>= 1) {
             const int lm = stride / NE;
             const bool keep_min = ((lane & lm) == 0) == (((NE * lane) & size) == 0);   // size >= 2 NE here
+            // (ds_bpermute exchanges: the 2 NE independent permutes of a stage pipeline through the LDS crossbar; a DPP /
+            // permlane-swap version of this network - lane_xor64 - measured SLOWER, 17.7 K against 12 K cycles for 256 keys with
+            // one wave per SIMD: its VALU moves sit in the stage's dependent chain, profiles/r2_select_stamps.txt)
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const uint64_t o = __shfl_xor(key[j], lm, kWave);

@@ -137,11 +137,13 @@ struct SmallPlan {
 };
 SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k);
 bool use_small_path(int64_t B, int64_t n_items, uint32_t options = 0);
-size_t small_ws_bytes(const SmallPlan& p);   // without the header
+size_t small_ws_bytes(const SmallPlan& p, const ScreenPlan* seed = nullptr);   // without the header; seed: see launch_small
 // keys -> per-query candidate lists: list_out (B, SMALL_LIST_CAP) packed keys, cnt_out (B) appended counts
+// seed (nullable): a screen plan with seed = 1 for the same search -> seeded mode: sample pre-pass, per-query tau0, ONE filtering pass
+// over the catalogue (no key matrix); NULL: every key is stored, thresholds from a sample of the key rows, collect pass
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
                  unsigned char* ws_after_header, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16 /*nullable*/,
-                 int x_exp, hipStream_t stream);
+                 int x_exp, hipStream_t stream, const ScreenPlan* seed = nullptr);
 // float16 storage variant of the small-batch screen (§8f-4): the table scaled by 2^x_exp and rounded to float16
 int f16_scale_exp(float hnorm_max);
 int pack_rows16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, hipStream_t stream);

@@ -595,10 +595,13 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     // above tau0 with probability < 1e-6 per query - and such a query is flagged (CNT_SEEDED_SHORT -> uncertified), never wrong.
     if (!p.dense && !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS)) && !diag_env("HWER_SCREEN_NOSEED")) {
         const int64_t n_tiles = cdiv64(n_items, 32);
-        int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t(0.045 * double(n_items)), 32)));
+        // small-batch path (one HBM-bound pass, list capacity 4 096 keys per query): half the sample, twice the keys kept
+        const bool small = use_small_path(B, n_items, options);
+        const double c_min = small ? 8.0 : 4.0;
+        int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t((small ? 0.0225 : 0.045) * double(n_items)), 32)));
         ns = std::min(ns, n_tiles);
         const double S = double(ns) * 32.0;
-        const double c = std::max(4.0, 44.0 * double(n_items) / (double(p.kprime) * S));
+        const double c = std::max(c_min, 44.0 * double(n_items) / (double(p.kprime) * S));
         const double frac = c * double(p.kprime) / double(n_items);
         if (frac <= 0.25) {   // (a catalogue of a few K' rows forced onto this path: nothing to gain)
             p.seed = 1;

@@ -93,7 +93,13 @@ struct EmitArgs {
     double* out_dist2;
     int32_t* out_flags;
     WsHeader* hdr;    // nullable: uncertified queries (flag 0) are appended to the header's list
+    unsigned long long* stamps;   // diagnostic build only (HWER_SELECT_STAMPS=1): per-query phase cycle counts, 8 per query
 };
+#ifdef HWER_DIAG_STAMPS
+#define SEL_STAMP(slot) do { if (a_stamps && (threadIdx.x & 63) == 0) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); a_stamps[(slot)] = t_; } } while (0)
+#else
+#define SEL_STAMP(slot) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // Wave-per-query back end.  One 64-lane wave owns one query from the candidate keys to the output rows; there
@@ -107,6 +113,9 @@ __host__ __device__ inline size_t wave_lds_bytes(int d, int kp) {
     (void)d;
     return size_t(kp) * (8 + 8 + 4) + size_t(64) * RR_RS * 4;
 }
+// COOP variant: ONE query per 256-thread workgroup - the four waves share the query's tables and split the re-rank rounds
+// (one staging area per wave); for launches with so few queries that a wave per query leaves most of the chip idle
+__host__ __device__ inline size_t coop_lds_bytes(int d, int kp) { return wave_lds_bytes(d, kp) + size_t(3) * 64 * RR_RS * 4; }
 
 __device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
     // |key32 - (q.x - 0.5||x||^2)| <= E32 for every item: fmaf chain of d+1 terms, float32 rounding of q and of the
@@ -126,13 +135,17 @@ __device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
 // exact float64 distance; the others are provably members (their screen key clears the k-th key by more than the
 // float32 error bound) and only need their score.  Distances are 60 % of the float64 work of a full re-rank.  Should two
 // members tie exactly in score with an unknown distance between them, the lanes that hold them compute it on the spot.
-template <int MODE>   // score_mode as a compile-time constant: the float64 and float32 score chains never share registers
+template <int MODE, bool COOP = false>   // score_mode as a compile-time constant: the float64 and float32 score chains never share registers
 __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b, unsigned char* lds, int kp, int n_r, int n_b, int flag) {
     const int d = a.d, lane = threadIdx.x & 63;
+    const int coop_wave = COOP ? int(threadIdx.x >> 6) : 0;
+    unsigned long long* const a_stamps = (a.stamps && coop_wave == 0) ? a.stamps + b * 16 : nullptr;
+    (void)a_stamps;
+    SEL_STAMP(3);
     double* t_d2 = reinterpret_cast<double*>(lds);
     double* t_sc = t_d2 + kp;
     uint32_t* cand = reinterpret_cast<uint32_t*>(t_sc + kp);
-    float* stage = reinterpret_cast<float*>(cand + kp);
+    float* stage = reinterpret_cast<float*>(cand + kp) + coop_wave * (64 * RR_RS);
 
     // The query and the anchor row are wave-uniform: they are read with SCALAR loads straight from global memory and
     // enter the float64 arithmetic as SGPR operands.  (Broadcasting them from LDS costs a full 1-KiB LDS return per
@@ -158,7 +171,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     const bool lazy = a.out_dist2 == nullptr && a.sort_by_score && mode != 2 && n_b < n_r;
 
 #pragma unroll 1
-    for (int g0 = 0; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += 64) {   // wave-uniform rounds of 64 candidates
+    for (int g0 = 64 * coop_wave; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += COOP ? 256 : 64) {   // wave-uniform rounds of 64 candidates
         const bool need_d2 = !lazy || g0 < n_b;   // wave-uniform
         const int ci = g0 + lane;
         const bool live = ci < n_r;
@@ -271,7 +284,13 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             t_sc[ci] = sco;
         }
     }
-    wave_lds_sync();
+    if constexpr (COOP) {   // all four waves' rounds are in the shared tables; wave 0 finishes the query
+        __syncthreads();
+        if (coop_wave != 0) return;
+    } else {
+        wave_lds_sync();
+    }
+    SEL_STAMP(4);
     // ---- membership and output order, two register sorts (NE keys per lane) ------------------------------------------------
     // (1) by (dist2, item): positions < k are the members and the position is the KD-tree's return order;
     // (2) by (score desc, position): the reference's stable sort by score.  Sort keys are 64-bit:
@@ -311,13 +330,16 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 rank += (dj < dm || (dj == dm && ij < im)) ? 1 : 0;
             }
             const bool member_b = mine && rank < n_keep;
+            SEL_STAMP(7);
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int i = 64 * j + lane;
                 const bool member = i < n_r && (i >= n_b || (j == 0 && member_b));
                 key[j] = member ? (uint64_t(~f32_orderable(float(t_sc[i]))) << 32) | uint64_t(uint32_t(i)) : ~0ull;
             }
+            SEL_STAMP(8);
             wave_sort_u64<NE>(key);
+            SEL_STAMP(9);
             wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
                 const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
                 const uint64_t ax = ~f64_orderable(t_sc[sx]), ay = ~f64_orderable(t_sc[sy]);
@@ -369,6 +391,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             }
         }
         }   // !rank_boundary
+        SEL_STAMP(5);
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int p = NE * lane + j;
@@ -384,6 +407,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     if (n_r <= 128) tail(std::integral_constant<int, 2>{});
     else if (n_r <= 256) tail(std::integral_constant<int, 4>{});
     else tail(std::integral_constant<int, 8>{});
+    SEL_STAMP(6);
     if (lane == 0) {
         a.out_flags[b] = flag;
         if (flag == 0 && a.hdr) {   // rare: hand the query to the exhaustive pass (hwer_knn_exact_device / _f64)
@@ -510,14 +534,19 @@ struct DenseSelectArgs {
 // LIST = false: dense select over the key row written by the DENSE screen (every item is a candidate).
 // LIST = true : the same selection over a candidate LIST of packed keys (knn_small.hip); items that are not in the list
 //               have keys below every list key, so the usual certificate applies (some candidate below t_k - 2 E32).
-template <int MAXV, int MODE, bool LIST>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys; score mode
+// COOP: one query per workgroup; its four waves run the selection redundantly (identical registers, identical LDS writes) and
+// split the re-rank rounds - a launch of a few hundred queries is latency-bound on the serial chain of one wave per query.
+template <int MAXV, int MODE, bool LIST, bool COOP = false>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys; score mode
 __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(const DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t b = int64_t(blockIdx.x) * 4 + wave;
-    if (b >= a.B) return;   // no workgroup barrier below
+    const int64_t b = COOP ? int64_t(blockIdx.x) : int64_t(blockIdx.x) * 4 + wave;
+    if (b >= a.B) return;   // block-uniform with COOP; otherwise no workgroup barrier below
     const int d = a.emit.d, k = a.emit.k, kp = a.kp;
-    unsigned char* lds_emit = smem_raw + size_t(wave) * wave_lds_bytes(d, kp);
+    unsigned long long* const a_stamps = (a.emit.stamps && (!COOP || wave == 0)) ? a.emit.stamps + b * 16 : nullptr;
+    (void)a_stamps;
+    SEL_STAMP(0);
+    unsigned char* lds_emit = smem_raw + (COOP ? size_t(0) : size_t(wave) * wave_lds_bytes(d, kp));
     uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);
     const float4* row = reinterpret_cast<const float4*>(a.keys + b * a.ld);
     const int n4 = int(a.ld / 4);
@@ -563,6 +592,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
+    SEL_STAMP(1);
     auto count_ge = [&](float t) {
         int c = 0;   // ballot counting: one v_cmp per key, the popcount and the sum run on the scalar unit
 #pragma unroll
@@ -576,6 +606,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     const bool lazy_ok = a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2;
     float t_hi;   // count(key32 >= t_hi) < k (and >= k - 12 when lazy_ok)
     const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo, &t_hi, lazy_ok);   // <= k-th largest key, at most c_lo - k extra keys above it
+    SEL_STAMP(2);
     double Q2 = 0.0;
     {
         const double* q = a.emit.Q64 + b * d;
@@ -656,7 +687,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         if (cnt_raw < a.list_min || cnt_raw > a.list_cap || n_r >= n_list) flag = 0;
         if (n_list < k) { n_r = 0; n_b = 0; }
     }
-    wave_rerank_emit_t<MODE>(a.emit, b, lds_emit, kp, n_r, n_b, flag);
+    wave_rerank_emit_t<MODE, COOP>(a.emit, b, lds_emit, kp, n_r, n_b, flag);
 }
 
 // pre-reduction when a query has more than MAX_LISTS_DIRECT lists: groups of 8 lists -> one list of K' keys
@@ -1245,6 +1276,40 @@ extern "C" int hwer_profile_read(int which, double* total_ms, int64_t* launches)
     return HWER_OK;
 }
 
+// Diagnostic builds (HWER_DIAG_STAMPS) with HWER_SELECT_STAMPS=1: a device buffer of 8 cycle stamps per query; the previous
+// launch's stamps are summarised on stderr when the next search starts.
+static unsigned long long* sel_stamps_buffer(int64_t B) {
+#ifdef HWER_DIAG_STAMPS
+    static unsigned long long* buf = nullptr;
+    static int64_t buf_B = 0;
+    if (!getenv("HWER_SELECT_STAMPS")) return nullptr;
+    if (buf) {
+        std::vector<unsigned long long> h(size_t(buf_B) * 16);
+        (void)hipMemcpy(h.data(), buf, h.size() * 8, hipMemcpyDeviceToHost);
+        double sum[6] = {0, 0, 0, 0, 0, 0}, tail[4] = {0, 0, 0, 0};
+        int64_t n = 0, nt = 0;
+        for (int64_t q = 0; q < buf_B; ++q) {
+            const unsigned long long* t = &h[size_t(q) * 16];
+            if (t[6] <= t[0] || t[0] == 0) continue;
+            for (int c = 0; c < 6; ++c) sum[c] += double(t[c + 1] - t[c]);
+            if (t[7] && t[8] && t[9]) { tail[0] += double(t[7] - t[4]); tail[1] += double(t[8] - t[7]); tail[2] += double(t[9] - t[8]); tail[3] += double(t[5] - t[9]); ++nt; }
+            ++n;
+        }
+        if (nt) fprintf(stderr, "[select stamps]   tail of %lld lazy queries: boundary-rank=%.0f keys=%.0f sort=%.0f fixup=%.0f\n", (long long)nt, tail[0] / nt, tail[1] / nt, tail[2] / nt, tail[3] / nt);
+        if (n) fprintf(stderr, "[select stamps] queries=%lld cycles/query: load+minmax=%.0f rank-search=%.0f collect=%.0f rerank-rounds=%.0f sorts=%.0f emit=%.0f total=%.0f\n",
+                       (long long)n, sum[0] / n, sum[1] / n, sum[2] / n, sum[3] / n, sum[4] / n, sum[5] / n, (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / n);
+        (void)hipFree(buf);
+        buf = nullptr;
+    }
+    if (hipMalloc(&buf, size_t(B) * 128) != hipSuccess || hipMemset(buf, 0, size_t(B) * 128) != hipSuccess) buf = nullptr;
+    buf_B = B;
+    return buf;
+#else
+    (void)B;
+    return nullptr;
+#endif
+}
+
 // workspace layout: [cand A][cnt A][cand B][cnt B]   (B only when lists must be pre-reduced)
 static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
@@ -1282,11 +1347,21 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     return w;
 }
 
+// Up to this many queries a launch gives every query a whole workgroup (COOP).  Measured: one query 49.5 -> ~36 us; at 943
+// queries (c1) the redundant selection of four waves per query costs more than the split rounds save (33.5 -> 36 us).
+constexpr int64_t COOP_MAX_QUERIES = 32;
+
 static int launch_select_list(const DenseSelectArgs& da, int d, int score_mode, hipStream_t st) {
     static_assert(SMALL_LIST_CAP == 256 * 16, "the list select keeps 16 float4-equivalents of the list per lane");
-    const size_t lds = size_t(4) * wave_lds_bytes(d, da.kp);
+    const bool coop = da.B <= COOP_MAX_QUERIES;
+    const size_t lds = coop ? coop_lds_bytes(d, da.kp) : size_t(4) * wave_lds_bytes(d, da.kp);
     auto launch = [&](auto md) -> int {
         constexpr int MD = decltype(md)::value;
+        if (coop) {
+            if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<16, MD, true, true>), lds, "knn_select_list")) return e;
+            hipLaunchKernelGGL((select_dense_kernel<16, MD, true, true>), dim3(unsigned(da.B)), dim3(256), lds, st, da);
+            return HWER_OK;
+        }
         if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<16, MD, true>), lds, "knn_select_list")) return e;
         hipLaunchKernelGGL((select_dense_kernel<16, MD, true>), dim3(unsigned(cdiv64(da.B, 4))), dim3(256), lds, st, da);
         return HWER_OK;
@@ -1348,7 +1423,10 @@ size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, u
     const int ldx = hwer_knn_padded_dim(d);
     if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
     const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
-    if (!conservative && use_small_path(B, n_items, options)) return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k));
+    if (!conservative && use_small_path(B, n_items, options)) {
+        const ScreenPlan sp = make_screen_plan(B, n_items, ldx, k, options);
+        return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k), sp.seed ? &sp : nullptr);
+    }
     return ws_layout(make_screen_plan(B, n_items, ldx, k, options), B).total;
 }
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) { return hwer_knn_workspace_bytes_opts(B, n_items, d, k, 0); }
@@ -1388,7 +1466,12 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     unsigned char* ws = static_cast<unsigned char*>(workspace);
     if (!conservative && use_small_path(B, n_items, options)) {   // a handful of queries over a large catalogue: HBM-bound path (knn_small.hip)
         const SmallPlan sp = make_small_plan(B, n_items, int(ldx), k);
-        const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp);
+        // seeded thresholds (the streaming screen's sample pre-pass): ONE filtering pass over the catalogue instead of a key
+        // matrix + threshold + collect passes
+        const ScreenPlan seed_plan = make_screen_plan(B, n_items, int(ldx), k, options);
+        const ScreenPlan* seed = seed_plan.seed ? &seed_plan : nullptr;
+        if (seed && X16 && !screen_f16_supported(seed_plan)) X16 = nullptr;   // d <= 32: the pre-pass has no float16 variant, use the float32 rows
+        const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp, seed);
         if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, need);
         WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
         uint64_t* list = nullptr;
@@ -1397,7 +1480,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         prof_next_call();
         {
             ProfScope ps(0, st);
-            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &list, &cnt, hdr, X16, x16_exp, st);
+            rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &list, &cnt, hdr, X16, x16_exp, st, seed);
         }
         if (rc) return rc;
         ProfScope ps_select(1, st);
@@ -1406,7 +1489,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.kp = sp.kprime;
         da.hnorm_max = hnorm_max;
         da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
-                           out_idx, out_score, out_dist2, out_flags, hdr};
+                           out_idx, out_score, out_dist2, out_flags, hdr, sel_stamps_buffer(B)};
         da.list = list;
         da.list_count = cnt;
         da.list_cap = SMALL_LIST_CAP;
@@ -1458,11 +1541,17 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.hnorm_max = hnorm_max;
         da.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;
         da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, diag_env("HWER_SELECT_SKIP") ? atoi(diag_env("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
-                           out_idx, out_score, out_dist2, out_flags, hdr};
-        const size_t lds = size_t(4) * wave_lds_bytes(d, plan.kprime);
+                           out_idx, out_score, out_dist2, out_flags, hdr, sel_stamps_buffer(B)};
+        const bool coop = B <= COOP_MAX_QUERIES;
+        const size_t lds = coop ? coop_lds_bytes(d, plan.kprime) : size_t(4) * wave_lds_bytes(d, plan.kprime);
         static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
         auto launch_dense2 = [&](auto mv, auto md) -> int {
             constexpr int MV = decltype(mv)::value, MD = decltype(md)::value;
+            if (coop) {
+                if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV, MD, false, true>), lds, "knn_select_dense")) return e;
+                hipLaunchKernelGGL((select_dense_kernel<MV, MD, false, true>), dim3(unsigned(B)), dim3(256), lds, st, da);
+                return HWER_OK;
+            }
             if (int e = set_max_lds(reinterpret_cast<const void*>(&select_dense_kernel<MV, MD, false>), lds, "knn_select_dense")) return e;
             hipLaunchKernelGGL((select_dense_kernel<MV, MD, false>), dim3(unsigned(cdiv64(B, 4))), dim3(256), lds, st, da);
             return HWER_OK;
@@ -1506,7 +1595,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     sa.hnorm_max = hnorm_max;
     sa.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;   // two float16 roundings per product (2^-11 each), as in the small-batch path
     sa.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, diag_env("HWER_SELECT_SKIP") ? atoi(diag_env("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
-                       out_idx, out_score, out_dist2, out_flags, hdr};
+                       out_idx, out_score, out_dist2, out_flags, hdr, sel_stamps_buffer(B)};
     return launch_select_rerank(sa, d, score_mode, st);
 }
 
@@ -1564,7 +1653,7 @@ int hwer_knn_exact_device(const float* X, int64_t n_items, int d, int64_t ldx, c
     ea.cand2 = reinterpret_cast<Ent*>(static_cast<unsigned char*>(workspace) + align256(size_t(EXACT_DEVICE_MAXQ) * size_t(ea.n_chunks) * size_t(k) * sizeof(Ent)));
     ea.missed_accum = missed_accum;
     ea.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, 0, row_ids, id_base, k,
-                       out_idx, out_score, out_dist2, out_flags, nullptr};
+                       out_idx, out_score, out_dist2, out_flags, nullptr, nullptr};
     // sort area | max(re-rank area of the emitting wave, four waves' staging areas of stage A)
     const size_t lds = size_t(EX_CHUNK) * sizeof(Ent) + std::max(wave_lds_bytes(d, ((k + 63) / 64) * 64), size_t(4) * 64 * RR_RS * 4);
     int rc;

@@ -19,6 +19,58 @@ namespace hwer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+// Seeded mode of the small-batch screens (FILTER = true): instead of storing every key, a wave compares its keys with the
+// query's seeded threshold tau0 (knn_screen.hip: seed pre-pass) and hands the few that pass (~4 K' per query over the whole
+// catalogue) to the query's candidate list.  Passing keys are first parked in a wave-private LDS buffer - the wave is the only
+// writer, so its fill count is a wave-uniform scalar, no atomics - and flushed in batches: the flush needs a RETURNING global
+// atomic per entry (the list position), whose wait drains the wave's DMA prefetch ring, so it must be rare.
+constexpr int SMALL_PARK = 256;   // entries (u64 key + i32 query) a wave parks before it flushes
+struct SmallSink {
+    const float* tau0;   // (B) seeded thresholds, real units
+    uint64_t* list;      // (B, SMALL_LIST_CAP)
+    int32_t* count;      // (B) appended keys (may exceed the capacity: overflow -> the query is not certified)
+};
+
+__device__ __forceinline__ void small_park_flush(const SmallSink& sk, const uint64_t* pk, const int32_t* pq, int n) {
+    const int lane = threadIdx.x & 63;
+    for (int i = lane; i < n; i += 64) {
+        const int32_t q = pq[i];
+        const int pos = atomicAdd(&sk.count[q], 1);
+        if (pos < SMALL_LIST_CAP) sk.list[int64_t(q) * SMALL_LIST_CAP + pos] = pk[i];
+    }
+}
+
+// keys of one tile vs the lane's thresholds; `scaled` keys are brought back to real units with 2^-e (exact) when they are parked
+template <int TQ, bool SCALED>
+__device__ __forceinline__ void small_filter_tile(const SmallSink& sk, const __attribute__((ext_vector_type(16))) float (&acc)[TQ], const float (&tau)[TQ],
+                                                  const int (&e_tot)[TQ], int64_t q0, int r, int h, int64_t i0, uint64_t* pk, int32_t* pq, int& n_park) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int b = 0; b < TQ; ++b) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const bool pass = acc[b][q] > tau[b];     // strict, like the streaming filter; dead queries carry tau = +inf
+            const uint64_t bal = __ballot(pass);
+            if (bal != 0ull) {                          // wave-uniform, rare (~4 K' / n_items per key)
+                if (n_park + 64 > SMALL_PARK) {         // wave-uniform
+                    wave_lds_sync();
+                    small_park_flush(sk, pk, pq, n_park);
+                    wave_lds_sync();
+                    n_park = 0;
+                }
+                if (pass) {
+                    const int pos = n_park + __builtin_popcountll(bal & lt_mask);
+                    const float kv = SCALED ? ldexpf(acc[b][q], -e_tot[b]) : acc[b][q];
+                    pk[pos] = pack_key(kv, uint32_t(i0) + uint32_t((q & 3) + 8 * (q >> 2) + 4 * h));
+                    pq[pos] = int32_t(q0 + 32 * b + r);
+                }
+                n_park += __builtin_popcountll(bal);
+            }
+        }
+    }
+}
+
 struct SmallArgs {
     const float* X;
     const float* hnorm;
@@ -30,12 +82,13 @@ struct SmallArgs {
     int64_t ld;
     int n_tiles;
     WsHeader* hdr;
+    SmallSink sink;   // FILTER kernels
 };
 
 // One wave = one stream of tiles through a wave-private ring of NSLOT tiles (NSLOT - 1 tiles in flight while one is
 // computed: with a single tile in flight the kernel is bound by HBM latency, 16 KB per wave per ~4 us).  NW waves per
 // workgroup only share the CU (LDS budget: NW * NSLOT tiles <= 160 KB).
-template <int NG, int TQ, int NW, int NSLOT>
+template <int NG, int TQ, int NW, int NSLOT, bool FILTER = false>
 __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArgs a) {
     constexpr int IB = 32;
     constexpr int CH = 2 * NG;                    // 16-byte chunks per row
@@ -48,15 +101,23 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     if (blockIdx.x == 0 && blockIdx.y == 0) hdr_reset(a.hdr, tid, 64 * NW);   // empty uncertified list, idle tickets
-    float* ring = reinterpret_cast<float*>(smem_raw + size_t(wave) * (NSLOT * TILE_BYTES + NSLOT * IB * 4));   // [NSLOT][IB][CH*4] wave-private
-    float* hn = ring + NSLOT * IB * CH * 4;                                                                   // [NSLOT][IB] half norms
+    constexpr int WAVE_LDS = NSLOT * TILE_BYTES + NSLOT * IB * 4 + (FILTER ? SMALL_PARK * 12 : 0);
+    float* ring = reinterpret_cast<float*>(smem_raw + size_t(wave) * WAVE_LDS);   // [NSLOT][IB][CH*4] wave-private
+    float* hn = ring + NSLOT * IB * CH * 4;                                        // [NSLOT][IB] half norms
+    uint64_t* pk = reinterpret_cast<uint64_t*>(hn + NSLOT * IB);                    // FILTER: parked keys | their queries
+    int32_t* pq = reinterpret_cast<int32_t*>(pk + SMALL_PARK);
+    int n_park = 0;
     const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
 
     float4 qf[TQ][NG];
+    float tau[TQ];
+    int e_zero[TQ];
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
         const int64_t q = q0 + 32 * b + r;
         const bool live = q < a.B;
+        tau[b] = (FILTER && live) ? a.sink.tau0[q] : INFINITY;
+        e_zero[b] = 0;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             qf[b][g] = reinterpret_cast<const float4*>(a.Q)[((q0 / 32 + b) * NG + g) * 64 + lane];   // fragment order (repack_queries)
@@ -129,6 +190,9 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, qf[b][g].w, acc[b], 0, 0, 0);
             }
         }
+        if constexpr (FILTER) {
+            small_filter_tile<TQ, false>(a.sink, acc, tau, e_zero, q0, r, h, i0, pk, pq, n_park);
+        } else {
         // lane (r, h): query q0 + 32 b + r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store each.  The key matrix has
         // bq >= B rows (whole query blocks), so every lane stores: a fixed store count keeps the vmcnt arithmetic exact.
 #pragma unroll
@@ -138,6 +202,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen_kernel(const SmallArg
             for (int rg = 0; rg < 4; ++rg)
                 *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
         }
+        }
+    }
+    if constexpr (FILTER) {
+        wave_lds_sync();
+        small_park_flush(a.sink, pk, pq, n_park);
     }
 }
 
@@ -173,9 +242,10 @@ struct Small16Args {
     int64_t ld;
     int n_tiles;
     WsHeader* hdr;
+    SmallSink sink;   // FILTER kernels
 };
 
-template <int NG, int TQ, int NW, int NSLOT>
+template <int NG, int TQ, int NW, int NSLOT, bool FILTER = false>
 __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small16Args a) {
     constexpr int IB = 32;
     constexpr int TILE_BYTES = IB * NG * 16;         // rows of NG 16-byte chunks
@@ -187,18 +257,25 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     if (blockIdx.x == 0 && blockIdx.y == 0) hdr_reset(a.hdr, tid, 64 * NW);   // empty uncertified list, idle tickets
-    unsigned char* ring = smem_raw + size_t(wave) * (NSLOT * TILE_BYTES + NSLOT * IB * 4);   // [NSLOT][IB][NG * 16 B] wave-private
+    constexpr int WAVE_LDS = NSLOT * TILE_BYTES + NSLOT * IB * 4 + (FILTER ? SMALL_PARK * 12 : 0);
+    unsigned char* ring = smem_raw + size_t(wave) * WAVE_LDS;                              // [NSLOT][IB][NG * 16 B] wave-private
     float* hn = reinterpret_cast<float*>(ring + NSLOT * TILE_BYTES);                       // [NSLOT][IB] half norms
+    uint64_t* pk = reinterpret_cast<uint64_t*>(hn + NSLOT * IB);                            // FILTER: parked keys | their queries
+    int32_t* pq = reinterpret_cast<int32_t*>(pk + SMALL_PARK);
+    int n_park = 0;
     const int64_t q0 = int64_t(blockIdx.y) * (32 * TQ);
 
     constexpr int KS = NG / 2;   // k-steps of 16 columns (one 16-byte chunk per lane half)
     half8_t qf[TQ][KS];
     int e_tot[TQ];
+    float tau[TQ];
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
 #pragma unroll
         for (int g = 0; g < KS; ++g) qf[b][g] = a.Qf16[((q0 / 32 + b) * KS + g) * 64 + lane];
         e_tot[b] = a.x_exp + a.qexp[q0 + 32 * b + r];
+        const int64_t q = q0 + 32 * b + r;
+        tau[b] = (FILTER && q < a.B) ? ldexpf(a.sink.tau0[q], e_tot[b]) : INFINITY;   // the filter compares in the query's scaled units
     }
     const int n_waves = gridDim.x * NW;
     const uint32_t row_bytes = uint32_t(a.ldx) * 2u;
@@ -259,6 +336,9 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
 #pragma unroll
             for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, qf[b][g], acc[b], 0, 0, 0);
         }
+        if constexpr (FILTER) {
+            small_filter_tile<TQ, true>(a.sink, acc, tau, e_tot, q0, r, h, i0, pk, pq, n_park);
+        } else {
 #pragma unroll
         for (int b = 0; b < TQ; ++b) {
             float* row = a.keys + (q0 + 32 * b + r) * a.ld + i0 + 4 * h;
@@ -267,6 +347,11 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
                 *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(ldexpf(acc[b][4 * rg], -e_tot[b]), ldexpf(acc[b][4 * rg + 1], -e_tot[b]),
                                                                       ldexpf(acc[b][4 * rg + 2], -e_tot[b]), ldexpf(acc[b][4 * rg + 3], -e_tot[b]));
         }
+        }
+    }
+    if constexpr (FILTER) {
+        wave_lds_sync();
+        small_park_flush(a.sink, pk, pq, n_park);
     }
 }
 
@@ -517,42 +602,51 @@ SmallPlan make_small_plan(int64_t B, int64_t n_items, int ldx, int k) {
 }
 
 struct SmallLayout { size_t qf, qexp, keys, thr, count, list, total; };
-static SmallLayout small_layout(const SmallPlan& p) {
+// `seed` (nullable): the screen plan whose sample pre-pass seeds the thresholds; then `keys` holds the SAMPLE keys
+// (seed->bq x seed->seed_ld) instead of every key, and the fragment areas cover the larger of the two query paddings
+static SmallLayout small_layout(const SmallPlan& p, const ScreenPlan* seed) {
     SmallLayout w{};
+    const size_t bq = size_t(seed ? std::max<int64_t>(p.bq, seed->bq) : p.bq);
     size_t off = 0;
-    w.qf = off;    off += al256(size_t(p.bq) * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32); float16 variant: half of it
-    w.qexp = off;  off += al256(size_t(p.bq) * 4);                      // per-query scale exponents of the float16 variant
-    w.keys = off;  off += al256(size_t(p.bq) * size_t(p.ld) * 4);
-    w.thr = off;   off += al256(size_t(p.bq) * 4);
-    w.count = off; off += al256(size_t(p.bq) * 4);
+    w.qf = off;    off += al256(bq * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32); float16 variant: half of it
+    w.qexp = off;  off += al256(bq * 4);                      // per-query scale exponents of the float16 variant
+    w.keys = off;  off += al256(seed ? size_t(seed->bq) * size_t(seed->seed_ld) * 4 : size_t(p.bq) * size_t(p.ld) * 4);
+    w.thr = off;   off += al256(bq * 4);
+    w.count = off; off += al256(bq * 4);
     w.list = off;  off += al256(size_t(p.bq) * SMALL_LIST_CAP * 8);
     w.total = off;
     return w;
 }
-size_t small_ws_bytes(const SmallPlan& p) { return small_layout(p).total; }
+size_t small_ws_bytes(const SmallPlan& p, const ScreenPlan* seed) { return small_layout(p, seed).total; }
 
 template <int NG, int TQ, int NW, int NSLOT>
 static int launch_small_screen(const SmallPlan& p, const SmallArgs& a, hipStream_t stream) {
-    const size_t lds = size_t(NW) * NSLOT * (32 * NG * 32 + 32 * 4);
-    static_assert(size_t(NW) * NSLOT * (32 * NG * 32 + 32 * 4) <= 160 * 1024, "ring must fit the CU's LDS");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_screen_kernel<NG, TQ, NW, NSLOT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    const bool filter = a.sink.tau0 != nullptr;
+    const size_t lds = size_t(NW) * (NSLOT * (32 * NG * 32 + 32 * 4) + (filter ? SMALL_PARK * 12 : 0));
+    static_assert(size_t(NW) * (NSLOT * (32 * NG * 32 + 32 * 4) + SMALL_PARK * 12) <= 160 * 1024, "ring must fit the CU's LDS");
+    const void* fn = filter ? reinterpret_cast<const void*>(&small_screen_kernel<NG, TQ, NW, NSLOT, true>)
+                            : reinterpret_cast<const void*>(&small_screen_kernel<NG, TQ, NW, NSLOT, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_small: hipFuncSetAttribute: %s", hipGetErrorString(e));
     // one workgroup per CU (LDS-limited); query blocks share the CUs: grid.x * grid.y ~ 256
     const int gx = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_tiles, NW), std::max(1, 256 / p.n_qblocks))));
-    hipLaunchKernelGGL((small_screen_kernel<NG, TQ, NW, NSLOT>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
+    if (filter) hipLaunchKernelGGL((small_screen_kernel<NG, TQ, NW, NSLOT, true>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
+    else hipLaunchKernelGGL((small_screen_kernel<NG, TQ, NW, NSLOT, false>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
     return check_launch("knn_small(screen)");
 }
 
 template <int NG, int TQ, int NW, int NSLOT>
 static int launch_small_screen16(const SmallPlan& p, const Small16Args& a, hipStream_t stream) {
-    const size_t lds = size_t(NW) * NSLOT * (32 * NG * 16 + 32 * 4);
-    static_assert(size_t(NW) * NSLOT * (32 * NG * 16 + 32 * 4) <= 160 * 1024, "ring must fit the CU's LDS");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&small_screen16_kernel<NG, TQ, NW, NSLOT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+    const bool filter = a.sink.tau0 != nullptr;
+    const size_t lds = size_t(NW) * (NSLOT * (32 * NG * 16 + 32 * 4) + (filter ? SMALL_PARK * 12 : 0));
+    static_assert(size_t(NW) * (NSLOT * (32 * NG * 16 + 32 * 4) + SMALL_PARK * 12) <= 160 * 1024, "ring must fit the CU's LDS");
+    const void* fn = filter ? reinterpret_cast<const void*>(&small_screen16_kernel<NG, TQ, NW, NSLOT, true>)
+                            : reinterpret_cast<const void*>(&small_screen16_kernel<NG, TQ, NW, NSLOT, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
     if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_small16: hipFuncSetAttribute: %s", hipGetErrorString(e));
     const int gx = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_tiles, NW), std::max(1, 256 / p.n_qblocks))));
-    hipLaunchKernelGGL((small_screen16_kernel<NG, TQ, NW, NSLOT>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
+    if (filter) hipLaunchKernelGGL((small_screen16_kernel<NG, TQ, NW, NSLOT, true>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
+    else hipLaunchKernelGGL((small_screen16_kernel<NG, TQ, NW, NSLOT, false>), dim3(gx, p.n_qblocks), dim3(64 * NW), lds, stream, a);
     return check_launch("knn_small(screen16)");
 }
 
@@ -592,16 +686,40 @@ int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, d
 }
 
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
-                 unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16, int x_exp, hipStream_t stream) {
-    const SmallLayout w = small_layout(p);
+                 unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16, int x_exp, hipStream_t stream,
+                 const ScreenPlan* seed) {
+    const SmallLayout w = small_layout(p, seed);
+    const int64_t bq_all = seed ? std::max<int64_t>(p.bq, seed->bq) : p.bq;   // rows of the fragment areas (zero beyond B)
+    float* thr = reinterpret_cast<float*>(ws + w.thr);
+    int32_t* count = reinterpret_cast<int32_t*>(ws + w.count);
+    uint64_t* list = reinterpret_cast<uint64_t*>(ws + w.list);
+    SmallSink sink{nullptr, list, count};
     int rc;
-    if (X16) {   // float16 storage: half the HBM bytes for the catalogue stream
-        half8_t* qf16 = reinterpret_cast<half8_t*>(ws + w.qf);
-        int32_t* qexp = reinterpret_cast<int32_t*>(ws + w.qexp);
-        hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(p.bq / 32)), dim3(256), 0, stream, Q32, B, int(ldx), p.ng, qf16, qexp);
+    const bool f16 = X16 != nullptr;
+    const bool seed16 = f16 && seed && screen_f16_supported(*seed);   // the seed pre-pass reads the float16 copy when its kernel can
+    float* qf = reinterpret_cast<float*>(ws + w.qf);
+    int32_t* qexp = reinterpret_cast<int32_t*>(ws + w.qexp);
+    if (f16) {
+        hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(bq_all / 32)), dim3(256), 0, stream, Q32, B, int(ldx), p.ng,
+                           reinterpret_cast<half8_t*>(qf), qexp);
         if ((rc = check_launch("knn_small(repack16)"))) return rc;
-        Small16Args a16{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, qf16, qexp, x_exp, B, reinterpret_cast<float*>(ws + w.keys), p.ld,
-                        int(p.ld / 32), hdr};
+    } else if ((rc = repack_queries(Q32, B, bq_all, int(ldx), qf, stream))) {
+        return rc;
+    }
+    if (seed) {
+        // Seeded mode: sample pre-pass (the dense mode of the streaming screen over every seed_stride-th tile) -> tau0 per query
+        // -> ONE pass over the catalogue that keeps only the keys above tau0.  No key matrix, no collect pass.
+        float* seed_keys = reinterpret_cast<float*>(ws + w.keys);
+        if (f16 && !seed16) return fail(HWER_EINVAL, "knn_small: the seeded float16 path needs a padded dim >= 64 (caller drops X16 below that)");
+        ScreenF16 sf{X16, qf, qexp, x_exp};
+        if ((rc = launch_seed_screen(*seed, X, hnorm, n_items, ldx, qf, B, seed_keys, hdr, stream, seed16 ? &sf : nullptr))) return rc;
+        // the threshold kernel also zeroes count[b] for the queries it handles (b < B)
+        if ((rc = launch_seed_threshold(seed_keys, seed->seed_ld, seed->seed_ld, B, seed->seed_frac, thr, count, stream))) return rc;
+        sink.tau0 = thr;
+    }
+    if (f16) {   // float16 storage: half the HBM bytes for the catalogue stream
+        Small16Args a16{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, reinterpret_cast<const half8_t*>(qf), qexp, x_exp, B,
+                        reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr, sink};
         switch (p.ng * 10 + p.tq) {   // float16 tiles are half as large: more ring slots per wave
             case 41: rc = launch_small_screen16<4, 1, 4, 8>(p, a16, stream); break;
             case 42: rc = launch_small_screen16<4, 2, 4, 8>(p, a16, stream); break;
@@ -614,24 +732,24 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         }
         if (rc) return rc;
     } else {
-    float* qf = reinterpret_cast<float*>(ws + w.qf);
-    if ((rc = repack_queries(Q32, B, p.bq, int(ldx), qf, stream))) return rc;
-    SmallArgs a{X, hnorm, n_items, ldx, qf, B, reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr};
-    switch (p.ng * 10 + p.tq) {
-        // waves x ring slots per CU: (NSLOT - 1) tiles in flight per wave, ~96 KB in flight per CU
-        case 41: rc = launch_small_screen<4, 1, 4, 8>(p, a, stream); break;      // 4 KB tiles
-        case 42: rc = launch_small_screen<4, 2, 4, 8>(p, a, stream); break;
-        case 81: rc = launch_small_screen<8, 1, 4, 4>(p, a, stream); break;      // 8 KB tiles
-        case 82: rc = launch_small_screen<8, 2, 4, 4>(p, a, stream); break;
-        case 161: rc = launch_small_screen<16, 1, 3, 3>(p, a, stream); break;    // 16 KB tiles
-        case 162: rc = launch_small_screen<16, 2, 3, 3>(p, a, stream); break;
-        case 321: rc = launch_small_screen<32, 1, 2, 2>(p, a, stream); break;    // 32 KB tiles
-        default: return fail(HWER_EINVAL, "knn_small: unsupported padded dim %d / tq %d", p.ng * 8, p.tq);
+        SmallArgs a{X, hnorm, n_items, ldx, qf, B, reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr, sink};
+        switch (p.ng * 10 + p.tq) {
+            // waves x ring slots per CU: (NSLOT - 1) tiles in flight per wave, ~96 KB in flight per CU
+            case 41: rc = launch_small_screen<4, 1, 4, 8>(p, a, stream); break;      // 4 KB tiles
+            case 42: rc = launch_small_screen<4, 2, 4, 8>(p, a, stream); break;
+            case 81: rc = launch_small_screen<8, 1, 4, 4>(p, a, stream); break;      // 8 KB tiles
+            case 82: rc = launch_small_screen<8, 2, 4, 4>(p, a, stream); break;
+            case 161: rc = launch_small_screen<16, 1, 3, 3>(p, a, stream); break;    // 16 KB tiles
+            case 162: rc = launch_small_screen<16, 2, 3, 3>(p, a, stream); break;
+            case 321: rc = launch_small_screen<32, 1, 2, 2>(p, a, stream); break;    // 32 KB tiles
+            default: return fail(HWER_EINVAL, "knn_small: unsupported padded dim %d / tq %d", p.ng * 8, p.tq);
+        }
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    }
-    SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, reinterpret_cast<float*>(ws + w.thr),
-                       reinterpret_cast<int32_t*>(ws + w.count), reinterpret_cast<uint64_t*>(ws + w.list), 0.0};
+    *list_out = list;
+    *cnt_out = count;
+    if (seed) return HWER_OK;
+    SmallSelectArgs sa{reinterpret_cast<const float*>(ws + w.keys), p.ld, n_items, B, p.kprime, thr, count, list, 0.0};
     // sample rank = 4.75 K' S / N must stay >= 16 (kept >= 32 here): one wave per query with a 1024- or 4096-key sample
     if (double(n_items) * 32.0 <= 1024.0 * 4.75 * double(p.kprime))
         hipLaunchKernelGGL(small_threshold_wave_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
@@ -641,10 +759,7 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         hipLaunchKernelGGL(small_threshold_kernel<SMALL_SAMPLE / 1024>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     if ((rc = check_launch("knn_small(threshold)"))) return rc;
     hipLaunchKernelGGL(small_collect_kernel, dim3(unsigned(cdiv64(p.ld / 4, 256 * 16)), unsigned(B)), dim3(256), 0, stream, sa);
-    if ((rc = check_launch("knn_small(collect)"))) return rc;
-    *list_out = sa.list;
-    *cnt_out = sa.count;
-    return HWER_OK;
+    return check_launch("knn_small(collect)");
 }
 
 }  // namespace hwer
