@@ -256,10 +256,9 @@ class Workload:
 
     def stage_pack(self):
         P, lib = self.native.ptr, self.lib
-        self.native.check(lib.hwer_pack_rows_f32(P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
-                                                 self.S()), "pack")
-        if self.f16_screen:
-            self.native.check(lib.hwer_pack_rows_f16(P(self.X), self.I_pad, self.ldx, self.x16_exp, P(self.X16), self.S()), "pack16")
+        # per-type table + half norms (+ the float16 copy in the same pass: its scale follows from the unit-norm audit bound)
+        self.native.check(lib.hwer_pack_rows_f32_f16(P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
+                                                     P(self.X16) if self.f16_screen else None, self.x16_exp, self.S()), "pack")
 
     def stage_queries(self):
         P, lib = self.native.ptr, self.lib
@@ -300,7 +299,7 @@ class Workload:
         per_row = self.cfg["per_row"]
         return {
             "blend_normalize_audit": N * (4.0 * d * (T + 1) + (4.0 * T if per_row else 0.0)),       # T rows in, one out (+ per-row alpha)
-            "pack_rows": I * (4.0 * d + 4.0 * self.ldx + 4.0 + 8.0) + (I * (4.0 + 2.0) * self.ldx if self.f16_screen else 0.0),
+            "pack_rows": I * (4.0 * d + 4.0 * self.ldx + 4.0 + 8.0) + (I * 2.0 * self.ldx if self.f16_screen else 0.0),
             "query_mix": U * (4.0 * d + 8.0 * d + 4.0 * self.ldx + 4.0),
         }
 

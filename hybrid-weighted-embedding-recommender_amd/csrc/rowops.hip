@@ -159,6 +159,10 @@ struct RowGroup {
 };
 
 // K9+K10 (+ optional norms): out[r] = unit(sum_t alpha * T_t[idx_t[r]])
+// NC = float4 chunks per lane (1 for d <= 256, MAXC above), U = rows a row group works on per iteration: with one chunk per
+// lane a wave had a single 16-byte load in flight per lane and table, and the kernel sat at ~4.5 TB/s on latency; four rows per
+// iteration put 4 T loads in flight before the first reduction.  The arithmetic of a row is unchanged.
+template <int NC, int U>
 __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const* __restrict__ tables,
                                                               int64_t ldt, const int32_t* const* __restrict__ row_idx,
                                                               const float* __restrict__ alpha, int alpha_per_row,
@@ -171,66 +175,84 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
     double a_dev = 0.0;
     const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
-    for (int64_t r0 = group_global - g.sub; r0 < R; r0 += group_stride) {  // r0: wave-uniform base row
-        const int64_t r = r0 + g.sub;
-        const bool live = r < R;
-        float4 acc[MAXC];
+    for (int64_t rb = group_global - g.sub; rb < R; rb += group_stride * U) {  // rb: wave-uniform base row of the first of U row groups
+        float4 acc[U][NC];
+        bool live[U];
+        int64_t rr[U];
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (live) {
-            for (int t = 0; t < T; ++t) {
-                const float a = alpha_per_row ? alpha[r * T + t] : alpha[t];
-                const int32_t* ri = row_idx ? row_idx[t] : nullptr;
-                const int64_t row = ri ? int64_t(ri[r]) : r;
-                const float* base = tables[t] + row * ldt;
+        for (int u = 0; u < U; ++u) {
+            rr[u] = rb + int64_t(u) * group_stride + g.sub;
+            live[u] = rr[u] < R;
 #pragma unroll
-                for (int i = 0; i < MAXC; ++i) {
-                    const int c = g.c0 + i * g.L;
-                    if (c < d4) {
-                        const float4 v = *reinterpret_cast<const float4*>(base + 4 * c);
-                        acc[i].x = fmaf(a, v.x, acc[i].x);
-                        acc[i].y = fmaf(a, v.y, acc[i].y);
-                        acc[i].z = fmaf(a, v.z, acc[i].z);
-                        acc[i].w = fmaf(a, v.w, acc[i].w);
+            for (int i = 0; i < NC; ++i) acc[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        for (int t = 0; t < T; ++t) {
+            const int32_t* ri = row_idx ? row_idx[t] : nullptr;
+            const float* tab = tables[t];
+            float4 v[U][NC];
+            float al[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {   // all loads of this table first
+                al[u] = 0.f;
+                if (live[u]) {
+                    al[u] = alpha_per_row ? alpha[rr[u] * T + t] : alpha[t];
+                    const int64_t row = ri ? int64_t(ri[rr[u]]) : rr[u];
+                    const float* base = tab + row * ldt;
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        const int c = g.c0 + i * g.L;
+                        v[u][i] = c < d4 ? *reinterpret_cast<const float4*>(base + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) v[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    acc[u][i].x = fmaf(al[u], v[u][i].x, acc[u][i].x);
+                    acc[u][i].y = fmaf(al[u], v[u][i].y, acc[u][i].y);
+                    acc[u][i].z = fmaf(al[u], v[u][i].z, acc[u][i].z);
+                    acc[u][i].w = fmaf(al[u], v[u][i].w, acc[u][i].w);
                 }
             }
         }
-        float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i) ss += acc[i].x * acc[i].x + acc[i].y * acc[i].y + acc[i].z * acc[i].z + acc[i].w * acc[i].w;
-        ss = group_sum(ss, g.L);
-        const float nrm = sqrtf(ss);  // no epsilon: a zero row becomes NaN like hwer/utils.py:43-44
-        if (live) {
+        for (int u = 0; u < U; ++u) {
+            if (rb + int64_t(u) * group_stride >= R) break;   // wave-uniform: this row group lies past the table
+            const int64_t r = rr[u];
+            float ss = 0.f;
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = g.c0 + i * g.L;
-                if (c < d4) {
-                    float4 o = make_float4(acc[i].x / nrm, acc[i].y / nrm, acc[i].z / nrm, acc[i].w / nrm);
-                    *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = o;
-                }
-            }
-            if (out_norm && g.c0 == 0) out_norm[r] = nrm;
-        }
-        if (audit_counts) {   // norm of the row as STORED (float32), exactly what a separate audit pass would read back
+            for (int i = 0; i < NC; ++i) ss += acc[u][i].x * acc[u][i].x + acc[u][i].y * acc[u][i].y + acc[u][i].z * acc[u][i].z + acc[u][i].w * acc[u][i].w;
+            ss = group_sum(ss, g.L);
+            const float nrm = sqrtf(ss);  // no epsilon: a zero row becomes NaN like hwer/utils.py:43-44
+            // one correctly rounded reciprocal per row, then multiplies: <= 1 ulp from x / nrm (the stage's contract is 1e-6 against
+            // the float64 oracle) instead of ~10 VALU instructions per IEEE division and element; 0 * inf = NaN keeps a zero row NaN
+            const float inv = 1.0f / nrm;
             float s2 = 0.f;
-            if (live) {
+            if (live[u]) {
 #pragma unroll
-                for (int i = 0; i < MAXC; ++i) {
+                for (int i = 0; i < NC; ++i) {
                     const int c = g.c0 + i * g.L;
                     if (c < d4) {
-                        const float ox = acc[i].x / nrm, oy = acc[i].y / nrm, oz = acc[i].z / nrm, ow = acc[i].w / nrm;
-                        s2 += ox * ox + oy * oy + oz * oz + ow * ow;
+                        const float4 o = make_float4(acc[u][i].x * inv, acc[u][i].y * inv, acc[u][i].z * inv, acc[u][i].w * inv);
+                        *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = o;
+                        s2 += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;   // norm of the row as STORED (float32): what a separate audit pass would read back
                     }
                 }
+                if (out_norm && g.c0 == 0) out_norm[r] = nrm;
             }
-            s2 = group_sum(s2, g.L);
-            if (live && g.c0 == 0) {
-                const float n = sqrtf(s2);
-                a_pos += double(n) > 1.0 + double(audit_eps);
-                a_neg += double(n) < 1.0 - double(audit_eps);
-                a_nan += (n != n);
-                a_dev += fabs(double(n) - 1.0);
+            if (audit_counts) {
+                s2 = group_sum(s2, g.L);
+                if (live[u] && g.c0 == 0) {
+                    const float n = sqrtf(s2);
+                    a_pos += double(n) > 1.0 + double(audit_eps);
+                    a_neg += double(n) < 1.0 - double(audit_eps);
+                    a_nan += (n != n);
+                    a_dev += fabs(double(n) - 1.0);
+                }
             }
         }
     }
@@ -395,47 +417,72 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
 }
 
 // K11 pass 1: row norms;  pack_rows: gather rows of one node type into the padded table + half norms
-template <bool PACK>
+typedef _Float16 half4_rt __attribute__((ext_vector_type(4)));
+// NC / U as in blend_normalize_kernel: rows of up to 256 columns keep one chunk per lane and four rows in flight per row group
+template <bool PACK, int NC, int U>
 __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ V, int64_t ldv, int d, int d4,
                                                        const int64_t* __restrict__ row_ids, int64_t n_rows,
                                                        float* __restrict__ X, int64_t ldx, int x4,
-                                                       float* __restrict__ out_norm) {
+                                                       float* __restrict__ out_norm, half4_rt* __restrict__ X16 = nullptr, int x_exp = 0) {
     const RowGroup g(PACK ? x4 : d4);
     const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
     const int64_t n_out = PACK ? ((n_rows + 31) / 32) * 32 : n_rows;   // PACK: pad rows (zeros, half norm +inf)
-    for (int64_t r0 = group_global - g.sub; r0 < n_out; r0 += group_stride) {
-        const int64_t r = r0 + g.sub;
-        const bool live = r < n_rows;
-        float ss = 0.f;
-        if (PACK && !live && r < n_out) {
+    for (int64_t rb = group_global - g.sub; rb < n_out; rb += group_stride * U) {
+        float4 v[U][NC];
+        int64_t rr[U];
+        bool live[U];
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = g.c0 + i * g.L;
-                if (c < x4) *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (g.c0 == 0) out_norm[r] = INFINITY;
-        }
-        if (live) {
-            const int64_t row = row_ids ? row_ids[r] : r;
+        for (int u = 0; u < U; ++u) {   // all loads first
+            rr[u] = rb + int64_t(u) * group_stride + g.sub;
+            live[u] = rr[u] < n_rows;
+            const int64_t row = live[u] ? (row_ids ? row_ids[rr[u]] : rr[u]) : 0;
             const float* base = V + row * ldv;
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
+            for (int i = 0; i < NC; ++i) {
                 const int c = g.c0 + i * g.L;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < d4) {
-                    v = *reinterpret_cast<const float4*>(base + 4 * c);
+                v[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live[u] && c < d4) {
+                    v[u][i] = *reinterpret_cast<const float4*>(base + 4 * c);
                     // columns >= d inside the last chunk are padding of the source table (must be zero there)
-                    if (4 * c + 1 >= d) v.y = 0.f;
-                    if (4 * c + 2 >= d) v.z = 0.f;
-                    if (4 * c + 3 >= d) v.w = 0.f;
+                    if (4 * c + 1 >= d) v[u][i].y = 0.f;
+                    if (4 * c + 2 >= d) v[u][i].z = 0.f;
+                    if (4 * c + 3 >= d) v[u][i].w = 0.f;
                 }
-                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-                if (PACK && c < x4) *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = v;
             }
         }
-        ss = group_sum(ss, g.L);
-        if (live && g.c0 == 0) out_norm[r] = PACK ? 0.5f * ss : sqrtf(ss);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rb + int64_t(u) * group_stride >= n_out) break;   // wave-uniform
+            const int64_t r = rr[u];
+            float ss = 0.f;
+            if (PACK && !live[u] && r < n_out) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int c = g.c0 + i * g.L;
+                    if (c < x4) {
+                        *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (X16) X16[(r * ldx) / 4 + c] = half4_rt{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    }
+                }
+                if (g.c0 == 0) out_norm[r] = INFINITY;
+            }
+            if (live[u]) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i) {
+                    const int c = g.c0 + i * g.L;
+                    const float4 w = v[u][i];
+                    ss += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+                    if (PACK && c < x4) {
+                        *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = w;
+                        if (X16)   // the float16 copy in the same pass (scaled by 2^x_exp: hwer_pack_rows_f16)
+                            X16[(r * ldx) / 4 + c] = half4_rt{(_Float16)ldexpf(w.x, x_exp), (_Float16)ldexpf(w.y, x_exp), (_Float16)ldexpf(w.z, x_exp), (_Float16)ldexpf(w.w, x_exp)};
+                    }
+                }
+            }
+            ss = group_sum(ss, g.L);
+            if (live[u] && g.c0 == 0) out_norm[r] = PACK ? 0.5f * ss : sqrtf(ss);
+        }
     }
 }
 
@@ -667,7 +714,16 @@ static int blend_impl(const float* const* tables, int64_t ld_tables, const int32
     // tables use fewer, longer blocks: about 32 rows per block, at least one block per CU, at most kMaxStreamBlocks
     int grid = rows_grid(R, d4);
     if (audit_counts) grid = std::min(grid, int(std::max<int64_t>(256, cdiv64(R, 32))));
-    hipLaunchKernelGGL(blend_normalize_kernel, dim3(grid), dim3(256), 0, as_stream(stream), tables,
+    if (d4 <= 64 && T <= 2)   // one float4 chunk per lane: four rows per iteration (2 x 4 loads in flight per lane)
+        hipLaunchKernelGGL((blend_normalize_kernel<1, 4>), dim3(grid), dim3(256), 0, as_stream(stream), tables,
+                       ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
+    else if (d4 <= 64)        // more tables: the rows of one iteration (measured at T = 4: U = 4 is 17 % slower than U = 1)
+        hipLaunchKernelGGL((blend_normalize_kernel<1, 1>), dim3(grid), dim3(256), 0, as_stream(stream), tables,
+                       ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
+    else
+        hipLaunchKernelGGL((blend_normalize_kernel<MAXC, 1>), dim3(grid), dim3(256), 0, as_stream(stream), tables,
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     return check_launch("blend_normalize");
@@ -744,8 +800,12 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
     if ((rc = check_table("unit_audit", V, ldv, d))) return rc;
     if (!row_norm_ws || !out_counts || !out_absdev_sum) return fail(HWER_EINVAL, "unit_audit: null output");
     const int d4 = (d + 3) / 4;
-    hipLaunchKernelGGL(row_norm_kernel<false>, dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
-                       (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws);
+    if (d4 <= 64)
+        hipLaunchKernelGGL((row_norm_kernel<false, 1, 4>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
+                           (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws, (half4_rt*)nullptr, 0);
+    else
+        hipLaunchKernelGGL((row_norm_kernel<false, MAXC, 1>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
+                           (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws, (half4_rt*)nullptr, 0);
     if ((rc = check_launch("unit_audit(norms)"))) return rc;
     // partials + ticket live behind the N row norms (callers size row_norm_ws with hwer_unit_audit_ws_floats(N))
     double* partial = reinterpret_cast<double*>(row_norm_ws + ((N + 3) / 4) * 4);
@@ -770,6 +830,11 @@ int hwer_knn_padded_dim(int d) {
 
 int hwer_pack_rows_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids, int64_t n_rows,
                        float* X, int64_t ldx, float* hnorm, void* stream) {
+    return hwer_pack_rows_f32_f16(V, N, d, ldv, row_ids, n_rows, X, ldx, hnorm, nullptr, 0, stream);
+}
+
+int hwer_pack_rows_f32_f16(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids, int64_t n_rows,
+                           float* X, int64_t ldx, float* hnorm, void* X16, int x_exp, void* stream) {
     if (n_rows == 0) return HWER_OK;
     int rc;
     if ((rc = check_table("pack_rows(V)", V, ldv, d))) return rc;
@@ -778,8 +843,13 @@ int hwer_pack_rows_f32(const float* V, int64_t N, int d, int64_t ldv, const int6
     if (!row_ids && n_rows > N) return fail(HWER_EINVAL, "pack_rows: n_rows > N without row_ids");
     const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
     if (x4 > 64 * MAXC) return fail(HWER_EINVAL, "pack_rows: ldx too large");
-    hipLaunchKernelGGL(row_norm_kernel<true>, dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), V, ldv, d,
-                       d4, row_ids, n_rows, X, ldx, x4, hnorm);
+    if (X16 && ((reinterpret_cast<uintptr_t>(X16) & 7) != 0 || ldx % 4 != 0)) return fail(HWER_EINVAL, "pack_rows: X16 must be 8-byte aligned");
+    if (x4 <= 64)
+        hipLaunchKernelGGL((row_norm_kernel<true, 1, 4>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), V, ldv, d,
+                           d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp);
+    else
+        hipLaunchKernelGGL((row_norm_kernel<true, MAXC, 1>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), V, ldv, d,
+                           d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp);
     return check_launch("pack_rows");
 }
 

@@ -132,6 +132,11 @@ int hwer_knn_padded_dim(int d); /* 32, 64, 128 or 256; -1 if d is unsupported (d
 int64_t hwer_knn_padded_rows(int64_t n_rows);
 int hwer_pack_rows_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids /*nullable*/,
                        int64_t n_rows, float* X, int64_t ldx, float* hnorm, void* stream);
+/* Same, writing the float16 copy of the table (hwer_pack_rows_f16: X scaled by 2^x_exp, rounded to float16) in the SAME pass over
+ * the rows - for callers that know a bound on the half norms beforehand (rows that passed the unit-norm audit: 0.5 (1 + eps)^2),
+ * x_exp = hwer_knn_f16_scale_exp(bound).  X16 (nullable): hwer_knn_padded_rows(n_rows) * ldx float16 values. */
+int hwer_pack_rows_f32_f16(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids /*nullable*/,
+                           int64_t n_rows, float* X, int64_t ldx, float* hnorm, void* X16 /*nullable*/, int x_exp, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * K3+K4  query construction — replaces get_average_embeddings + the list average at
