@@ -13,6 +13,13 @@ constexpr int SLACK = 56;            // K' = roundup64(k + SLACK)
 constexpr int COMPACT_SLACK = 32;    // a compaction keeps between K' and K' + 32 keys (bisection stops early)
 constexpr int KEEP_MAX = KPRIME_MAX + COMPACT_SLACK;   // most keys one list hands to the select stage (480)
 constexpr int K_MAX = KPRIME_MAX - SLACK;
+// Streaming screen: stage a lane's appended keys in LDS and write them as whole 64-byte lines (true), or append every key with
+// its own 8-byte store (false).  Measured at c3 (profiles/r2_*): staging cuts the bytes written 4x but its flush sits in the pop
+// loop of the filter epilogue - the step got SLOWER; kept as a compile-time switch.
+#ifndef HWER_STAGE_APPENDS
+#define HWER_STAGE_APPENDS 0
+#endif
+constexpr bool STAGE_APPENDS = HWER_STAGE_APPENDS != 0;
 constexpr int SCREEN_IB = 32;        // item rows per LDS tile (one 32-row MFMA subtile)
 constexpr int DENSE_MAX_ITEMS = 8192; // catalogues up to this size take the dense path
 constexpr int MAX_LISTS_DIRECT = 8;  // lists the select kernel can take in one pass (8 * 1024 keys = 64 KB LDS)

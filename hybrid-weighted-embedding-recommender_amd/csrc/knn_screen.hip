@@ -159,6 +159,10 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     float* xs = reinterpret_cast<float*>(smem_raw);                         // [2][IB][CH*4]
     float* hn = xs + 2 * IB * CH * 4;                                       // [2][IB]
     float* keypark_all = hn + 2 * IB;                                       // [4][64][16 * TQ]: a wave's keys per lane
+    // streaming mode: append staging, per wave [8 slots][TQ][64 lanes] packed keys.  A lane's stream grows by 8-byte keys a few
+    // tiles apart; written one by one, every key costs a 32-byte memory write (measured: 4.3 GB written for 1.1 GB of keys at
+    // c3).  Keys wait here until a group of 8 is complete and leave as ONE 64-byte line (4 x 16-byte stores back to back).
+    uint64_t* abuf_all = reinterpret_cast<uint64_t*>(keypark_all + 4 * 64 * 16 * TQ);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,6 +175,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     const int list = split * wi_n + wii;
     const int64_t qw0 = int64_t(qblock) * (wq * 32 * TQ) + int64_t(wqi) * 32 * TQ;  // wave's first query
     float* keypark = keypark_all + wave * (64 * 16 * TQ);
+    uint64_t* const abuf = abuf_all + wave * (8 * TQ * 64) + lane;   // slot s of subtile b: abuf[(s * TQ + b) * 64]
+    int lo[TQ];          // stream positions [lo, cnt) of the current group of 8 live in abuf, everything below is in memory
 
     // ---- resident query fragments (MFMA B operand): lane (r, h) holds Q[qw0 + 32 b + r][8 g + 4 h .. +3] -------
     // float32: NG k-groups of 8 columns (float4 per lane half); float16: NG / 2 k-steps of 16 columns (half8 per lane half)
@@ -192,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         seeded[b] = a.tau0 != nullptr && live && t0 > -INFINITY;
         tau[b] = (live && !a.debug_nofilter) ? (F16 ? ldexpf(t0, e_tot[b]) : t0) : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
+        lo[b] = 0;
         first[b] = true;
         scaled[b] = false;
         soff[b] = (uint32_t(32 * b + r) * 2u + uint32_t(h)) * CAPH;
@@ -247,6 +254,35 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             lds_dma4(hn_split + int64_t(ptile) * hn_tile, uint32_t(lane) * 4u, hn_addr0 + uint32_t(t & 1) * uint32_t(IB * 4));
     };
 
+    // staged appends (streaming mode).  stage(b, key): park the key; a completed group of 8 leaves as one 64-byte line when all
+    // of it is staged (lo <= group start), else - once after every compaction - its staged part goes out key by key.
+    auto flush_tail = [&](int b) {       // write the staged keys [lo, cnt) of subtile b (fewer than 8) key by key
+        for (int p = lo[b]; p < cnt[b]; ++p) wg_cand[soff[b] + uint32_t(p)] = abuf[((p & 7) * TQ + b) * 64];
+        lo[b] = cnt[b];
+    };
+    auto stage = [&](int b, uint64_t key) {
+        if constexpr (!STAGE_APPENDS) {   // direct append: one 8-byte store per key
+            wg_cand[soff[b] + uint32_t(cnt[b])] = key;
+            ++cnt[b];
+            lo[b] = cnt[b];
+            return;
+        }
+        abuf[((cnt[b] & 7) * TQ + b) * 64] = key;
+        ++cnt[b];
+        if ((cnt[b] & 7) == 0) {
+            if (lo[b] <= cnt[b] - 8) {
+                uint4* dst = reinterpret_cast<uint4*>(wg_cand + soff[b] + uint32_t(cnt[b] - 8));   // 64-byte aligned
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    const uint64_t k0 = abuf[((2 * s2) * TQ + b) * 64], k1 = abuf[((2 * s2 + 1) * TQ + b) * 64];
+                    dst[s2] = make_uint4(uint32_t(k0), uint32_t(k0 >> 32), uint32_t(k1), uint32_t(k1 >> 32));
+                }
+                lo[b] = cnt[b];
+            } else {
+                flush_tail(b);
+            }
+        }
+    };
     __builtin_amdgcn_s_setprio(3);
     int p_cur = 0;                       // perm(t)
     int p_dma = perm_next(0);            // perm(t + 1), then perm(t + 2) while tile t is computed
@@ -401,13 +437,10 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                         if constexpr (F16) kval = ldexpf(kval, -((TQ == 2 && (bit & 16)) ? e_tot[TQ - 1] : e_tot[0]));   // back to real units (exact)
                         const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
                         if constexpr (TQ == 1) {
-                            wg_cand[soff[0] + uint32_t(cnt[0])] = key;
-                            ++cnt[0];
+                            stage(0, key);
                         } else {
-                            const bool second = (bit & 16) != 0;   // half-word 1 = subtile 1
-                            wg_cand[(second ? soff[1] : soff[0]) + uint32_t(second ? cnt[1] : cnt[0])] = key;
-                            cnt[0] += second ? 0 : 1;
-                            cnt[1] += second ? 1 : 0;
+                            if ((bit & 16) != 0) stage(1, key);   // half-word 1 = subtile 1
+                            else stage(0, key);
                         }
                     }
                 }
@@ -466,11 +499,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 }
                 float T;
                 int n0, n1;
+                if (r == jj) flush_tail(b);   // the compaction reads the streams from memory: the owner lanes' staged keys first
                 // in-loop compactions may keep up to 32 keys more than asked (a stream then holds <= K' + 32 <= CAPH - 32)
                 compact_query(s0, s0 + CAPH, c0, c1, rank, rank == a.kprime ? COMPACT_SLACK : min(COMPACT_SLACK, rank / 4 + 1), T, n0, n1);
                 if (r == jj) {
                     tau[b] = F16 ? ldexpf(T, e_tot[b]) : T;   // the filter compares in the query's scaled units
                     cnt[b] = h == 0 ? n0 : n1;
+                    lo[b] = cnt[b];                            // the rewritten stream is in memory; nothing is staged
                     scaled[b] = scaled[b] || (rank != a.kprime);
                     first[b] = false;
                 }
@@ -490,6 +525,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel clock = o[6] / o[7] x 100 MHz
     }
     if constexpr (DENSE) return;
+#pragma unroll
+    for (int b = 0; b < TQ; ++b) flush_tail(b);   // every staged key reaches its stream before the hand-over
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
         // final compaction: queries holding more than K' keys keep exactly their K' best
@@ -562,7 +599,9 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     // >= 4096 items per list (shorter lists were measured slower: more list-reduce work than the extra parallelism buys).  Callers chunk B to multiples of 512 * qb queries (DeviceIndex.QUERY_CHUNK).
     const int64_t slots = 512;
     int64_t splits = std::max<int64_t>(1, slots / p.n_qblocks);
-    int64_t min_list = 4096;
+    // (seeded thresholds - decided below from the same quantities - make a list nearly free: then lists may be 4x shorter)
+    const bool seedable = !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS)) && n_items > DENSE_MAX_ITEMS;
+    int64_t min_list = seedable ? 1024 : 4096;
     if (const char* e = diag_env("HWER_SCREEN_SPLITS")) splits = std::max(1, atoi(e));  // tuning / ablation overrides
     if (const char* e = diag_env("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
     const int64_t max_splits = std::max<int64_t>(1, n_items / (min_list * wi));
@@ -621,7 +660,7 @@ bool screen_f16_supported(const ScreenPlan& plan) { return plan.ng >= 8; }
 template <int NG, int TQ, bool DENSE>
 static int launch_screen_t2(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     // tile ring 2 x 32 rows x (NG*32 B) | half norms 2 x 32 | key park 4 x 64 x 16 TQ
-    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
+    size_t lds = size_t(2) * 32 * NG * 32 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4 + ((DENSE || !STAGE_APPENDS) ? 0 : size_t(4) * 8 * TQ * 64 * 8);   // + append staging
     if (const char* e = diag_env("HWER_SCREEN_LDS_PAD_KB")) lds += size_t(atoi(e)) * 1024;   // occupancy experiments
     static uint64_t attr_done = 0;   // per device
     int dev;
@@ -642,27 +681,28 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 // float16 screen (streaming mode): tiles of 32 rows x NG 16-byte chunks
 template <int NG, int TQ>
 static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    const size_t lds = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
+    const size_t lds_dense = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
+    const size_t lds_stream = lds_dense + (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);   // + append staging
     static uint64_t attr_done = 0, attr_done_d = 0;   // per device
     int dev;
-    if (attr_pending(attr_done, &dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, false, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done |= 1ull << dev;
-    }
     const int grid = plan.n_qblocks * plan.n_splits;
     if (plan.dense) {
         if (attr_pending(attr_done_d, &dev)) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, true, true>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_dense));
             if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16(dense): hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_done_d |= 1ull << dev;
         }
-        hipLaunchKernelGGL((screen_kernel<NG, TQ, true, true>), dim3(grid), dim3(256), lds, stream, a);
+        hipLaunchKernelGGL((screen_kernel<NG, TQ, true, true>), dim3(grid), dim3(256), lds_dense, stream, a);
         return check_launch("knn_screen16(dense)");
     }
-    hipLaunchKernelGGL((screen_kernel<NG, TQ, false, true>), dim3(grid), dim3(256), lds, stream, a);
+    if (attr_pending(attr_done, &dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, false, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_stream));
+        if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done |= 1ull << dev;
+    }
+    hipLaunchKernelGGL((screen_kernel<NG, TQ, false, true>), dim3(grid), dim3(256), lds_stream, stream, a);
     return check_launch("knn_screen16");
 }
 

@@ -1425,7 +1425,7 @@ size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, u
     const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
     if (!conservative && use_small_path(B, n_items, options)) {
         const ScreenPlan sp = make_screen_plan(B, n_items, ldx, k, options);
-        return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k), sp.seed ? &sp : nullptr);
+        return WS_HEADER_BYTES + small_ws_bytes(make_small_plan(B, n_items, ldx, k), (sp.seed && sp.seed_frac <= 0.01) ? &sp : nullptr);
     }
     return ws_layout(make_screen_plan(B, n_items, ldx, k, options), B).total;
 }
@@ -1469,7 +1469,9 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         // seeded thresholds (the streaming screen's sample pre-pass): ONE filtering pass over the catalogue instead of a key
         // matrix + threshold + collect passes
         const ScreenPlan seed_plan = make_screen_plan(B, n_items, int(ldx), k, options);
-        const ScreenPlan* seed = seed_plan.seed ? &seed_plan : nullptr;
+        // (only where few keys pass - above ~1 % of the catalogue per query the filtering pass spends its time parking keys and the
+        // key-matrix passes are faster: small catalogues)
+        const ScreenPlan* seed = (seed_plan.seed && seed_plan.seed_frac <= 0.01) ? &seed_plan : nullptr;
         if (seed && X16 && !screen_f16_supported(seed_plan)) X16 = nullptr;   // d <= 32: the pre-pass has no float16 variant, use the float32 rows
         const size_t need = WS_HEADER_BYTES + small_ws_bytes(sp, seed);
         if (workspace_bytes < need) return fail(HWER_EWORKSPACE, "knn_search: workspace %zu < %zu", workspace_bytes, need);

@@ -582,6 +582,9 @@ bool use_small_path(int64_t B, int64_t n_items, uint32_t options) {
     if (n_items <= DENSE_MAX_ITEMS || B * n_items * 4 > SMALL_MAX_KEY_BYTES) return false;
     if (const char* e = diag_env("HWER_SMALL_MAXQ")) return B <= atoi(e);   // tuning override
     if (B <= SMALL_MAX_QUERIES) return true;
+    // With seeded thresholds a candidate list costs next to nothing, so the streaming screen splits the items as finely as it
+    // needs to fill the machine and the dense-key detour below no longer pays (c3's last 7 421 users: 1.0 -> 0.5 ms).
+    if (!(options & HWER_KNN_NO_SEED)) return false;
     // Beyond that the streaming screen wins once its launch can fill the machine: 512 workgroup slots, one workgroup per
     // 256 queries and item split, lists of at least 4096 items.  A launch that cannot (e.g. the last 7 421 of C3's users
     // against 26 744 items: 29 query blocks x 6 splits) is 1.8x faster through the dense-key path.
@@ -678,6 +681,7 @@ int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, d
                           hipStream_t stream) {
     SmallSelectArgs sa{keys, ld, n, B, 0, tau0, count_scratch, nullptr, want_frac};
     if (n <= 1024) hipLaunchKernelGGL(small_threshold_wave_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 2048) hipLaunchKernelGGL(small_threshold_wave_kernel<32>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
     else if (n <= 4096) hipLaunchKernelGGL(small_threshold_wave_kernel<64>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
     else if (n <= 16384) hipLaunchKernelGGL(small_threshold_kernel<16>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     else if (n <= 32768) hipLaunchKernelGGL(small_threshold_kernel<32>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
