@@ -587,6 +587,11 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     // phases (measured, C4 4 096 x 1.25 M: screen 12.5 -> 11.9 ms, select 1.0 -> 0.56 ms; a third resident workgroup per
     // CU - 168 VGPRs - was measured too and does not help).
     p.tq = (p.ng <= 16 && B > 65536) ? 2 : 1;
+    // With seeded thresholds (below) a candidate list is nearly free, so the item splits that TQ = 2 doubles no longer cost a
+    // warm-up each, while the per-tile barrier / DMA issue / accumulator set-up is shared by twice the queries
+    // (c4, 4 096 x 1.25 M: screen 3.20 -> 2.53 ms, select + list reduction 0.41 -> 0.55 ms).
+    // (long lists only: on a 26 744-row catalogue - c3's last 7 421 users - the extra lists cost more in the list reduction)
+    if (p.ng <= 16 && B >= 2048 && n_items >= 65536 && !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS | HWER_KNN_NO_DENSE))) p.tq = 2;
     if (const char* e = diag_env("HWER_SCREEN_TQ")) p.tq = atoi(e) == 1 ? 1 : ((atoi(e) == 2 && p.ng <= 16 && B > 32) ? 2 : p.tq);   // tuning override
     const int qpw = 32 * p.tq;
     p.wq = B > 2 * qpw ? 4 : (B > qpw ? 2 : 1);
