@@ -437,12 +437,19 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
                     "vs_fp32_mfma_peak": (flops / (screen_step_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if screen_step_ms > 0 else 0.0,
                     "launches_per_step": searches_per_step, "avg_launch_ms": screen_ms, "algorithmic_flops": flops,
                     "traffic": traffic, "traffic_source": traffic_src})
-    # re-rank: per query ~ (k + boundary) candidates x d x 3 float64 operations for the score chain (+ 4 d per boundary candidate)
-    rr_flops = float(U) * (K + 16) * d * 3.0
-    kernels.append({"kernel": "knn_select_rerank (float64 re-rank + certificate + sort)", "ms_per_step": select_step_ms, "share": select_step_ms / ms_per_step,
-                    "bound": "valu_f64", "achieved": rr_flops / (select_step_ms * 1e-3) / 1e12 if select_step_ms > 0 else 0.0, "peak": VALU_F64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": (rr_flops / (select_step_ms * 1e-3) / 1e12 / VALU_F64_PEAK_TFLOPS) if select_step_ms > 0 else 0.0,
-                    "note": "instruction-count-bound selection + gather code around the float64 chains; its useful work is tiny next to the screen's"})
+    # select / re-rank: every query gathers its ~k + 16 candidate rows (4 * ldx bytes each, float32: the exact re-rank reads the
+    # float32 rows whatever the screen read) from a table that lives in L2, in the Infinity Cache or in HBM by its size; the
+    # gathered-row rates are the measured ones of /opt/skills/guides/MI355X_MICROARCH.md "Indexed rows: gather" (L2-resident
+    # rows 17.8 TB/s chip-wide, Infinity Cache 8.6 TB/s, HBM random rows 5.6 TB/s).  profiles/r2_rocprof_pmc_c3.txt: the
+    # select kernel of c3 fetches 2 * 5.5 GB per launch = the candidates' rows.
+    table_bytes = float(w.I_pad) * w.ldx * 4
+    level, gather_peak = ("l2", 17800.0) if table_bytes <= 4.0e6 else (("infinity_cache", 8600.0) if table_bytes <= 2.56e8 else ("hbm_random_rows", 5600.0))
+    gather_bytes = float(U) * (K + 16) * 4.0 * w.ldx
+    kernels.append({"kernel": "knn_select_rerank (candidate-row gather + float64 re-rank + certificate + sort)", "ms_per_step": select_step_ms,
+                    "share": select_step_ms / ms_per_step, "bound": "gather:" + level,
+                    "achieved": gather_bytes / (select_step_ms * 1e-3) / 1e9 if select_step_ms > 0 else 0.0, "peak": gather_peak, "unit": "GB/s",
+                    "frac": (gather_bytes / (select_step_ms * 1e-3) / 1e9 / gather_peak) if select_step_ms > 0 else 0.0, "algorithmic_bytes": gather_bytes,
+                    "note": "one wave per query; beside the row gather the kernel is bound by its instruction count (rank search, register sorts: profiles/r2_select_stamps.txt)"})
     dominant = max(kernels, key=lambda kk: kk["ms_per_step"])
     stage_tf = flops / ((screen_step_ms + select_step_ms) * 1e-3) / 1e12 if screen_step_ms + select_step_ms > 0 else 0.0
     res = {
