@@ -478,7 +478,8 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
     if (rank < 16) rank = 16;
     if (rank > S) rank = int(S);
     int c_lo;
-    const float t = wave_find_rank_fn(count_ge, vmin, vmax, rank, rank / 8, c_lo);
+    // (seed pre-pass: any threshold with at least `rank` sample keys above it will do - a wide stopping window saves probes)
+    const float t = wave_find_rank_fn(count_ge, vmin, vmax, rank, a.want_frac > 0.0 ? rank / 2 : rank / 8, c_lo);
     if (threadIdx.x == 0) {
         a.thr[b] = t;
         a.count[b] = 0;
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSe
     if (rank < 16) rank = 16;
     if (rank > 64 * PER) rank = 64 * PER;
     int c_lo;
-    const float t = wave_find_rank<PER>(v, rank, rank / 8, c_lo);
+    const float t = wave_find_rank<PER>(v, rank, a.want_frac > 0.0 ? rank / 2 : rank / 8, c_lo);
     if (lane == 0) {
         a.thr[b] = t;
         a.count[b] = 0;
