@@ -642,7 +642,9 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         // a handful of queries (latency: the pre-pass and its threshold kernel are a visible part of the search, the kept keys
         // are not): half the sample, twice the keys kept.  Measured on 1.25 M rows, one query: 0.161 -> 0.147 ms; with 32+
         // queries the parked keys dominate and c = 4 is faster (64 queries: 0.42 -> 0.28 ms).
-        const bool few = B <= 4 && use_small_path(B, n_items, options);
+        // Large catalogues with item splits (c4: 32 lists per query): the kept keys are spread over many short lists and cost
+        // little, the pre-pass and its threshold kernel do not (0.22 + 0.38 ms of a 3.6 ms step at c = 4): c = 8 there too.
+        const bool few = (B <= 4 && use_small_path(B, n_items, options)) || (n_items >= 400000 && !use_small_path(B, n_items, options));
         const double c_min = few ? 8.0 : 4.0;
         int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t((few ? 0.0225 : 0.045) * double(n_items)), 32)));
         ns = std::min(ns, n_tiles);

@@ -699,6 +699,7 @@ struct ReduceArgs {
     int32_t* cnt_out;
     int64_t bq;
     int kprime;
+    const int32_t* todo;   // nullable: reduce only the queries with todo[b] != 0 (the others were merged by reduce_lists_wave_kernel)
 };
 
 __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
@@ -706,6 +707,7 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
     int* s_off = reinterpret_cast<int*>(smem_raw);
     uint64_t* keys = reinterpret_cast<uint64_t*>(smem_raw + 128);
     const int64_t b = blockIdx.x;
+    if (a.todo && a.todo[b] == 0) return;   // block-uniform
     const int group = blockIdx.y;
     const int l0 = group * MAX_LISTS_DIRECT;
     const int nl = min(MAX_LISTS_DIRECT, a.n_lists_in - l0);
@@ -737,6 +739,99 @@ __global__ __launch_bounds__(256) void reduce_lists_kernel(const ReduceArgs a) {
     if (threadIdx.x == 0) {
         a.cnt_out[(int64_t(group) * a.bq + b) * 2 + 0] = min(n_c, CAPH) | s_off[25];
         a.cnt_out[(int64_t(group) * a.bq + b) * 2 + 1] = max(n_c - CAPH, 0);
+    }
+}
+
+// All lists of a query in ONE pass by ONE wave, for the short lists seeded thresholds leave behind (a query's 16 - 32 lists
+// then hold 4 - 8 K' keys together): the keys are gathered into wave-private LDS (up to REDW_MAX, scores in registers), the K'-th
+// largest is bracketed by counting probes (wave_find_rank, exact: slack 0) and the K' best are written out as the query's
+// single list - what two rounds of reduce_lists_kernel (workgroup per query and group of 8 lists, LDS bitonic sorts) did before.
+// A query whose lists hold more than REDW_MAX keys is left to those kernels (todo[b] = 1).
+constexpr int REDW_NV = 64;                 // keys per lane (their scores live in registers, the packed keys stay in LDS)
+constexpr int REDW_MAX = REDW_NV * 64;      // 4 096 keys per query
+constexpr int REDW_WAVES = 2;               // waves (= queries) per workgroup: 32 KB of LDS each
+constexpr int REDW_MAX_LISTS = 32;          // one lane per stream
+struct ReduceWaveArgs {
+    const uint64_t* cand_in;
+    const int32_t* cnt_in;
+    int n_lists;
+    uint64_t* cand_out;
+    int32_t* cnt_out;
+    int64_t bq;
+    int64_t B;
+    int kprime;
+    int32_t* todo;
+};
+
+__global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(const ReduceWaveArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = int64_t(blockIdx.x) * REDW_WAVES + wave;
+    if (b >= a.B) return;   // no workgroup barrier below
+    uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw) + size_t(wave) * REDW_MAX;
+    const int n_streams = 2 * a.n_lists;   // <= 64: lane s owns stream s = (list s / 2, half s % 2)
+    const int craw = lane < n_streams ? a.cnt_in[(int64_t(lane >> 1) * a.bq + b) * 2 + (lane & 1)] : 0;
+    const int n = craw & ~CNT_FLAGS;
+    int flags = craw & CNT_FLAGS, incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        flags |= __shfl_xor(flags, off, kWave);
+        const int t = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += t;
+    }
+    const int M = __shfl(incl, 63, kWave);
+    if (M > REDW_MAX) {   // wave-uniform: too many keys for the registers - the workgroup kernels take this query
+        if (lane == 0) a.todo[b] = 1;
+        return;
+    }
+    if (lane == 0) a.todo[b] = 0;
+    const int excl = incl - n;
+    for (int s2 = 0; s2 < n_streams; ++s2) {   // coalesced copy of every stream into the wave's LDS array
+        const int ns = __shfl(n, s2, kWave), os = __shfl(excl, s2, kWave);
+        const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH;
+        for (int i = lane; i < ns; i += 64) lds[os + i] = src[i];
+    }
+    wave_lds_sync();
+    float sv[REDW_NV];
+#pragma unroll
+    for (int r = 0; r < REDW_NV; ++r) {
+        const int e = 64 * r + lane;
+        const uint64_t kk = e < M ? lds[e] : 0ull;
+        sv[r] = kk != 0ull ? key_score(kk) : -INFINITY;
+    }
+    uint64_t* dst = a.cand_out + (b * 2) * CAPH;   // streams 0 and 1 of the output list are contiguous
+    int n_c = M;
+    if (M > a.kprime) {
+        // exactly the K' best: every key above the K'-th largest score plus as many of the keys equal to it as fit
+        int c_ge;
+        const float t = wave_find_rank<REDW_NV>(sv, a.kprime, 0, c_ge);
+        int c_gt = 0;
+#pragma unroll
+        for (int r = 0; r < REDW_NV; ++r) c_gt += __builtin_popcountll(__ballot(sv[r] > t));
+        const int want_eq = min(c_ge - c_gt, a.kprime - c_gt);
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
+        int eq_seen = 0, out = 0;
+#pragma unroll
+        for (int r = 0; r < REDW_NV; ++r) {
+            const bool gt = sv[r] > t, eq = sv[r] == t;
+            const uint64_t be = __ballot(eq);
+            const bool keep = gt || (eq && eq_seen + __builtin_popcountll(be & lt_mask) < want_eq);
+            const uint64_t bk = __ballot(keep);
+            if (keep) dst[out + __builtin_popcountll(bk & lt_mask)] = lds[64 * r + lane];
+            out += __builtin_popcountll(bk);
+            eq_seen += __builtin_popcountll(be);
+        }
+        n_c = out;   // == K'
+    } else {
+#pragma unroll
+        for (int r = 0; r < REDW_NV; ++r) {
+            const int e = 64 * r + lane;
+            if (e < M) dst[e] = lds[e];
+        }
+    }
+    if (lane == 0) {
+        a.cnt_out[b * 2 + 0] = min(n_c, CAPH) | flags;
+        a.cnt_out[b * 2 + 1] = max(n_c - CAPH, 0);
     }
 }
 
@@ -1314,7 +1409,7 @@ static unsigned long long* sel_stamps_buffer(int64_t B) {
 static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 struct WsLayout {
-    size_t qf, cand_a, cnt_a, cand_b, cnt_b, seed_keys, seed_tau, seed_cnt, total;
+    size_t qf, cand_a, cnt_a, cand_b, cnt_b, seed_keys, seed_tau, seed_cnt, todo, total;
 };
 static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     WsLayout w{};
@@ -1335,6 +1430,8 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     off += align256(size_t(groups) * p.bq * 2 * CAPH * 8);
     w.cnt_b = off;
     off += align256(size_t(groups) * p.bq * 2 * 4);
+    w.todo = off;   // per query: lists left to the workgroup reduce kernels
+    off += align256(size_t(p.bq) * 4);
     if (p.seed) {   // seed pre-pass: sample keys (bq, seed_ld), thresholds, a scratch counter row
         w.seed_keys = off;
         off += align256(size_t(p.bq) * size_t(p.seed_ld) * 4);
@@ -1576,9 +1673,25 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     int n_lists = plan.n_lists;
     uint64_t* cand_other = reinterpret_cast<uint64_t*>(ws + w.cand_b);
     int32_t* cnt_other = reinterpret_cast<int32_t*>(ws + w.cnt_b);
+    const int32_t* todo = nullptr;
+    if (n_lists > 1 && n_lists <= REDW_MAX_LISTS && plan.seed) {
+        // seeded thresholds: the lists of a query are short - one wave merges ALL of them (up to 4 096 keys) in one pass and
+        // writes where the rounds below would leave their result; only queries with more than 4 096 keys go through the rounds
+        int rounds = 0;
+        for (int nl = n_lists; nl > 1; nl = int(cdiv64(nl, MAX_LISTS_DIRECT))) ++rounds;
+        uint64_t* cand_final = (rounds & 1) ? cand_other : cand;
+        int32_t* cnt_final = (rounds & 1) ? cnt_other : cnt;
+        int32_t* todo_w = reinterpret_cast<int32_t*>(ws + w.todo);
+        ReduceWaveArgs rw{cand, cnt, n_lists, cand_final, cnt_final, plan.bq, B, plan.kprime, todo_w};
+        const size_t lds_w = size_t(REDW_WAVES) * REDW_MAX * 8;
+        if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_wave_kernel), lds_w, "knn_reduce_wave"))) return rc;
+        hipLaunchKernelGGL(reduce_lists_wave_kernel, dim3(unsigned(cdiv64(B, REDW_WAVES))), dim3(64 * REDW_WAVES), lds_w, st, rw);
+        if ((rc = check_launch("knn_reduce_wave"))) return rc;
+        todo = todo_w;
+    }
     while (n_lists > 1) {   // item splits / shared-query waves: merge the lists of a query into one list of K' keys
         const int groups = int(cdiv64(n_lists, MAX_LISTS_DIRECT));
-        ReduceArgs ra{cand, cnt, n_lists, cand_other, cnt_other, plan.bq, plan.kprime};
+        ReduceArgs ra{cand, cnt, n_lists, cand_other, cnt_other, plan.bq, plan.kprime, todo};
         const size_t lds = 128 + size_t(MAX_LISTS_DIRECT) * 512 * 8;  // 8 lists x K' <= 8 x 448 keys -> 4096 slots
         if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_kernel), lds, "knn_reduce"))) return rc;
         hipLaunchKernelGGL(reduce_lists_kernel, dim3(unsigned(B), unsigned(groups)), dim3(256), lds, st, ra);
