@@ -633,23 +633,33 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         p.n_lists = 0;
         p.ld_dense = n_tiles * 32;
     }
-    // Seeded thresholds (streaming mode).  The sample: ~4.5 % of the catalogue's 32-row tiles at a regular stride (1 024 to
-    // 65 536 items); tau0 = the sample key whose rank corresponds to c K' keys of the whole catalogue, c >= 4 and large enough
-    // for a sample rank of >= 44: with the rank's relative spread 1 / sqrt(rank) the catalogue then holds fewer than K' keys
-    // above tau0 with probability < 1e-6 per query - and such a query is flagged (CNT_SEEDED_SHORT -> uncertified), never wrong.
+    // Seeded thresholds (streaming mode).  The sample: 2 - 7 % of the catalogue's 32-row tiles at a regular stride (1 024 to
+    // 65 536 items); tau0 = the sample key whose rank corresponds to c K' keys of the whole catalogue, c chosen below and large
+    // enough for a sample rank of >= 44: with the rank's relative spread 1 / sqrt(rank) the catalogue then holds fewer than K'
+    // keys above tau0 with probability ~2e-6 per query (c = 2.75; far less at c >= 4) - and such a query is flagged
+    // (CNT_SEEDED_SHORT -> uncertified -> exhaustive pass), never wrong.
     if (!p.dense && !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS)) && !diag_env("HWER_SCREEN_NOSEED")) {
         const int64_t n_tiles = cdiv64(n_items, 32);
-        // a handful of queries (latency: the pre-pass and its threshold kernel are a visible part of the search, the kept keys
-        // are not): half the sample, twice the keys kept.  Measured on 1.25 M rows, one query: 0.161 -> 0.147 ms; with 32+
-        // queries the parked keys dominate and c = 4 is faster (64 queries: 0.42 -> 0.28 ms).
-        // Large catalogues with item splits (c4: 32 lists per query): the kept keys are spread over many short lists and cost
-        // little, the pre-pass and its threshold kernel do not (0.22 + 0.38 ms of a 3.6 ms step at c = 4): c = 8 there too.
-        const bool few = (B <= 4 && use_small_path(B, n_items, options)) || (n_items >= 400000 && !use_small_path(B, n_items, options));
-        const double c_min = few ? 8.0 : 4.0;
-        int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t((few ? 0.0225 : 0.045) * double(n_items)), 32)));
+        const bool small = use_small_path(B, n_items, options);
+        // How many keys tau0 lets through, c K' per query (c_min; more when the sample is capped):
+        //   4    by default;
+        //   8    where the kept keys are cheap and the pre-pass is not: a handful of queries on the small-batch path (latency: one
+        //        query on 1.25 M rows 0.161 -> 0.147 ms; from 32 queries on the parked keys dominate and 4 is faster), and large
+        //        catalogues with item splits (c4: 32 short lists per query; pre-pass + threshold kernel 0.60 -> 0.30 ms);
+        //   2.75 when a query has ONE list (c3): 4 K' keys overflow the list's two 480-key streams, and every in-loop compaction
+        //        (~5 K cycles of one wave) stalls the three other waves of its workgroup at the tile barrier - measured 24 % of
+        //        the launch; 2.75 K' stay below the trigger (the pre-pass grows from 4.5 % to 7.4 % of the catalogue).
+        const bool single_list = p.n_lists == 1 && !small;
+        const double c_min = single_list ? 2.75 : (((B <= 4 && small) || (n_items >= 400000 && !small)) ? 8.0 : 4.0);
+        // sample rank r: the catalogue's count above tau0 has a relative spread of 1 / sqrt(r), and it must not fall below K' =
+        // (1 / c) of its expectation: (1 - 1/c) sqrt(r) standard deviations - 5 at c = 4, r = 44; 4.6 at c = 2.75, r = 52
+        // (~2e-6 per query: a query every few c3 steps takes the exhaustive pass)
+        const double r_min = single_list ? 52.0 : 44.0;
+        // sample size for that rank at c_min (+ 2 %), in 32-row tiles: 1 024 ... 65 536 items
+        int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t(1.02 * r_min * double(n_items) / (c_min * double(p.kprime))), 32)));
         ns = std::min(ns, n_tiles);
         const double S = double(ns) * 32.0;
-        const double c = std::max(c_min, 44.0 * double(n_items) / (double(p.kprime) * S));
+        const double c = std::max(c_min, r_min * double(n_items) / (double(p.kprime) * S));
         const double frac = c * double(p.kprime) / double(n_items);
         if (frac <= 0.25) {   // (a catalogue of a few K' rows forced onto this path: nothing to gain)
             p.seed = 1;
