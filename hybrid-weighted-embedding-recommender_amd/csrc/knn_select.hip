@@ -786,10 +786,28 @@ __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(cons
     }
     if (lane == 0) a.todo[b] = 0;
     const int excl = incl - n;
-    for (int s2 = 0; s2 < n_streams; ++s2) {   // coalesced copy of every stream into the wave's LDS array
-        const int ns = __shfl(n, s2, kWave), os = __shfl(excl, s2, kWave);
-        const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH;
-        for (int i = lane; i < ns; i += 64) lds[os + i] = src[i];
+    // coalesced copy of every stream into the wave's LDS array, eight streams' first 64 entries in flight at a time (seeded
+    // streams are short: a stream-by-stream loop is a chain of dependent global-load latencies)
+    for (int s0 = 0; s0 < n_streams; s0 += 8) {
+        uint64_t v[8];
+        int ns[8], os[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s2 = min(s0 + j, n_streams - 1);
+            ns[j] = s0 + j < n_streams ? __shfl(n, s2, kWave) : 0;
+            os[j] = __shfl(excl, s2, kWave);
+            const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH;
+            v[j] = lane < ns[j] ? src[lane] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (lane < ns[j]) lds[os[j] + lane] = v[j];
+            if (ns[j] > 64) {   // wave-uniform, rare: the rest of a long stream
+                const int s2 = s0 + j;
+                const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH;
+                for (int i = 64 + lane; i < ns[j]; i += 64) lds[os[j] + i] = src[i];
+            }
+        }
     }
     wave_lds_sync();
     float sv[REDW_NV];

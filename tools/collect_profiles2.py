@@ -31,9 +31,9 @@ def pmc_rows(path):
 
 traffic = {"_comment": "HBM-side traffic per launch from rocprofv3 PMC passes of `" + CMD % "<c>" + " --steps 3 --warmup 1` "
            "(profiles/r2_rocprof_pmc_<c>.txt): bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE is doubled per MI355X_MICROARCH.md "
-           "(gfx950 counts wide reads at half their bytes).  knn_screen_bytes_per_launch = the screen stage of one search: the seed pre-pass "
-           "(dense-mode screen over the sample), its threshold kernel and the filtering screen; streaming configurations add their "
-           "small-batch tail launch where there is one (c3)."}
+           "(gfx950 counts wide reads at half their bytes).  knn_screen_bytes_per_launch = the screen stage of the configuration's main search, "
+           "per-launch averages of the kernels listed in knn_screen_kernels: the filtering screen and - streaming configurations - the seed "
+           "pre-pass (dense-mode screen over the sample) and its threshold kernel."}
 for c in cfgs:
     j = json.load(open(f"{src}/stats_{c}_bench.json"))
     hdr = [f"# rocprofv3 --kernel-trace --stats -- {CMD % c} --steps N --warmup 5   (MI355X, round 2, final kernels; tools/profile_round2.sh)",
@@ -52,14 +52,27 @@ for c in cfgs:
         if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
             b = (2 * d["FETCH_SIZE"][0] + d["WRITE_SIZE"][0]) * 1024
             ent["kernels"][kern] = {"fetch_size_kb": d["FETCH_SIZE"][0], "write_size_kb": d["WRITE_SIZE"][0], "bytes_per_launch": int(b), "launches": d["FETCH_SIZE"][1]}
-    # the screen stage of one search: per-launch averages x launches per step of each screen-side kernel
-    steps_profiled = 4
-    for kern, e in ent["kernels"].items():
-        if any(t in kern for t in ("screen_kernel", "small_screen", "small_threshold")):
-            total += e["bytes_per_launch"] * e["launches"] / steps_profiled
-    searches_per_step = 2 if c == "c3" else 1
-    ent["knn_screen_bytes_per_step"] = int(total)
-    ent["knn_screen_bytes_per_launch"] = int(total / searches_per_step)
+    # the screen stage of the configuration's MAIN search (per-launch averages): the filtering screen kernel with the largest
+    # traffic, plus - streaming configurations - the seed pre-pass (dense-mode screen of the same template arguments) and the
+    # threshold kernel that precede it in the same search
+    def pick(pred):
+        best = None
+        for kern, e in ent["kernels"].items():
+            if pred(kern) and (best is None or e["bytes_per_launch"] > ent["kernels"][best]["bytes_per_launch"]):
+                best = kern
+        return best
+    main = pick(lambda k: "screen_kernel<" in k and ", false, " in k) or pick(lambda k: "screen_kernel<" in k)
+    parts = [main]
+    if main and ", false, " in main:
+        seed = main.replace(", false, ", ", true, ")
+        if seed in ent["kernels"]:
+            parts.append(seed)
+        thr = pick(lambda k: "small_threshold" in k)
+        if thr:
+            parts.append(thr)
+    total = sum(ent["kernels"][k]["bytes_per_launch"] for k in parts if k)
+    ent["knn_screen_kernels"] = [k for k in parts if k]
+    ent["knn_screen_bytes_per_launch"] = int(total)
     traffic[c] = ent
 json.dump(traffic, open("profiles/r2_pmc_traffic.json", "w"), indent=1)
 for c in cfgs:

@@ -20,5 +20,7 @@ for i, st in enumerate(steps[:-1]):
         agg.setdefault((j, n), []).append(((s - t0) / 1e3, (e - s) / 1e3))
     tot.append((steps[i + 1][0][0] - t0) / 1e3)
 for (j, n), v in agg.items():
+    if len(v) < max(2, len(steps) // 4):   # one-off launches between the steps (set-up, result checks)
+        continue
     print("%2d %-50s start %8.1f us  dur %8.1f us  (n=%d)" % (j, n, sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v), len(v)))
 print("step period %.1f us over %d steps" % (sum(tot) / len(tot), len(tot)))
