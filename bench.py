@@ -229,6 +229,11 @@ class Workload:
         self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
         self.id_base = U + lo
         self.arith = 0                  # float64 score arithmetic (ContentRecommendation flavour)
+        # Small catalogues (dense path): the prologue's two latency-floor kernels run as ONE launch that also writes the search's
+        # query fragments (hwer_prepare_search_f32 + HWER_KNN_QUERIES_READY); one search call per step only.
+        self.fused_prologue = I <= 8192 and U <= self.CH and not os.environ.get("HWER_BENCH_NO_FUSED_PROLOGUE")
+        self.fused_fragments = self.fused_prologue and not self.f16_screen
+        self.bq_frag = int(lib.hwer_knn_query_padding(U, I, d, K, self.opts)) if self.fused_fragments else 0
 
     def _alpha_rows(self, seed, lo, hi):
         torch = self.torch
@@ -285,12 +290,24 @@ class Workload:
                 self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
                 P(self.ws), P(self.missed), P(self.ws_exact), self.ws_exact.numel(), self.S()), "knn_exact_device")
 
+    def stage_prepare(self):
+        """per-type table + queries (+ the search's float32 query fragments) in ONE launch: hwer_prepare_search_f32"""
+        P, lib = self.native.ptr, self.lib
+        self.native.check(lib.hwer_prepare_search_f32(
+            P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
+            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), None, None, None, None, self.U, self.arith,
+            P(self.Q64), P(self.Q32), self.ldx, P(self.ws) if self.fused_fragments else None, self.bq_frag, self.S()), "prepare_search")
+
     def step(self, o=None):
         o = self.sets[0] if o is None else o
         self.stage_blend()
-        self.stage_pack()
-        self.stage_queries()
-        self.stage_search(o)
+        if self.fused_prologue:       # small searches: the launch-floor kernels of the prologue fused (DESIGN.md 6)
+            self.stage_prepare()
+            self.stage_search(o, opts=self.opts | (32 if self.fused_fragments else 0))
+        else:
+            self.stage_pack()
+            self.stage_queries()
+            self.stage_search(o)
         return o
 
     # ---- algorithmic work (SURVEY.md §8d) -----------------------------------------------------------------------------------
@@ -421,12 +438,15 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
               "query_mix": cuda_time(torch, w.stage_queries, stage_reps)}
     stages["knn_search"] = cuda_time(torch, lambda: w.stage_search(o), max(3, stage_reps // 2), warm=1)
     sbytes = w.stage_bytes()
+    if w.fused_prologue:   # what the step actually runs instead of pack_rows + query_mix (+ the search's repacking launch)
+        stages["prepare_search"] = cuda_time(torch, w.stage_prepare, stage_reps)
+        sbytes["prepare_search"] = sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
     f16 = w.f16_screen
     flops = 2.0 * U * I * d
     mfma_peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
     screen_step_ms, select_step_ms = screen_ms * searches_per_step, select_ms * searches_per_step
     kernels = []
-    for sname in ("blend_normalize_audit", "pack_rows", "query_mix"):
+    for sname in (("blend_normalize_audit", "prepare_search") if w.fused_prologue else ("blend_normalize_audit", "pack_rows", "query_mix")):
         ms = stages[sname]
         kernels.append({"kernel": sname, "ms_per_step": ms, "share": ms / ms_per_step, "bound": "hbm", "achieved": sbytes[sname] / ms / 1e6,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sbytes[sname] / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": sbytes[sname]})

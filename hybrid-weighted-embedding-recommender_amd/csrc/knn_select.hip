@@ -1545,6 +1545,11 @@ size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, u
     return ws_layout(make_screen_plan(B, n_items, ldx, k, options), B).total;
 }
 size_t hwer_knn_workspace_bytes(int64_t B, int64_t n_items, int d, int k) { return hwer_knn_workspace_bytes_opts(B, n_items, d, k, 0); }
+int64_t hwer_knn_query_padding(int64_t B, int64_t n_items, int d, int k, uint32_t options) {
+    const int ldx = hwer_knn_padded_dim(d);
+    if (ldx < 0 || B < 1 || n_items < 1 || k < 1 || k > K_MAX) return 0;
+    return make_screen_plan(B, n_items, ldx, k, options).bq;
+}
 
 int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                         const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k, int score_mode,
@@ -1631,8 +1636,8 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     ScreenF16 f16{X16, qf, reinterpret_cast<const int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), x16_exp};
     if (f16_screen) {
         if ((rc = repack_queries16(Q32, B, plan.bq, int(ldx), qf, reinterpret_cast<int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), st))) return rc;
-    } else if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) {
-        return rc;
+    } else if (!(options & HWER_KNN_QUERIES_READY)) {   // (else: hwer_prepare_search_f32 wrote the fragments already)
+        if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) return rc;
     }
     {
         ProfScope ps(0, st);

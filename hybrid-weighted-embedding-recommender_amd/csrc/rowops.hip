@@ -419,14 +419,31 @@ __global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restri
 // K11 pass 1: row norms;  pack_rows: gather rows of one node type into the padded table + half norms
 typedef _Float16 half4_rt __attribute__((ext_vector_type(4)));
 // NC / U as in blend_normalize_kernel: rows of up to 256 columns keep one chunk per lane and four rows in flight per row group
+struct RowNormArgs {
+    const float* V;
+    int64_t ldv;
+    int d, d4;
+    const int64_t* row_ids;
+    int64_t n_rows;
+    float* X;
+    int64_t ldx;
+    int x4;
+    float* out_norm;
+    half4_rt* X16;
+    int x_exp;
+};
 template <bool PACK, int NC, int U>
-__global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__ V, int64_t ldv, int d, int d4,
-                                                       const int64_t* __restrict__ row_ids, int64_t n_rows,
-                                                       float* __restrict__ X, int64_t ldx, int x4,
-                                                       float* __restrict__ out_norm, half4_rt* __restrict__ X16 = nullptr, int x_exp = 0) {
+__device__ __forceinline__ void row_norm_body(const RowNormArgs& a, int64_t blk, int64_t nblk) {
+    const float* __restrict__ V = a.V;
+    const int64_t ldv = a.ldv, n_rows = a.n_rows, ldx = a.ldx;
+    const int d = a.d, d4 = a.d4, x4 = a.x4, x_exp = a.x_exp;
+    const int64_t* __restrict__ row_ids = a.row_ids;
+    float* __restrict__ X = a.X;
+    float* __restrict__ out_norm = a.out_norm;
+    half4_rt* __restrict__ X16 = a.X16;
     const RowGroup g(PACK ? x4 : d4);
-    const int64_t group_global = (int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
-    const int64_t group_stride = int64_t(gridDim.x) * 4 * g.groups_per_wave;
+    const int64_t group_global = (blk * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
+    const int64_t group_stride = nblk * 4 * g.groups_per_wave;
     const int64_t n_out = PACK ? ((n_rows + 31) / 32) * 32 : n_rows;   // PACK: pad rows (zeros, half norm +inf)
     for (int64_t rb = group_global - g.sub; rb < n_out; rb += group_stride * U) {
         float4 v[U][NC];
@@ -484,6 +501,10 @@ __global__ __launch_bounds__(256) void row_norm_kernel(const float* __restrict__
             if (live[u] && g.c0 == 0) out_norm[r] = PACK ? 0.5f * ss : sqrtf(ss);
         }
     }
+}
+template <bool PACK, int NC, int U>
+__global__ __launch_bounds__(256) void row_norm_kernel(const RowNormArgs a) {
+    row_norm_body<PACK, NC, U>(a, blockIdx.x, gridDim.x);
 }
 
 // K11 pass 2: AUDIT_BLOCKS blocks write partials, the last block to finish (ticket) combines them in block order:
@@ -562,26 +583,57 @@ __device__ __forceinline__ void unit_mean_rows(const float* V, int64_t ldv, int 
     for (int j = k; j < d; j += 8) vec[j] = vec[j] / nrm;
 }
 
+struct QueryMixArgs {
+    const float* V;
+    int64_t ldv;
+    int d;
+    const int32_t* anchor;
+    const int64_t* pos_ptr;
+    const int32_t* pos_idx;
+    const int64_t* neg_ptr;
+    const int32_t* neg_idx;
+    int64_t B;
+    double* Q64;
+    float* Q32;
+    int64_t ldq32;
+    // optional: the float32 MFMA query fragments of the search that follows (knn_internal.h: repack_queries layout), rows [0, bq):
+    //   Qf[((b / 32) * (ldq32 / 8) + j / 8) * 64 + (b % 32) + 32 * ((j % 8) / 4)][j % 4] = q_b[j], zero for b >= B and j >= d
+    float* Qf;
+    int64_t bq;
+};
 template <typename T>
-__global__ __launch_bounds__(256) void query_mix_kernel(const float* __restrict__ V, int64_t ldv, int d,
-                                                        const int32_t* __restrict__ anchor,
-                                                        const int64_t* __restrict__ pos_ptr,
-                                                        const int32_t* __restrict__ pos_idx,
-                                                        const int64_t* __restrict__ neg_ptr,
-                                                        const int32_t* __restrict__ neg_idx, int64_t B,
-                                                        double* __restrict__ Q64, float* __restrict__ Q32,
-                                                        int64_t ldq32) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb) {
+    const float* __restrict__ V = a.V;
+    const int64_t ldv = a.ldv, B = a.B, ldq32 = a.ldq32;
+    const int d = a.d;
+    const int32_t* __restrict__ anchor = a.anchor;
+    const int64_t* __restrict__ pos_ptr = a.pos_ptr;
+    const int32_t* __restrict__ pos_idx = a.pos_idx;
+    const int64_t* __restrict__ neg_ptr = a.neg_ptr;
+    const int32_t* __restrict__ neg_idx = a.neg_idx;
+    double* __restrict__ Q64 = a.Q64;
+    float* __restrict__ Q32 = a.Q32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= wpb) return;          // fused launches run 256-thread blocks whatever wpb is
     const int g8 = lane >> 3, k = lane & 7;
     T* base = reinterpret_cast<T*>(smem_raw) + size_t(wave * 8 + g8) * 3 * d;
     T* vec = base;
     T* sq = base + d;
     T* q = base + 2 * d;
-    const int wpb = blockDim.x >> 6;  // waves per block (1 when the LDS slab of 4 waves would not fit)
-    const int64_t q0 = (int64_t(blockIdx.x) * wpb + wave) * 8;
-    const int64_t qstride = int64_t(gridDim.x) * wpb * 8;
-    for (int64_t qb = q0; qb < B; qb += qstride) {  // qb wave-uniform
+    const int64_t q0 = (blk * wpb + wave) * 8;
+    const int64_t qstride = nblk * wpb * 8;
+    const int ngq = int(ldq32 / 8);
+    auto frag_at = [&](int64_t b, int j) -> float& {
+        return a.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)];
+    };
+    const int64_t n_rows_all = a.Qf ? (a.bq > B ? a.bq : B) : B;
+    for (int64_t qb = q0; qb < n_rows_all; qb += qstride) {  // qb wave-uniform
+        if (qb >= B) {   // wave-uniform: only fragment padding rows are left in this group of 8
+            const int64_t b = qb + g8;
+            if (b < a.bq)
+                for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+            continue;
+        }
         const int64_t b = qb + g8;
         const bool live = b < B;
         // every lane of the wave runs the same control flow; dead groups compute on anchor 0 and skip the store
@@ -608,11 +660,31 @@ __global__ __launch_bounds__(256) void query_mix_kernel(const float* __restrict_
                 const T v = q[j] / T(double(cnt));
                 Q64[b * d + j] = double(v);
                 Q32[b * ldq32 + j] = float(v);
+                if (a.Qf) frag_at(b, j) = float(v);
             }
-            for (int j = d + k; j < ldq32; j += 8) Q32[b * ldq32 + j] = 0.f;
+            for (int j = d + k; j < ldq32; j += 8) {
+                Q32[b * ldq32 + j] = 0.f;
+                if (a.Qf) frag_at(b, j) = 0.f;
+            }
+        } else if (a.Qf && b < a.bq) {
+            for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
         }
         wave_lds_sync();
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void query_mix_kernel(const QueryMixArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    query_mix_body<T>(a, smem_raw, blockIdx.x, gridDim.x, int(blockDim.x >> 6));
+}
+
+// Fused search prologue: the first `n_pack_blocks` workgroups build the per-type table (row_norm_body<PACK>), the others the
+// queries (query_mix_body) - two latency-floor kernels of a small search in ONE launch, plus the search's query fragments.
+template <typename T, int NC, int U>
+__global__ __launch_bounds__(256) void prepare_search_kernel(const RowNormArgs pa, const QueryMixArgs qa, int n_pack_blocks, int wpb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (int(blockIdx.x) < n_pack_blocks) row_norm_body<true, NC, U>(pa, blockIdx.x, n_pack_blocks);
+    else query_mix_body<T>(qa, smem_raw, int64_t(blockIdx.x) - n_pack_blocks, int64_t(gridDim.x) - n_pack_blocks, wpb);
 }
 
 }  // namespace hwer
@@ -800,12 +872,11 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
     if ((rc = check_table("unit_audit", V, ldv, d))) return rc;
     if (!row_norm_ws || !out_counts || !out_absdev_sum) return fail(HWER_EINVAL, "unit_audit: null output");
     const int d4 = (d + 3) / 4;
+    const RowNormArgs ra{V, ldv, d, d4, nullptr, N, nullptr, 0, 0, row_norm_ws, nullptr, 0};
     if (d4 <= 64)
-        hipLaunchKernelGGL((row_norm_kernel<false, 1, 4>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
-                           (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws, (half4_rt*)nullptr, 0);
+        hipLaunchKernelGGL((row_norm_kernel<false, 1, 4>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), ra);
     else
-        hipLaunchKernelGGL((row_norm_kernel<false, MAXC, 1>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), V, ldv, d, d4,
-                           (const int64_t*)nullptr, N, (float*)nullptr, int64_t(0), 0, row_norm_ws, (half4_rt*)nullptr, 0);
+        hipLaunchKernelGGL((row_norm_kernel<false, MAXC, 1>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), ra);
     if ((rc = check_launch("unit_audit(norms)"))) return rc;
     // partials + ticket live behind the N row norms (callers size row_norm_ws with hwer_unit_audit_ws_floats(N))
     double* partial = reinterpret_cast<double*>(row_norm_ws + ((N + 3) / 4) * 4);
@@ -844,12 +915,11 @@ int hwer_pack_rows_f32_f16(const float* V, int64_t N, int d, int64_t ldv, const 
     const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
     if (x4 > 64 * MAXC) return fail(HWER_EINVAL, "pack_rows: ldx too large");
     if (X16 && ((reinterpret_cast<uintptr_t>(X16) & 7) != 0 || ldx % 4 != 0)) return fail(HWER_EINVAL, "pack_rows: X16 must be 8-byte aligned");
+    const RowNormArgs ra{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
     if (x4 <= 64)
-        hipLaunchKernelGGL((row_norm_kernel<true, 1, 4>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), V, ldv, d,
-                           d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp);
+        hipLaunchKernelGGL((row_norm_kernel<true, 1, 4>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), ra);
     else
-        hipLaunchKernelGGL((row_norm_kernel<true, MAXC, 1>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), V, ldv, d,
-                           d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp);
+        hipLaunchKernelGGL((row_norm_kernel<true, MAXC, 1>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), ra);
     return check_launch("pack_rows");
 }
 
@@ -864,14 +934,48 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
     const size_t per_wave = size_t(8) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));
     const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
     const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, 8 * wpb), kMaxStreamBlocks * 4)));
-    if (arith == 0) {
-        hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), V,
-                           ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32);
-    } else {
-        hipLaunchKernelGGL(query_mix_kernel<float>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), V,
-                           ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32);
-    }
+    const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0};
+    if (arith == 0) hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
+    else hipLaunchKernelGGL(query_mix_kernel<float>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     return check_launch("query_mix");
+}
+
+int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids, int64_t n_rows, float* X, int64_t ldx,
+                            float* hnorm, void* X16, int x_exp, const int32_t* anchor, const int64_t* pos_ptr, const int32_t* pos_idx,
+                            const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, int arith, double* Q64, float* Q32, int64_t ldq32,
+                            void* knn_workspace, int64_t bq, void* stream) {
+    if (n_rows == 0 || B == 0) {   // nothing to fuse: the two stages on their own
+        int rc = hwer_pack_rows_f32_f16(V, N, d, ldv, row_ids, n_rows, X, ldx, hnorm, X16, x_exp, stream);
+        if (rc) return rc;
+        return hwer_query_mix(V, N, d, ldv, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, arith, Q64, Q32, ldq32, stream);
+    }
+    int rc;
+    if ((rc = check_table("prepare_search(V)", V, ldv, d))) return rc;
+    if ((rc = check_table("prepare_search(X)", X, ldx, d))) return rc;
+    if (!hnorm || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "prepare_search: null pointer");
+    if (!row_ids && n_rows > N) return fail(HWER_EINVAL, "prepare_search: n_rows > N without row_ids");
+    if (N < 1 || ldq32 < d || ldq32 % 8 != 0) return fail(HWER_EINVAL, "prepare_search: ldq32 must be a multiple of 8 and >= d");
+    if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "prepare_search: ptr without idx");
+    if (arith != 0 && arith != 1) return fail(HWER_EINVAL, "prepare_search: arith must be 0 (float64) or 1 (float32)");
+    if (X16 && (reinterpret_cast<uintptr_t>(X16) & 7) != 0) return fail(HWER_EINVAL, "prepare_search: X16 must be 8-byte aligned");
+    if (knn_workspace && ((reinterpret_cast<uintptr_t>(knn_workspace) & 255) != 0 || bq < B || bq % 32 != 0))
+        return fail(HWER_EINVAL, "prepare_search: workspace must be 256-byte aligned and bq = hwer_knn_query_padding(...) >= B");
+    const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
+    if (x4 > 64) return fail(HWER_EINVAL, "prepare_search: d <= 256 only");
+    const size_t per_wave = size_t(8) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));
+    const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+    const int64_t q_rows = knn_workspace ? std::max(B, bq) : B;
+    const int n_pack = rows_grid(n_rows, x4);
+    const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, 8 * wpb), kMaxStreamBlocks * 4)));
+    const RowNormArgs pa{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
+    // WS_HEADER_BYTES (4 096) into the search workspace: where hwer_knn_search_opts_f32 keeps its query fragments
+    float* qf = knn_workspace ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + 4096) : nullptr;
+    const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, qf, bq};
+    if (arith == 0)
+        hipLaunchKernelGGL((prepare_search_kernel<double, 1, 4>), dim3(n_pack + n_mix), dim3(256), per_wave * wpb, as_stream(stream), pa, qa, n_pack, wpb);
+    else
+        hipLaunchKernelGGL((prepare_search_kernel<float, 1, 4>), dim3(n_pack + n_mix), dim3(256), per_wave * wpb, as_stream(stream), pa, qa, n_pack, wpb);
+    return check_launch("prepare_search");
 }
 
 }  // extern "C"

@@ -34,6 +34,9 @@ PROTOTYPES = {
     "hwer_pack_rows_f32_f16": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int, _P]),
     "hwer_query_mix": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_int64, _P]),
     "hwer_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int, c_int]),
+    "hwer_knn_query_padding": (c_int64, [c_int64, c_int64, c_int, c_int, ctypes.c_uint32]),
+    "hwer_prepare_search_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int,
+                                        _P, _P, c_int64, _P, c_int64, _P]),
     "hwer_knn_max_dim": (c_int, []),
     "hwer_knn_max_k": (c_int, []),
     "hwer_knn_search_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int,

@@ -150,6 +150,15 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
                    int arith /* 0: float64 arithmetic (reference with float64 vectors), 1: float32 */,
                    double* Q64, float* Q32, int64_t ldq32, void* stream);
 
+/* Fused search prologue for small, latency-bound searches: hwer_pack_rows_f32_f16 and hwer_query_mix in ONE launch (both read only
+ * the vector table), and - when `knn_workspace` is given - the float32 query fragments of the search that follows, written straight
+ * into that workspace: pass the same workspace to hwer_knn_search_opts_f32 with HWER_KNN_QUERIES_READY and it skips its own repacking
+ * launch.  bq = hwer_knn_query_padding(B, n_items, d, k, options) of that search.  Same arguments as the two functions; d <= 256. */
+int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids /*nullable*/, int64_t n_rows, float* X,
+                            int64_t ldx, float* hnorm, void* X16 /*nullable*/, int x_exp, const int32_t* anchor, const int64_t* pos_ptr,
+                            const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, int arith, double* Q64,
+                            float* Q32, int64_t ldq32, void* knn_workspace /*nullable*/, int64_t bq, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K5-K7  exact k-NN + re-score + sort — replaces MultiKNN.query (KDTree, hwer/recommendation_base.py:78-83)
  *        and the re-score / sort at :171-173 (variant hwer/gcn_ncf.py:377-386).
@@ -204,7 +213,11 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
 /* HWER_KNN_NO_SEED: the streaming screen starts every candidate list with an open threshold (collect, then select) instead of the
  * per-query threshold seeded from a sample pre-pass.  Same results; kept for A/B measurements and path coverage in the tests. */
 #define HWER_KNN_NO_SEED 16u
+/* HWER_KNN_QUERIES_READY: the float32 query fragments are already in the workspace (hwer_prepare_search_f32 wrote them for
+ * hwer_knn_query_padding(...) rows); honoured by the float32 dense / streaming screens, ignored (the search repacks) elsewhere. */
+#define HWER_KNN_QUERIES_READY 32u
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
+int64_t hwer_knn_query_padding(int64_t B, int64_t n_items, int d, int k, uint32_t options); /* rows of query fragments the search reads (>= B) */
 int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k,
                              int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max,

@@ -316,3 +316,61 @@ def test_two_process_exchange_rccl(hw, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs (RCCL); the same worker runs over gloo on one GPU in the test above")
     _run_workers("nccl", 2, tmp_path, (20011, 64, 97, 200))
+
+
+# ------------------------------------------------------------------------------------------------- fused search prologue
+@pytest.mark.parametrize("d,U,I,flav", [(64, 943, 1682, "f64"), (128, 300, 3706, "f32"), (66, 77, 500, "f64")])
+def test_prepare_search_fused_prologue(hw, d, U, I, flav):
+    """hwer_prepare_search_f32 = hwer_pack_rows_f32_f16 + hwer_query_mix (+ the search's query fragments) in one launch: same
+    table, half norms, float16 copy, Q64 / Q32 as the two separate calls, bit for bit; a search that is told the fragments are
+    ready (HWER_KNN_QUERIES_READY) returns exactly what the ordinary search returns."""
+    import ctypes
+    import torch
+    from hwer import native
+    from hwer.device_index import DeviceIndex
+    lib = native.lib()
+    P = native.ptr
+    V32 = np.concatenate([unit_rows_f32(21, U, d), unit_rows_f32(22, I, d)])
+    ix = make_index(V32.astype(np.float64) if flav == "f64" else V32, U, I)
+    dev, arith, k = ix.device, ix.arith, min(200, I)
+    tt = ix.tables["item"]
+    S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(3)
+    anchors = np.arange(U)
+    pos = [list(rng.integers(-1, U + I, rng.integers(0, 3))) for _ in range(U)]
+    neg = [list(rng.integers(0, U + I, rng.integers(0, 2))) for _ in range(U)]
+    Q64, Q32, a_dev = ix.build_queries(anchors, pos, neg)           # the separate path (hwer_query_mix)
+
+    def csr(lists):
+        ptr = np.zeros(U + 1, dtype=np.int64)
+        flat = []
+        for i, l in enumerate(lists):
+            flat.extend(l)
+            ptr[i + 1] = len(flat)
+        return torch.from_numpy(ptr).to(dev), torch.from_numpy(np.asarray(flat + [0], dtype=np.int32)).to(dev)
+    pp, pi = csr(pos)
+    np_, ni = csr(neg)
+    n_pad = tt.X.shape[0]
+    X2 = torch.full_like(tt.X, 7.0)
+    hn2 = torch.zeros_like(tt.hnorm)
+    x_exp = int(lib.hwer_knn_f16_scale_exp(0.5 * 1.0001 ** 2))
+    X16a = torch.zeros((n_pad, ix.ldx), dtype=torch.float16, device=dev)
+    X16b = torch.zeros_like(X16a)
+    native.check(lib.hwer_pack_rows_f16(P(tt.X), n_pad, ix.ldx, x_exp, P(X16a), S), "pack16")
+    q64b, q32b = torch.zeros_like(Q64), torch.full_like(Q32, 3.0)
+    opts = 0
+    bq = int(lib.hwer_knn_query_padding(U, I, d, k, opts))
+    assert bq >= U and bq % 32 == 0
+    ws = torch.empty(lib.hwer_knn_workspace_bytes_opts(U, I, d, k, opts), dtype=torch.uint8, device=dev)
+    native.check(lib.hwer_prepare_search_f32(P(ix.V), ix.N, d, ix.ldv, P(tt.rows_dev), I, P(X2), ix.ldx, P(hn2), P(X16b), x_exp,
+                                             P(a_dev), P(pp), P(pi), P(np_), P(ni), U, arith, P(q64b), P(q32b), ix.ldx, P(ws), bq, S), "prepare_search")
+    assert torch.equal(X2, tt.X) and torch.equal(hn2, tt.hnorm) and torch.equal(X16b, X16a)
+    assert torch.equal(q64b, Q64) and torch.equal(q32b, Q32)
+    # the ordinary search vs the search that trusts the fragments in the workspace
+    ref = ix.search_queries("item", Q64, Q32, k, a_dev)
+    out = [torch.empty_like(t) for t in ref]
+    native.check(lib.hwer_knn_search_opts_f32(P(tt.X), P(tt.hnorm), I, d, ix.ldx, P(q32b), P(q64b), P(ix.V), ix.ldv, P(a_dev), U, k, arith, 1,
+                                              P(tt.rows_dev), 0, tt.hnorm_max, P(out[0]), P(out[1]), P(out[2]), P(out[3]), P(ws), ws.numel(), 32, None, 0, S),
+                 "knn_search(queries ready)")
+    for a_, b_ in zip(out, ref):
+        assert torch.equal(a_, b_)
