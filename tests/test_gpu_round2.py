@@ -374,3 +374,43 @@ def test_prepare_search_fused_prologue(hw, d, U, I, flav):
                  "knn_search(queries ready)")
     for a_, b_ in zip(out, ref):
         assert torch.equal(a_, b_)
+
+
+# ------------------------------------------------------------------------------------------------- seeded thresholds under stress
+@pytest.mark.parametrize("B", [3, 300, 1500])
+def test_seeded_paths_on_a_catalogue_of_duplicates(hw, B):
+    """A large catalogue made of a few hundred distinct rows repeated many times: the seeded threshold of a query coincides with
+    whole groups of equal keys, lists come back short or overflow, certificates fail - every such query must still end exact
+    (on-device exhaustive pass, exact-threshold retry, host-driven exhaustive pass) with the build's tie rule (distance, then id)."""
+    d, n_distinct, N, k = 32, 300, 40000, 150
+    rng = np.random.default_rng(B)
+    base = unit_rows_f32(31, n_distinct, d)
+    items = base[rng.integers(0, n_distinct, N)]
+    users = unit_rows_f32(32, B, d)
+    V = np.concatenate([users, items]).astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all()
+    Qh = np.stack([orc.query_vector(V, u) for u in range(B)])
+    o_idx, o_score, o_d2 = c_oracle.find_closest_f64(items, Qh, V[:B], k, threads=4)
+    assert np.array_equal(idx, o_idx + B) and np.array_equal(score, o_score) and np.array_equal(dist, np.sqrt(o_d2))
+
+
+def test_seeded_streaming_cluster_sorted_catalogue(hw):
+    """Catalogue sorted by cluster (the adversarial row order for sampled thresholds): the regular-stride sample of the seed
+    pre-pass still sees every cluster, so nearly every query is certified directly; all results exact."""
+    d, N, B, k = 64, 120000, 3000, 100
+    rng = np.random.default_rng(5)
+    centres = rng.standard_normal((40, d))
+    lab = np.sort(rng.integers(0, 40, N))
+    x = 0.6 * rng.standard_normal((N, d)) + centres[lab]
+    items = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+    users = unit_rows_f32(9, B, d)
+    V = np.concatenate([users, items]).astype(np.float64)
+    ix = make_index(V, B, N)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all() and (flags == 2).sum() <= B // 100      # at most 1 % through the exhaustive pass
+    sel = np.arange(0, B, 25)
+    Qh = np.stack([orc.query_vector(V, int(u)) for u in sel])
+    o_idx, o_score, o_d2 = c_oracle.find_closest_f64(items, Qh, V[sel], k, threads=4)
+    assert np.array_equal(idx[sel], o_idx + B) and np.array_equal(score[sel], o_score) and np.array_equal(dist[sel], np.sqrt(o_d2))
