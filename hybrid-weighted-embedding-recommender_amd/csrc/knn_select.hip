@@ -534,8 +534,11 @@ struct DenseSelectArgs {
 // LIST = false: dense select over the key row written by the DENSE screen (every item is a candidate).
 // LIST = true : the same selection over a candidate LIST of packed keys (knn_small.hip); items that are not in the list
 //               have keys below every list key, so the usual certificate applies (some candidate below t_k - 2 E32).
-// COOP: one query per workgroup; its four waves run the selection redundantly (identical registers, identical LDS writes) and
-// split the re-rank rounds - a launch of a few hundred queries is latency-bound on the serial chain of one wave per query.
+// COOP: one query per workgroup, for launches of so few queries that a wave per query leaves most of the chip idle and the
+// kernel's time is the serial chain of ONE wave.  The four waves split the query: every wave keeps a quarter of the key
+// slices in registers (a quarter of the compares per counting probe; counts, extrema and write offsets are combined through a
+// few LDS words and workgroup barriers - all waves run the same probes on the same totals, so their control flow is identical),
+// then they split the re-rank rounds, and wave 0 finishes (sorts, output).
 template <int MAXV, int MODE, bool LIST, bool COOP = false>   // float4 slices of the key row per lane: rows up to 256 * MAXV keys; score mode
 __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(const DenseSelectArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -550,11 +553,19 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);
     const float4* row = reinterpret_cast<const float4*>(a.keys + b * a.ld);
     const int n4 = int(a.ld / 4);
+    // COOP: wave w owns slices w, w + 4, ...: MV = MAXV / 4 per lane; s_x = the workgroup's exchange words
+    constexpr int MV = COOP ? (MAXV + 3) / 4 : MAXV;
+    __shared__ float s_mm[COOP ? 8 : 1];
+    __shared__ int s_cnt[COOP ? 8 : 1];
+    __shared__ int s_tot[COOP ? 4 : 1];
+    auto slice = [&](int mm) { return COOP ? wave + 4 * mm : mm; };
+    int probe_parity = 0;
+    (void)probe_parity;
     // The lane's slice of the key row lives in registers (rows up to 256 * MAXV keys): every load is in flight at once,
     // and the k-th key is bracketed by a float BISECTION on those registers (per-lane counting + one wave reduction per
     // step).  A byte-radix histogram in LDS is the wrong tool here: thousands of keys share their top bytes, so every
     // LDS atomic would serialise 64 lanes on one bin.
-    float kv[MAXV][4];   // slices beyond the row hold -inf (below every real key; pad items are -inf too)
+    float kv[MV][4];   // slices beyond the row hold -inf (below every real key; pad items are -inf too)
     const uint64_t* lst = nullptr;
     int n_list = 0, cnt_raw = 0;
     if constexpr (LIST) {
@@ -562,25 +573,25 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         cnt_raw = a.list_count[b];
         n_list = min(cnt_raw, a.list_cap);
 #pragma unroll
-        for (int m = 0; m < MAXV; ++m) {
+        for (int mm = 0; mm < MV; ++mm) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int j = 4 * (lane + 64 * m) + c;
-                kv[m][c] = j < n_list ? key_score(lst[j]) : -INFINITY;
+                const int j = 4 * (lane + 64 * slice(mm)) + c;
+                kv[mm][c] = (slice(mm) < MAXV && j < n_list) ? key_score(lst[j]) : -INFINITY;
             }
         }
     } else {
 #pragma unroll
-        for (int m = 0; m < MAXV; ++m) {
-            const int i = lane + 64 * m;
+        for (int mm = 0; mm < MV; ++mm) {
+            const int i = lane + 64 * slice(mm);
             float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            if (i < n4) v = row[i];
-            kv[m][0] = v.x; kv[m][1] = v.y; kv[m][2] = v.z; kv[m][3] = v.w;
+            if (slice(mm) < MAXV && i < n4) v = row[i];
+            kv[mm][0] = v.x; kv[mm][1] = v.y; kv[mm][2] = v.z; kv[mm][3] = v.w;
         }
     }
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
-    for (int m = 0; m < MAXV; ++m) {
+    for (int m = 0; m < MV; ++m) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             vmax = fmaxf(vmax, kv[m][c]);
@@ -592,13 +603,26 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
+    if constexpr (COOP) {   // extrema of the whole row: the four waves' values through LDS
+        if (lane == 0) { s_mm[wave] = vmax; s_mm[4 + wave] = vmin; }
+        __syncthreads();
+        vmax = fmaxf(fmaxf(s_mm[0], s_mm[1]), fmaxf(s_mm[2], s_mm[3]));
+        vmin = fminf(fminf(s_mm[4], s_mm[5]), fminf(s_mm[6], s_mm[7]));
+    }
     SEL_STAMP(1);
     auto count_ge = [&](float t) {
         int c = 0;   // ballot counting: one v_cmp per key, the popcount and the sum run on the scalar unit
 #pragma unroll
-        for (int m = 0; m < MAXV; ++m) {
+        for (int m = 0; m < MV; ++m) {
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) c += __builtin_popcountll(__ballot(kv[m][cc] >= t));
+        }
+        if constexpr (COOP) {   // + the other waves' counts: one barrier per probe (two alternating sets of words)
+            int* slot = s_cnt + 4 * probe_parity;
+            probe_parity ^= 1;
+            if (lane == 0) slot[wave] = c;
+            __syncthreads();
+            c = (slot[0] + slot[1]) + (slot[2] + slot[3]);
         }
         return c;
     };
@@ -621,14 +645,14 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     // re-rank set = keys >= thr (a few per lane): per-lane pass masks (2 VALU per key and class: the sign of key - thr is
     // funnel-shifted into the mask), wave scans for the write offsets, then every lane pops its set bits.  The BOUNDARY
     // candidates (thr <= key < s) go first, the sure ones after them.
-    constexpr int NW = (4 * MAXV + 31) / 32;
-    constexpr int KW = 4 * MAXV < 32 ? 4 * MAXV : 32;   // keys per mask word (MAXV = 4: one half-filled word)
+    constexpr int NW = (4 * MV + 31) / 32;
+    constexpr int KW = 4 * MV < 32 ? 4 * MV : 32;   // keys per mask word (4 slices: one half-filled word)
     constexpr uint32_t WMASK = KW == 32 ? 0xFFFFFFFFu : ((1u << KW) - 1u);
     uint32_t fail[NW], fail_s[NW];   // bit (KW - 1 - (e % KW)) of word e / KW <-> key e = 4 m + c of this lane; set = below the bound
 #pragma unroll
     for (int w = 0; w < NW; ++w) fail[w] = fail_s[w] = 0u;
 #pragma unroll
-    for (int m = 0; m < MAXV; ++m) {
+    for (int m = 0; m < MV; ++m) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int e = 4 * m + c;
@@ -652,11 +676,22 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         const int t = __shfl_up(incl, off, kWave);
         if (lane >= off) incl += t;
     }
-    const int tot = __shfl(incl, 63, kWave);
+    int tot = __shfl(incl, 63, kWave);
+    int wave_off = 0;   // COOP: boundary / sure candidates of the waves before this one (packed like `incl`)
+    if constexpr (COOP) {
+        if (lane == 0) s_tot[wave] = tot;
+        __syncthreads();
+        tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            if (w2 < wave) wave_off += s_tot[w2];
+            tot += s_tot[w2];
+        }
+    }
     int n_b = tot >> 16;
     int n_r = n_b + (tot & 0xFFFF);
     bool overflow = false;
-    int pos_b = (incl >> 16) - mine_b, pos_s = n_b + (incl & 0xFFFF) - mine_s;
+    int pos_b = (wave_off >> 16) + (incl >> 16) - mine_b, pos_s = n_b + (wave_off & 0xFFFF) + (incl & 0xFFFF) - mine_s;
     auto pop = [&](uint32_t (&pm)[NW], int& pos) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
@@ -665,7 +700,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
                     const int bit = __builtin_ctz(pm[w]);
                     pm[w] &= pm[w] - 1u;
                     const int e = KW * w + KW - 1 - bit;
-                    const uint32_t j = uint32_t(4 * (lane + 64 * (e >> 2)) + (e & 3));   // position in the row / list
+                    const uint32_t j = uint32_t(4 * (lane + 64 * slice(e >> 2)) + (e & 3));   // position in the row / list
                     if (pos < kp) cand_item[pos] = LIST ? key_item(lst[j]) : j;
                     ++pos;
                 }
@@ -679,7 +714,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         n_r = kp;
         n_b = min(n_b, kp);
     }
-    wave_lds_sync();
+    if constexpr (COOP) __syncthreads();   // every wave's candidates are in the shared list before any wave's rounds read it
+    else wave_lds_sync();
     int flag = overflow ? 0 : 1;
     if constexpr (LIST) {
         // the list must be complete (no overflow, not cut short by a threshold above the K'-th key) and reach below the
@@ -1462,9 +1498,9 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     return w;
 }
 
-// Up to this many queries a launch gives every query a whole workgroup (COOP).  Measured: one query 49.5 -> ~36 us; at 943
-// queries (c1) the redundant selection of four waves per query costs more than the split rounds save (33.5 -> 36 us).
-constexpr int64_t COOP_MAX_QUERIES = 32;
+// Up to this many queries a launch gives every query a whole workgroup (COOP): with fewer queries than ~2 waves per SIMD the
+// kernel's time is the serial chain of one wave, which the four waves of a workgroup split.
+constexpr int64_t COOP_MAX_QUERIES = 2048;
 
 static int launch_select_list(const DenseSelectArgs& da, int d, int score_mode, hipStream_t st) {
     static_assert(SMALL_LIST_CAP == 256 * 16, "the list select keeps 16 float4-equivalents of the list per lane");
