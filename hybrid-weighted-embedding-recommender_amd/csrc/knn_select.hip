@@ -284,8 +284,47 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             t_sc[ci] = sco;
         }
     }
-    if constexpr (COOP) {   // all four waves' rounds are in the shared tables; wave 0 finishes the query
+    // COOP, usual (lazy, one-round boundary, <= 256 candidates) case: the whole workgroup puts the candidates in score order - one
+    // candidate per thread, position = number of keys below its own, counted over the 256 keys in LDS (independent broadcast
+    // reads instead of the 36 dependent exchange stages of a register sort by one wave: 12.4 K -> ~4 K cycles) - and wave 0 only
+    // resolves colliding approximations and writes the rows.
+    bool presorted = false;
+    const uint64_t* s_sorted = nullptr;
+    if constexpr (COOP) {   // all four waves' rounds are in the shared tables
         __syncthreads();
+        if (lazy && n_b <= 64 && n_r <= 256 && !(a.debug_skip & 2)) {   // block-uniform
+            uint64_t* skeys = reinterpret_cast<uint64_t*>(cand + kp);     // the four staging areas (20 KB) are free now
+            uint64_t* sfinal = skeys + 256;
+            const int i = 64 * coop_wave + lane;
+            bool member = i < n_r && i >= n_b;
+            if (coop_wave == 0 && lane < n_b) {   // boundary candidates: the k - n_sure nearest are in (counting rank by distance)
+                const uint64_t dm = f64_orderable(t_d2[lane]);
+                const uint32_t im = cand[lane];
+                int rank = 0;
+#pragma unroll 4
+                for (int j = 0; j < n_b; ++j) {
+                    const uint64_t dj = f64_orderable(t_d2[j]);
+                    const uint32_t ij = cand[j];
+                    rank += (dj < dm || (dj == dm && ij < im)) ? 1 : 0;
+                }
+                member = rank < a.k - (n_r - n_b);
+            }
+            // unique keys: members by (approximate score, slot), everything else behind them by slot
+            const uint64_t mykey = (uint64_t(member ? ~f32_orderable(float(t_sc[min(i, kp - 1)])) : 0xFFFFFFFFu) << 32) | uint64_t(uint32_t(i));
+            skeys[i] = mykey;
+            __syncthreads();
+            int pos = 0;
+#pragma unroll 8
+            for (int j = 0; j < 256; j += 2) {
+                const uint4 two = *reinterpret_cast<const uint4*>(skeys + j);   // broadcast read of two keys
+                const uint64_t k0 = (uint64_t(two.y) << 32) | two.x, k1 = (uint64_t(two.w) << 32) | two.z;
+                pos += (k0 < mykey ? 1 : 0) + (k1 < mykey ? 1 : 0);
+            }
+            sfinal[pos] = mykey;
+            __syncthreads();
+            presorted = true;
+            s_sorted = sfinal;
+        }
         if (coop_wave != 0) return;
     } else {
         wave_lds_sync();
@@ -318,7 +357,20 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         // of the n_b <= 64 boundary candidates (slots 0 .. n_b - 1, one per lane) the k - n_sure nearest are in, found
         // by counting, per candidate, the boundary candidates that beat it.
         const bool rank_boundary = lazy && n_b <= 64 && !(a.debug_skip & 2);
-        if (rank_boundary) {
+        if (presorted) {   // (NE == 4) the workgroup's counting sort left sorted position p in s_sorted[p]
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const uint64_t kk = s_sorted[(NE * lane + j) & 255];
+                key[j] = (kk >> 32) == 0xFFFFFFFFull ? ~0ull : kk;   // non-members: the padding pattern of the register path
+            }
+            wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
+                const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
+                const uint64_t ax = ~f64_orderable(t_sc[sx]), ay = ~f64_orderable(t_sc[sy]);
+                if (ax != ay) return ax < ay;
+                const uint64_t dx = f64_orderable(ensure_d2(sx)), dy = f64_orderable(ensure_d2(sy));
+                return dx < dy || (dx == dy && cand[sx] < cand[sy]);
+            });
+        } else if (rank_boundary) {
             const int n_keep = k - (n_r - n_b);
             const bool mine = lane < n_b;
             const uint64_t dm = mine ? f64_orderable(t_d2[lane]) : ~0ull;
@@ -404,7 +456,8 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             }
         }
     };
-    if (n_r <= 128) tail(std::integral_constant<int, 2>{});
+    if (presorted) tail(std::integral_constant<int, 4>{});
+    else if (n_r <= 128) tail(std::integral_constant<int, 2>{});
     else if (n_r <= 256) tail(std::integral_constant<int, 4>{});
     else tail(std::integral_constant<int, 8>{});
     SEL_STAMP(6);
