@@ -658,10 +658,14 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         // sample size for that rank at c_min (+ 2 %), in 32-row tiles: 1 024 ... 65 536 items
         int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t(1.02 * r_min * double(n_items) / (c_min * double(p.kprime))), 32)));
         ns = std::min(ns, n_tiles);
+        // the sample keys of all queries live in the workspace: at most 2 GiB of them (131 072 queries: a 4 096-item sample)
+        ns = std::min<int64_t>(ns, std::max<int64_t>(32, (int64_t(1) << 29) / (p.bq * 32)));
         const double S = double(ns) * 32.0;
         const double c = std::max(c_min, r_min * double(n_items) / (double(p.kprime) * S));
         const double frac = c * double(p.kprime) / double(n_items);
-        if (frac <= 0.25) {   // (a catalogue of a few K' rows forced onto this path: nothing to gain)
+        // (not worth it: a catalogue of a few K' rows forced onto this path, or a sample capped so hard that tau0 would let
+        // more than 64 K' keys per query through)
+        if (frac <= 0.25 && c <= 64.0) {
             p.seed = 1;
             p.seed_tiles = int(ns);
             p.seed_stride = int(n_tiles / ns);
