@@ -4,6 +4,7 @@
 #include <algorithm>
 
 #include "hwer_common.h"
+#include "knn_internal.h"   // WS_HEADER_BYTES: where a search workspace keeps its query fragments (hwer_prepare_search_f32)
 
 namespace hwer {
 
@@ -968,8 +969,8 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
     const int n_pack = rows_grid(n_rows, x4);
     const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, 8 * wpb), kMaxStreamBlocks * 4)));
     const RowNormArgs pa{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
-    // WS_HEADER_BYTES (4 096) into the search workspace: where hwer_knn_search_opts_f32 keeps its query fragments
-    float* qf = knn_workspace ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + 4096) : nullptr;
+    // right behind the workspace header: where hwer_knn_search_opts_f32 keeps its query fragments (ws_layout: w.qf)
+    float* qf = knn_workspace ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
     const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, qf, bq};
     if (arith == 0)
         hipLaunchKernelGGL((prepare_search_kernel<double, 1, 4>), dim3(n_pack + n_mix), dim3(256), per_wave * wpb, as_stream(stream), pa, qa, n_pack, wpb);
