@@ -18,9 +18,9 @@ void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 int check_launch(const char* what);
 
-// Tuning / ablation switches read from the environment exist only in diagnostic builds (HIPCC_EXTRA=-DHWER_DIAG_STAMPS):
+// Tuning / ablation switches read from the environment exist only in diagnostic builds (HIPCC_EXTRA=-DHWER_DIAG_STAMPS or -DHWER_DIAG_ABLATE):
 // the production library never calls getenv() on the search path, and no stray variable can change its results.
-#ifdef HWER_DIAG_STAMPS
+#if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
 static inline const char* diag_env(const char* name) { return getenv(name); }
 #else
 static inline const char* diag_env(const char*) { return nullptr; }

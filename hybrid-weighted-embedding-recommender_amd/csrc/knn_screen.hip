@@ -26,6 +26,7 @@ namespace hwer {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));      // operand pair of v_pk_mul_f32 / v_pk_add_f32
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_32x32x16_f16
 
 struct ScreenArgs {
@@ -142,6 +143,13 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define DIAG_STAMPS false
 #endif
 #define STAMP(var) if (DIAG_STAMPS) { var = stamp(); }
+// A/B switches of diagnostic builds (-DHWER_DIAG_STAMPS or -DHWER_DIAG_ABLATE; HWER_SCREEN_NOFILTER=<bit mask>: 1 no appends,
+// 256 no XCD-aware workgroup order)
+#if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
+#define ABLATE(bit) ((a.debug_nofilter & (bit)) != 0)
+#else
+#define ABLATE(bit) false
+#endif
 
 // F16: the item tiles come from the float16 copy of the table and the tile product runs on v_mfma_f32_32x32x16_f16 (float32
 // accumulation, a quarter of the MFMA cycles): keys are computed in per-query scaled units (thresholds too) and unscaled
@@ -171,7 +179,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     if (blockIdx.x == 0) hdr_reset(a.hdr, tid, 256);   // empty uncertified list, idle tickets
     const int wq = a.wq, wi_n = 4 / wq;
     const int wqi = wave % wq, wii = wave / wq;
-    const int qblock = blockIdx.x % a.n_qblocks, split = blockIdx.x / a.n_qblocks;
+    // Workgroups go to the 8 XCDs round-robin (workgroup i -> XCD i % 8), each with its own L2.  The logical id below hands
+    // every XCD one contiguous eighth of the (split, query block) grid, so the query blocks that stream the SAME item split run on
+    // the same XCD and share its L2: the catalogue is then pulled from HBM / Infinity Cache once, not once per XCD.
+    const unsigned n_wg = gridDim.x;
+    const unsigned wg = ((n_wg & 7u) == 0u && !ABLATE(256)) ? (blockIdx.x & 7u) * (n_wg >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int qblock = int(wg % unsigned(a.n_qblocks)), split = int(wg / unsigned(a.n_qblocks));
     const int list = split * wi_n + wii;
     const int64_t qw0 = int64_t(qblock) * (wq * 32 * TQ) + int64_t(wqi) * 32 * TQ;  // wave's first query
     float* keypark = keypark_all + wave * (64 * 16 * TQ);
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     constexpr int NQF = F16 ? NG / 2 : NG;
     QF qf[TQ][NQF];
     int e_tot[TQ];       // F16: key scale of this lane's query (2^e_tot)
+    float2_t nscale[TQ]; // F16: (-2^e_tot, -2^e_tot)
     float tau[TQ];
     int cnt[TQ];
     bool first[TQ], scaled[TQ], seeded[TQ];
@@ -194,9 +208,10 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         const int64_t q = qw0 + 32 * b + r;
         const bool live = q < a.B;
         e_tot[b] = F16 ? a.x_exp + a.qexp[q] : 0;                        // qexp has bq entries
+        nscale[b] = float2_t{-ldexpf(1.0f, e_tot[b]), -ldexpf(1.0f, e_tot[b])};
         const float t0 = (a.tau0 && live) ? a.tau0[q] : a.debug_tau0;    // seeded threshold of this query (real units), or open
         seeded[b] = a.tau0 != nullptr && live && t0 > -INFINITY;
-        tau[b] = (live && !a.debug_nofilter) ? (F16 ? ldexpf(t0, e_tot[b]) : t0) : INFINITY;  // strict '>' filter: dead queries never append
+        tau[b] = (live && !(a.debug_nofilter & 1)) ? (F16 ? ldexpf(t0, e_tot[b]) : t0) : INFINITY;  // strict '>' filter: dead queries never append
         cnt[b] = 0;
         lo[b] = 0;
         first[b] = true;
@@ -318,11 +333,12 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
-                    if constexpr (F16) {   // scaled units: exact (powers of two)
-                        acc[b][4 * rg + 0] = -ldexpf(hv.x, e_tot[b]);
-                        acc[b][4 * rg + 1] = -ldexpf(hv.y, e_tot[b]);
-                        acc[b][4 * rg + 2] = -ldexpf(hv.z, e_tot[b]);
-                        acc[b][4 * rg + 3] = -ldexpf(hv.w, e_tot[b]);
+                    if constexpr (F16) {   // scaled units: exact (powers of two); two keys per v_pk_mul_f32
+                        const float2_t lo = float2_t{hv.x, hv.y} * nscale[b], hi = float2_t{hv.z, hv.w} * nscale[b];
+                        acc[b][4 * rg + 0] = lo.x;
+                        acc[b][4 * rg + 1] = lo.y;
+                        acc[b][4 * rg + 2] = hi.x;
+                        acc[b][4 * rg + 3] = hi.y;
                     } else {
                     acc[b][4 * rg + 0] = -hv.x;
                     acc[b][4 * rg + 1] = -hv.y;
@@ -415,9 +431,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             uint32_t mask = 0;
 #pragma unroll
             for (int b = TQ - 1; b >= 0; --b) {
+                const float2_t tau2 = {tau[b], tau[b]};
 #pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(tau[b] - acc[b][q]), 31);
+                for (int q = 0; q < 16; q += 2) {   // (two differences per v_pk_add_f32)
+                    const float2_t df = tau2 - float2_t{acc[b][q], acc[b][q + 1]};
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.x), 31);
+                    mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.y), 31);
+                }
             }
             if (__any(mask != 0u)) {
                 const uint32_t item0 = uint32_t(i0) + 4 * h;

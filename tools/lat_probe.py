@@ -20,7 +20,7 @@ def main():
     from hwer import native
     lib = native.lib()
     dev = torch.device("cuda", 0)
-    w = bench.Workload(torch, lib, bench.CONFIGS["c4"], dev)
+    w = bench.Workload(torch, lib, bench.CONFIGS[os.environ.get("HWER_PROBE_CFG", "c4")], dev)
     w.step()
     o = w.sets[0]
     ob = dict(idx=o["idx"][:B], score=o["score"][:B], dist2=None, flags=o["flags"][:B])
