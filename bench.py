@@ -206,7 +206,8 @@ class Workload:
         self.I_pad = I_pad
         self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
         self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
-        self.f16_screen = ((not f32_screen) and I > 8192) or (f16_dense and I <= 8192)
+        # float16 screen wherever it pays (hwer_knn_f16_screen_pays: every streamed catalogue, dense ones from ~1e9 multiply-adds)
+        self.f16_screen = ((not f32_screen) and bool(lib.hwer_knn_f16_screen_pays(min(U, 131072), I, d))) or (f16_dense and I <= 8192)
         self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
         self.Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
         self.Q32 = torch.empty((U, self.ldx), dtype=torch.float32, device=dev)
@@ -222,6 +223,7 @@ class Workload:
                        lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(U, 64), I, d, K, 0))
         assert ws_bytes > 0
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        self.native.check(lib.hwer_knn_workspace_init(self.native.ptr(self.ws), self.ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "knn_workspace_init")   # once per allocation
         self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
         self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
         # rows passed the 1e-4 unit-norm audit (checked after the timed region) => 0.5||x||^2 <= 0.5 (1 + 1e-4)^2
@@ -233,6 +235,8 @@ class Workload:
         # query fragments (hwer_prepare_search_f32 + HWER_KNN_QUERIES_READY); one search call per step only.
         self.fused_prologue = I <= 8192 and U <= self.CH and not os.environ.get("HWER_BENCH_NO_FUSED_PROLOGUE")
         self.fused_fragments = self.fused_prologue and not self.f16_screen
+        # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel)
+        self.fused_blend = self.fused_prologue and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")
         self.bq_frag = int(lib.hwer_knn_query_padding(U, I, d, K, self.opts)) if self.fused_fragments else 0
 
     def _alpha_rows(self, seed, lo, hi):
@@ -298,13 +302,26 @@ class Workload:
             P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), None, None, None, None, self.U, self.arith,
             P(self.Q64), P(self.Q32), self.ldx, P(self.ws) if self.fused_fragments else None, self.bq_frag, self.S()), "prepare_search")
 
+    def stage_blend_prepare(self):
+        """blend + audit + per-type table + queries (+ query fragments) in ONE launch: hwer_blend_prepare_search_f32"""
+        P, lib, c = self.native.ptr, self.lib, self.cfg
+        self.native.check(lib.hwer_blend_prepare_search_f32(
+            P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if c["per_row"] else 0, self.T, self.d, P(self.V), self.ldv, 1e-4,
+            P(self.audit_counts), P(self.audit_dev), None, self.U, self.I, None, 0, self.U, P(self.X), self.ldx, P(self.hnorm),
+            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), self.U, self.arith, P(self.Q64), P(self.Q32), self.ldx,
+            P(self.ws), self.bq_frag, self.S()), "blend_prepare_search")
+
     def step(self, o=None):
         o = self.sets[0] if o is None else o
-        self.stage_blend()
-        if self.fused_prologue:       # small searches: the launch-floor kernels of the prologue fused
+        if self.fused_blend:          # small searches: the whole prologue is one launch (DESIGN.md 6)
+            self.stage_blend_prepare()
+            self.stage_search(o, opts=self.opts | (32 if self.fused_fragments else 0))
+        elif self.fused_prologue:     # (HWER_BENCH_NO_FUSED_BLEND: blend, then the fused table + queries launch)
+            self.stage_blend()
             self.stage_prepare()
             self.stage_search(o, opts=self.opts | (32 if self.fused_fragments else 0))
         else:
+            self.stage_blend()
             self.stage_pack()
             self.stage_queries()
             self.stage_search(o)
@@ -441,12 +458,15 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     if w.fused_prologue:   # what the step actually runs instead of pack_rows + query_mix (+ the search's repacking launch)
         stages["prepare_search"] = cuda_time(torch, w.stage_prepare, stage_reps)
         sbytes["prepare_search"] = sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
+    if w.fused_blend:      # ... and the blend with them: the step's whole prologue
+        stages["blend_prepare_search"] = cuda_time(torch, w.stage_blend_prepare, stage_reps)
+        sbytes["blend_prepare_search"] = sbytes["blend_normalize_audit"] + sbytes["prepare_search"] - 4.0 * d * (I + U)   # V is not read back
     f16 = w.f16_screen
     flops = 2.0 * U * I * d
     mfma_peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
     screen_step_ms, select_step_ms = screen_ms * searches_per_step, select_ms * searches_per_step
     kernels = []
-    for sname in (("blend_normalize_audit", "prepare_search") if w.fused_prologue else ("blend_normalize_audit", "pack_rows", "query_mix")):
+    for sname in (("blend_prepare_search",) if w.fused_blend else (("blend_normalize_audit", "prepare_search") if w.fused_prologue else ("blend_normalize_audit", "pack_rows", "query_mix"))):
         ms = stages[sname]
         kernels.append({"kernel": sname, "ms_per_step": ms, "share": ms / ms_per_step, "bound": "hbm", "achieved": sbytes[sname] / ms / 1e6,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sbytes[sname] / ms / 1e6 / HBM_PEAK_GBS, "algorithmic_bytes": sbytes[sname]})

@@ -62,6 +62,12 @@ struct WsHeader {
     int32_t tickets[EXACT_DEVICE_MAXQ];                            // second-level arrival counters of the exhaustive pass
     int32_t group_tickets[EXACT_DEVICE_MAXQ][EXACT_DEVICE_GROUPS]; // first-level arrival counters
     int32_t uncert_list[UNCERT_LIST_MAX];
+    // unit-norm audit of hwer_blend_prepare_search_f32 (rowops.hip): block partials are added here, the last block to arrive moves
+    // the totals to the caller's outputs and leaves these fields zero again.  NOT touched by hdr_reset: zero once after the
+    // workspace is allocated (hwer_knn_workspace_init).
+    unsigned long long audit_acc[3];
+    double audit_dev;
+    unsigned int audit_ticket;
 };
 constexpr int HDR_RESET_INTS = 2 + EXACT_DEVICE_MAXQ + EXACT_DEVICE_MAXQ * EXACT_DEVICE_GROUPS;
 // called by block 0 of the first kernel of every search: empty uncertified list, idle tickets

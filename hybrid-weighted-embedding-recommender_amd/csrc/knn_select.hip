@@ -1615,6 +1615,11 @@ int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, 
 }
 
 int hwer_knn_f16_scale_exp(float hnorm_max) { return f16_scale_exp(hnorm_max); }
+int hwer_knn_f16_screen_pays(int64_t B, int64_t n_items, int d) {
+    if (B < 1 || n_items < 1 || d < 1 || hwer_knn_padded_dim(d) < 64) return 0;   // the float16 MFMA tiles start at 64 columns
+    if (n_items > DENSE_MAX_ITEMS) return 1;
+    return double(B) * double(n_items) * double(d) >= 1e9 ? 1 : 0;
+}
 
 int hwer_pack_rows_f16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, void* stream) {
     if (!X || !X16) return fail(HWER_EINVAL, "pack_rows_f16: null pointer");

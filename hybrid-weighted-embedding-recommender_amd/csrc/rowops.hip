@@ -688,6 +688,281 @@ __global__ __launch_bounds__(256) void prepare_search_kernel(const RowNormArgs p
     else query_mix_body<T>(qa, smem_raw, int64_t(blockIdx.x) - n_pack_blocks, int64_t(gridDim.x) - n_pack_blocks, wpb);
 }
 
+
+// =====================================================================================================
+// Fused step prologue (hwer_blend_prepare_search_f32): blend + unit-norm audit + per-type table + anchor queries in ONE launch.
+// Three block roles; none waits for another:
+//   PACK   : rows of the searched type - blended, written to V AND to the padded table X (+ half norms, + float16 copy);
+//   OTHER  : the remaining rows - blended, written to V;
+//   QUERY  : 8 anchors per wave - the anchor's row is blended AGAIN by the same code (bit-identical to the row a PACK / OTHER
+//            block stores in V) into LDS, then the reference's query arithmetic runs on it (anchor-only queries).
+// Row arithmetic = blend_normalize_kernel<1, U> / row_norm_body<true, 1, U> / query_mix_body: the outputs are bit-identical to
+// the three separate launches (tests/test_gpu_round2.py).
+// =====================================================================================================
+struct BlendArgs {
+    const float* const* tables;
+    int64_t ldt;
+    const int32_t* const* row_idx;
+    const float* alpha;
+    int alpha_per_row, T, d, d4;
+    float* V;
+    int64_t ldv;
+    float audit_eps;
+    WsHeader* hdr;
+    unsigned long long* audit_counts;
+    double* audit_absdev;
+    unsigned int n_audit_blocks;
+};
+struct AuditAcc {
+    unsigned long long pos = 0, neg = 0, nan = 0;
+    double dev = 0.0;
+};
+
+// o[u] <- this lane's chunk (c0) of unit(sum_t alpha_t T_t[row]) for the U rows rr[u] of the lane's row group
+template <int U>
+__device__ __forceinline__ void blend_unit_rows(const BlendArgs& a, const RowGroup& g, const int64_t (&rr)[U], const bool (&live)[U], float4 (&o)[U]) {
+    float4 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < a.T; ++t) {
+        const int32_t* ri = a.row_idx ? a.row_idx[t] : nullptr;
+        const float* tab = a.tables[t];
+        float4 v[U];
+        float al[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {   // all loads of this table first
+            al[u] = 0.f;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live[u]) {
+                al[u] = a.alpha_per_row ? a.alpha[rr[u] * a.T + t] : a.alpha[t];
+                const int64_t row = ri ? int64_t(ri[rr[u]]) : rr[u];
+                if (g.c0 < a.d4) v[u] = *reinterpret_cast<const float4*>(tab + row * a.ldt + 4 * g.c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u].x = fmaf(al[u], v[u].x, acc[u].x);
+            acc[u].y = fmaf(al[u], v[u].y, acc[u].y);
+            acc[u].z = fmaf(al[u], v[u].z, acc[u].z);
+            acc[u].w = fmaf(al[u], v[u].w, acc[u].w);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        float ss = acc[u].x * acc[u].x + acc[u].y * acc[u].y + acc[u].z * acc[u].z + acc[u].w * acc[u].w;
+        ss = group_sum(ss, g.L);      // lanes past d4 hold exact zeros: the sum is that of the pow2ceil(d4)-lane group
+        const float inv = 1.0f / sqrtf(ss);
+        o[u] = make_float4(acc[u].x * inv, acc[u].y * inv, acc[u].z * inv, acc[u].w * inv);
+    }
+}
+// store the row in V and audit its norm AS STORED
+__device__ __forceinline__ void store_audit_row(const BlendArgs& a, const RowGroup& g, int64_t r, bool live, const float4& o, AuditAcc& au) {
+    float s2 = 0.f;
+    if (live && g.c0 < a.d4) {
+        *reinterpret_cast<float4*>(a.V + r * a.ldv + 4 * g.c0) = o;
+        s2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+    }
+    s2 = group_sum(s2, g.L);
+    if (live && g.c0 == 0) {
+        const float n = sqrtf(s2);
+        au.pos += double(n) > 1.0 + double(a.audit_eps);
+        au.neg += double(n) < 1.0 - double(a.audit_eps);
+        au.nan += (n != n);
+        au.dev += fabs(double(n) - 1.0);
+    }
+}
+// block partials -> header accumulators; the last PACK / OTHER block moves the totals out and re-zeroes the accumulators
+__device__ __forceinline__ void audit_finish(const BlendArgs& a, AuditAcc au) {
+    __shared__ unsigned long long s_cnt[4][3];
+    __shared__ double s_dev[4];
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        au.pos += __shfl_xor(au.pos, off, kWave);
+        au.neg += __shfl_xor(au.neg, off, kWave);
+        au.nan += __shfl_xor(au.nan, off, kWave);
+        au.dev += __shfl_xor(au.dev, off, kWave);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[wave][0] = au.pos; s_cnt[wave][1] = au.neg; s_cnt[wave][2] = au.nan;
+        s_dev[wave] = au.dev;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        WsHeader* h = a.hdr;
+        const unsigned long long p = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+        const unsigned long long n = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+        const unsigned long long q = s_cnt[0][2] + s_cnt[1][2] + s_cnt[2][2] + s_cnt[3][2];
+        const double dv = (s_dev[0] + s_dev[1]) + (s_dev[2] + s_dev[3]);
+        if (p) atomicAdd(&h->audit_acc[0], p);
+        if (n) atomicAdd(&h->audit_acc[1], n);
+        if (q) atomicAdd(&h->audit_acc[2], q);
+        if (dv != 0.0) atomicAdd(&h->audit_dev, dv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = __hip_atomic_fetch_add(&h->audit_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == a.n_audit_blocks - 1u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            for (int c = 0; c < 3; ++c) {
+                a.audit_counts[c] = __hip_atomic_load(&h->audit_acc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&h->audit_acc[c], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            a.audit_counts[3] = 0ull;
+            a.audit_absdev[0] = __hip_atomic_load(&h->audit_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&h->audit_dev, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&h->audit_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+struct RowRange {          // rows of V: ids[i] (or row0 + i), i < n
+    const int64_t* ids;
+    int64_t row0, n;
+};
+
+template <bool PACK, int U>
+__device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRange& rg, const RowNormArgs& pk, int64_t blk, int64_t nblk, AuditAcc& au) {
+    const RowGroup g(PACK ? pk.x4 : a.d4);
+    const int64_t group_global = (blk * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
+    const int64_t group_stride = nblk * 4 * g.groups_per_wave;
+    const int64_t n_out = PACK ? ((rg.n + 31) / 32) * 32 : rg.n;   // PACK: pad rows (zeros, half norm +inf)
+    for (int64_t rb = group_global - g.sub; rb < n_out; rb += group_stride * U) {
+        int64_t pos[U], rr[U];
+        bool live[U];
+        float4 o[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            pos[u] = rb + int64_t(u) * group_stride + g.sub;
+            live[u] = pos[u] < rg.n;
+            rr[u] = live[u] ? (rg.ids ? rg.ids[pos[u]] : rg.row0 + pos[u]) : 0;
+        }
+        blend_unit_rows<U>(a, g, rr, live, o);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (rb + int64_t(u) * group_stride >= n_out) break;   // wave-uniform
+            store_audit_row(a, g, rr[u], live[u], o[u], au);
+            if constexpr (PACK) {
+                const int64_t r = pos[u];
+                const int c = g.c0;
+                float ss = 0.f;
+                if (!live[u] && r < n_out) {
+                    if (c < pk.x4) {
+                        *reinterpret_cast<float4*>(pk.X + r * pk.ldx + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (pk.X16) pk.X16[(r * pk.ldx) / 4 + c] = half4_rt{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    }
+                    if (c == 0) pk.out_norm[r] = INFINITY;
+                }
+                if (live[u]) {
+                    float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c < a.d4) {
+                        w = o[u];   // = the row as stored in V; columns >= d of the last chunk are table padding
+                        if (4 * c + 1 >= a.d) w.y = 0.f;
+                        if (4 * c + 2 >= a.d) w.z = 0.f;
+                        if (4 * c + 3 >= a.d) w.w = 0.f;
+                    }
+                    ss = w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+                    if (c < pk.x4) {
+                        *reinterpret_cast<float4*>(pk.X + r * pk.ldx + 4 * c) = w;
+                        if (pk.X16)
+                            pk.X16[(r * pk.ldx) / 4 + c] = half4_rt{(_Float16)ldexpf(w.x, pk.x_exp), (_Float16)ldexpf(w.y, pk.x_exp), (_Float16)ldexpf(w.z, pk.x_exp), (_Float16)ldexpf(w.w, pk.x_exp)};
+                    }
+                }
+                ss = group_sum(ss, g.L);
+                if (live[u] && c == 0) pk.out_norm[r] = 0.5f * ss;
+            }
+        }
+    }
+}
+
+// anchor-only queries from rows blended in place (LDS): query_mix_body with np_ = nn_ = 0
+template <typename T>
+__device__ __forceinline__ void blend_query_body(const BlendArgs& a, const QueryMixArgs& qa, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb) {
+    const int64_t B = qa.B, ldq32 = qa.ldq32;
+    const int d = qa.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave >= wpb) return;
+    const int g8 = lane >> 3, k = lane & 7;
+    // per wave: 8 x (vec, sq) of T, then 8 rows of 4 d4 floats
+    const size_t per_wave = size_t(8) * 2 * d * sizeof(T) + size_t(8) * 4 * a.d4 * sizeof(float);
+    unsigned char* wbase = smem_raw + size_t(wave) * per_wave;
+    T* vec = reinterpret_cast<T*>(wbase) + size_t(g8) * 2 * d;
+    T* sq = vec + d;
+    float* rows = reinterpret_cast<float*>(wbase + size_t(8) * 2 * d * sizeof(T));
+    const RowGroup g(a.d4);
+    const int64_t q0 = (blk * wpb + wave) * 8;
+    const int64_t qstride = nblk * wpb * 8;
+    const int ngq = int(ldq32 / 8);
+    auto frag_at = [&](int64_t b, int j) -> float& {
+        return qa.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)];
+    };
+    const int64_t n_rows_all = qa.Qf ? (qa.bq > B ? qa.bq : B) : B;
+    for (int64_t qb = q0; qb < n_rows_all; qb += qstride) {  // qb wave-uniform
+        if (qb >= B) {   // only fragment padding rows are left in this group of 8
+            const int64_t b = qb + g8;
+            if (b < qa.bq)
+                for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+            continue;
+        }
+        // the 8 anchor rows of this trip, blended exactly as the PACK / OTHER blocks blend them, into LDS
+        for (int s0 = 0; s0 < 8; s0 += g.groups_per_wave) {   // (L <= 64: at least one row per pass)
+            const int s = s0 + g.sub;
+            int64_t rr[1];
+            bool live[1];
+            float4 o[1];
+            const int64_t bq_ = qb + s;
+            const int32_t an = (s < 8 && bq_ < B) ? qa.anchor[bq_] : 0;
+            rr[0] = an < 0 ? 0 : an;                 // unknown node: row 0 (clipped below)
+            live[0] = s < 8;
+            blend_unit_rows<1>(a, g, rr, live, o);
+            if (s < 8 && g.c0 < a.d4) *reinterpret_cast<float4*>(rows + size_t(s) * 4 * a.d4 + 4 * g.c0) = o[0];
+        }
+        wave_lds_sync();
+        const int64_t b = qb + g8;
+        const bool live = b < B;
+        const bool unknown = live && qa.anchor[b] < 0;
+        const float* row = rows + size_t(g8) * 4 * a.d4;
+        // unit_mean_rows(idx == nullptr): mean of one row = the row, then unit length in T arithmetic
+        for (int j = k; j < d; j += 8) {
+            const T acc = unknown ? clip_unknown<T>(T(row[j])) : T(row[j]);
+            vec[j] = acc;
+            sq[j] = acc * acc;
+        }
+        wave_lds_sync();
+        const T nrm = sqrt(np_pairwise<T, kPairwiseDepth>(sq, d, k));
+        wave_lds_sync();
+        if (live) {
+            for (int j = k; j < d; j += 8) {
+                const T v = (vec[j] / nrm) / T(1.0);
+                qa.Q64[b * d + j] = double(v);
+                qa.Q32[b * ldq32 + j] = float(v);
+                if (qa.Qf) frag_at(b, j) = float(v);
+            }
+            for (int j = d + k; j < ldq32; j += 8) {
+                qa.Q32[b * ldq32 + j] = 0.f;
+                if (qa.Qf) frag_at(b, j) = 0.f;
+            }
+        } else if (qa.Qf && b < qa.bq) {
+            for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+        }
+        wave_lds_sync();
+    }
+}
+
+template <typename T, int U>
+__global__ __launch_bounds__(256) void blend_prepare_search_kernel(const BlendArgs ba, const RowRange pack, const RowRange other, const RowNormArgs pk,
+                                                                   const QueryMixArgs qa, int n_pack_blocks, int n_other_blocks, int wpb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int blk = int(blockIdx.x);
+    if (blk < n_pack_blocks + n_other_blocks) {
+        AuditAcc au;
+        if (blk < n_pack_blocks) blend_rows_body<true, U>(ba, pack, pk, blk, n_pack_blocks, au);
+        else blend_rows_body<false, U>(ba, other, pk, blk - n_pack_blocks, n_other_blocks, au);
+        audit_finish(ba, au);
+    } else {
+        blend_query_body<T>(ba, qa, smem_raw, int64_t(blk) - n_pack_blocks - n_other_blocks, int64_t(gridDim.x) - n_pack_blocks - n_other_blocks, wpb);
+    }
+}
+
 }  // namespace hwer
 
 using namespace hwer;
@@ -977,6 +1252,60 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
     else
         hipLaunchKernelGGL((prepare_search_kernel<float, 1, 4>), dim3(n_pack + n_mix), dim3(256), per_wave * wpb, as_stream(stream), pa, qa, n_pack, wpb);
     return check_launch("prepare_search");
+}
+
+
+int hwer_knn_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
+    if (!workspace || workspace_bytes < size_t(WS_HEADER_BYTES)) return fail(HWER_EINVAL, "knn_workspace_init: workspace too small");
+    if (hipMemsetAsync(workspace, 0, WS_HEADER_BYTES, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "knn_workspace_init: memset failed");
+    return HWER_OK;
+}
+
+int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx, const float* alpha,
+                                  int alpha_per_row, int T, int d, float* V, int64_t ldv, float eps, uint64_t* audit_counts,
+                                  double* audit_absdev_sum, const int64_t* pack_ids, int64_t pack_row0, int64_t n_rows,
+                                  const int64_t* other_ids, int64_t other_row0, int64_t n_other, float* X, int64_t ldx, float* hnorm,
+                                  void* X16, int x_exp, const int32_t* anchor, int64_t B, int arith, double* Q64, float* Q32,
+                                  int64_t ldq32, void* knn_workspace, int64_t bq, void* stream) {
+    if (!tables || !alpha || T < 1) return fail(HWER_EINVAL, "blend_prepare_search: null tables/alpha or T < 1");
+    if (!audit_counts || !audit_absdev_sum) return fail(HWER_EINVAL, "blend_prepare_search: null audit output");
+    int rc;
+    if ((rc = check_table("blend_prepare_search(V)", V, ldv, d))) return rc;
+    if ((rc = check_table("blend_prepare_search(X)", X, ldx, d))) return rc;
+    if (ld_tables % 4 != 0 || ld_tables < d) return fail(HWER_EINVAL, "blend_prepare_search: ld_tables must be a multiple of 4 and >= d");
+    if (n_rows < 1 || n_other < 0 || B < 1) return fail(HWER_EINVAL, "blend_prepare_search: need n_rows >= 1, n_other >= 0, B >= 1");
+    if (!hnorm || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "blend_prepare_search: null pointer");
+    if (ldq32 < d || ldq32 % 8 != 0) return fail(HWER_EINVAL, "blend_prepare_search: ldq32 must be a multiple of 8 and >= d");
+    if (arith != 0 && arith != 1) return fail(HWER_EINVAL, "blend_prepare_search: arith must be 0 (float64) or 1 (float32)");
+    if (X16 && (reinterpret_cast<uintptr_t>(X16) & 7) != 0) return fail(HWER_EINVAL, "blend_prepare_search: X16 must be 8-byte aligned");
+    if (!knn_workspace || (reinterpret_cast<uintptr_t>(knn_workspace) & 255) != 0)
+        return fail(HWER_EINVAL, "blend_prepare_search: needs the (256-byte aligned, hwer_knn_workspace_init-ed) search workspace");
+    if (bq != 0 && (bq < B || bq % 32 != 0)) return fail(HWER_EINVAL, "blend_prepare_search: bq must be 0 (no fragments) or hwer_knn_query_padding(...) >= B");
+    const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
+    if (x4 > 64) return fail(HWER_EINVAL, "blend_prepare_search: d <= 256 only");
+    const size_t per_wave = size_t(8) * 2 * d * (arith == 0 ? sizeof(double) : sizeof(float)) + size_t(8) * 4 * d4 * sizeof(float);
+    const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+    const int64_t q_rows = bq ? std::max(B, bq) : B;
+    // about 32 rows per PACK / OTHER block, at least ... at most the streaming grid (every such block ends with one set of atomics)
+    const int n_pack = int(std::min<int64_t>(rows_grid(n_rows, x4), std::max<int64_t>(64, cdiv64(n_rows, 32))));
+    const int n_oth = n_other ? int(std::min<int64_t>(rows_grid(n_other, d4), std::max<int64_t>(64, cdiv64(n_other, 32)))) : 0;
+    const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, 8 * wpb), kMaxStreamBlocks * 4)));
+    WsHeader* hdr = static_cast<WsHeader*>(knn_workspace);
+    const BlendArgs ba{tables, ld_tables, row_idx, alpha, alpha_per_row, T, d, d4, V, ldv, eps, hdr,
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, unsigned(n_pack + n_oth)};
+    const RowRange pack{pack_ids, pack_row0, n_rows}, other{other_ids, other_row0, n_other};
+    const RowNormArgs pk{V, ldv, d, d4, nullptr, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
+    float* qf = bq ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
+    const QueryMixArgs qa{V, ldv, d, anchor, nullptr, nullptr, nullptr, nullptr, B, Q64, Q32, ldq32, qf, bq};
+    const dim3 grid(n_pack + n_oth + n_mix);
+    if (T <= 2) {   // four rows in flight per row group (blend_normalize_kernel<1, 4>)
+        if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
+        else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
+    } else {
+        if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 1>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
+        else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 1>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
+    }
+    return check_launch("blend_prepare_search");
 }
 
 }  // extern "C"

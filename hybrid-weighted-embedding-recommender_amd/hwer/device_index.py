@@ -204,9 +204,13 @@ class DeviceIndex:
     f16_screen = bool(int(os.environ.get("HWER_F16_SCREEN", "1") or 0))
     KNN_F16_SCREEN = 2
 
-    def _x16(self, tt):
-        """float16 copy of the type's table, built on first use (half the bytes streamed by the small-batch screen)."""
-        if not self.use_f16_storage or tt.n < self.F16_MIN_ROWS:
+    def _x16(self, tt, nb=0):
+        """float16 copy of the type's table, built on first use (half the bytes streamed by the small-batch screen; the float16
+        MFMA screen of larger batches).  Small catalogues (dense path) get one when a batch of `nb` queries makes the float16
+        screen pay (hwer_knn_f16_screen_pays)."""
+        if not self.use_f16_storage:
+            return None, 0
+        if tt.n < self.F16_MIN_ROWS and not (self.f16_screen and nb and self.lib.hwer_knn_f16_screen_pays(int(nb), int(tt.n), int(self.d))):
             return None, 0
         if tt.X16 is None:
             torch = _torch()
@@ -272,7 +276,7 @@ class DeviceIndex:
             ws = self._workspace(wsb)
             a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
             # the small-batch screen always reads the float16 copy; the streaming screen only with f16_screen
-            x16, x16_exp = self._x16(tt) if (nb <= 1024 or self.f16_screen) else (None, 0)
+            x16, x16_exp = self._x16(tt, nb) if (nb <= 1024 or self.f16_screen) else (None, 0)
             opt = (self.KNN_F16_SCREEN if (self.f16_screen and x16 is not None) else 0) | path_opt
             native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),

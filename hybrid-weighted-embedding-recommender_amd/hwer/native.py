@@ -37,6 +37,12 @@ PROTOTYPES = {
     "hwer_knn_query_padding": (c_int64, [c_int64, c_int64, c_int, c_int, ctypes.c_uint32]),
     "hwer_prepare_search_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int, _P, _P, _P, _P, _P, c_int64, c_int,
                                         _P, _P, c_int64, _P, c_int64, _P]),
+    "hwer_knn_workspace_init": (c_int, [_P, c_size_t, _P]),
+    # tables, ld, row_idx, alpha, per_row, T, d, V, ldv, eps, counts, absdev, pack_ids, pack_row0, n_rows, other_ids, other_row0, n_other,
+    # X, ldx, hnorm, X16, x_exp, anchor, B, arith, Q64, Q32, ldq32, workspace, bq, stream
+    "hwer_blend_prepare_search_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int, _P, c_int64, c_float, _P, _P, _P, c_int64, c_int64,
+                                              _P, c_int64, c_int64, _P, c_int64, _P, _P, c_int, _P, c_int64, c_int, _P, _P, c_int64, _P,
+                                              c_int64, _P]),
     "hwer_knn_max_dim": (c_int, []),
     "hwer_knn_max_k": (c_int, []),
     "hwer_knn_search_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int,
@@ -45,6 +51,7 @@ PROTOTYPES = {
     "hwer_knn_search_opts_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                          c_int, _P, c_int64, c_float, _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, c_int, _P]),
     "hwer_knn_f16_scale_exp": (c_int, [c_float]),
+    "hwer_knn_f16_screen_pays": (c_int, [c_int64, c_int64, c_int]),
     "hwer_pack_rows_f16": (c_int, [_P, c_int64, c_int64, c_int, _P, _P]),
     "hwer_knn_exact_workspace_bytes": (c_size_t, [c_int64, c_int]),
     "hwer_knn_exact_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int,

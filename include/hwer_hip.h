@@ -159,6 +159,27 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
                             const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, int arith, double* Q64,
                             float* Q32, int64_t ldq32, void* knn_workspace /*nullable*/, int64_t bq, void* stream);
 
+/* The whole prologue of a blended-table search step in ONE launch: hwer_blend_normalize_audit_f32 over the rows listed below,
+ * hwer_pack_rows_f32_f16 of the `n_rows` rows of the searched type and anchor-only hwer_query_mix (no positive / negative lists)
+ * - for small, latency-bound steps (MovieLens-100K / 1M shapes: three launch-floor kernels and a memset node become one kernel).
+ * Outputs are bit-identical to the separate calls.
+ *   rows of V to blend : the searched type's rows  pack_ids[j] (or pack_row0 + j), j < n_rows   -> V, X, hnorm, X16
+ *                        and the other rows        other_ids[i] (or other_row0 + i), i < n_other -> V
+ *   queries            : q_b = unit(V[anchor[b]]) in `arith` arithmetic (anchor -1: the reference's clipped row 0); the anchor row
+ *                        is re-blended inside the kernel, so no block waits for another
+ *   knn_workspace      : REQUIRED - the search's workspace, zeroed once by hwer_knn_workspace_init after allocation (the audit totals
+ *                        are accumulated in its header and handed to audit_counts / audit_absdev_sum by the last block);
+ *                        bq = hwer_knn_query_padding(...) to also write the float32 query fragments (then search with
+ *                        HWER_KNN_QUERIES_READY), 0 to skip them.
+ * d <= 256. */
+int hwer_knn_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
+int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx /*nullable*/, const float* alpha,
+                                  int alpha_per_row, int T, int d, float* V, int64_t ldv, float eps, uint64_t* audit_counts,
+                                  double* audit_absdev_sum, const int64_t* pack_ids /*nullable*/, int64_t pack_row0, int64_t n_rows,
+                                  const int64_t* other_ids /*nullable*/, int64_t other_row0, int64_t n_other, float* X, int64_t ldx,
+                                  float* hnorm, void* X16 /*nullable*/, int x_exp, const int32_t* anchor, int64_t B, int arith,
+                                  double* Q64, float* Q32, int64_t ldq32, void* knn_workspace, int64_t bq, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * K5-K7  exact k-NN + re-score + sort — replaces MultiKNN.query (KDTree, hwer/recommendation_base.py:78-83)
  *        and the re-score / sort at :171-173 (variant hwer/gcn_ncf.py:377-386).
@@ -230,6 +251,10 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
  * the bytes streamed); the select stage widens its error bound by 2^-10 ||q|| ||x||max and the float64 re-rank still
  * reads the float32 rows, so the results are identical.  X16: n_rows_padded * ldx * 2 bytes. */
 int hwer_knn_f16_scale_exp(float hnorm_max);
+/* 1 when HWER_KNN_F16_SCREEN pays for B queries against n_items rows of width d (measured on MI355X): always on the streaming
+ * path (catalogues above 8 192 rows: 1.8-2.5x), and on the dense path once the screen is 2 B n_items d >= 2e9 flops
+ * (6 040 x 3 706 x 128: screen 66 -> 26 us, step 0.224 -> 0.196 ms; 943 x 1 682 x 64: the float16 copy costs more than it saves). */
+int hwer_knn_f16_screen_pays(int64_t B, int64_t n_items, int d);
 int hwer_pack_rows_f16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, void* stream);
 
 /* out_count[0] = number of queries with flags == 0 (device int32): one 4-byte read tells the host whether the

@@ -376,6 +376,92 @@ def test_prepare_search_fused_prologue(hw, d, U, I, flav):
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("d,U,I,T,per_row,arith,ids", [(64, 50, 700, 2, False, 0, False), (100, 33, 1000, 4, True, 1, True), (128, 257, 3000, 2, True, 0, True),
+                                                     (256, 9, 333, 3, False, 1, False), (20, 16, 200, 1, False, 0, True)])
+def test_blend_prepare_search_one_launch(hw, d, U, I, T, per_row, arith, ids):
+    """hwer_blend_prepare_search_f32 = hwer_blend_normalize_audit_f32 + hwer_pack_rows_f32_f16 + anchor-only hwer_query_mix (+ the
+    search's float32 query fragments) in ONE launch: V, audit, X, half norms, float16 copy, Q64 / Q32 and the fragment-ready search
+    result are those of the separate calls, bit for bit - twice in a row (the header's audit accumulators re-arm themselves)."""
+    import ctypes
+    import torch
+    from hwer import native
+    lib = native.lib()
+    P = native.ptr
+    dev = torch.device("cuda", 0)
+    S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    N = U + I
+    g = torch.Generator(device="cpu").manual_seed(d * 1000 + U)
+    ld = (d + 3) // 4 * 4
+    tabs = []
+    for _ in range(T):
+        t = torch.zeros((N, ld), dtype=torch.float32)
+        t[:, :d] = torch.randn((N, d), generator=g)
+        tabs.append(t.to(dev))
+    tab_ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=dev)
+    alpha = (torch.rand((N, T), generator=g) + 0.1).to(dev) if per_row else (torch.rand((T,), generator=g) + 0.1).to(dev)
+    ldv = ld
+    ldx = int(lib.hwer_knn_padded_dim(d))
+    n_pad = int(lib.hwer_knn_padded_rows(I))
+    k = min(50, I)
+    # the searched type's rows: a contiguous range behind the users, or (ids) an interleaved set given by id lists
+    if ids:
+        perm = torch.randperm(N, generator=g)
+        item_rows = torch.sort(perm[:I]).values.to(torch.int64).to(dev)
+        user_rows = torch.sort(perm[I:]).values.to(torch.int64).to(dev)
+    else:
+        user_rows = torch.arange(0, U, dtype=torch.int64, device=dev)
+        item_rows = torch.arange(U, N, dtype=torch.int64, device=dev)
+    anchors = user_rows.to(torch.int32).clone()
+    anchors[U // 2] = -1                                     # an unknown node among the anchors
+    x_exp = int(lib.hwer_knn_f16_scale_exp(0.5 * 1.0001 ** 2))
+    f16 = ldx >= 64
+
+    def outputs():
+        return dict(V=torch.full((N, ldv), 5.0, dtype=torch.float32, device=dev), audit=torch.full((6,), 9, dtype=torch.int64, device=dev),
+                    X=torch.full((n_pad, ldx), 7.0, dtype=torch.float32, device=dev), hn=torch.zeros(n_pad, dtype=torch.float32, device=dev),
+                    X16=torch.zeros((n_pad, ldx), dtype=torch.float16, device=dev) if f16 else None,
+                    Q64=torch.zeros((U, d), dtype=torch.float64, device=dev), Q32=torch.full((U, ldx), 3.0, dtype=torch.float32, device=dev))
+    a, b = outputs(), outputs()
+    # separate launches
+    native.check(lib.hwer_blend_normalize_audit_f32(P(tab_ptrs), ld, None, P(alpha), 1 if per_row else 0, T, N, d, P(a["V"]), ldv, 1e-4,
+                                                    P(a["audit"][:4]), P(a["audit"][4:5].view(torch.float64)), S), "blend")
+    native.check(lib.hwer_pack_rows_f32_f16(P(a["V"]), N, d, ldv, P(item_rows), I, P(a["X"]), ldx, P(a["hn"]), P(a["X16"]), x_exp, S), "pack")
+    native.check(lib.hwer_query_mix(P(a["V"]), N, d, ldv, P(anchors), None, None, None, None, U, arith, P(a["Q64"]), P(a["Q32"]), ldx, S), "mix")
+    # one launch (twice: the second call must find the header's accumulators re-armed)
+    bq = int(lib.hwer_knn_query_padding(U, I, d, k, 0))
+    ws = torch.empty(lib.hwer_knn_workspace_bytes_opts(U, I, d, k, 0), dtype=torch.uint8, device=dev)
+    ws.fill_(0xAB)
+    native.check(lib.hwer_knn_workspace_init(P(ws), ws.numel(), S), "ws_init")
+    for rep in range(2):
+        if rep:
+            b = outputs()
+        native.check(lib.hwer_blend_prepare_search_f32(
+            P(tab_ptrs), ld, None, P(alpha), 1 if per_row else 0, T, d, P(b["V"]), ldv, 1e-4, P(b["audit"][:4]), P(b["audit"][4:5].view(torch.float64)),
+            P(item_rows) if ids else None, U, I, P(user_rows) if ids else None, 0, U, P(b["X"]), ldx, P(b["hn"]), P(b["X16"]), x_exp,
+            P(anchors), U, arith, P(b["Q64"]), P(b["Q32"]), ldx, P(ws), bq, S), "blend_prepare_search")
+        torch.cuda.synchronize()
+        assert torch.equal(a["V"][:, :d], b["V"][:, :d])
+        assert torch.equal(a["audit"][:3], b["audit"][:3]), (a["audit"], b["audit"])
+        dev_a, dev_b = float(a["audit"][4:5].view(torch.float64)), float(b["audit"][4:5].view(torch.float64))
+        assert abs(dev_a - dev_b) <= 1e-9 * max(1.0, abs(dev_a))          # a float64 atomic sum: order-dependent in the last ulps
+        assert torch.equal(a["X"], b["X"]) and torch.equal(a["hn"], b["hn"])
+        assert (not f16) or torch.equal(a["X16"], b["X16"])
+        assert torch.equal(a["Q64"], b["Q64"]) and torch.equal(a["Q32"], b["Q32"])
+    # the search that trusts the fragments the fused launch left in the workspace = the ordinary search
+    res = []
+    for opts, q32, q64, x, hn, v in ((0, a["Q32"], a["Q64"], a["X"], a["hn"], a["V"]), (32, b["Q32"], b["Q64"], b["X"], b["hn"], b["V"])):
+        o = dict(idx=torch.empty((U, k), dtype=torch.int64, device=dev), score=torch.empty((U, k), dtype=torch.float64, device=dev),
+                 d2=torch.empty((U, k), dtype=torch.float64, device=dev), fl=torch.empty(U, dtype=torch.int32, device=dev))
+        a32 = torch.where(anchors < 0, torch.zeros_like(anchors), anchors)
+        w = ws if opts else torch.empty_like(ws)
+        native.check(lib.hwer_knn_search_opts_f32(P(x), P(hn), I, d, ldx, P(q32), P(q64), P(v), ldv, P(a32), U, k, arith, 1, P(item_rows), 0,
+                                                  0.5 * 1.0001 ** 2, P(o["idx"]), P(o["score"]), P(o["d2"]), P(o["fl"]), P(w), w.numel(), opts, None, 0, S), "search")
+        res.append(o)
+    torch.cuda.synchronize()
+    for key in ("idx", "score", "d2", "fl"):
+        assert torch.equal(res[0][key], res[1][key]), key
+
+
 # ------------------------------------------------------------------------------------------------- seeded thresholds under stress
 @pytest.mark.parametrize("B", [3, 300, 1500])
 def test_seeded_paths_on_a_catalogue_of_duplicates(hw, B):

@@ -15,8 +15,8 @@ for which in new old; do
     [ -n "$f" ] || { echo "$which $c: no stats" >> $out/summary.txt; exit 1; }
     python3 - "$f" "$which $c" "$out/$which$c.out" >> $out/summary.txt <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "hwer" in r["Name"]]
-print("%s: %s | %s" % (sys.argv[2], " | ".join("%s n=%s avg=%.1f min=%.1f" % (r["Name"].replace("void hwer::", "")[:34], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3) for r in rows[:6]), open(sys.argv[3]).read().strip()))
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "hwer" in r["Name"] and int(r["Calls"]) > 1 or "screen_kernel" in r["Name"]]
+print("%s: %s | %s" % (sys.argv[2], " | ".join("%s n=%s avg=%.1f min=%.1f" % (r["Name"].replace("void hwer::", "").replace("hwer::", "")[:30], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3) for r in rows[:7]), open(sys.argv[3]).read().strip()))
 PY
     rm -rf $out/$which$c
   done
