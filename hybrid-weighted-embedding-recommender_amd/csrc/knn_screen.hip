@@ -58,6 +58,7 @@ struct ScreenArgs {
     int x_exp;
     const float* tau0;   // streaming mode: per-query initial threshold from the seed pre-pass (NULL: open thresholds)
     int tile_stride;     // 1; the seed pre-pass visits every tile_stride-th tile of the catalogue (its items are sample-local)
+    int dense_f16;       // DENSE mode: `dense` holds float16 keys (the seed pre-pass: its keys only place a threshold - half the bytes)
 };
 
 // sc1 load: served by L2, never by a stale L1 line
@@ -408,6 +409,17 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 // instructions per wave and tile, which the counted wait at the tile boundary relies on.
                 for (int b = 0; b < TQ; ++b) {
                     const int64_t q = qw0 + 32 * b + r;
+                    if (a.dense_f16) {   // (wave-uniform) sample keys of the seed pre-pass, rounded to float16: still 4 stores per subtile
+                        half4_t* row16 = reinterpret_cast<half4_t*>(reinterpret_cast<_Float16*>(a.dense) + q * a.ld_dense + i0 + 4 * h);
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            half4_t kv;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) kv[j] = (_Float16)(F16 ? ldexpf(acc[b][4 * rg + j], -e_tot[b]) : acc[b][4 * rg + j]);
+                            row16[2 * rg] = kv;
+                        }
+                        continue;
+                    }
                     float* row = a.dense + q * a.ld_dense + i0 + 4 * h;
 #pragma unroll
                     for (int rg = 0; rg < 4; ++rg) {
@@ -763,7 +775,7 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
     sp.n_lists = 0;
     ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
                  plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
-                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride};
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, 1};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {
@@ -811,7 +823,7 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !diag_env("HWER_SCREEN_EXACT")) ? 1 : 0, diag_env("HWER_SCREEN_NOFILTER") ? atoi(diag_env("HWER_SCREEN_NOFILTER")) : 0,
                  diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
-                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1};
+                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

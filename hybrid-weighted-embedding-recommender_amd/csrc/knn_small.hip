@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void pack_rows16_kernel(const float4* __restri
 
 // ---------------------------------------------------------------------------------------------------------------------
 struct SmallSelectArgs {
-    const float* keys;
+    const float* keys;  // (seed pre-pass: float16 keys behind this pointer, KT = _Float16 in the threshold kernels)
     int64_t ld;         // multiple of 32 (pad items hold -inf)
     int64_t n_items;
     int64_t B;
@@ -424,22 +424,54 @@ struct SmallSelectArgs {
 
 // threshold of one query from a strided sample of its key row: the r-th largest sample key, r chosen so that about
 // 4.75 K' keys of the row clear it (never fewer than 16 sample keys: the row count then has a relative spread <= 25 %)
-template <int PER>   // samples per thread: 16 (16 384-key sample), 32 or 64 (65 536): a probe is PER compares + one block reduction
+// A threshold taken from float16 keys is lowered by their rounding error (2^-11 relative): it must not rise above the float32 key
+// it stands for, or the catalogue would hold fewer keys above it than the sample rank promises.
+template <typename KT>
+__device__ __forceinline__ float seed_margin(float t) {
+    if constexpr (std::is_same<KT, float>::value) return t;
+    else return t - fabsf(t) * 0x1p-10f - 1e-7f;
+}
+template <int PER, typename KT = float>   // samples per thread: 16 (16 384-key sample), 32 or 64 (65 536): a probe is PER compares + one block reduction
 __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelectArgs a) {
     constexpr int NT = 1024, NWV = NT / 64;
     __shared__ int s_cnt[NWV];
     __shared__ float s_mm[2 * NWV];
     const int64_t b = blockIdx.x;
-    const float* row = a.keys + b * a.ld;
+    const KT* row = reinterpret_cast<const KT*>(a.keys) + b * a.ld;
     const int64_t n = a.n_items;
     const int64_t S = n < int64_t(NT) * PER ? n : int64_t(NT) * PER;
     const double step = double(n) / double(S);
     const int wave = threadIdx.x >> 6;
     float v[PER];
+    if (S == n) {   // the whole row is the sample (seed pre-pass; short rows): 16-byte loads - the row is padded to 32 keys (pad keys -inf)
+        constexpr int VEC = 16 / int(sizeof(KT));
+        static_assert(PER % VEC == 0, "whole vectors per thread");
+#pragma unroll
+        for (int m = 0; m < PER / VEC; ++m) {
+            const int64_t j0 = (int64_t(threadIdx.x) + NT * m) * VEC;
+            if (j0 < a.ld) {
+                if constexpr (std::is_same<KT, float>::value) {
+                    const float4 x = *reinterpret_cast<const float4*>(row + j0);
+                    v[VEC * m + 0] = x.x; v[VEC * m + 1] = x.y; v[VEC * m + 2] = x.z; v[VEC * m + 3] = x.w;
+                } else {
+                    const half8_t x = *reinterpret_cast<const half8_t*>(row + j0);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) v[VEC * m + j] = float(x[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (j0 + j >= n) v[VEC * m + j] = -INFINITY;
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[VEC * m + j] = -INFINITY;
+            }
+        }
+    } else {
 #pragma unroll
     for (int m = 0; m < PER; ++m) {
         const int64_t j = int64_t(threadIdx.x) + NT * m;
-        v[m] = j < S ? row[min(int64_t(double(j) * step), n - 1)] : -INFINITY;
+        v[m] = j < S ? float(row[min(int64_t(double(j) * step), n - 1)]) : -INFINITY;
+    }
     }
     float vmax = -INFINITY, vmin = INFINITY;
 #pragma unroll
@@ -481,7 +513,7 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
     // (seed pre-pass: any threshold with at least `rank` sample keys above it will do - a wide stopping window saves probes)
     const float t = wave_find_rank_fn(count_ge, vmin, vmax, rank, a.want_frac > 0.0 ? rank / 2 : rank / 8, c_lo);
     if (threadIdx.x == 0) {
-        a.thr[b] = t;
+        a.thr[b] = seed_margin<KT>(t);
         a.count[b] = 0;
     }
 }
@@ -489,13 +521,13 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
 // Same threshold by ONE wave per query (no workgroup barriers) from a sample of 64 * PER keys taken as 16-key segments
 // (64 contiguous bytes each) spread evenly over the row: a strided single-key sample would touch nearly every cache line
 // of a short row.  Enough whenever the sample rank stays >= 16.  Four queries per 256-thread block.
-template <int PER>   // keys per lane: 16 (1024-key sample) or 64 (4096-key sample)
+template <int PER, typename KT = float>   // keys per lane: 16 (1024-key sample) or 64 (4096-key sample)
 __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSelectArgs a) {
     constexpr int NSEG = 64 * PER / 16;
     const int lane = threadIdx.x & 63;
     const int64_t b = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (b >= a.B) return;
-    const float* row = a.keys + b * a.ld;
+    const KT* row = reinterpret_cast<const KT*>(a.keys) + b * a.ld;
     const int64_t n = a.n_items;      // rows are padded to a multiple of 32 keys (pad keys are -inf): segments stay in the row
     const double step = n > 16 ? double(n - 16) / double(NSEG - 1) : 0.0;
     float v[PER];
@@ -503,11 +535,21 @@ __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSe
 #pragma unroll
     for (int m = 0; m < PER / 16; ++m) {
         const int seg = lane + 64 * m;
-        const int64_t p0 = (int64_t(double(seg) * step) >> 2) << 2;   // 16-byte aligned start
+        if constexpr (std::is_same<KT, float>::value) {
+            const int64_t p0 = (int64_t(double(seg) * step) >> 2) << 2;   // 16-byte aligned start
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float4 x = *reinterpret_cast<const float4*>(row + p0 + 4 * c);
-            v[16 * m + 4 * c + 0] = x.x; v[16 * m + 4 * c + 1] = x.y; v[16 * m + 4 * c + 2] = x.z; v[16 * m + 4 * c + 3] = x.w;
+            for (int c = 0; c < 4; ++c) {
+                const float4 x = *reinterpret_cast<const float4*>(row + p0 + 4 * c);
+                v[16 * m + 4 * c + 0] = x.x; v[16 * m + 4 * c + 1] = x.y; v[16 * m + 4 * c + 2] = x.z; v[16 * m + 4 * c + 3] = x.w;
+            }
+        } else {
+            const int64_t p0 = (int64_t(double(seg) * step) >> 3) << 3;   // 16-byte aligned start (8 float16 keys)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const half8_t x = *reinterpret_cast<const half8_t*>(row + p0 + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[16 * m + 8 * c + j] = float(x[j]);
+            }
         }
         n_sample += 16;
     }
@@ -519,7 +561,7 @@ __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSe
     int c_lo;
     const float t = wave_find_rank<PER>(v, rank, a.want_frac > 0.0 ? rank / 2 : rank / 8, c_lo);
     if (lane == 0) {
-        a.thr[b] = t;
+        a.thr[b] = seed_margin<KT>(t);
         a.count[b] = 0;
     }
 }
@@ -680,13 +722,15 @@ int pack_rows16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, v
 
 int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, double want_frac, float* tau0, int32_t* count_scratch,
                           hipStream_t stream) {
+    // the seed pre-pass stores its sample keys as float16 (launch_seed_screen)
+    using H = _Float16;
     SmallSelectArgs sa{keys, ld, n, B, 0, tau0, count_scratch, nullptr, want_frac};
-    if (n <= 1024) hipLaunchKernelGGL(small_threshold_wave_kernel<16>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
-    else if (n <= 2048) hipLaunchKernelGGL(small_threshold_wave_kernel<32>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
-    else if (n <= 4096) hipLaunchKernelGGL(small_threshold_wave_kernel<64>, dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
-    else if (n <= 16384) hipLaunchKernelGGL(small_threshold_kernel<16>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
-    else if (n <= 32768) hipLaunchKernelGGL(small_threshold_kernel<32>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
-    else hipLaunchKernelGGL(small_threshold_kernel<64>, dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    if (n <= 1024) hipLaunchKernelGGL((small_threshold_wave_kernel<16, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 2048) hipLaunchKernelGGL((small_threshold_wave_kernel<32, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 4096) hipLaunchKernelGGL((small_threshold_wave_kernel<64, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 16384) hipLaunchKernelGGL((small_threshold_kernel<16, H>), dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    else if (n <= 32768) hipLaunchKernelGGL((small_threshold_kernel<32, H>), dim3(unsigned(B)), dim3(1024), 0, stream, sa);
+    else hipLaunchKernelGGL((small_threshold_kernel<64, H>), dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     return check_launch("knn_seed(threshold)");
 }
 
