@@ -236,7 +236,11 @@ class Workload:
         self.fused_prologue = I <= 8192 and U <= self.CH and not os.environ.get("HWER_BENCH_NO_FUSED_PROLOGUE")
         self.fused_fragments = self.fused_prologue and not self.f16_screen
         # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel)
-        self.fused_blend = self.fused_prologue and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")
+        # (large catalogues too: the per-type table and its float16 copy are written from the blended row in registers instead of
+        # being re-read from V - one pass over the rows less.  Measured: c4full 21.6 -> 20.5 ms, c4 3.03 -> 3.00; NOT where the
+        # anchors outnumber the rows (c3: every anchor row is blended a second time for its query, 5.85 -> 6.12 ms) and not with four
+        # tables and per-row weights (c5: one row in flight per wave, 5.89 -> 7.43 ms) - those keep the separate launches.)
+        self.fused_blend = (self.fused_prologue or (self.d <= 256 and self.T <= 2 and 8 * U <= I)) and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")
         self.bq_frag = int(lib.hwer_knn_query_padding(U, I, d, K, self.opts)) if self.fused_fragments else 0
 
     def _alpha_rows(self, seed, lo, hi):
@@ -460,7 +464,8 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         sbytes["prepare_search"] = sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
     if w.fused_blend:      # ... and the blend with them: the step's whole prologue
         stages["blend_prepare_search"] = cuda_time(torch, w.stage_blend_prepare, stage_reps)
-        sbytes["blend_prepare_search"] = sbytes["blend_normalize_audit"] + sbytes["prepare_search"] - 4.0 * d * (I + U)   # V is not read back
+        sbytes["blend_prepare_search"] = (sbytes["blend_normalize_audit"] + sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
+                                          - 4.0 * d * (I + U))   # V is not read back
     f16 = w.f16_screen
     flops = 2.0 * U * I * d
     mfma_peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
