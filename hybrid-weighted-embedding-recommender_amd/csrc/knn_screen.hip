@@ -144,8 +144,16 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define DIAG_STAMPS false
 #endif
 #define STAMP(var) if (DIAG_STAMPS) { var = stamp(); }
-// A/B switches of diagnostic builds (-DHWER_DIAG_STAMPS or -DHWER_DIAG_ABLATE; HWER_SCREEN_NOFILTER=<bit mask>: 1 no appends,
-// 256 no XCD-aware workgroup order)
+#ifndef HWER_F16_MFMA_PRIO
+#define HWER_F16_MFMA_PRIO 0   // wave priority during the float16 MFMA phase ...
+#endif
+#ifndef HWER_F16_REST_PRIO
+#define HWER_F16_REST_PRIO 3   // ... and during everything else (measured: 0 / 3 beats 3 / 3 by 6 % at c4)
+#endif
+// A/B switches of diagnostic builds (-DHWER_DIAG_STAMPS or -DHWER_DIAG_ABLATE; HWER_SCREEN_NOFILTER=<bit mask>, float16 streaming
+// loop: 1 no appends, 4 no pass masks, 8 no accumulator set-up, 16 no LDS-DMA requests after the first two tiles, 32 one fragment
+// read per tile instead of NQF, 64 no tile barrier, 128 no MFMAs; any kernel: 256 no XCD-aware workgroup order).  Results are
+// wrong under 4 .. 128 - tools/ablate_screen.sh only reads the kernel durations.
 #if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
 #define ABLATE(bit) ((a.debug_nofilter & (bit)) != 0)
 #else
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
         }
     };
-    __builtin_amdgcn_s_setprio(3);
+    if constexpr (F16) __builtin_amdgcn_s_setprio(HWER_F16_REST_PRIO); else __builtin_amdgcn_s_setprio(3);
     int p_cur = 0;                       // perm(t)
     int p_dma = perm_next(0);            // perm(t + 1), then perm(t + 2) while tile t is computed
     if (n_tiles > 0) tile_dma(0, 0);
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
                     if constexpr (F16) {   // scaled units: exact (powers of two); two keys per v_pk_mul_f32
+                        if (ABLATE(8)) { acc[b][4 * rg + 0] = acc[b][4 * rg + 1] = acc[b][4 * rg + 2] = acc[b][4 * rg + 3] = 0.f; continue; }
                         const float2_t lo = float2_t{hv.x, hv.y} * nscale[b], hi = float2_t{hv.z, hv.w} * nscale[b];
                         acc[b][4 * rg + 0] = lo.x;
                         acc[b][4 * rg + 1] = lo.y;
@@ -356,12 +365,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 const unsigned char* abase = reinterpret_cast<const unsigned char*>(xb) + r * (NG * 16);
                 auto a_ptr = [&](int g) { return abase + 16 * ((2 * g + h) ^ sw); };
                 half8_t av_next = *reinterpret_cast<const half8_t*>(a_ptr(0));
-                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_s_setprio(HWER_F16_MFMA_PRIO);
                 STAMP(t1);
 #pragma unroll
                 for (int g = 0; g < NQF; ++g) {
                     const half8_t av = av_next;
-                    if (g + 1 < NQF) av_next = *reinterpret_cast<const half8_t*>(a_ptr(g + 1));
+                    if (g + 1 < NQF && !ABLATE(32)) av_next = *reinterpret_cast<const half8_t*>(a_ptr(g + 1));
+                    if (ABLATE(128)) continue;
 #pragma unroll
                     for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, qf[b][g], acc[b], 0, 0, 0);
                 }
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 }
             }
             }
-            __builtin_amdgcn_s_setprio(3);
+            if constexpr (F16) __builtin_amdgcn_s_setprio(HWER_F16_REST_PRIO); else __builtin_amdgcn_s_setprio(3);
             if (DIAG_STAMPS) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
             // Streaming mode: outstanding VMEM here = the DMA of tile t+1 (issued a whole MFMA phase ago) and the appends
             // of the previous tile (a whole tile ago): this wait is free, and it lets this tile's appends go straight to
@@ -441,6 +451,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // query subtile b.  Both subtiles share ONE park and ONE pop loop: the loop runs max-over-lanes of the lane's
             // total pops, not the sum of the per-subtile maxima.
             uint32_t mask = 0;
+            if (ABLATE(4)) asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15]));
+            else
 #pragma unroll
             for (int b = TQ - 1; b >= 0; --b) {
                 const float2_t tau2 = {tau[b], tau[b]};
@@ -490,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // waves that computed this tile waited for the DMA of tile t+1 before their appends; the others do it here
             if ((t & wi_mask) != wii) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();
+        if (!ABLATE(64)) __syncthreads();
         STAMP(t4);
         if constexpr (DENSE) {
             if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         unsigned long long t4a = 0, t4b = 0;
         STAMP(t4a);
         if (DIAG_STAMPS && getenv_calib) { t4 = stamp(); t4a = stamp(); }   // calibration: flush := cost of one stamp
-        if (t + 2 < n_tiles) tile_dma(t + 2, p_dma);      // refill the ring slot every wave has just finished reading
+        if (t + 2 < n_tiles && !ABLATE(16)) tile_dma(t + 2, p_dma);      // refill the ring slot every wave has just finished reading
         p_dma = perm_next(p_dma);
         STAMP(t4b);
         // ---- stream capacity: a lane appends at most 16 keys per tile, so checking every SECOND tile against CAPH - 32
