@@ -1553,11 +1553,15 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
 
 // Up to this many queries a launch gives every query a whole workgroup (COOP): with fewer queries than ~2 waves per SIMD the
 // kernel's time is the serial chain of one wave, which the four waves of a workgroup split.
-constexpr int64_t COOP_MAX_QUERIES = 2048;
+constexpr int64_t COOP_MAX_QUERIES_DEFAULT = 2048;
+static int64_t coop_max_queries() {   // (diagnostic builds: HWER_COOP_MAX overrides)
+    const char* e = diag_env("HWER_COOP_MAX");
+    return e ? atoll(e) : COOP_MAX_QUERIES_DEFAULT;
+}
 
 static int launch_select_list(const DenseSelectArgs& da, int d, int score_mode, hipStream_t st) {
     static_assert(SMALL_LIST_CAP == 256 * 16, "the list select keeps 16 float4-equivalents of the list per lane");
-    const bool coop = da.B <= COOP_MAX_QUERIES;
+    const bool coop = da.B <= coop_max_queries();
     const size_t lds = coop ? coop_lds_bytes(d, da.kp) : size_t(4) * wave_lds_bytes(d, da.kp);
     auto launch = [&](auto md) -> int {
         constexpr int MD = decltype(md)::value;
@@ -1758,7 +1762,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         da.key_rel_err = f16_screen ? 1.02f * 0.0009765625f : 0.f;
         da.emit = EmitArgs{X, uint32_t(n_items - 1), ldx, d, Q64, A32, lda, a_idx, score_mode, sort_by_score, diag_env("HWER_SELECT_SKIP") ? atoi(diag_env("HWER_SELECT_SKIP")) : 0, row_ids, id_base, k,
                            out_idx, out_score, out_dist2, out_flags, hdr, sel_stamps_buffer(B)};
-        const bool coop = B <= COOP_MAX_QUERIES;
+        const bool coop = B <= coop_max_queries();
         const size_t lds = coop ? coop_lds_bytes(d, plan.kprime) : size_t(4) * wave_lds_bytes(d, plan.kprime);
         static_assert(DENSE_MAX_ITEMS <= 256 * 32, "dense select keeps at most 32 float4 of the row per lane");
         auto launch_dense2 = [&](auto mv, auto md) -> int {
