@@ -646,7 +646,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     // item splits: every split re-pays the selection warm-up (~4 K' appends + a compaction per query), so split
     // only when the query blocks alone cannot fill the 512 workgroup slots (256 CUs x 2 resident), and keep
     // >= 4096 items per list (shorter lists were measured slower: more list-reduce work than the extra parallelism buys).  Callers chunk B to multiples of 512 * qb queries (DeviceIndex.QUERY_CHUNK).
-    const int64_t slots = 512;
+    int64_t slots = 512;
+    if (const char* e = diag_env("HWER_SCREEN_SLOTS")) slots = std::max(1, atoi(e));   // tuning override
     int64_t splits = std::max<int64_t>(1, slots / p.n_qblocks);
     // (seeded thresholds - decided below from the same quantities - make a list nearly free: then lists may be 4x shorter)
     const bool seedable = !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS)) && n_items > DENSE_MAX_ITEMS;
