@@ -26,6 +26,18 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     assert lib.hwer_knn_workspace_bytes(6040, 3706, 128, 200) > 0      # dense plan
     assert lib.hwer_knn_workspace_bytes(4096, 1_250_000, 128, 200) > 0  # streaming plan with item splits
     assert lib.hwer_knn_workspace_bytes(10, 100, 128, 100000) == 0      # k beyond the supported maximum
+    # host-side plan helpers (no GPU call)
+    assert lib.hwer_knn_f16_screen_pays(6040, 3706, 128) == 1           # dense catalogue, ~3e9 multiply-adds: float16 screen
+    assert lib.hwer_knn_f16_screen_pays(943, 1682, 64) == 0             # too small: the float16 copy costs more than it saves
+    assert lib.hwer_knn_f16_screen_pays(1, 1_250_000, 128) == 1         # every streamed catalogue
+    assert lib.hwer_knn_f16_screen_pays(100000, 100000, 16) == 0        # float16 MFMA tiles start at a padded dim of 64
+    bq = lib.hwer_knn_query_padding(943, 1682, 64, 200, 0)
+    assert bq >= 943 and bq % 32 == 0
+    # argument checks of the one-launch prologue come before any GPU call
+    assert lib.hwer_blend_prepare_search_f32(None, 64, None, None, 0, 2, 64, None, 64, 1e-4, None, None, None, 0, 10, None, 0, 0, None, 64, None, None, 0,
+                                             None, 1, 0, None, None, 64, None, 0, None) != 0
+    assert b"null tables" in lib.hwer_last_error()
+    assert lib.hwer_knn_workspace_init(None, 0, None) != 0
 
 
 def test_product_path_fails_loudly_without_library(monkeypatch):
