@@ -159,22 +159,6 @@ struct RowGroup {
     }
 };
 
-// Streamed-once traffic of the row kernels on LARGE tables (`nt`, wave-uniform: set by the host when the rows do not fit the
-// Infinity Cache anyway): non-temporal loads of the source tables and stores of V / X.  Measured on the 10 M-row catalogue: the
-// one-launch prologue 5.0 -> 4.2 ms; small tables keep the default policy - the next kernels read V / X back from the caches.
-constexpr double kRowNtBytes = 256.0 * 1024.0 * 1024.0;
-typedef float float4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_f4_stream(const float* p, bool nt) {
-    if (nt) {
-        const float4v v = __builtin_nontemporal_load(reinterpret_cast<const float4v*>(p));
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    return *reinterpret_cast<const float4*>(p);
-}
-__device__ __forceinline__ void st_f4_stream(float* p, const float4& o, bool nt) {
-    if (nt) __builtin_nontemporal_store(float4v{o.x, o.y, o.z, o.w}, reinterpret_cast<float4v*>(p));
-    else *reinterpret_cast<float4*>(p) = o;
-}
 // K9+K10 (+ optional norms): out[r] = unit(sum_t alpha * T_t[idx_t[r]])
 // NC = float4 chunks per lane (1 for d <= 256, MAXC above), U = rows a row group works on per iteration: with one chunk per
 // lane a wave had a single 16-byte load in flight per lane and table, and the kernel sat at ~4.5 TB/s on latency; four rows per
@@ -186,7 +170,7 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
                                                               int T, int64_t R, int d4, float* __restrict__ out,
                                                               int64_t ldo, float* __restrict__ out_norm, float audit_eps,
                                                               unsigned long long* __restrict__ audit_counts,
-                                                              double* __restrict__ audit_absdev, int nt) {
+                                                              double* __restrict__ audit_absdev) {
     const RowGroup g(d4);
     unsigned long long a_pos = 0, a_neg = 0, a_nan = 0;   // fused K11 audit of the rows this thread finishes
     double a_dev = 0.0;
@@ -218,7 +202,7 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
 #pragma unroll
                     for (int i = 0; i < NC; ++i) {
                         const int c = g.c0 + i * g.L;
-                        v[u][i] = c < d4 ? ld_f4_stream(base + 4 * c, nt != 0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        v[u][i] = c < d4 ? *reinterpret_cast<const float4*>(base + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 } else {
 #pragma unroll
@@ -255,7 +239,7 @@ __global__ __launch_bounds__(256) void blend_normalize_kernel(const float* const
                     const int c = g.c0 + i * g.L;
                     if (c < d4) {
                         const float4 o = make_float4(acc[u][i].x * inv, acc[u][i].y * inv, acc[u][i].z * inv, acc[u][i].w * inv);
-                        st_f4_stream(out + r * ldo + 4 * c, o, nt != 0);
+                        *reinterpret_cast<float4*>(out + r * ldo + 4 * c) = o;
                         s2 += o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;   // norm of the row as STORED (float32): what a separate audit pass would read back
                     }
                 }
@@ -448,7 +432,6 @@ struct RowNormArgs {
     float* out_norm;
     half4_rt* X16;
     int x_exp;
-    int nt;   // large tables: non-temporal stores of X (st_f4_stream)
 };
 template <bool PACK, int NC, int U>
 __device__ __forceinline__ void row_norm_body(const RowNormArgs& a, int64_t blk, int64_t nblk) {
@@ -509,7 +492,7 @@ __device__ __forceinline__ void row_norm_body(const RowNormArgs& a, int64_t blk,
                     const float4 w = v[u][i];
                     ss += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
                     if (PACK && c < x4) {
-                        st_f4_stream(X + r * ldx + 4 * c, w, a.nt != 0);
+                        *reinterpret_cast<float4*>(X + r * ldx + 4 * c) = w;
                         if (X16)   // the float16 copy in the same pass (scaled by 2^x_exp: hwer_pack_rows_f16)
                             X16[(r * ldx) / 4 + c] = half4_rt{(_Float16)ldexpf(w.x, x_exp), (_Float16)ldexpf(w.y, x_exp), (_Float16)ldexpf(w.z, x_exp), (_Float16)ldexpf(w.w, x_exp)};
                     }
@@ -729,7 +712,6 @@ struct BlendArgs {
     unsigned long long* audit_counts;
     double* audit_absdev;
     unsigned int n_audit_blocks;
-    int nt;   // large tables: non-temporal table loads and V / X stores
 };
 struct AuditAcc {
     unsigned long long pos = 0, neg = 0, nan = 0;
@@ -754,7 +736,7 @@ __device__ __forceinline__ void blend_unit_rows(const BlendArgs& a, const RowGro
             if (live[u]) {
                 al[u] = a.alpha_per_row ? a.alpha[rr[u] * a.T + t] : a.alpha[t];
                 const int64_t row = ri ? int64_t(ri[rr[u]]) : rr[u];
-                if (g.c0 < a.d4) v[u] = ld_f4_stream(tab + row * a.ldt + 4 * g.c0, a.nt != 0);
+                if (g.c0 < a.d4) v[u] = *reinterpret_cast<const float4*>(tab + row * a.ldt + 4 * g.c0);
             }
         }
 #pragma unroll
@@ -777,7 +759,7 @@ __device__ __forceinline__ void blend_unit_rows(const BlendArgs& a, const RowGro
 __device__ __forceinline__ void store_audit_row(const BlendArgs& a, const RowGroup& g, int64_t r, bool live, const float4& o, AuditAcc& au) {
     float s2 = 0.f;
     if (live && g.c0 < a.d4) {
-        st_f4_stream(a.V + r * a.ldv + 4 * g.c0, o, a.nt != 0);
+        *reinterpret_cast<float4*>(a.V + r * a.ldv + 4 * g.c0) = o;
         s2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
     }
     s2 = group_sum(s2, g.L);
@@ -880,7 +862,7 @@ __device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRan
                     }
                     ss = w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
                     if (c < pk.x4) {
-                        st_f4_stream(pk.X + r * pk.ldx + 4 * c, w, a.nt != 0);
+                        *reinterpret_cast<float4*>(pk.X + r * pk.ldx + 4 * c) = w;
                         if (pk.X16)
                             pk.X16[(r * pk.ldx) / 4 + c] = half4_rt{(_Float16)ldexpf(w.x, pk.x_exp), (_Float16)ldexpf(w.y, pk.x_exp), (_Float16)ldexpf(w.z, pk.x_exp), (_Float16)ldexpf(w.w, pk.x_exp)};
                     }
@@ -1078,21 +1060,20 @@ static int blend_impl(const float* const* tables, int64_t ld_tables, const int32
     const int d4 = (d + 3) / 4;
     // every block ends with one float64 atomic on the audit sum (same address for all blocks: they serialise in L2), so small
     // tables use fewer, longer blocks: about 32 rows per block, at least one block per CU, at most kMaxStreamBlocks
-    const int nt = double(R) * double(d) * 4.0 * double(T + 1) > kRowNtBytes ? 1 : 0;
     int grid = rows_grid(R, d4);
     if (audit_counts) grid = std::min(grid, int(std::max<int64_t>(256, cdiv64(R, 32))));
     if (d4 <= 64 && T <= 2)   // one float4 chunk per lane: four rows per iteration (2 x 4 loads in flight per lane)
         hipLaunchKernelGGL((blend_normalize_kernel<1, 4>), dim3(grid), dim3(256), 0, as_stream(stream), tables,
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
-                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev, nt);
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     else if (d4 <= 64)        // more tables: the rows of one iteration (measured at T = 4: U = 4 is 17 % slower than U = 1)
         hipLaunchKernelGGL((blend_normalize_kernel<1, 1>), dim3(grid), dim3(256), 0, as_stream(stream), tables,
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
-                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev, nt);
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     else
         hipLaunchKernelGGL((blend_normalize_kernel<MAXC, 1>), dim3(grid), dim3(256), 0, as_stream(stream), tables,
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
-                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev, nt);
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     return check_launch("blend_normalize");
 }
 
@@ -1167,7 +1148,7 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
     if ((rc = check_table("unit_audit", V, ldv, d))) return rc;
     if (!row_norm_ws || !out_counts || !out_absdev_sum) return fail(HWER_EINVAL, "unit_audit: null output");
     const int d4 = (d + 3) / 4;
-    const RowNormArgs ra{V, ldv, d, d4, nullptr, N, nullptr, 0, 0, row_norm_ws, nullptr, 0, 0};
+    const RowNormArgs ra{V, ldv, d, d4, nullptr, N, nullptr, 0, 0, row_norm_ws, nullptr, 0};
     if (d4 <= 64)
         hipLaunchKernelGGL((row_norm_kernel<false, 1, 4>), dim3(rows_grid(N, d4)), dim3(256), 0, as_stream(stream), ra);
     else
@@ -1210,8 +1191,7 @@ int hwer_pack_rows_f32_f16(const float* V, int64_t N, int d, int64_t ldv, const 
     const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
     if (x4 > 64 * MAXC) return fail(HWER_EINVAL, "pack_rows: ldx too large");
     if (X16 && ((reinterpret_cast<uintptr_t>(X16) & 7) != 0 || ldx % 4 != 0)) return fail(HWER_EINVAL, "pack_rows: X16 must be 8-byte aligned");
-    const RowNormArgs ra{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp,
-                         double(n_rows) * double(ldx) * 4.0 > kRowNtBytes ? 1 : 0};
+    const RowNormArgs ra{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
     if (x4 <= 64)
         hipLaunchKernelGGL((row_norm_kernel<true, 1, 4>), dim3(rows_grid(n_rows, x4)), dim3(256), 0, as_stream(stream), ra);
     else
@@ -1263,8 +1243,7 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
     const int64_t q_rows = knn_workspace ? std::max(B, bq) : B;
     const int n_pack = rows_grid(n_rows, x4);
     const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, 8 * wpb), kMaxStreamBlocks * 4)));
-    const RowNormArgs pa{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp,
-                         double(n_rows) * double(ldx) * 4.0 > kRowNtBytes ? 1 : 0};
+    const RowNormArgs pa{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
     // right behind the workspace header: where hwer_knn_search_opts_f32 keeps its query fragments (ws_layout: w.qf)
     float* qf = knn_workspace ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
     const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, qf, bq};
@@ -1312,11 +1291,10 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     const int n_oth = n_other ? int(std::min<int64_t>(rows_grid(n_other, d4), std::max<int64_t>(64, cdiv64(n_other, 32)))) : 0;
     const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, 8 * wpb), kMaxStreamBlocks * 4)));
     WsHeader* hdr = static_cast<WsHeader*>(knn_workspace);
-    const int nt = double(n_rows + n_other) * double(d) * 4.0 * double(T + 1) > kRowNtBytes ? 1 : 0;
     const BlendArgs ba{tables, ld_tables, row_idx, alpha, alpha_per_row, T, d, d4, V, ldv, eps, hdr,
-                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, unsigned(n_pack + n_oth), nt};
+                       reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, unsigned(n_pack + n_oth)};
     const RowRange pack{pack_ids, pack_row0, n_rows}, other{other_ids, other_row0, n_other};
-    const RowNormArgs pk{V, ldv, d, d4, nullptr, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp, nt};
+    const RowNormArgs pk{V, ldv, d, d4, nullptr, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
     float* qf = bq ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
     const QueryMixArgs qa{V, ldv, d, anchor, nullptr, nullptr, nullptr, nullptr, B, Q64, Q32, ldq32, qf, bq};
     const dim3 grid(n_pack + n_oth + n_mix);
