@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // instead of keeping per-register waits (ending in vmcnt(0), i.e. a drain of the tile prefetch and the appends in flight)
     // inside the tile loop.  Measured against the kernel without it on the same box: c5 screen -2.7 %; at d = 128 (TQ = 2) +0.8 %,
     // so only the wide shape takes it.
-    if constexpr (NG >= 32) {
+    if constexpr (F16 && NG >= 32) {   // (the float32 kernel of this width has no register to spare: 23.6 -> 26.2 ms with it)
 #pragma unroll
         for (int b = 0; b < TQ; ++b)
 #pragma unroll
