@@ -876,52 +876,57 @@ __device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRan
 
 // anchor-only queries from rows blended in place (LDS): query_mix_body with np_ = nn_ = 0
 template <typename T>
-__device__ __forceinline__ void blend_query_body(const BlendArgs& a, const QueryMixArgs& qa, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb) {
+// G = queries per wave and trip (8, or fewer for wide rows: the launch has ONE dynamic-LDS size, and the row-streaming PACK / OTHER
+// blocks need many workgroups per CU - 40 KB of query staging per block made the d = 256 launch 1.8x slower than three launches)
+__device__ __forceinline__ void blend_query_body(const BlendArgs& a, const QueryMixArgs& qa, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb, int G) {
     const int64_t B = qa.B, ldq32 = qa.ldq32;
     const int d = qa.d;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= wpb) return;
     const int g8 = lane >> 3, k = lane & 7;
-    // per wave: 8 x (vec, sq) of T, then 8 rows of 4 d4 floats
-    const size_t per_wave = size_t(8) * 2 * d * sizeof(T) + size_t(8) * 4 * a.d4 * sizeof(float);
+    const bool grp = g8 < G;                 // lane groups beyond G idle (their pointers stay inside the wave's area)
+    const int g8c = grp ? g8 : G - 1;
+    // per wave: G x (vec, sq) of T, then G rows of 4 d4 floats
+    const size_t per_wave = size_t(G) * 2 * d * sizeof(T) + size_t(G) * 4 * a.d4 * sizeof(float);
     unsigned char* wbase = smem_raw + size_t(wave) * per_wave;
-    T* vec = reinterpret_cast<T*>(wbase) + size_t(g8) * 2 * d;
+    T* vec = reinterpret_cast<T*>(wbase) + size_t(g8c) * 2 * d;
     T* sq = vec + d;
-    float* rows = reinterpret_cast<float*>(wbase + size_t(8) * 2 * d * sizeof(T));
+    float* rows = reinterpret_cast<float*>(wbase + size_t(G) * 2 * d * sizeof(T));
     const RowGroup g(a.d4);
-    const int64_t q0 = (blk * wpb + wave) * 8;
-    const int64_t qstride = nblk * wpb * 8;
+    const int64_t q0 = (blk * wpb + wave) * G;
+    const int64_t qstride = nblk * wpb * G;
     const int ngq = int(ldq32 / 8);
     auto frag_at = [&](int64_t b, int j) -> float& {
         return qa.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)];
     };
     const int64_t n_rows_all = qa.Qf ? (qa.bq > B ? qa.bq : B) : B;
     for (int64_t qb = q0; qb < n_rows_all; qb += qstride) {  // qb wave-uniform
-        if (qb >= B) {   // only fragment padding rows are left in this group of 8
+        if (qb >= B) {   // only fragment padding rows are left in this group
             const int64_t b = qb + g8;
-            if (b < qa.bq)
+            if (grp && b < qa.bq)
                 for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
             continue;
         }
-        // the 8 anchor rows of this trip, blended exactly as the PACK / OTHER blocks blend them, into LDS
-        for (int s0 = 0; s0 < 8; s0 += g.groups_per_wave) {   // (L <= 64: at least one row per pass)
+        // the G anchor rows of this trip, blended exactly as the PACK / OTHER blocks blend them, into LDS
+        for (int s0 = 0; s0 < G; s0 += g.groups_per_wave) {   // (L <= 64: at least one row per pass)
             const int s = s0 + g.sub;
             int64_t rr[1];
             bool live[1];
             float4 o[1];
             const int64_t bq_ = qb + s;
-            const int32_t an = (s < 8 && bq_ < B) ? qa.anchor[bq_] : 0;
+            const int32_t an = (s < G && bq_ < B) ? qa.anchor[bq_] : 0;
             rr[0] = an < 0 ? 0 : an;                 // unknown node: row 0 (clipped below)
-            live[0] = s < 8;
+            live[0] = s < G;
             blend_unit_rows<1>(a, g, rr, live, o);
-            if (s < 8 && g.c0 < a.d4) *reinterpret_cast<float4*>(rows + size_t(s) * 4 * a.d4 + 4 * g.c0) = o[0];
+            if (s < G && g.c0 < a.d4) *reinterpret_cast<float4*>(rows + size_t(s) * 4 * a.d4 + 4 * g.c0) = o[0];
         }
         wave_lds_sync();
         const int64_t b = qb + g8;
-        const bool live = b < B;
+        const bool live = grp && b < B;
         const bool unknown = live && qa.anchor[b] < 0;
-        const float* row = rows + size_t(g8) * 4 * a.d4;
+        const float* row = rows + size_t(g8c) * 4 * a.d4;
         // unit_mean_rows(idx == nullptr): mean of one row = the row, then unit length in T arithmetic
+        if (grp)
         for (int j = k; j < d; j += 8) {
             const T acc = unknown ? clip_unknown<T>(T(row[j])) : T(row[j]);
             vec[j] = acc;
@@ -941,7 +946,7 @@ __device__ __forceinline__ void blend_query_body(const BlendArgs& a, const Query
                 qa.Q32[b * ldq32 + j] = 0.f;
                 if (qa.Qf) frag_at(b, j) = 0.f;
             }
-        } else if (qa.Qf && b < qa.bq) {
+        } else if (grp && qa.Qf && b < qa.bq) {
             for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
         }
         wave_lds_sync();
@@ -950,7 +955,7 @@ __device__ __forceinline__ void blend_query_body(const BlendArgs& a, const Query
 
 template <typename T, int U>
 __global__ __launch_bounds__(256) void blend_prepare_search_kernel(const BlendArgs ba, const RowRange pack, const RowRange other, const RowNormArgs pk,
-                                                                   const QueryMixArgs qa, int n_pack_blocks, int n_other_blocks, int wpb) {
+                                                                   const QueryMixArgs qa, int n_pack_blocks, int n_other_blocks, int wpb, int gq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int blk = int(blockIdx.x);
     if (blk < n_pack_blocks + n_other_blocks) {
@@ -959,7 +964,7 @@ __global__ __launch_bounds__(256) void blend_prepare_search_kernel(const BlendAr
         else blend_rows_body<false, U>(ba, other, pk, blk - n_pack_blocks, n_other_blocks, au);
         audit_finish(ba, au);
     } else {
-        blend_query_body<T>(ba, qa, smem_raw, int64_t(blk) - n_pack_blocks - n_other_blocks, int64_t(gridDim.x) - n_pack_blocks - n_other_blocks, wpb);
+        blend_query_body<T>(ba, qa, smem_raw, int64_t(blk) - n_pack_blocks - n_other_blocks, int64_t(gridDim.x) - n_pack_blocks - n_other_blocks, wpb, gq);
     }
 }
 
@@ -1283,13 +1288,18 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     if (bq != 0 && (bq < B || bq % 32 != 0)) return fail(HWER_EINVAL, "blend_prepare_search: bq must be 0 (no fragments) or hwer_knn_query_padding(...) >= B");
     const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
     if (x4 > 64) return fail(HWER_EINVAL, "blend_prepare_search: d <= 256 only");
-    const size_t per_wave = size_t(8) * 2 * d * (arith == 0 ? sizeof(double) : sizeof(float)) + size_t(8) * 4 * d4 * sizeof(float);
-    const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+    // query staging: G queries per wave and trip, as many as keep the block's LDS (4 waves) within 32 KB - the same launch streams
+    // the rows, and those blocks want many workgroups per CU
+    const size_t per_query = size_t(2) * d * (arith == 0 ? sizeof(double) : sizeof(float)) + size_t(4) * d4 * sizeof(float);
+    int gq = 8;
+    while (gq > 1 && size_t(4) * gq * per_query > 32 * 1024) gq /= 2;
+    const size_t per_wave = gq * per_query;
+    const int wpb = 4;
     const int64_t q_rows = bq ? std::max(B, bq) : B;
     // about 32 rows per PACK / OTHER block, at least ... at most the streaming grid (every such block ends with one set of atomics)
     const int n_pack = int(std::min<int64_t>(rows_grid(n_rows, x4), std::max<int64_t>(64, cdiv64(n_rows, 32))));
     const int n_oth = n_other ? int(std::min<int64_t>(rows_grid(n_other, d4), std::max<int64_t>(64, cdiv64(n_other, 32)))) : 0;
-    const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, 8 * wpb), kMaxStreamBlocks * 4)));
+    const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, gq * wpb), kMaxStreamBlocks * 4)));
     WsHeader* hdr = static_cast<WsHeader*>(knn_workspace);
     const BlendArgs ba{tables, ld_tables, row_idx, alpha, alpha_per_row, T, d, d4, V, ldv, eps, hdr,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, unsigned(n_pack + n_oth)};
@@ -1299,11 +1309,11 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     const QueryMixArgs qa{V, ldv, d, anchor, nullptr, nullptr, nullptr, nullptr, B, Q64, Q32, ldq32, qf, bq};
     const dim3 grid(n_pack + n_oth + n_mix);
     if (T <= 2) {   // four rows in flight per row group (blend_normalize_kernel<1, 4>)
-        if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
-        else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
+        if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb, gq);
+        else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb, gq);
     } else {
-        if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 1>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
-        else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 1>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb);
+        if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 1>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb, gq);
+        else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 1>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb, gq);
     }
     return check_launch("blend_prepare_search");
 }
