@@ -993,7 +993,9 @@ static int rows_grid(int64_t rows, int d4) {
     int L = 1;
     while (L < d4 && L < 64) L <<= 1;
     const int64_t rows_per_block = 4 * (64 / L);
-    return int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(rows, rows_per_block), kMaxStreamBlocks)));
+    int64_t cap = kMaxStreamBlocks;
+    if (const char* e = diag_env("HWER_ROW_BLOCKS")) cap = std::max(1, atoi(e));   // tuning override (diagnostic builds)
+    return int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(rows, rows_per_block), cap)));
 }
 
 static int check_table(const char* fn, const void* p, int64_t ld, int d) {
