@@ -538,8 +538,11 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     if f32_beside and f16:
         def step32():
             w.stage_blend(); w.stage_pack(); w.stage_queries(); w.stage_search(o, opts=0)   # noqa: E702
-        lib.hwer_profile_enable(1)
         ms32 = cuda_time(torch, step32, max(3, min(steps, 5)), warm=1)
+        lib.hwer_profile_enable(1)     # kernel durations from a second pass, searches one after the other (see above)
+        w.overlap_tail = False
+        cuda_time(torch, step32, 3, warm=0)
+        w.overlap_tail = True
         lib.hwer_profile_enable(0)
         s32, sel32, _ = read_profile(lib)
         res["f32_screen"] = {"ms_per_step": ms32, "value": float(U) * I / ms32 * 1e3, "knn_screen_ms": s32 * searches_per_step,
