@@ -247,9 +247,9 @@ class Workload:
         # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel)
         # (large catalogues too: the per-type table and its float16 copy are written from the blended row in registers instead of
         # being re-read from V - one pass over the rows less.  Measured: c4full 21.6 -> 20.5 ms, c4 3.03 -> 3.00; NOT where the
-        # anchors outnumber the rows (c3: every anchor row is blended a second time for its query, 5.85 -> 6.12 ms) and not with four
-        # tables and per-row weights (c5: one row in flight per wave, 5.89 -> 7.43 ms) - those keep the separate launches.)
-        self.fused_blend = ((self.fused_prologue or (self.d <= 256 and self.T <= 2 and 8 * U <= I)) and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")) or bool(os.environ.get("HWER_BENCH_FORCE_FUSED_BLEND"))
+        # anchors outnumber the rows (c3: every anchor row is blended a second time for its query, 5.85 -> 6.12 ms) - that shape keeps
+        # the separate launches.  c5 (four tables, per-row weights, d = 256): prologue 1.84 -> 1.63 ms.)
+        self.fused_blend = ((self.fused_prologue or (self.d <= 256 and 8 * U <= I)) and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")) or bool(os.environ.get("HWER_BENCH_FORCE_FUSED_BLEND"))
         self.bq_frag = int(lib.hwer_knn_query_padding(U, I, d, K, self.opts)) if self.fused_fragments else 0
 
     def _alpha_rows(self, seed, lo, hi):
