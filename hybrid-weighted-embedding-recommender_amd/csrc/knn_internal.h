@@ -68,7 +68,9 @@ struct WsHeader {
     unsigned long long audit_acc[3];
     double audit_dev;
     unsigned int audit_ticket;
+    unsigned int init_magic;            // WS_INIT_MAGIC once hwer_knn_workspace_init has run on this workspace
 };
+constexpr unsigned int WS_INIT_MAGIC = 0x48574552u;   // "HWER"
 constexpr int HDR_RESET_INTS = 2 + EXACT_DEVICE_MAXQ + EXACT_DEVICE_MAXQ * EXACT_DEVICE_GROUPS;
 // called by block 0 of the first kernel of every search: empty uncertified list, idle tickets
 __device__ __forceinline__ void hdr_reset(WsHeader* hdr, int tid, int n_threads) {

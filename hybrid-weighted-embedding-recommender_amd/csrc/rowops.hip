@@ -958,6 +958,12 @@ __global__ __launch_bounds__(256) void blend_prepare_search_kernel(const BlendAr
                                                                    const QueryMixArgs qa, int n_pack_blocks, int n_other_blocks, int wpb, int gq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int blk = int(blockIdx.x);
+    if (blk == 0 && threadIdx.x == 0 && ba.hdr->init_magic != WS_INIT_MAGIC) {
+        // the workspace never went through hwer_knn_workspace_init: its audit accumulators are garbage and no block may ever
+        // see the last ticket - make the audit FAIL instead of leaving stale "all rows fine" counts in the caller's buffer
+        ba.audit_counts[0] = ba.audit_counts[1] = ba.audit_counts[2] = ~0ull;
+        ba.audit_counts[3] = ~0ull;
+    }
     if (blk < n_pack_blocks + n_other_blocks) {
         AuditAcc au;
         if (blk < n_pack_blocks) blend_rows_body<true, U>(ba, pack, pk, blk, n_pack_blocks, au);
@@ -1265,6 +1271,9 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
 int hwer_knn_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     if (!workspace || workspace_bytes < size_t(WS_HEADER_BYTES)) return fail(HWER_EINVAL, "knn_workspace_init: workspace too small");
     if (hipMemsetAsync(workspace, 0, WS_HEADER_BYTES, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "knn_workspace_init: memset failed");
+    const unsigned int magic = WS_INIT_MAGIC;
+    if (hipMemcpyAsync(&static_cast<WsHeader*>(workspace)->init_magic, &magic, sizeof(magic), hipMemcpyHostToDevice, as_stream(stream)) != hipSuccess)
+        return fail(HWER_ELAUNCH, "knn_workspace_init: copy failed");
     return HWER_OK;
 }
 

@@ -168,7 +168,8 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
  *   queries            : q_b = unit(V[anchor[b]]) in `arith` arithmetic (anchor -1: the reference's clipped row 0); the anchor row
  *                        is re-blended inside the kernel, so no block waits for another
  *   knn_workspace      : REQUIRED - the search's workspace, zeroed once by hwer_knn_workspace_init after allocation (the audit totals
- *                        are accumulated in its header and handed to audit_counts / audit_absdev_sum by the last block);
+ *                        are accumulated in its header and handed to audit_counts / audit_absdev_sum by the last block; on a
+ *                        workspace that was never initialised the audit counts come back as all-ones: the audit fails loudly);
  *                        bq = hwer_knn_query_padding(...) to also write the float32 query fragments (then search with
  *                        HWER_KNN_QUERIES_READY), 0 to skip them.
  * d <= 256. */

@@ -447,6 +447,17 @@ def test_blend_prepare_search_one_launch(hw, d, U, I, T, per_row, arith, ids):
         assert torch.equal(a["X"], b["X"]) and torch.equal(a["hn"], b["hn"])
         assert (not f16) or torch.equal(a["X16"], b["X16"])
         assert torch.equal(a["Q64"], b["Q64"]) and torch.equal(a["Q32"], b["Q32"])
+    # a workspace that never saw hwer_knn_workspace_init: the audit must FAIL loudly (all-ones counts), not report stale zeros
+    ws_raw = torch.empty_like(ws)
+    ws_raw.fill_(0xAB)
+    c = outputs()
+    c["audit"].zero_()
+    native.check(lib.hwer_blend_prepare_search_f32(
+        P(tab_ptrs), ld, None, P(alpha), 1 if per_row else 0, T, d, P(c["V"]), ldv, 1e-4, P(c["audit"][:4]), P(c["audit"][4:5].view(torch.float64)),
+        P(item_rows) if ids else None, U, I, P(user_rows) if ids else None, 0, U, P(c["X"]), ldx, P(c["hn"]), P(c["X16"]), x_exp,
+        P(anchors), U, arith, P(c["Q64"]), P(c["Q32"]), ldx, P(ws_raw), bq, S), "blend_prepare_search(raw workspace)")
+    torch.cuda.synchronize()
+    assert int(c["audit"][0]) == -1 and int(c["audit"][1]) == -1 and int(c["audit"][2]) == -1
     # the search that trusts the fragments the fused launch left in the workspace = the ordinary search
     res = []
     for opts, q32, q64, x, hn, v in ((0, a["Q32"], a["Q64"], a["X"], a["hn"], a["V"]), (32, b["Q32"], b["Q64"], b["X"], b["hn"], b["V"])):
