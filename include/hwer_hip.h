@@ -159,7 +159,10 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
                             const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, int arith, double* Q64,
                             float* Q32, int64_t ldq32, void* knn_workspace /*nullable*/, int64_t bq, void* stream);
 
-/* The whole prologue of a blended-table search step in ONE launch: hwer_blend_normalize_audit_f32 over the rows listed below,
+/* (reference lines covered: the weighted blend + unit_length of hwer/content_recommender.py:77-96 / hwer/utils.py:43-44, the unit
+ * audit of hwer/recommendation_base.py:106-107, the per-type table of MultiKNN.__init__ :64-76 and get_average_embeddings of the
+ * anchor :153-155,164-170 - the same lines as the three entry points it fuses.)
+ * The whole prologue of a blended-table search step in ONE launch: hwer_blend_normalize_audit_f32 over the rows listed below,
  * hwer_pack_rows_f32_f16 of the `n_rows` rows of the searched type and anchor-only hwer_query_mix (no positive / negative lists)
  * - for small, latency-bound steps (MovieLens-100K / 1M shapes: three launch-floor kernels and a memset node become one kernel).
  * Outputs are bit-identical to the separate calls.
