@@ -633,6 +633,10 @@ int repack_queries(const float* Q32, int64_t B, int64_t B_padded, int ldx, float
 // =====================================================================================================
 // host side: plan + launch
 // =====================================================================================================
+#ifndef HWER_SEED_MAX_TILES
+#define HWER_SEED_MAX_TILES 8192
+#endif
+constexpr int64_t SEED_MAX_TILES = HWER_SEED_MAX_TILES;   // largest sample: 262 144 rows
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options) {
     ScreenPlan p{};
     p.ng = ldx / 8;
@@ -713,11 +717,13 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         // (1 / c) of its expectation: (1 - 1/c) sqrt(r) standard deviations - 5 at c = 4, r = 44; 4.6 at c = 2.75, r = 52
         // (~2e-6 per query: a query every few c3 steps takes the exhaustive pass)
         const double r_min = single_list ? 52.0 : 44.0;
-        // sample size for that rank at c_min (+ 2 %), in 32-row tiles: 1 024 ... 65 536 items
-        int64_t ns = std::min<int64_t>(2048, std::max<int64_t>(32, cdiv64(int64_t(1.02 * r_min * double(n_items) / (c_min * double(p.kprime))), 32)));
+        // sample size for that rank at c_min (+ 2 %), in 32-row tiles: 1 024 ... 262 144 items (a 10 M-row catalogue at c = 8 takes
+        // 219 K: with the 65 536-row cap of before, c was 26 - three times the appends, and more keys per query than the one-wave list
+        // merge holds: c4full 20.2 -> 18.7 ms)
+        int64_t ns = std::min<int64_t>(SEED_MAX_TILES, std::max<int64_t>(32, cdiv64(int64_t(1.02 * r_min * double(n_items) / (c_min * double(p.kprime))), 32)));
         ns = std::min(ns, n_tiles);
-        // the sample keys of all queries live in the workspace: at most 2 GiB of them (131 072 queries: a 4 096-item sample)
-        ns = std::min<int64_t>(ns, std::max<int64_t>(32, (int64_t(1) << 29) / (p.bq * 32)));
+        // the sample keys of all queries live in the workspace (float16): at most 2 GiB of them (131 072 queries: an 8 192-item sample)
+        ns = std::min<int64_t>(ns, std::max<int64_t>(32, (int64_t(1) << 30) / (p.bq * 32)));   // (float16 keys: 2 GiB)
         const double S = double(ns) * 32.0;
         const double c = std::max(c_min, r_min * double(n_items) / (double(p.kprime) * S));
         const double frac = c * double(p.kprime) / double(n_items);

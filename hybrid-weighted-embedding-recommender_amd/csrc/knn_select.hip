@@ -1541,7 +1541,7 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     off += align256(size_t(p.bq) * 4);
     if (p.seed) {   // seed pre-pass: sample keys (bq, seed_ld), thresholds, a scratch counter row
         w.seed_keys = off;
-        off += align256(size_t(p.bq) * size_t(p.seed_ld) * 4);
+        off += align256(size_t(p.bq) * size_t(p.seed_ld) * 2);   // float16 keys
         w.seed_tau = off;
         off += align256(size_t(p.bq) * 4);
         w.seed_cnt = off;

@@ -656,7 +656,7 @@ static SmallLayout small_layout(const SmallPlan& p, const ScreenPlan* seed) {
     size_t off = 0;
     w.qf = off;    off += al256(bq * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32); float16 variant: half of it
     w.qexp = off;  off += al256(bq * 4);                      // per-query scale exponents of the float16 variant
-    w.keys = off;  off += al256(seed ? size_t(seed->bq) * size_t(seed->seed_ld) * 4 : size_t(p.bq) * size_t(p.ld) * 4);
+    w.keys = off;  off += al256(seed ? size_t(seed->bq) * size_t(seed->seed_ld) * 2 /* float16 sample keys */ : size_t(p.bq) * size_t(p.ld) * 4);
     w.thr = off;   off += al256(bq * 4);
     w.count = off; off += al256(bq * 4);
     w.list = off;  off += al256(size_t(p.bq) * SMALL_LIST_CAP * 8);
