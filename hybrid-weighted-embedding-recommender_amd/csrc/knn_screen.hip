@@ -712,7 +712,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         //        (~5 K cycles of one wave) stalls the three other waves of its workgroup at the tile barrier - measured 24 % of
         //        the launch; 2.75 K' stay below the trigger (the pre-pass grows from 4.5 % to 7.4 % of the catalogue).
         const bool single_list = p.n_lists == 1 && !small;
-        const double c_min = single_list ? 2.75 : (((B <= 4 && small) || (n_items >= 400000 && !small)) ? 8.0 : 4.0);
+        double c_min = single_list ? 2.75 : (((B <= 4 && small) || (n_items >= 400000 && !small)) ? 8.0 : 4.0);
+        if (const char* e = diag_env("HWER_SEED_C")) c_min = std::max(1.5, atof(e));   // tuning override (diagnostic builds)
         // sample rank r: the catalogue's count above tau0 has a relative spread of 1 / sqrt(r), and it must not fall below K' =
         // (1 / c) of its expectation: (1 - 1/c) sqrt(r) standard deviations - 5 at c = 4, r = 44; 4.6 at c = 2.75, r = 52
         // (~2e-6 per query: a query every few c3 steps takes the exhaustive pass)
