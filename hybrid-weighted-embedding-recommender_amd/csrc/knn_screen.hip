@@ -695,11 +695,13 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         p.n_lists = 0;
         p.ld_dense = n_tiles * 32;
     }
-    // Seeded thresholds (streaming mode).  The sample: 2 - 7 % of the catalogue's 32-row tiles at a regular stride (1 024 to
-    // 65 536 items); tau0 = the sample key whose rank corresponds to c K' keys of the whole catalogue, c chosen below and large
-    // enough for a sample rank of >= 44: with the rank's relative spread 1 / sqrt(rank) the catalogue then holds fewer than K'
-    // keys above tau0 with probability ~2e-6 per query (c = 2.75; far less at c >= 4) - and such a query is flagged
-    // (CNT_SEEDED_SHORT -> uncertified -> exhaustive pass), never wrong.
+    // Seeded thresholds (streaming mode).  The sample: 0.6 - 9 % of the catalogue's 32-row tiles at a regular stride (1 024 to
+    // 65 536 items); tau0 = the sample key of rank r, which stands for c K' keys of the whole catalogue.  The fraction of the
+    // catalogue above the r-th of S sample keys is Beta(r, S - r + 1) ~ Gamma(r) / S, so the catalogue holds fewer than K' keys
+    // above tau0 - the only way a seed can hurt: the query is flagged CNT_SEEDED_SHORT -> uncertified -> exhaustive pass, never
+    // wrong - with probability P(Gamma(r) < r / c) = P(Poisson(r / c) >= r): 4e-10 at (c, r) = (8, 16), 1.4e-9 at (4, 28),
+    // 9e-8 at (2.25, 52).  (The normal approximation used earlier - (1 - 1/c) sqrt(r) sigmas - overstates that tail by orders of
+    // magnitude and had the samples 1.6 - 2.7x larger than they need to be.)
     if (!p.dense && !(options & (HWER_KNN_NO_SEED | HWER_KNN_EXACT_THRESHOLDS)) && !diag_env("HWER_SCREEN_NOSEED")) {
         const int64_t n_tiles = cdiv64(n_items, 32);
         const bool small = use_small_path(B, n_items, options);
@@ -708,19 +710,17 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         //   8    where the kept keys are cheap and the pre-pass is not: a handful of queries on the small-batch path (latency: one
         //        query on 1.25 M rows 0.161 -> 0.147 ms; from 32 queries on the parked keys dominate and 4 is faster), and large
         //        catalogues with item splits (c4: 32 short lists per query; pre-pass + threshold kernel 0.60 -> 0.30 ms);
-        //   2.75 when a query has ONE list (c3): 4 K' keys overflow the list's two 480-key streams, and every in-loop compaction
+        //   2.25 when a query has ONE list (c3): 4 K' keys overflow the list's two 480-key streams, and every in-loop compaction
         //        (~5 K cycles of one wave) stalls the three other waves of its workgroup at the tile barrier - measured 24 % of
-        //        the launch; 2.75 K' stay below the trigger (the pre-pass grows from 4.5 % to 7.4 % of the catalogue).
+        //        the launch; 2.25 K' stay below the trigger for all but ~2e-4 of the queries (the pre-pass is 9 % of the catalogue;
+        //        measured against 2.75: c3's main search 5.27 -> 5.03 ms).
         const bool single_list = p.n_lists == 1 && !small;
-        double c_min = single_list ? 2.75 : (((B <= 4 && small) || (n_items >= 400000 && !small)) ? 8.0 : 4.0);
+        double c_min = single_list ? 2.25 : (((B <= 4 && small) || (n_items >= 400000 && !small)) ? 8.0 : 4.0);
         if (const char* e = diag_env("HWER_SEED_C")) c_min = std::max(1.5, atof(e));   // tuning override (diagnostic builds)
-        // sample rank r: the catalogue's count above tau0 has a relative spread of 1 / sqrt(r), and it must not fall below K' =
-        // (1 / c) of its expectation: (1 - 1/c) sqrt(r) standard deviations - 5 at c = 4, r = 44; 4.6 at c = 2.75, r = 52
-        // (~2e-6 per query: a query every few c3 steps takes the exhaustive pass)
-        const double r_min = single_list ? 52.0 : 44.0;
-        // sample size for that rank at c_min (+ 2 %), in 32-row tiles: 1 024 ... 262 144 items (a 10 M-row catalogue at c = 8 takes
-        // 219 K: with the 65 536-row cap of before, c was 26 - three times the appends, and more keys per query than the one-wave list
-        // merge holds: c4full 20.2 -> 18.7 ms)
+        // sample rank r by c (probabilities above; the threshold kernels never take a rank below 16)
+        const double r_min = single_list ? 52.0 : (c_min >= 8.0 ? 16.0 : 28.0);
+        // sample size for that rank at c_min (+ 2 %), in 32-row tiles: 1 024 ... 262 144 items (the 10 M-row catalogue: 80 K rows
+        // for c = 8, r = 16; the threshold kernel reads up to 65 536 keys of a row, at a regular stride beyond that)
         int64_t ns = std::min<int64_t>(SEED_MAX_TILES, std::max<int64_t>(32, cdiv64(int64_t(1.02 * r_min * double(n_items) / (c_min * double(p.kprime))), 32)));
         ns = std::min(ns, n_tiles);
         // the sample keys of all queries live in the workspace (float16): at most 2 GiB of them (131 072 queries: an 8 192-item sample)
