@@ -409,6 +409,10 @@ __global__ __launch_bounds__(256) void pack_rows16_kernel(const float4* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef HWER_SEED_SLACK_DIV
+#define HWER_SEED_SLACK_DIV 6   // seed thresholds: the bisection stops with rank .. rank + rank / DIV sample keys above the threshold
+                                // (measured 2 -> 6: one more probe, ~12 % fewer appended keys: c3 -3.7 %, c4 -1 %; 12 = 6)
+#endif
 struct SmallSelectArgs {
     const float* keys;  // (seed pre-pass: float16 keys behind this pointer, KT = _Float16 in the threshold kernels)
     int64_t ld;         // multiple of 32 (pad items hold -inf)
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
     if (rank > S) rank = int(S);
     int c_lo;
     // (seed pre-pass: any threshold with at least `rank` sample keys above it will do - a wide stopping window saves probes)
-    const float t = wave_find_rank_fn(count_ge, vmin, vmax, rank, a.want_frac > 0.0 ? rank / 2 : rank / 8, c_lo);
+    const float t = wave_find_rank_fn(count_ge, vmin, vmax, rank, a.want_frac > 0.0 ? rank / HWER_SEED_SLACK_DIV : rank / 8, c_lo);
     if (threadIdx.x == 0) {
         a.thr[b] = seed_margin<KT>(t);
         a.count[b] = 0;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSe
     if (rank < 16) rank = 16;
     if (rank > 64 * PER) rank = 64 * PER;
     int c_lo;
-    const float t = wave_find_rank<PER>(v, rank, a.want_frac > 0.0 ? rank / 2 : rank / 8, c_lo);
+    const float t = wave_find_rank<PER>(v, rank, a.want_frac > 0.0 ? rank / HWER_SEED_SLACK_DIV : rank / 8, c_lo);
     if (lane == 0) {
         a.thr[b] = seed_margin<KT>(t);
         a.count[b] = 0;
