@@ -47,7 +47,8 @@ CONFIGS = {
     "c2": dict(U=6040, I=3706, d=128, T=2, per_row=False, name="ML-1M-shaped synthetic (6040x3706, d=128, alpha=0.5)"),
     "c3": dict(U=138493, I=26744, d=128, T=2, per_row=False, name="ML-20M-shaped synthetic (138493x26744, d=128)"),
     "c4": dict(U=4096, I=1250000, d=128, T=2, per_row=False, name="one shard of the 10M-item catalogue (4096 queries x 1.25M items, d=128)"),
-    "c5": dict(U=4096, I=1250000, d=256, T=4, per_row=True, name="multi-alpha hybrid shard (3 content + 1 collaborative, per-row alpha, d=256, 4096 x 1.25M)"),
+    "c5": dict(U=131072, B=4096, I=1250000, d=256, T=4, per_row=True,
+               name="multi-alpha hybrid shard (3 content + 1 collaborative, per-row alpha, d=256; 131072 user + 1.25M item rows blended, 4096 queries)"),
     "c4full": dict(U=4096, I=10000000, d=128, T=2, per_row=False, name="10M-item catalogue (4096 queries x 10M items, d=128)"),
 }
 K = 200
@@ -176,6 +177,7 @@ class Workload:
         hi = I_total if hi is None else hi
         I = hi - lo
         self.U, self.I, self.d, self.T, self.lo, self.hi = U, I, d, T, lo, hi
+        self.B = B = int(cfg.get("B", U))     # queries per step = the first B users (default: every user)
         self.N = N = U + I
         self.ldv = roundup(d, 4)
         assert self.ldv == d, "bench tables are passed with row stride d"
@@ -197,7 +199,7 @@ class Workload:
             self.alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
         self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
         self.item_rows = torch.arange(U, N, dtype=torch.int64, device=dev)
-        self.anchors = torch.arange(0, U, dtype=torch.int32, device=dev)
+        self.anchors = torch.arange(0, B, dtype=torch.int32, device=dev)
         self.V = torch.zeros((N, self.ldv), dtype=torch.float32, device=dev)
         self.audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)     # counts[4] | sum |norm-1| (f64) | pad
         self.audit_counts = self.audit_buf[:4]
@@ -207,20 +209,20 @@ class Workload:
         self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
         self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
         # float16 screen wherever it pays (hwer_knn_f16_screen_pays: every streamed catalogue, dense ones from ~1e9 multiply-adds)
-        self.f16_screen = ((not f32_screen) and bool(lib.hwer_knn_f16_screen_pays(min(U, 131072), I, d))) or (f16_dense and I <= 8192)
+        self.f16_screen = ((not f32_screen) and bool(lib.hwer_knn_f16_screen_pays(min(B, 131072), I, d))) or (f16_dense and I <= 8192)
         self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
-        self.Q64 = torch.empty((U, d), dtype=torch.float64, device=dev)
-        self.Q32 = torch.empty((U, self.ldx), dtype=torch.float32, device=dev)
+        self.Q64 = torch.empty((B, d), dtype=torch.float64, device=dev)
+        self.Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=dev)
         self.want_dist = want_dist
         self.sort_by_score = 0 if local_order else 1
-        self.sets = [dict(idx=torch.empty((U, K), dtype=torch.int64, device=dev), score=torch.empty((U, K), dtype=torch.float64, device=dev),
-                          dist2=torch.empty((U, K), dtype=torch.float64, device=dev) if want_dist else None,
-                          flags=torch.empty(U, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
+        self.sets = [dict(idx=torch.empty((B, K), dtype=torch.int64, device=dev), score=torch.empty((B, K), dtype=torch.float64, device=dev),
+                          dist2=torch.empty((B, K), dtype=torch.float64, device=dev) if want_dist else None,
+                          flags=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
         self.CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
         # HWER_KNN_F16_SCREEN (2) above 8 192 rows; HWER_BENCH_OPTS ORs in further option bits for A/B runs (e.g. 16 = HWER_KNN_NO_SEED)
         self.opts = (2 if self.f16_screen else 0) | int(os.environ.get("HWER_BENCH_OPTS", "0"))
-        ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(U, self.CH), I, d, K, self.opts),
-                       lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(U, 64), I, d, K, 0))
+        ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(B, self.CH), I, d, K, self.opts),
+                       lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(B, 64), I, d, K, 0))
         assert ws_bytes > 0
         self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         self.native.check(lib.hwer_knn_workspace_init(self.native.ptr(self.ws), self.ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "knn_workspace_init")   # once per allocation
@@ -229,7 +231,7 @@ class Workload:
         # More users than one search takes (c3: 131 072 + 7 421): the short last search runs on a second stream with its own
         # workspaces, beside the first one - its MFMA-bound screen fills the issue slots the first search's gather-bound select
         # leaves idle (c3: the 0.64 ms of the last 7 421 users disappear behind the main search).
-        self.tail = U % self.CH if (U > self.CH and not os.environ.get("HWER_BENCH_NO_TAIL_STREAM")) else 0
+        self.tail = B % self.CH if (B > self.CH and not os.environ.get("HWER_BENCH_NO_TAIL_STREAM")) else 0
         self.overlap_tail = True
         if self.tail:
             self.side = torch.cuda.Stream(device=dev)
@@ -242,15 +244,15 @@ class Workload:
         self.arith = 0                  # float64 score arithmetic (ContentRecommendation flavour)
         # Small catalogues (dense path): the prologue's two latency-floor kernels run as ONE launch that also writes the search's
         # query fragments (hwer_prepare_search_f32 + HWER_KNN_QUERIES_READY); one search call per step only.
-        self.fused_prologue = I <= 8192 and U <= self.CH and not os.environ.get("HWER_BENCH_NO_FUSED_PROLOGUE")
+        self.fused_prologue = I <= 8192 and B <= self.CH and not os.environ.get("HWER_BENCH_NO_FUSED_PROLOGUE")
         self.fused_fragments = self.fused_prologue and not self.f16_screen
         # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel)
         # (large catalogues too: the per-type table and its float16 copy are written from the blended row in registers instead of
         # being re-read from V - one pass over the rows less.  Measured: c4full 21.6 -> 20.5 ms, c4 3.03 -> 3.00; NOT where the
         # anchors outnumber the rows (c3: every anchor row is blended a second time for its query, 5.85 -> 6.12 ms) - that shape keeps
         # the separate launches.  c5 (four tables, per-row weights, d = 256): prologue 1.84 -> 1.63 ms.)
-        self.fused_blend = ((self.fused_prologue or (self.d <= 256 and 8 * U <= I)) and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")) or bool(os.environ.get("HWER_BENCH_FORCE_FUSED_BLEND"))
-        self.bq_frag = int(lib.hwer_knn_query_padding(U, I, d, K, self.opts)) if self.fused_fragments else 0
+        self.fused_blend = ((self.fused_prologue or (self.d <= 256 and 8 * B <= I)) and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")) or bool(os.environ.get("HWER_BENCH_FORCE_FUSED_BLEND"))
+        self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) if self.fused_fragments else 0
 
     def _alpha_rows(self, seed, lo, hi):
         torch = self.torch
@@ -284,7 +286,7 @@ class Workload:
 
     def stage_queries(self):
         P, lib = self.native.ptr, self.lib
-        self.native.check(lib.hwer_query_mix(P(self.V), self.N, self.d, self.ldv, P(self.anchors), None, None, None, None, self.U, self.arith,
+        self.native.check(lib.hwer_query_mix(P(self.V), self.N, self.d, self.ldv, P(self.anchors), None, None, None, None, self.B, self.arith,
                                              P(self.Q64), P(self.Q32), self.ldx, self.S()), "query_mix")
 
     def stage_search(self, o, B=None, opts=None):
@@ -292,7 +294,7 @@ class Workload:
         or a sample-scaled threshold that was too tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the
         device (no host round trip): the step always returns exact results."""
         P, lib = self.native.ptr, self.lib
-        U = self.U if B is None else B
+        U = self.B if B is None else B
         opts = self.opts if opts is None else opts
         oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
 
@@ -306,7 +308,7 @@ class Workload:
                 P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
                 self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
                 P(ws), P(self.missed), P(ws_exact), ws_exact.numel(), self.S()), "knn_exact_device")
-        side_tail = self.tail and U == self.U and self.overlap_tail
+        side_tail = self.tail and U == self.B and self.overlap_tail
         if side_tail:   # the short last search, on the second stream
             torch = self.torch
             cur = torch.cuda.current_stream()
@@ -323,7 +325,7 @@ class Workload:
         P, lib = self.native.ptr, self.lib
         self.native.check(lib.hwer_prepare_search_f32(
             P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
-            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), None, None, None, None, self.U, self.arith,
+            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), None, None, None, None, self.B, self.arith,
             P(self.Q64), P(self.Q32), self.ldx, P(self.ws) if self.fused_fragments else None, self.bq_frag, self.S()), "prepare_search")
 
     def stage_blend_prepare(self):
@@ -332,7 +334,7 @@ class Workload:
         self.native.check(lib.hwer_blend_prepare_search_f32(
             P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if c["per_row"] else 0, self.T, self.d, P(self.V), self.ldv, 1e-4,
             P(self.audit_counts), P(self.audit_dev), None, self.U, self.I, None, 0, self.U, P(self.X), self.ldx, P(self.hnorm),
-            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), self.U, self.arith, P(self.Q64), P(self.Q32), self.ldx,
+            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), self.B, self.arith, P(self.Q64), P(self.Q32), self.ldx,
             P(self.ws), self.bq_frag, self.S()), "blend_prepare_search")
 
     def step(self, o=None):
@@ -358,7 +360,7 @@ class Workload:
         return {
             "blend_normalize_audit": N * (4.0 * d * (T + 1) + (4.0 * T if per_row else 0.0)),       # T rows in, one out (+ per-row alpha)
             "pack_rows": I * (4.0 * d + 4.0 * self.ldx + 4.0 + 8.0) + (I * 2.0 * self.ldx if self.f16_screen else 0.0),
-            "query_mix": U * (4.0 * d + 8.0 * d + 4.0 * self.ldx + 4.0),
+            "query_mix": self.B * (4.0 * d + 8.0 * d + 4.0 * self.ldx + 4.0),
         }
 
     def checks(self, o):
@@ -413,7 +415,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     from hwer import native
     cfg = CONFIGS[name]
     w = Workload(torch, lib, cfg, dev, f32_screen=args.f32_screen, f16_dense=args.f16_dense)
-    U, I, d = w.U, w.I, w.d
+    U, I, d = w.B, w.I, w.d      # U = queries per step from here on (w.U user rows are blended; c5: 131 072 rows, 4 096 queries)
     # Small catalogues: a step is ~8 launches of a few microseconds each, so issuing them from Python costs as much as running
     # them.  The step is captured ONCE into a hipGraph (every buffer is preallocated, nothing in the step synchronises or
     # allocates) and the timed region replays it.
@@ -441,12 +443,29 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     torch.cuda.synchronize()
     if graph is None and not w.tail:
         lib.hwer_profile_enable(PROFILE_EVERY)   # HIP events around every PROFILE_EVERY-th search (a pair costs ~10 us of stream time)
+    # The timed region: EXACTLY `steps` steps between two synchronisations, wall clock (the contract's ms_per_step / value).  Eager
+    # steps (>= ~0.2 ms each) also get one HIP event per step boundary inside the region - the per-step distribution
+    # (median / min / max) costs nothing there; graph-replayed steps (c1 / c2: ~0.05-0.2 ms) get theirs from a second pass.
+    in_loop = graph is None
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(steps):
+    if in_loop:
+        evs[0].record()
+    for i in range(steps):
         run_step()
+        if in_loop:
+            evs[i + 1].record()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lib.hwer_profile_enable(0)
+    if not in_loop:
+        evs[0].record()
+        for i in range(steps):
+            run_step()
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+    series = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    del evs
     if graph is not None or w.tail:    # kernel durations: an eager pass with event brackets after the timed region
         lib.hwer_profile_enable(1)     # (searches one after the other: overlapped searches would stretch each other's brackets)
         w.overlap_tail = False
@@ -459,7 +478,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     o = w.sets[0]
     n_exhaustive = w.checks(o)
     ms_per_step = elapsed / steps * 1e3
-    value = float(U) * float(I) / (elapsed / steps)
+    value = float(w.B) * float(I) / (elapsed / steps)
     idx_h, score_h = o["idx"].cpu().numpy(), o["score"].cpu().numpy()
 
     # ---- parity of the timed step's result: sampled users against the oracle's C brute force on the same float32 rows -------
@@ -471,8 +490,8 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     sel = np.unique(np.linspace(0, U - 1, n_par).astype(np.int64))
     V64u = Vh[:U].astype(np.float64)
     Qh = np.stack([orc.query_vector(V64u, int(s)) for s in sel])
-    oi, osc, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64u[sel], K, threads=cores)
-    assert np.array_equal(idx_h[sel], oi + U), "GPU indices differ from the oracle (%s)" % name
+    oi, osc, _ = c_oracle.find_closest_f64(Vh[w.U:], Qh, V64u[sel], K, threads=cores)
+    assert np.array_equal(idx_h[sel], oi + w.U), "GPU indices differ from the oracle (%s)" % name
     assert np.array_equal(score_h[sel], osc), "GPU scores differ from the oracle (%s)" % name
 
     # ---- per-stage times (outside the timed region), per-kernel rooflines ----------------------------------------------------
@@ -487,7 +506,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     if w.fused_blend:      # ... and the blend with them: the step's whole prologue
         stages["blend_prepare_search"] = cuda_time(torch, w.stage_blend_prepare, stage_reps)
         sbytes["blend_prepare_search"] = (sbytes["blend_normalize_audit"] + sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
-                                          - 4.0 * d * (I + U))   # V is not read back
+                                          - 4.0 * d * (I + w.B))   # the table pass and the queries read registers, not V
     f16 = w.f16_screen
     flops = 2.0 * U * I * d
     mfma_peak = MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS
@@ -523,6 +542,9 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         "workload": cfg["name"], "users": U, "items": I, "d": d, "k": K, "tables": w.T, "alpha": "per-row" if cfg["per_row"] else "scalar",
         "f16_screen": f16, "dtype": "f16" if f16 else "f32", "steps": steps, "warmup": warmup, "hip_graph": graph is not None,
         "value": value, "unit": "pairs/s", "ms_per_step": ms_per_step,
+        "ms_median": float(np.median(series)), "ms_min": float(series.min()), "ms_max": float(series.max()), "ms_mean_events": float(series.mean()),
+        "ms_series": [round(float(x), 4) for x in series], "ms_series_note": "HIP-event interval of every step" + ("" if in_loop else " (second pass: the timed steps are graph replays)"),
+        "user_rows": w.U,
         "roofline": {k_: dominant[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
         "stage_frac": stage_tf / MFMA_F32_PEAK_TFLOPS,
         "stage_frac_note": "2*B*N*d / (screen + select time) / 157.3 TF: the cosine_topk unit of SURVEY.md 8d against the float32-MFMA peak",
@@ -533,6 +555,18 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     res["roofline"]["traffic"] = traffic
     res["roofline"]["traffic_source"] = traffic_src
     res["roofline"]["share_of_step"] = dominant["share"]
+    res["dominant_kernel"] = {"name": dominant["kernel"][:40], "ms": _r(dominant["ms_per_step"], 4), "share": _r(dominant["share"], 3),
+                              "bound": dominant["bound"], "frac": _r(dominant["frac"], 3)}
+    if not dominant["kernel"].startswith("knn_screen") and not dominant["bound"].startswith("hbm"):
+        # Dense path (c1 / c2): the dominant kernel is the select / re-rank stage, which has no "hbm" | "mfma" roofline of its own
+        # (L2 row gathers + a serial selection chain).  The line's `roofline` is then SURVEY.md 8d's cosine_topk unit - 2 B N d flops
+        # over the screen + select time against the float32-MFMA peak (= stage_frac); the kernel's own pricing stays in
+        # `dominant_kernel` and `kernels`.
+        res["roofline"] = {"kernel": "cosine_topk = knn_screen + knn_select (SURVEY 8d unit)", "bound": "mfma", "achieved": stage_tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": stage_tf / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                           "share_of_step": (screen_step_ms + select_step_ms) / ms_per_step}
+    prologue = "blend_prepare_search" if w.fused_blend else None
+    res["stage_sum_ms"] = (stages[prologue] if prologue else (stages["blend_normalize_audit"] + (stages["prepare_search"] if w.fused_prologue else stages["pack_rows"] + stages["query_mix"]))) + stages["knn_search"]
 
     # ---- the same step with the float32 screen, beside the float16 number (streaming configurations) -------------------------
     if f32_beside and f16:
@@ -567,8 +601,8 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     if not args.sweep_only:
         n_pairs = 1000209 if I < 100000 else 16000000
         gp = torch.Generator(device=dev).manual_seed(4001)
-        p_src = torch.randint(0, U, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
-        p_dst = torch.randint(U, w.N, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
+        p_src = torch.randint(0, w.U, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
+        p_dst = torch.randint(w.U, w.N, (n_pairs,), generator=gp, device=dev, dtype=torch.int32)
         p_out = torch.empty(n_pairs, dtype=torch.float64, device=dev)
         P = native.ptr
         ps_ms = cuda_time(torch, lambda: native.check(lib.hwer_pair_score_f64(P(w.V), w.N, d, w.ldv, P(p_src), P(p_dst), n_pairs, P(p_out), w.S()), "pair_score"), 20, warm=3)
@@ -751,22 +785,28 @@ def run_single(args):
     lib = native.lib()
     base = {"metric": METRIC, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
+    cpu = (lambda s_: 0.0 if args.no_cpu_baseline else s_)
     if args.config:      # one configuration only (profiling runs)
-        r = run_config(torch, lib, args.config, dev, args.steps, args.warmup, args, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0,
+        r = run_config(torch, lib, args.config, dev, args.steps, args.warmup, args, cpu_budget_s=cpu(8.0),
                        latencies=() if args.sweep_only else ((1,) if args.config != "c4" else (1, 64, 4096)), f32_beside=not args.sweep_only)
         return finish_line(base, r)
     t_start = time.perf_counter()
-    top = run_config(torch, lib, "c1", dev, args.steps, args.warmup, args, cpu_budget_s=0.0 if args.no_cpu_baseline else 8.0, api=True, latencies=(1,))
+    top = run_config(torch, lib, "c1", dev, args.steps, args.warmup, args, cpu_budget_s=cpu(8.0), api=True, latencies=(1,))
     configs = {}
-    configs["c2"] = run_config(torch, lib, "c2", dev, args.steps, args.warmup, args, cpu_budget_s=0.0 if args.no_cpu_baseline else 5.0, api=True, latencies=(1,))
-    configs["c3"] = run_config(torch, lib, "c3", dev, min(args.steps, 20), min(args.warmup, 3), args, cpu_budget_s=0.0 if args.no_cpu_baseline else 4.0,
+    configs["c2"] = run_config(torch, lib, "c2", dev, args.steps, args.warmup, args, cpu_budget_s=cpu(5.0), api=True, latencies=(1,))
+    configs["c3"] = run_config(torch, lib, "c3", dev, max(10, min(args.steps, 20)), max(3, min(args.warmup, 5)), args, cpu_budget_s=cpu(4.0),
                                api="arrays", stage_reps=5, f32_beside=True)
-    configs["c4"] = run_config(torch, lib, "c4", dev, min(args.steps, 10), min(args.warmup, 2), args, latencies=(1, 64, 4096), stage_reps=5, f32_beside=True)
-    configs["c4full"] = run_config(torch, lib, "c4full", dev, min(args.steps, 5), min(args.warmup, 2), args, stage_reps=3)
+    # the big shapes: >= 5 warm-ups and >= 20 (c4, c5) / >= 10 (c4full) steps whatever --steps says - a 2-warm-up, 10-step wall-clock
+    # mean right after the previous configuration's tensors were freed was what the round-2 driver run caught at 4.41 ms
+    configs["c4"] = run_config(torch, lib, "c4", dev, max(20, min(args.steps, 40)), max(5, min(args.warmup, 10)), args, latencies=(1, 64, 4096), stage_reps=10, f32_beside=True)
+    configs["c5"] = run_config(torch, lib, "c5", dev, max(20, min(args.steps, 40)), max(5, min(args.warmup, 10)), args, stage_reps=10, f32_beside=True)
+    configs["c4full"] = run_config(torch, lib, "c4full", dev, max(10, min(args.steps, 20)), max(5, min(args.warmup, 5)), args, stage_reps=3)
     configs["c4full"]["note"] = ("the whole 10M-item catalogue on ONE GPU: the 1-GPU value of the workload that `bench.py --gpus N` (N > 1) strong-scales; "
                                  "use this value as the N = 1 point of the scaling curve")
     out = finish_line(base, top)
     out["configs"] = configs
+    out["strong_scaling_headroom"] = {"c4full_over_c4_median": configs["c4full"]["ms_median"] / configs["c4"]["ms_median"],
+                                      "note": "one GPU's step on the whole 10M-row catalogue / its step on one 1.25M-row shard: the 8-GPU speedup before exchange effects"}
     out["bench_wall_s"] = time.perf_counter() - t_start
     return out
 
@@ -776,7 +816,8 @@ def finish_line(base, r):
     out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "steps": r["steps"], "warmup": r["warmup"],
                 "config": {"workload": r["workload"], "users": r["users"], "items_per_gpu": r["items"], "items_total": r["items"], "d": r["d"],
                            "k": r["k"], "tables": r["tables"], "alpha": r["alpha"], "f16_screen": r["f16_screen"], "sharding": "none"}})
-    for k_ in ("roofline", "stage_frac", "stage_frac_note", "kernels", "stages_ms", "certified_queries", "exhaustive_fallback_queries",
+    for k_ in ("ms_median", "ms_min", "ms_max", "ms_mean_events", "ms_series", "ms_series_note", "roofline", "dominant_kernel", "stage_frac", "stage_frac_note",
+               "kernels", "stages_ms", "stage_sum_ms", "certified_queries", "exhaustive_fallback_queries",
                "parity_checked_queries", "hip_graph", "f32_screen", "query_latency_ms", "pair_score", "cpu_baseline", "speedup_vs_cpu",
                "speedup_vs_reference_shaped_loop", "api_latency_ms"):
         if k_ in r:
@@ -785,6 +826,184 @@ def finish_line(base, r):
         out["recall_latency_ms"] = r["api_latency_ms"]["model_get_topk"]
         out["recall_latency_note"] = "wall time of model_get_topk for all anchors through the drop-in API (the reference's retrieval_time), results on the host"
     return out
+
+
+def _r(x, sig=5):
+    """float -> `sig` significant digits (the compact line is capped at ~3 KB)"""
+    if x is None or isinstance(x, (bool, int, str)):
+        return x
+    x = float(x)
+    if x == 0.0 or x != x or x in (float("inf"), float("-inf")):
+        return x
+    from math import floor, log10
+    return round(x, sig - 1 - int(floor(log10(abs(x)))))
+
+
+def compact_line(full, detail_path):
+    """The LAST stdout line: <= 3 KB, everything the driver / judge reads first; the full object goes to `detail_path`."""
+    def roof(r):
+        if not r:
+            return None
+        out = {k_: (_r(r[k_]) if k_ in ("achieved", "peak", "frac") else r.get(k_)) for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source") if k_ in r}
+        out["kernel"] = str(out.get("kernel", ""))[:48]
+        return out
+    out = {k_: full.get(k_) for k_ in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_median", "ms_min", "ms_max", "higher_is_better",
+                                      "scaling", "vs_baseline", "dtype", "data")}
+    for k_ in ("value", "ms_per_step", "ms_median", "ms_min", "ms_max"):
+        out[k_] = _r(out.get(k_), 6)
+    c = full.get("config", {})
+    out["config"] = {k_: c.get(k_) for k_ in ("workload", "users", "items_total", "d", "k", "tables", "alpha", "sharding") if k_ in c}
+    out["roofline"] = roof(full.get("roofline"))
+    if "dominant_kernel" in full:
+        out["dominant_kernel"] = full["dominant_kernel"]
+    cb = full.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"][:72],
+                               "cpu_model": (cb.get("host") or {}).get("cpu_model"),
+                               "reference_shaped_value": _r((cb.get("reference_shaped") or {}).get("value"))}
+        out["speedup_vs_cpu"] = _r(full.get("speedup_vs_cpu"), 4)
+        out["speedup_vs_reference_shaped_loop"] = _r(full.get("speedup_vs_reference_shaped_loop"), 4)
+    if "recall_latency_ms" in full:
+        out["recall_latency_ms"] = _r(full["recall_latency_ms"], 4)
+    if full.get("query_latency_ms"):
+        out["query_latency_ms"] = {str(e["batch"]): _r(e["ms"], 4) for e in full["query_latency_ms"]}
+    cfgs = {}
+    for name, r in (full.get("configs") or {}).items():
+        e = {"ms_per_step": _r(r["ms_per_step"]), "ms_median": _r(r["ms_median"]), "ms_min": _r(r["ms_min"]), "value": _r(r["value"]), "dtype": r["dtype"],
+             "frac": _r(r["roofline"]["frac"], 3), "bound": r["roofline"]["bound"], "stage_sum_ms": _r(r.get("stage_sum_ms"), 4),
+             "parity_checked_queries": r["parity_checked_queries"]}
+        if "f32_screen" in r:
+            e["f32_screen_ms"] = _r(r["f32_screen"]["ms_per_step"], 4)
+            e["f32_screen_frac"] = _r(r["f32_screen"].get("knn_screen_frac_of_fp32_mfma_peak"), 3)
+        if r.get("query_latency_ms"):
+            e["query_latency_ms"] = {str(q["batch"]): _r(q["ms"], 4) for q in r["query_latency_ms"]}
+        if "speedup_vs_cpu" in r:
+            e["speedup_vs_cpu"] = _r(r["speedup_vs_cpu"], 4)
+        cfgs[name] = e
+    if cfgs:
+        out["configs"] = cfgs
+    for k_ in ("strong_scaling_headroom", "emulated_shards"):
+        if k_ in full:
+            v = full[k_]
+            out[k_] = {kk: (_r(vv) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "note" and not isinstance(vv, (list, dict))}
+    out["bench_wall_s"] = _r(full.get("bench_wall_s"), 4)
+    out["detail"] = detail_path
+    return out
+
+
+def write_detail(full, path):
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(full, fh)
+        return path
+    except OSError as e:
+        sys.stderr.write("[bench] could not write %s: %s\n" % (path, e))
+        return None
+
+
+# ====================================================================================================================
+# one GPU rehearses the G-GPU job (--emulate-shards G): same shards, same pack / merge kernels, same buffer layout - no collective
+# ====================================================================================================================
+def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_screen=False, log=None):
+    """-> dict.  The catalogue of `cfg` on ONE GPU, three ways: (1) as a single table (the N = 1 job); (2) cut into the G
+    `shard_bounds` ranges, each searched with ids = id_base + local row exactly as rank g of `bench.py --gpus G` does (its own blend,
+    its own per-type table, local (distance, id) order), packed by hwer_pack_exchange into slice g of ONE (G, 3, B, k) int64 buffer -
+    the layout `all_gather_into_tensor` gives the receive buffer - and merged in place by hwer_merge_topk_strided; (3) the oracle's
+    brute force over the whole catalogue on `n_oracle` sampled queries.  Asserts (2) == (1) for every query (ids, scores, squared
+    distances) and (2) == (3) on the sample."""
+    from hwer import native
+    from hwer.distributed import merge_on_device, pack_send_buffer, shard_bounds
+    from oracle import c_oracle
+    from oracle import hwer_oracle as orc
+    I_total, d = cfg["I"], cfg["d"]
+    say = log or (lambda *_: None)
+    # (1) the single table
+    w1 = Workload(torch, lib, cfg, dev, f32_screen=f32_screen, want_dist=True)
+    B, U = w1.B, w1.U
+    for _ in range(warmup):
+        w1.step()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    e[0].record()
+    for i in range(steps):
+        w1.step()
+        e[i + 1].record()
+    torch.cuda.synchronize()
+    single_ms = float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(steps)]))
+    n_exh_single = w1.checks(w1.sets[0])
+    one = {k_: w1.sets[0][k_].clone() for k_ in ("idx", "score", "dist2")}
+    items_h = w1.V[U:, :d].cpu().numpy() if n_oracle else None
+    users_h = w1.V[:U, :d].cpu().numpy().astype(np.float64)
+    del w1
+    torch.cuda.empty_cache()
+    say("single table: %.3f ms / step" % single_ms)
+    # (2) the G shards, one after the other, into the all-gather's receive layout
+    recv = torch.empty((G, 3, B, K), dtype=torch.int64, device=dev)
+    shard_ms, n_exh = [], 0
+    for g in range(G):
+        lo, hi = shard_bounds(I_total, G, g)
+        w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=f32_screen, want_dist=True, local_order=True)
+        for _ in range(warmup):
+            w.step()
+        e[0].record()
+        for i in range(steps):
+            w.step()
+            e[i + 1].record()
+        torch.cuda.synchronize()
+        shard_ms.append(float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(steps)])))
+        n_exh += w.checks(w.sets[0])
+        o = w.sets[0]
+        recv[g].copy_(pack_send_buffer(o["idx"], o["score"], o["dist2"], 1)[0])
+        say("shard %d rows [%d, %d): %.3f ms / step" % (g, lo, hi, shard_ms[-1]))
+        del w, o
+        torch.cuda.empty_cache()
+    views = (recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64))     # strided: list stride 3 B k
+    m = merge_on_device(*views, True)
+    merge_ms = cuda_time(torch, lambda: merge_on_device(*views, True), 5, warm=1)
+    m_idx, m_score, m_d2 = (t.cpu().numpy() for t in m)
+    same = {"idx": bool(np.array_equal(m_idx, one["idx"].cpu().numpy())), "score": bool(np.array_equal(m_score, one["score"].cpu().numpy())),
+            "dist2": bool(np.array_equal(m_d2, one["dist2"].cpu().numpy()))}
+    assert all(same.values()), "merged shards differ from the single table: %s" % same
+    # (3) oracle on sampled queries
+    n_par = 0
+    if n_oracle:
+        cores, _ = effective_cpus()
+        sel = np.unique(np.linspace(0, B - 1, n_oracle).astype(np.int64))
+        Qh = np.stack([orc.query_vector(users_h, int(q)) for q in sel])
+        oi, osc, od2 = c_oracle.find_closest_f64(items_h, Qh, users_h[sel], K, threads=cores)
+        assert np.array_equal(m_idx[sel], oi + U), "merged indices differ from the oracle"
+        assert np.array_equal(m_score[sel], osc), "merged scores differ from the oracle"
+        assert np.array_equal(m_d2[sel], od2), "merged distances differ from the oracle"
+        n_par = int(len(sel))
+    return {"shards": G, "queries": B, "items_total": I_total, "single_table_ms": single_ms, "shard_ms": shard_ms, "shard_ms_max": max(shard_ms),
+            "merge_ms": merge_ms, "speedup_before_exchange": single_ms / (max(shard_ms) + merge_ms), "merged_equals_single_table": True,
+            "queries_compared": B, "oracle_checked_queries": n_par, "exhaustive_fallback_queries": {"single": n_exh_single, "shards": n_exh},
+            "recv_layout": "(G, 3, B, k) int64 = all_gather_into_tensor's receive buffer; merged in place (list stride 3*B*k)"}
+
+
+def run_emulated_shards(args):
+    import torch
+    from hwer import native
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    lib = native.lib()
+    name = args.config or "c4full"
+    cfg = dict(CONFIGS[name])
+    if os.environ.get("HWER_BENCH_ITEMS"):
+        cfg["I"] = int(os.environ["HWER_BENCH_ITEMS"])
+        cfg["name"] += " [catalogue cut to %d items]" % cfg["I"]
+    t0 = time.perf_counter()
+    r = emulate_shards(torch, lib, cfg, dev, args.emulate_shards, steps=max(3, min(args.steps, 10)), warmup=max(2, min(args.warmup, 3)),
+                       f32_screen=args.f32_screen, log=lambda m: sys.stderr.write("[emulate] %s\n" % m))
+    B, I = r["queries"], r["items_total"]
+    step_ms = r["shard_ms_max"] + r["merge_ms"]
+    return {"metric": METRIC, "value": float(B) * I / (step_ms * 1e-3), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": step_ms, "ms_median": step_ms, "ms_min": min(r["shard_ms"]) + r["merge_ms"], "ms_max": step_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.f32_screen else "f16", "data": "synthetic",
+            "config": {"workload": cfg["name"] + ": %d-GPU job REHEARSED on one GPU (slowest shard + merge; no collective)" % r["shards"], "users": B,
+                       "items_total": I, "d": cfg["d"], "k": K, "tables": cfg["T"], "alpha": "per-row" if cfg["per_row"] else "scalar",
+                       "sharding": "emulated x%d" % r["shards"]},
+            "emulated_shards": r, "bench_wall_s": time.perf_counter() - t0}
 
 
 # ====================================================================================================================
@@ -812,6 +1031,7 @@ def run_sharded(args, rank, local_rank, world):
         cfg["I"] = int(os.environ["HWER_BENCH_ITEMS"])
         cfg["name"] += " [catalogue cut to %d items]" % cfg["I"]
     I_total, U, d = cfg["I"], cfg["U"], cfg["d"]
+    assert cfg.get("B", U) == U, "the strong-scaling job expects every user row to be a query (c4full, c4)"
     lo, hi = shard_bounds(I_total, world, rank)
     w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2)
     comm = torch.cuda.Stream(device=dev)
@@ -985,16 +1205,29 @@ def main():
     ap.add_argument("--sweep-only", action="store_true",
                     help="profiling runs: skip the latency / pair-score / float32-screen measurements after the timed region, so that "
                          "the launches in a rocprofv3 summary are (almost only) those of the timed sweep")
+    ap.add_argument("--emulate-shards", type=int, default=0, metavar="G",
+                    help="one GPU rehearses the G-GPU job: the 10M-row catalogue cut into the G shard_bounds ranges, every shard searched in turn "
+                         "(ids = id_base + local row), packed by hwer_pack_exchange into a (G, 3, B, k) buffer laid out like the all-gather's "
+                         "receive buffer, merged by hwer_merge_topk_strided and compared with the single-table result")
+    ap.add_argument("--detail-out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where the full (~25 KB) result object goes; stdout carries ONE compact (<= 3 KB) JSON line")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         if world != 1:
             raise SystemExit("bench.py --gpus %d launched with WORLD_SIZE=%d" % (args.gpus, world))
         sys.exit(self_launch(args, sys.argv[1:]))      # nothing has touched a GPU in this process
+    # the oracle's checker library is built / loaded BEFORE anything touches a GPU (its `make` is a fork + exec)
+    from oracle import c_oracle
+    c_oracle.lib()
     if world > 1:
         run_sharded(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world)
         return
-    print(json.dumps(run_single(args)))
+    full = run_emulated_shards(args) if args.emulate_shards else run_single(args)
+    path = write_detail(full, args.detail_out)
+    line = json.dumps(compact_line(full, os.path.relpath(path, ROOT) if path else None), separators=(",", ":"))
+    print(line)
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

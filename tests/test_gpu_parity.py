@@ -967,10 +967,10 @@ def test_fit_feature_table_vs_oracle_shapes(hw, case):
     (128, 9000, 70000, 200, "one list, TQ = 2"),
 ])
 def test_knn_f16_streaming_screen_is_invisible(hw, monkeypatch, d, N, B, k, splits):
-    """HWER_KNN_F16_SCREEN: the streaming screen on the float16 copy of the table (v_mfma_f32_32x32x8_f16) must return the
+    """HWER_KNN_F16_SCREEN: the streaming screen on the float16 copy of the table (v_mfma_f32_32x32x16_f16) must return the
     same ids / scores / distances as the float32 screen and the oracle - bit for bit; non-unit row norms included.
-    (HWER_NO_SMALL keeps these modest shapes on the streaming path: by default launches that cannot fill the machine are
-    routed through the dense-key small-batch path.)"""
+    (All five shapes hold more than 1 024 queries and therefore stream anyway; HWER_NO_SMALL - read by the host mirror,
+    DeviceIndex._path_options -> HWER_KNN_NO_SMALL - only pins that choice against future changes of the path rule.)"""
     from hwer.device_index import DeviceIndex
     monkeypatch.setenv("HWER_NO_SMALL", "1")
     X = unit_rows_f32(135 + d, N, d)
