@@ -1271,9 +1271,9 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
 int hwer_knn_workspace_init(void* workspace, size_t workspace_bytes, void* stream) {
     if (!workspace || workspace_bytes < size_t(WS_HEADER_BYTES)) return fail(HWER_EINVAL, "knn_workspace_init: workspace too small");
     if (hipMemsetAsync(workspace, 0, WS_HEADER_BYTES, as_stream(stream)) != hipSuccess) return fail(HWER_ELAUNCH, "knn_workspace_init: memset failed");
-    const unsigned int magic = WS_INIT_MAGIC;
-    if (hipMemcpyAsync(&static_cast<WsHeader*>(workspace)->init_magic, &magic, sizeof(magic), hipMemcpyHostToDevice, as_stream(stream)) != hipSuccess)
-        return fail(HWER_ELAUNCH, "knn_workspace_init: copy failed");
+    // (a device-side fill: no pageable host source, valid under stream capture)
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&static_cast<WsHeader*>(workspace)->init_magic), int(WS_INIT_MAGIC), 1, as_stream(stream)) != hipSuccess)
+        return fail(HWER_ELAUNCH, "knn_workspace_init: fill failed");
     return HWER_OK;
 }
 

@@ -135,14 +135,19 @@ def on_device_kw(fn):
     """Decorator for host-mirror functions with a `device=None` keyword: resolve it once and run the body with that device
     current, so that every allocation, launch and stream query inside refers to the same GPU."""
     import functools
+    import inspect
+    sig = inspect.signature(fn)
 
     @functools.wraps(fn)
-    def wrapped(*a, device=None, **kw):
+    def wrapped(*a, **kw):
         import torch
         if not torch.cuda.is_available():
             raise HwerNativeError("hwer (MI355X build) needs a ROCm GPU: torch.cuda.is_available() is False; "
                                   "there is no CPU fallback for this path")
+        bound = sig.bind_partial(*a, **kw)     # `device` may arrive positionally or by keyword
+        device = bound.arguments.get("device")
         dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        bound.arguments["device"] = dev
         with torch.cuda.device(dev):
-            return fn(*a, device=dev, **kw)
+            return fn(*bound.args, **bound.kwargs)
     return wrapped

@@ -10,7 +10,7 @@ import operator
 import random
 import time
 from collections import defaultdict
-from collections.abc import Mapping
+from collections.abc import MutableMapping
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -24,22 +24,37 @@ def model_get_topk_arrays(model, anchors: List[Node], node_type: NodeType, k: in
     return model.find_closest_neighbours_batch(node_type, anchors, k=k)
 
 
-class LazyRows(Mapping):
-    """Read-only {key: list} whose lists are built from array rows on first access (and cached).  The retrieval sweep returns
-    U x 200 neighbours; as eager Python objects that is millions of tuples built after a sub-millisecond search - most
-    callers only look at some users, or only iterate once.  Supports the dict read API (`[]`, `in`, `len`, iteration,
-    keys / values / items, get) - what the reference's callers use on the dict they get (hwer/validation.py:133-141)."""
+class LazyRows(MutableMapping):
+    """{key: list} with `defaultdict(list)` semantics (what the reference returns, hwer/validation.py:30-35) whose lists are built
+    from array rows on first access (and cached).  The retrieval sweep returns U x 200 neighbours; as eager Python objects that is
+    millions of tuples built after a sub-millisecond search - most callers only look at some users, or only iterate once.
+    Full dict API: `[]` (an unknown key gives - and stores - an empty list, like the reference's defaultdict), `in`, `len`,
+    iteration, keys / values / items, get, assignment, `del`, pop, update."""
 
     def __init__(self, keys, build_row):
-        self._pos = {k: j for j, k in enumerate(keys)}
+        self._pos = {k: j for j, k in enumerate(keys)}   # keys whose list still lives in the arrays (or in the cache)
         self._build = build_row
         self._cache = {}
 
     def __getitem__(self, key):
         got = self._cache.get(key)
         if got is None:
-            got = self._cache[key] = self._build(self._pos[key])   # KeyError for an unknown key, like a dict
+            j = self._pos.get(key)
+            got = self._cache[key] = self._build(j) if j is not None else []   # defaultdict(list).__missing__
+            if j is None:
+                self._pos[key] = None
         return got
+
+    def get(self, key, default=None):   # like dict.get: no insertion for unknown keys
+        return self[key] if key in self._pos else default
+
+    def __setitem__(self, key, value):
+        self._pos.setdefault(key, None)
+        self._cache[key] = value
+
+    def __delitem__(self, key):
+        del self._pos[key]              # KeyError for an unknown key, like a dict
+        self._cache.pop(key, None)
 
     def __iter__(self):
         return iter(self._pos)

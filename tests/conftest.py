@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the oracle's C checker is built / loaded here, before any test touches a GPU (its `make` is a fork + exec, which a
+# GPU-initialised process must not do - oracle/c_oracle.py refuses it)
+from oracle import c_oracle as _c_oracle  # noqa: E402
+_c_oracle.lib()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
