@@ -163,213 +163,83 @@ def gen_unit_rows(torch, seed, lo, hi, d, dev):
     return out
 
 
-class Workload:
-    """The resident tensors of one configuration on one GPU and the step over them.  `lo:hi` = the item rows this GPU holds
-    (the whole catalogue at N = 1); ids reported by the search are global: users 0..U-1, then the items."""
+def make_workload_class():
+    from hwer.pipeline import BlendSearchStep
 
-    def __init__(self, torch, lib, cfg, dev, lo=None, hi=None, f32_screen=False, f16_dense=False, want_dist=False, local_order=False,
-                 n_sets=1):
-        from hwer import native
-        from hwer.device_index import roundup
-        self.torch, self.lib, self.cfg, self.dev, self.native = torch, lib, cfg, dev, native
-        U, I_total, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
-        lo = 0 if lo is None else lo
-        hi = I_total if hi is None else hi
-        I = hi - lo
-        self.U, self.I, self.d, self.T, self.lo, self.hi = U, I, d, T, lo, hi
-        self.B = B = int(cfg.get("B", U))     # queries per step = the first B users (default: every user)
-        self.N = N = U + I
-        self.ldv = roundup(d, 4)
-        assert self.ldv == d, "bench tables are passed with row stride d"
-        self.ldx = lib.hwer_knn_padded_dim(d)
-        self.tables = []
-        for t in range(T):
-            tab = torch.empty((N, d), dtype=torch.float32, device=dev)
-            tab[:U] = gen_unit_rows(torch, 3000 + 20 * t, 0, U, d, dev)          # users: identical on every rank
-            tab[U:] = gen_unit_rows(torch, 3001 + 20 * t, lo, hi, d, dev)        # items: rows lo..hi of the catalogue
-            self.tables.append(tab)
-        if cfg["per_row"]:
-            # Dirichlet(1, .., 1) = normalised unit exponentials; 20 % cold-start rows (alpha_collab = 0, renormalised).
-            # Row-wise deterministic like the tables: generated per global row block.
-            al = torch.empty((N, T), dtype=torch.float32, device=dev)
-            al[:U] = self._alpha_rows(5005, 0, U)
-            al[U:] = self._alpha_rows(5006, lo, hi)
-            self.alpha = al.contiguous()
-        else:
-            self.alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
-        self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
-        self.item_rows = torch.arange(U, N, dtype=torch.int64, device=dev)
-        self.anchors = torch.arange(0, B, dtype=torch.int32, device=dev)
-        self.V = torch.zeros((N, self.ldv), dtype=torch.float32, device=dev)
-        self.audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)     # counts[4] | sum |norm-1| (f64) | pad
-        self.audit_counts = self.audit_buf[:4]
-        self.audit_dev = self.audit_buf[4:5].view(torch.float64)
-        I_pad = lib.hwer_knn_padded_rows(I)
-        self.I_pad = I_pad
-        self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
-        self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
-        # float16 screen wherever it pays (hwer_knn_f16_screen_pays: every streamed catalogue, dense ones from ~1e9 multiply-adds)
-        self.f16_screen = ((not f32_screen) and bool(lib.hwer_knn_f16_screen_pays(min(B, 131072), I, d))) or (f16_dense and I <= 8192)
-        self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
-        self.Q64 = torch.empty((B, d), dtype=torch.float64, device=dev)
-        self.Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=dev)
-        self.want_dist = want_dist
-        self.sort_by_score = 0 if local_order else 1
-        self.sets = [dict(idx=torch.empty((B, K), dtype=torch.int64, device=dev), score=torch.empty((B, K), dtype=torch.float64, device=dev),
-                          dist2=torch.empty((B, K), dtype=torch.float64, device=dev) if want_dist else None,
-                          flags=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
-        self.CH = 131072   # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per launch
-        # HWER_KNN_F16_SCREEN (2) above 8 192 rows; HWER_BENCH_OPTS ORs in further option bits for A/B runs (e.g. 16 = HWER_KNN_NO_SEED)
-        self.opts = (2 if self.f16_screen else 0) | int(os.environ.get("HWER_BENCH_OPTS", "0"))
-        ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(B, self.CH), I, d, K, self.opts),
-                       lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(B, 64), I, d, K, 0))
-        assert ws_bytes > 0
-        self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        self.native.check(lib.hwer_knn_workspace_init(self.native.ptr(self.ws), self.ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "knn_workspace_init")   # once per allocation
-        self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
-        self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
-        # More users than one search takes (c3: 131 072 + 7 421): the short last search runs on a second stream with its own
-        # workspaces, beside the first one - its MFMA-bound screen fills the issue slots the first search's gather-bound select
-        # leaves idle (c3: the 0.64 ms of the last 7 421 users disappear behind the main search).
-        self.tail = B % self.CH if (B > self.CH and not os.environ.get("HWER_BENCH_NO_TAIL_STREAM")) else 0
-        self.overlap_tail = True
-        if self.tail:
-            self.side = torch.cuda.Stream(device=dev)
-            self.ws_tail = torch.empty(lib.hwer_knn_workspace_bytes_opts(self.tail, I, d, K, self.opts), dtype=torch.uint8, device=dev)
-            self.ws_exact_tail = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
-        # rows passed the 1e-4 unit-norm audit (checked after the timed region) => 0.5||x||^2 <= 0.5 (1 + 1e-4)^2
-        self.hnorm_max = 0.5 * (1.0 + 1e-4) ** 2
-        self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
-        self.id_base = U + lo
-        self.arith = 0                  # float64 score arithmetic (ContentRecommendation flavour)
-        # Small catalogues (dense path): the prologue's two latency-floor kernels run as ONE launch that also writes the search's
-        # query fragments (hwer_prepare_search_f32 + HWER_KNN_QUERIES_READY); one search call per step only.
-        self.fused_prologue = I <= 8192 and B <= self.CH and not os.environ.get("HWER_BENCH_NO_FUSED_PROLOGUE")
-        self.fused_fragments = self.fused_prologue and not self.f16_screen
-        # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel)
-        # (large catalogues too: the per-type table and its float16 copy are written from the blended row in registers instead of
-        # being re-read from V - one pass over the rows less.  Measured: c4full 21.6 -> 20.5 ms, c4 3.03 -> 3.00; NOT where the
-        # anchors outnumber the rows (c3: every anchor row is blended a second time for its query, 5.85 -> 6.12 ms) - that shape keeps
-        # the separate launches.  c5 (four tables, per-row weights, d = 256): prologue 1.84 -> 1.63 ms.)
-        self.fused_blend = ((self.fused_prologue or (self.d <= 256 and 8 * B <= I)) and not os.environ.get("HWER_BENCH_NO_FUSED_BLEND")) or bool(os.environ.get("HWER_BENCH_FORCE_FUSED_BLEND"))
-        self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) if self.fused_fragments else 0
+    class Workload(BlendSearchStep):
+        """One configuration on one GPU: the synthetic resident tables + the LIBRARY's step over them (hwer.pipeline.BlendSearchStep:
+        the timed step is exactly what `ContentRecommendation.blend_search_step(...).run()` launches).  `lo:hi` = the item rows this
+        GPU holds (the whole catalogue at N = 1); ids reported by the search are global: users 0..U-1, then the items."""
 
-    def _alpha_rows(self, seed, lo, hi):
-        torch = self.torch
-        T = self.T
-        out = torch.empty((hi - lo, T), dtype=torch.float32, device=self.dev)
-        gen = torch.Generator(device=self.dev)
-        for blk in range(lo // GEN_BLOCK, (hi + GEN_BLOCK - 1) // GEN_BLOCK):
-            gen.manual_seed(seed * 1000003 + blk)
-            e = -torch.log(torch.rand((GEN_BLOCK, T), generator=gen, device=self.dev, dtype=torch.float64).clamp_min(1e-300))
-            cold = torch.rand((GEN_BLOCK,), generator=gen, device=self.dev) < 0.2
-            e[cold, T - 1] = 0.0
-            e = (e / e.sum(1, keepdim=True)).to(torch.float32)
-            a, b = max(lo, blk * GEN_BLOCK), min(hi, (blk + 1) * GEN_BLOCK)
-            out[a - lo:b - lo] = e[a - blk * GEN_BLOCK:b - blk * GEN_BLOCK]
-        return out
+        def __init__(self, torch, lib, cfg, dev, lo=None, hi=None, f32_screen=False, f16_dense=False, want_dist=False, local_order=False,
+                     n_sets=1):
+            self.torch, self.cfg, self.dev = torch, cfg, dev
+            U, I_total, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
+            lo = 0 if lo is None else lo
+            hi = I_total if hi is None else hi
+            I = hi - lo
+            self.T, self.lo, self.hi = T, lo, hi
+            B = int(cfg.get("B", U))     # queries per step = the first B users (default: every user)
+            N = U + I
+            tables = []
+            for t in range(T):
+                tab = torch.empty((N, d), dtype=torch.float32, device=dev)
+                tab[:U] = gen_unit_rows(torch, 3000 + 20 * t, 0, U, d, dev)          # users: identical on every rank
+                tab[U:] = gen_unit_rows(torch, 3001 + 20 * t, lo, hi, d, dev)        # items: rows lo..hi of the catalogue
+                tables.append(tab)
+            if cfg["per_row"]:
+                # Dirichlet(1, .., 1) = normalised unit exponentials; 20 % cold-start rows (alpha_collab = 0, renormalised).
+                # Row-wise deterministic like the tables: generated per global row block.
+                al = torch.empty((N, T), dtype=torch.float32, device=dev)
+                al[:U] = self._alpha_rows(5005, 0, U)
+                al[U:] = self._alpha_rows(5006, lo, hi)
+                alpha = al.contiguous()
+            else:
+                alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
+            env = os.environ.get
+            super().__init__(tables, alpha, search_row0=U, n_search=I, other_row0=0, n_other=U,
+                             anchors=torch.arange(0, B, dtype=torch.int32, device=dev), k=K, id_base=U + lo, arith=0,   # float64 score flavour
+                             want_dist=want_dist, sort_by_score=not local_order, f16_screen=False if f32_screen else None, f16_dense=f16_dense,
+                             n_sets=n_sets, extra_options=int(env("HWER_BENCH_OPTS", "0")),     # A/B runs: e.g. 16 = HWER_KNN_NO_SEED
+                             fused_blend=True if env("HWER_BENCH_FORCE_FUSED_BLEND") else (False if env("HWER_BENCH_NO_FUSED_BLEND") else None),
+                             fused_prologue=False if env("HWER_BENCH_NO_FUSED_PROLOGUE") else None, tail_stream=not env("HWER_BENCH_NO_TAIL_STREAM"))
 
-    # ---- stages of a step (each a closure over the resident tensors; S() = the current torch stream) -----------------------
-    def S(self):
-        return ctypes.c_void_p(self.torch.cuda.current_stream().cuda_stream)
-
-    def stage_blend(self):
-        P, lib, c = self.native.ptr, self.lib, self.cfg
-        self.native.check(lib.hwer_blend_normalize_audit_f32(P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if c["per_row"] else 0, self.T, self.N,
-                                                             self.d, P(self.V), self.ldv, 1e-4, P(self.audit_counts), P(self.audit_dev), self.S()), "blend+audit")
-
-    def stage_pack(self):
-        P, lib = self.native.ptr, self.lib
-        # per-type table + half norms (+ the float16 copy in the same pass: its scale follows from the unit-norm audit bound)
-        self.native.check(lib.hwer_pack_rows_f32_f16(P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
-                                                     P(self.X16) if self.f16_screen else None, self.x16_exp, self.S()), "pack")
-
-    def stage_queries(self):
-        P, lib = self.native.ptr, self.lib
-        self.native.check(lib.hwer_query_mix(P(self.V), self.N, self.d, self.ldv, P(self.anchors), None, None, None, None, self.B, self.arith,
-                                             P(self.Q64), P(self.Q32), self.ldx, self.S()), "query_mix")
-
-    def stage_search(self, o, B=None, opts=None):
-        """exact top-K of queries 0..B-1 (default: all) into result set `o`; uncertified queries (rare: near-ties at the cut,
-        or a sample-scaled threshold that was too tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the
-        device (no host round trip): the step always returns exact results."""
-        P, lib = self.native.ptr, self.lib
-        U = self.B if B is None else B
-        opts = self.opts if opts is None else opts
-        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
-
-        def search(b0, b1, ws, ws_exact):   # on the CURRENT torch stream
-            self.native.check(lib.hwer_knn_search_opts_f32(
-                P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.V), self.ldv,
-                P(self.anchors[b0:b1]), b1 - b0, K, self.arith, self.sort_by_score, None, self.id_base, self.hnorm_max, P(oi[b0:b1]),
-                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(ws), ws.numel(), opts,
-                P(self.X16) if self.f16_screen else None, self.x16_exp, self.S()), "knn_search")
-            self.native.check(lib.hwer_knn_exact_device(
-                P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
-                self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
-                P(ws), P(self.missed), P(ws_exact), ws_exact.numel(), self.S()), "knn_exact_device")
-        side_tail = self.tail and U == self.B and self.overlap_tail
-        if side_tail:   # the short last search, on the second stream
+        def _alpha_rows(self, seed, lo, hi):
             torch = self.torch
-            cur = torch.cuda.current_stream()
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
-                search(U - self.tail, U, self.ws_tail, self.ws_exact_tail)
-        for b0 in range(0, U - (self.tail if side_tail else 0), self.CH):
-            search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
-        if side_tail:
-            cur.wait_stream(self.side)
+            T = self.T
+            out = torch.empty((hi - lo, T), dtype=torch.float32, device=self.dev)
+            gen = torch.Generator(device=self.dev)
+            for blk in range(lo // GEN_BLOCK, (hi + GEN_BLOCK - 1) // GEN_BLOCK):
+                gen.manual_seed(seed * 1000003 + blk)
+                e = -torch.log(torch.rand((GEN_BLOCK, T), generator=gen, device=self.dev, dtype=torch.float64).clamp_min(1e-300))
+                cold = torch.rand((GEN_BLOCK,), generator=gen, device=self.dev) < 0.2
+                e[cold, T - 1] = 0.0
+                e = (e / e.sum(1, keepdim=True)).to(torch.float32)
+                a, b = max(lo, blk * GEN_BLOCK), min(hi, (blk + 1) * GEN_BLOCK)
+                out[a - lo:b - lo] = e[a - blk * GEN_BLOCK:b - blk * GEN_BLOCK]
+            return out
 
-    def stage_prepare(self):
-        """per-type table + queries (+ the search's float32 query fragments) in ONE launch: hwer_prepare_search_f32"""
-        P, lib = self.native.ptr, self.lib
-        self.native.check(lib.hwer_prepare_search_f32(
-            P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
-            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), None, None, None, None, self.B, self.arith,
-            P(self.Q64), P(self.Q32), self.ldx, P(self.ws) if self.fused_fragments else None, self.bq_frag, self.S()), "prepare_search")
+        # ---- algorithmic work (SURVEY.md §8d) -----------------------------------------------------------------------------------
+        def stage_bytes(self):
+            d, T, N, U, I = self.d, self.T, self.N, self.U, self.I
+            per_row = self.cfg["per_row"]
+            return {
+                "blend_normalize_audit": N * (4.0 * d * (T + 1) + (4.0 * T if per_row else 0.0)),       # T rows in, one out (+ per-row alpha)
+                "pack_rows": I * (4.0 * d + 4.0 * self.ldx + 4.0 + 8.0) + (I * 2.0 * self.ldx if self.f16_screen else 0.0),
+                "query_mix": self.B * (4.0 * d + 8.0 * d + 4.0 * self.ldx + 4.0),
+            }
 
-    def stage_blend_prepare(self):
-        """blend + audit + per-type table + queries (+ query fragments) in ONE launch: hwer_blend_prepare_search_f32"""
-        P, lib, c = self.native.ptr, self.lib, self.cfg
-        self.native.check(lib.hwer_blend_prepare_search_f32(
-            P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if c["per_row"] else 0, self.T, self.d, P(self.V), self.ldv, 1e-4,
-            P(self.audit_counts), P(self.audit_dev), None, self.U, self.I, None, 0, self.U, P(self.X), self.ldx, P(self.hnorm),
-            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), self.B, self.arith, P(self.Q64), P(self.Q32), self.ldx,
-            P(self.ws), self.bq_frag, self.S()), "blend_prepare_search")
+    return Workload
 
-    def step(self, o=None):
-        o = self.sets[0] if o is None else o
-        if self.fused_blend:          # small searches: the whole prologue is one launch (DESIGN.md 6)
-            self.stage_blend_prepare()
-            self.stage_search(o, opts=self.opts | (32 if self.fused_fragments else 0))
-        elif self.fused_prologue:     # (HWER_BENCH_NO_FUSED_BLEND: blend, then the fused table + queries launch)
-            self.stage_blend()
-            self.stage_prepare()
-            self.stage_search(o, opts=self.opts | (32 if self.fused_fragments else 0))
-        else:
-            self.stage_blend()
-            self.stage_pack()
-            self.stage_queries()
-            self.stage_search(o)
-        return o
 
-    # ---- algorithmic work (SURVEY.md §8d) -----------------------------------------------------------------------------------
-    def stage_bytes(self):
-        d, T, N, U, I = self.d, self.T, self.N, self.U, self.I
-        per_row = self.cfg["per_row"]
-        return {
-            "blend_normalize_audit": N * (4.0 * d * (T + 1) + (4.0 * T if per_row else 0.0)),       # T rows in, one out (+ per-row alpha)
-            "pack_rows": I * (4.0 * d + 4.0 * self.ldx + 4.0 + 8.0) + (I * 2.0 * self.ldx if self.f16_screen else 0.0),
-            "query_mix": self.B * (4.0 * d + 8.0 * d + 4.0 * self.ldx + 4.0),
-        }
+_WORKLOAD = None
 
-    def checks(self, o):
-        pos, neg, nan = self.audit_counts.tolist()[:3]
-        assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
-        n_uncert = int((o["flags"] == 0).sum().item())
-        assert n_uncert == 0, "%d queries left without an exact result" % n_uncert
-        assert int(self.missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(self.missed.item())
-        return int((o["flags"] == 2).sum().item())
+
+def Workload(*a, **kw):
+    global _WORKLOAD
+    if _WORKLOAD is None:
+        _WORKLOAD = make_workload_class()
+    return _WORKLOAD(*a, **kw)
 
 
 def cuda_time(torch, fn, reps, warm=2):

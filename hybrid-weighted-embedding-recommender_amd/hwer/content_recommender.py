@@ -192,4 +192,42 @@ class ContentRecommendation(RecommendationBase):
         return vec
 
 
+    def blend_search_step(self, nodes: List[Node], tables: Sequence, alpha, node_type: str, anchors: Sequence[Node], k: int = 200,
+                          want_dist: bool = False, capture: Optional[bool] = None, **step_kwargs):
+        """The whole hot path as ONE resident step (hwer.pipeline.BlendSearchStep): re-blend `tables` with `alpha` -> unit rows ->
+        audit -> table of `node_type` -> anchor queries -> exact top-k, every buffer preallocated.  For callers whose tables or
+        weights change between retrievals: write new values into `step.tables[t]` / `step.alpha` (device tensors) and call
+        `step.run()` again - one fused prologue launch + the search, no allocation, no host round trip; small shapes are replayed as
+        a hipGraph (`capture`, default: catalogues up to 8 192 rows).  Registers `nodes` like fit_tables (rows in `nodes` order).
+        -> the step; `step.results()` gives (global row ids (B, k), scores (B, k)) in find_closest_neighbours' order and
+        `self.knn.idx_to_node()`-style lookups map ids back to Nodes."""
+        import torch
+        from .device_index import _require_gpu
+        from .pipeline import BlendSearchStep
+        if not self.nodes_to_idx:
+            self.add_nodes(nodes)
+        assert len(nodes) == len(self.nodes_to_idx) and node_type in self.node_types
+        dev = _require_gpu(self.device)
+        with native.device_guard(dev):
+            N = len(nodes)
+            tabs = [t if (isinstance(t, torch.Tensor) and t.is_cuda) else _dev_table(t, dev, tables[0].shape[1]) for t in tables]
+            al = alpha if isinstance(alpha, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(alpha, dtype=np.float32))
+            al = al.to(device=dev, dtype=torch.float32).contiguous()
+            is_t = np.fromiter((n.node_type == node_type for n in nodes), dtype=bool, count=N)
+            rows_t, rows_o = np.flatnonzero(is_t), np.flatnonzero(~is_t)
+
+            def rng(r):      # a contiguous range -> (row0, n, None); else an id list
+                if len(r) == 0 or int(r[-1]) - int(r[0]) + 1 == len(r):
+                    return (int(r[0]) if len(r) else 0), len(r), None
+                return 0, len(r), torch.from_numpy(r.astype(np.int64)).to(dev)
+            s0, ns, s_ids = rng(rows_t)
+            o0, no, o_ids = rng(rows_o)
+            a = np.fromiter((self.nodes_to_idx.get(n, -1) for n in anchors), dtype=np.int32, count=len(anchors))
+            step = BlendSearchStep(tabs, al, s0, ns, o0, no, torch.from_numpy(a).to(dev), k=k, want_dist=want_dist, search_ids=s_ids,
+                                   other_ids=o_ids, arith=0, **step_kwargs)
+            if capture if capture is not None else ns <= 8192:
+                step.capture()
+        return step
+
+
 ContentRecommender = ContentRecommendation  # the name BASELINE.json's north_star uses

@@ -1,0 +1,280 @@
+"""The hot path as ONE resident, allocation-free step (north_star): weighted blend of T embedding tables -> L2-normalise ->
+unit-norm audit -> per-type table (+ half norms, + float16 copy) -> anchor queries -> exact top-k retrieval (MFMA screen +
+float64 re-rank + re-score + sort; on-device exhaustive pass for any query the screen cannot certify).
+
+Reference lines covered, in one object: hwer/content_recommender.py:77-96 (blend + unit_length), hwer/recommendation_base.py:
+105-110 (audit + index build), :64-76 (per-type table), :153-155,164-170 (anchor query), :78-83,171-173 (k-NN + re-score +
+sort).  `DeviceIndex` answers queries against a STATIC table; `BlendSearchStep` is for callers whose tables or weights change
+between retrievals (new collaborative vectors after a training epoch, per-user alpha updates): every buffer is preallocated at
+construction, `run()` only launches kernels on the current stream - no allocation, no host synchronisation - so a step can be
+captured into a hipGraph and replayed (`capture()`).  It is what `bench.py` times, and what `ContentRecommendation.
+blend_search_step` hands to library users.
+
+Launch plan (chosen at construction, the same rules `bench.py` measured - DESIGN.md 4.6 / 6):
+  * few anchors (8 B <= rows of the searched type) or a small catalogue: the whole prologue is ONE launch,
+    hwer_blend_prepare_search_f32 (blend + audit + table + float16 copy + queries, and on float32 dense screens the search's
+    MFMA query fragments: HWER_KNN_QUERIES_READY);
+  * more anchors than rows: hwer_blend_normalize_audit_f32, hwer_pack_rows_f32_f16, hwer_query_mix (three launches);
+  * then hwer_knn_search_opts_f32 per 131 072 queries (a short last chunk runs beside the first on a second stream) and
+    hwer_knn_exact_device.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+from . import native
+from .device_index import roundup
+
+KNN_F16_SCREEN, KNN_QUERIES_READY = 2, 32
+QUERY_CHUNK = 131072       # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per search launch
+
+
+class BlendSearchStep:
+    """tables: T float32 device tensors (N, d) with row stride d (d % 4 == 0); alpha: (T,) or (N, T) float32 device tensor.
+    Rows [search_row0, search_row0 + n_search) are the searched node type, rows [other_row0, other_row0 + n_other) everything
+    else (both contiguous: the layout `RecommendationBase.add_nodes` gives when the nodes of a type are added together).
+    anchors: int32 device tensor of B row ids (-1 = unknown node).  Reported ids = id_base + local row of the searched range
+    (default: the row id in V).  search_ids / other_ids (int64 device tensors, ascending): the same two row sets as id lists, for
+    registries whose types are interleaved (then reported ids = the listed row ids).  arith 0 / 1: the reference's float64 / float32 score flavour.  sort_by_score False: ascending
+    (distance, id) order - what the multi-GPU merge consumes (then want_dist is forced)."""
+
+    def __init__(self, tables: Sequence, alpha, search_row0: int, n_search: int, other_row0: int, n_other: int, anchors, k: int = 200,
+                 id_base: Optional[int] = None, arith: int = 0, want_dist: bool = False, sort_by_score: bool = True,
+                 f16_screen: Optional[bool] = None, f16_dense: bool = False, n_sets: int = 1, extra_options: int = 0,
+                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = True, eps: float = 1e-4,
+                 search_ids=None, other_ids=None):
+        import torch
+        lib = self.lib = native.lib()
+        self.torch, self.native = torch, native
+        self.tables = list(tables)
+        T = self.T = len(self.tables)
+        dev = self.dev = self.tables[0].device
+        N, d = self.tables[0].shape
+        self.N, self.d = int(N), int(d)
+        for t in self.tables:
+            assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == (N, d), "tables: contiguous float32 (N, d)"
+        self.ldv = roundup(d, 4)
+        assert self.ldv == d, "tables are passed with row stride d (d % 4 == 0)"
+        self.ldx = lib.hwer_knn_padded_dim(d)
+        if self.ldx < 0:
+            raise native.HwerNativeError("BlendSearchStep: d=%d unsupported (1..%d)" % (d, lib.hwer_knn_max_dim()))
+        self.alpha = alpha
+        self.per_row = alpha.dim() == 2
+        assert alpha.dtype == torch.float32 and alpha.is_contiguous() and tuple(alpha.shape) in ((T,), (N, T))
+        self.search_ids, self.other_ids = search_ids, other_ids
+        if search_ids is not None:
+            n_search, search_row0 = int(search_ids.numel()), 0
+            assert search_ids.dtype == torch.int64 and search_ids.is_contiguous()
+        if other_ids is not None:
+            n_other, other_row0 = int(other_ids.numel()), 0
+            assert other_ids.dtype == torch.int64 and other_ids.is_contiguous()
+        self.U, self.I = int(n_other), int(n_search)        # (bench vocabulary: U user rows, I item rows)
+        self.search_row0, self.other_row0 = int(search_row0), int(other_row0)
+        assert self.I >= 1 and self.search_row0 + self.I <= N and self.other_row0 + self.U <= N
+        I, K = self.I, int(k)
+        self.k = K
+        self.anchors = anchors
+        B = self.B = int(anchors.numel())
+        assert anchors.dtype == torch.int32 and B >= 1
+        self.eps = float(eps)
+        with native.device_guard(dev):
+            self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
+            self.item_rows = search_ids if search_ids is not None else torch.arange(self.search_row0, self.search_row0 + I, dtype=torch.int64, device=dev)
+            self.V = torch.zeros((N, self.ldv), dtype=torch.float32, device=dev)
+            self.audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)     # counts[4] | sum |norm-1| (f64) | pad
+            self.audit_counts = self.audit_buf[:4]
+            self.audit_dev = self.audit_buf[4:5].view(torch.float64)
+            I_pad = self.I_pad = lib.hwer_knn_padded_rows(I)
+            self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
+            self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
+            # float16 screen wherever it pays (hwer_knn_f16_screen_pays: every streamed catalogue, dense ones from ~1e9 multiply-adds)
+            if f16_screen is None:
+                f16_screen = bool(lib.hwer_knn_f16_screen_pays(min(B, QUERY_CHUNK), I, d))
+            self.f16_screen = bool(f16_screen and lib.hwer_knn_padded_dim(d) >= 64) or (f16_dense and I <= 8192)
+            self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
+            self.Q64 = torch.empty((B, d), dtype=torch.float64, device=dev)
+            self.Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=dev)
+            if not sort_by_score:
+                want_dist = True
+            self.want_dist = want_dist
+            self.sort_by_score = 1 if sort_by_score else 0
+            self.sets = [dict(idx=torch.empty((B, K), dtype=torch.int64, device=dev), score=torch.empty((B, K), dtype=torch.float64, device=dev),
+                              dist2=torch.empty((B, K), dtype=torch.float64, device=dev) if want_dist else None,
+                              flags=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
+            self.CH = QUERY_CHUNK
+            self.opts = (KNN_F16_SCREEN if self.f16_screen else 0) | int(extra_options)
+            ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(B, self.CH), I, d, K, self.opts),
+                           lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(B, 64), I, d, K, 0))
+            if ws_bytes == 0:
+                raise native.HwerNativeError("BlendSearchStep: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" % (B, I, d, K, lib.hwer_knn_max_k()))
+            self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws), self.ws.numel(), self.S()), "knn_workspace_init")   # once per allocation
+            self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
+            self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
+            # More anchors than one search takes (ML-20M shape: 131 072 + 7 421): the short last search runs on a second stream with its
+            # own workspaces, beside the first one - its MFMA-bound screen fills the issue slots the first search's gather-bound
+            # select leaves idle.
+            self.tail = B % self.CH if (B > self.CH and tail_stream) else 0
+            self.overlap_tail = True
+            if self.tail:
+                self.side = torch.cuda.Stream(device=dev)
+                self.ws_tail = torch.empty(lib.hwer_knn_workspace_bytes_opts(self.tail, I, d, K, self.opts), dtype=torch.uint8, device=dev)
+                self.ws_exact_tail = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
+        # rows pass the eps unit-norm audit (checked by `check()` after the step) => 0.5||x||^2 <= 0.5 (1 + eps)^2
+        self.hnorm_max = 0.5 * (1.0 + self.eps) ** 2
+        self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
+        self.id_base = 0 if search_ids is not None else (self.search_row0 if id_base is None else int(id_base))
+        self.arith = int(arith)
+        # Small catalogues (dense path): the prologue's two latency-floor kernels run as ONE launch that also writes the search's
+        # query fragments (hwer_prepare_search_f32 + HWER_KNN_QUERIES_READY); one search call per step only.
+        self.fused_prologue = (I <= 8192 and B <= self.CH) if fused_prologue is None else bool(fused_prologue)
+        self.fused_fragments = self.fused_prologue and not self.f16_screen
+        # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel).  Large
+        # catalogues too: the per-type table and its float16 copy are written from the blended row in registers instead of being
+        # re-read from V - one pass over the rows less.  NOT where the anchors outnumber the rows (every anchor row is blended a
+        # second time for its query): that shape keeps the separate launches.
+        self.fused_blend = (self.fused_prologue or (self.d <= 256 and 8 * B <= I)) if fused_blend is None else bool(fused_blend)
+        self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) if self.fused_fragments else 0
+        self._graph = None
+
+    # ---- stages of a step (S() = the current torch stream of the step's device) -----------------------------------------------
+    def S(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def stage_blend(self):
+        P, lib = native.ptr, self.lib
+        native.check(lib.hwer_blend_normalize_audit_f32(P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if self.per_row else 0, self.T, self.N,
+                                                        self.d, P(self.V), self.ldv, self.eps, P(self.audit_counts), P(self.audit_dev), self.S()), "blend+audit")
+
+    def stage_pack(self):
+        P, lib = native.ptr, self.lib
+        # per-type table + half norms (+ the float16 copy in the same pass: its scale follows from the unit-norm audit bound)
+        native.check(lib.hwer_pack_rows_f32_f16(P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
+                                                P(self.X16) if self.f16_screen else None, self.x16_exp, self.S()), "pack")
+
+    def stage_queries(self):
+        P, lib = native.ptr, self.lib
+        native.check(lib.hwer_query_mix(P(self.V), self.N, self.d, self.ldv, P(self.anchors), None, None, None, None, self.B, self.arith,
+                                        P(self.Q64), P(self.Q32), self.ldx, self.S()), "query_mix")
+
+    def stage_search(self, o, B=None, opts=None):
+        """exact top-k of queries 0..B-1 (default: all) into result set `o`; uncertified queries (rare: near-ties at the cut, or a
+        sampled threshold that was too tight) are recomputed by the exhaustive float64 pass INSIDE the step, on the device (no host
+        round trip): up to 8 per search call; anything beyond is counted in `self.missed` and reported by check()."""
+        P, lib, K = native.ptr, self.lib, self.k
+        U = self.B if B is None else B
+        opts = self.opts if opts is None else opts
+        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
+
+        def search(b0, b1, ws, ws_exact):   # on the CURRENT torch stream
+            native.check(lib.hwer_knn_search_opts_f32(
+                P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.V), self.ldv,
+                P(self.anchors[b0:b1]), b1 - b0, K, self.arith, self.sort_by_score, P(self.search_ids), self.id_base, self.hnorm_max, P(oi[b0:b1]),
+                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(ws), ws.numel(), opts,
+                P(self.X16) if self.f16_screen else None, self.x16_exp, self.S()), "knn_search")
+            native.check(lib.hwer_knn_exact_device(
+                P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
+                self.sort_by_score, P(self.search_ids), self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
+                P(ws), P(self.missed), P(ws_exact), ws_exact.numel(), self.S()), "knn_exact_device")
+        side_tail = self.tail and U == self.B and self.overlap_tail
+        if side_tail:   # the short last search, on the second stream
+            torch = self.torch
+            cur = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                search(U - self.tail, U, self.ws_tail, self.ws_exact_tail)
+        for b0 in range(0, U - (self.tail if side_tail else 0), self.CH):
+            search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
+        if side_tail:
+            cur.wait_stream(self.side)
+
+    def stage_prepare(self):
+        """per-type table + queries (+ the search's float32 query fragments) in ONE launch: hwer_prepare_search_f32"""
+        P, lib = native.ptr, self.lib
+        native.check(lib.hwer_prepare_search_f32(
+            P(self.V), self.N, self.d, self.ldv, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
+            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), None, None, None, None, self.B, self.arith,
+            P(self.Q64), P(self.Q32), self.ldx, P(self.ws) if self.fused_fragments else None, self.bq_frag, self.S()), "prepare_search")
+
+    def stage_blend_prepare(self):
+        """blend + audit + per-type table + queries (+ query fragments) in ONE launch: hwer_blend_prepare_search_f32"""
+        P, lib = native.ptr, self.lib
+        native.check(lib.hwer_blend_prepare_search_f32(
+            P(self.tab_ptrs), self.d, None, P(self.alpha), 1 if self.per_row else 0, self.T, self.d, P(self.V), self.ldv, self.eps,
+            P(self.audit_counts), P(self.audit_dev), P(self.search_ids), self.search_row0, self.I, P(self.other_ids), self.other_row0, self.U, P(self.X), self.ldx, P(self.hnorm),
+            P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), self.B, self.arith, P(self.Q64), P(self.Q32), self.ldx,
+            P(self.ws), self.bq_frag, self.S()), "blend_prepare_search")
+
+    def step(self, o=None):
+        """launch one whole step on the current stream into result set `o` (default: set 0); returns the result set"""
+        o = self.sets[0] if o is None else o
+        if self.fused_blend:          # the whole prologue is one launch
+            self.stage_blend_prepare()
+            self.stage_search(o, opts=self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0))
+        elif self.fused_prologue:     # blend, then the fused table + queries launch
+            self.stage_blend()
+            self.stage_prepare()
+            self.stage_search(o, opts=self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0))
+        else:
+            self.stage_blend()
+            self.stage_pack()
+            self.stage_queries()
+            self.stage_search(o)
+        return o
+
+    # ---- library-facing helpers -------------------------------------------------------------------------------------------------
+    def run(self, o=None):
+        """one step with the step's device current; replays the captured hipGraph when capture() was called (set 0 only)"""
+        with native.device_guard(self.dev):
+            if self._graph is not None and o is None:
+                self._graph.replay()
+                return self.sets[0]
+            return self.step(o)
+
+    def capture(self, warm_steps: int = 2):
+        """capture the step into a hipGraph (small, launch-bound shapes: 4-6 launches of a few microseconds each); run() then
+        replays it.  Every buffer is preallocated and nothing in the step synchronises, so the capture is legal."""
+        torch = self.torch
+        with native.device_guard(self.dev):
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(warm_steps):
+                    self.step()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self._graph = g
+        return self
+
+    def audit(self):
+        """(violations, mean |len - 1|, positive, negative, nan_rows) of the blended rows - utils.unit_length_violations
+        (hwer/utils.py:51-57) as RecommendationBase.__build_knn__ uses it; synchronises."""
+        pos, neg, nan = (int(x) for x in self.audit_counts.tolist()[:3])
+        return pos + neg, float(self.audit_dev.item()) / (self.I + self.U), pos, neg, nan
+
+    def checks(self, o=None):
+        """host-side verdict on a finished step (synchronises): the unit-norm audit passed (the reference asserts it,
+        hwer/recommendation_base.py:106-107), every query has an exact result.  -> queries that took the exhaustive pass"""
+        o = self.sets[0] if o is None else o
+        pos, neg, nan = self.audit_counts.tolist()[:3]
+        assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
+        n_uncert = int((o["flags"] == 0).sum().item())
+        assert n_uncert == 0, "%d queries left without an exact result" % n_uncert
+        assert int(self.missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(self.missed.item())
+        return int((o["flags"] == 2).sum().item())
+
+    def results(self, o=None):
+        """-> numpy (idx (B, k) int64 ids, score (B, k) in the reference's dtype [, dist (B, k) float64]) after checks()"""
+        import numpy as np
+        o = self.sets[0] if o is None else o
+        self.checks(o)
+        sc = o["score"].cpu().numpy()
+        if self.arith == 1:
+            sc = sc.astype(np.float32)      # exact: the kernel widened float32 values
+        out = (o["idx"].cpu().numpy(), sc)
+        return out + (np.sqrt(o["dist2"].cpu().numpy()),) if o["dist2"] is not None else out

@@ -48,3 +48,55 @@ def test_emulated_shards_equal_single_table(hw, bench_mod, name, items, G):
     r = bench_mod.emulate_shards(torch, native.lib(), cfg, dev, G, steps=1, warmup=1, n_oracle=32)
     assert r["merged_equals_single_table"] and r["queries_compared"] == 4096 and r["oracle_checked_queries"] == 32
     assert len(r["shard_ms"]) == G
+
+
+# ------------------------------------------------------------------------------------------------- the step as library code
+@pytest.mark.parametrize("layout,U,I,d,T,per_row", [("contiguous", 300, 1700, 64, 2, False), ("interleaved", 257, 2100, 128, 3, True),
+                                                    ("contiguous", 90, 9001, 64, 4, True)])
+def test_blend_search_step_equals_the_separate_calls(hw, layout, U, I, d, T, per_row):
+    """ContentRecommendation.blend_search_step (hwer.pipeline.BlendSearchStep: the ONE-launch prologue hwer_blend_prepare_search_f32,
+    HWER_KNN_QUERIES_READY, audit-derived float16 scale, hipGraph replay - what bench.py times) must return exactly what the
+    ordinary library path returns (fit_tables -> find_closest_neighbours_batch: hwer_blend_normalize_f32, upload, hwer_unit_audit,
+    hwer_pack_rows, hwer_query_mix, search) and what the oracle computes from the float64 blend of the same tables (ids ==,
+    scores ==); contiguous and interleaved node types (id-list row sets), scalar and per-row alpha; a second run after the
+    weights changed in place follows the new weights."""
+    import torch
+    from hwer import ContentRecommendation, Node
+    rng = np.random.default_rng(7 + U)
+    N = U + I
+    if layout == "contiguous":
+        types = ["user"] * U + ["item"] * I
+    else:
+        types = ["item" if (i % (N // U)) else "user" for i in range(N)]
+        types = types[:N]
+    nodes = [Node(t, i) for i, t in enumerate(types)]
+    n_user = sum(1 for t in types if t == "user")
+    tables = [unit_rows_f32(900 + 13 * t + d, N, d) for t in range(T)]
+    if per_row:
+        alpha = rng.dirichlet(np.ones(T), size=N).astype(np.float32)
+    else:
+        alpha = np.full(T, 1.0 / T, dtype=np.float32)
+    users = [n for n in nodes if n.node_type == "user"]
+    k = 200 if I >= 200 else 50
+
+    def reference(al):
+        m = ContentRecommendation({}, {"user", "item"}, n_dims=d)
+        m.fit_tables(nodes, tables, al)
+        return m.find_closest_neighbours_batch("item", users, k=k)
+
+    model = ContentRecommendation({}, {"user", "item"}, n_dims=d)
+    step = model.blend_search_step(nodes, tables, alpha, "item", users, k=k)
+    assert step.fused_blend and (step._graph is not None) == (I <= 8192)
+    step.run()
+    idx, score = step.results()
+    r_idx, r_score = reference(alpha)
+    assert np.array_equal(idx, r_idx) and np.array_equal(score, r_score)
+    assert step.audit()[0] == 0
+    # new weights, written in place into the resident tensor: the replayed step follows them
+    alpha2 = (rng.dirichlet(np.ones(T), size=N) if per_row else rng.dirichlet(np.ones(T))).astype(np.float32)
+    step.alpha.copy_(torch.from_numpy(alpha2).to(step.alpha.device))
+    step.run()
+    idx2, score2 = step.results()
+    r_idx2, r_score2 = reference(alpha2)
+    assert np.array_equal(idx2, r_idx2) and np.array_equal(score2, r_score2)
+    assert not np.array_equal(idx2, idx)
