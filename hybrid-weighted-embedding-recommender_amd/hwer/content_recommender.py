@@ -186,7 +186,9 @@ class ContentRecommendation(RecommendationBase):
         """Index a weighted blend of precomputed embedding tables (content + collaborative, optionally per-row alpha)."""
         assert not self.fit_done
         self.add_nodes(nodes)
-        vec = blend_tables(tables, alpha, row_idx, device=self.device)
+        # like fit(): the model's `vectors` are float64 (the reference's ContentRecommendation flavour: float64 score arithmetic) -
+        # the device's float32 rows widened
+        vec = blend_tables(tables, alpha, row_idx, device=self.device).astype(np.float64)
         self.__build_knn__(vec)
         self.fit_done = True
         return vec
