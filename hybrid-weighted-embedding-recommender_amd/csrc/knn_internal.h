@@ -46,6 +46,10 @@ struct ScreenPlan {
     int seed_tiles, seed_stride, seed_splits;
     int64_t seed_ld;       // = seed_tiles * 32
     double seed_frac;      // expected fraction of the catalogue's keys above tau0 (= seed_c * K' / n_items)
+    int seed_top_m;        // > 0: the pre-pass keeps M candidates per (workgroup, wave, lane half) instead of every sample key
+    int seed_rank;         // ... and tau0 = the seed_rank-th largest candidate (= sample rank seed_frac * sample size)
+    int64_t seed_cand_ld;  // ... row stride of the candidate matrix (bins * M rounded up to 64; the tail is never read)
+    int seed_cand_n;       // ... candidates per query = bins * M
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options = 0);
@@ -99,6 +103,9 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
 // per query: tau0[b] = the (want_frac * sample size)-th largest key of its row of `keys` (B, ld), n valid keys per row (knn_small.hip)
 int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, double want_frac, float* tau0, int32_t* count_scratch,
                           hipStream_t stream);
+// the same from the plan: dispatches to the candidate pick (seed_top_m) or to the sample-row kernels above
+int launch_seed_tau0(const ScreenPlan& plan, const float* seed_keys, int64_t B, float* tau0, int32_t* count_scratch, hipStream_t stream);
+size_t seed_keys_bytes(const ScreenPlan& plan);   // workspace bytes of the pre-pass output (bq rows)
 // queries -> float16 MFMA fragments + per-query scale exponents (knn_small.hip); Qf16: bq * ng * 16 bytes, qexp: bq ints
 int repack_queries16(const float* Q32, int64_t B, int64_t bq, int ldx, void* Qf16, int32_t* qexp, hipStream_t stream);
 

@@ -59,6 +59,8 @@ struct ScreenArgs {
     const float* tau0;   // streaming mode: per-query initial threshold from the seed pre-pass (NULL: open thresholds)
     int tile_stride;     // 1; the seed pre-pass visits every tile_stride-th tile of the catalogue (its items are sample-local)
     int dense_f16;       // DENSE mode: `dense` holds float16 keys (the seed pre-pass: its keys only place a threshold - half the bytes)
+    int seed_m;          // DENSE mode, seed pre-pass (round 3): 0 = store every key; M in {1, 2, 4} = every lane keeps the M largest keys it
+                         // sees for its query and stores only those: dense[q * ld_dense + bin * M + j], bin = (split * wi + wave_i) * 2 + lane half
 };
 
 // sc1 load: served by L2, never by a stale L1 line
@@ -338,6 +340,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     if (n_tiles > 1) tile_dma(1, p_dma);
     p_dma = perm_next(p_dma);
 
+    float top[DENSE ? TQ : 1][4];   // seed pre-pass (seed_m): the lane's best keys per query subtile (scaled units when F16)
+#pragma unroll
+    for (int b = 0; b < (DENSE ? TQ : 1); ++b) top[b][0] = top[b][1] = top[b][2] = top[b][3] = -INFINITY;
     const bool getenv_calib = a.debug_nofilter == 2;
     unsigned long long clk0 = 0, rt0 = 0;
     if (DIAG_STAMPS) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
@@ -426,6 +431,20 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // HBM and stay in flight across the barrier below (no LDS staging of the appends, no flush).
             if constexpr (!DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if constexpr (DENSE) {
+                if (a.seed_m) {   // (wave-uniform) seed pre-pass: the lane's running top-4 per query subtile, sorted descending
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            const float x = acc[b][q];
+                            if (__any(x > top[b][3])) {   // rare after the first tiles: a lane's 4th best rises quickly
+                                const float m0 = fmaxf(top[b][0], x), r0 = fminf(top[b][0], x);
+                                const float m1 = fmaxf(top[b][1], r0), r1 = fminf(top[b][1], r0);
+                                const float m2 = fmaxf(top[b][2], r1), r2 = fminf(top[b][2], r1);
+                                top[b][0] = m0; top[b][1] = m1; top[b][2] = m2; top[b][3] = fmaxf(top[b][3], r2);
+                            }
+                        }
+                } else {
                 // small catalogues: keep every key (lane (r, h): query r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store)
 #pragma unroll
                 // The key matrix has bq >= B rows, so every lane stores unconditionally: exactly 4 * TQ store
@@ -453,6 +472,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                             *reinterpret_cast<float4*>(row + 8 * rg) = make_float4(acc[b][4 * rg], acc[b][4 * rg + 1], acc[b][4 * rg + 2], acc[b][4 * rg + 3]);
                     }
                 }
+                }   // !seed_m
             } else {
             // ---- streaming filter ---------------------------------------------------------------------------------
             // Lane (r, h) holds 16 keys of query r.  Passing keys are rare (K'/n per key), so instead of 16 predicated
@@ -509,7 +529,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         if constexpr (DENSE) {
             // the 4 * TQ key stores of this tile are YOUNGER than the DMA of tile t+1 (vmcnt retires in issue order):
             // wait for everything but them, so the DMA has landed while the stores stay in flight
-            if ((t & wi_mask) == wii) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
+            // (the seed pre-pass with seed_m stores nothing in the loop: plain wait)
+            if ((t & wi_mask) == wii && !a.seed_m) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             // waves that computed this tile waited for the DMA of tile t+1 before their appends; the others do it here
@@ -581,7 +602,19 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         o[0] = rt0 - rt_entry; o[1] = acc_mfma; o[2] = acc_epi; o[3] = acc_wait; o[4] = acc_post; o[5] = n_tiles;   // o[0]: prologue in 10-ns ticks
         o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel clock = o[6] / o[7] x 100 MHz
     }
-    if constexpr (DENSE) return;
+    if constexpr (DENSE) {
+        if (a.seed_m) {   // hand over the lane's top-M (real units; -inf where the lane saw fewer keys)
+            const int bin = ((split * wi_n + wii) * 2 + h) * a.seed_m;
+#pragma unroll
+            for (int b = 0; b < TQ; ++b) {
+                float* dst = a.dense + (qw0 + 32 * b + r) * a.ld_dense + bin;   // bq rows: every lane stores
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < a.seed_m) dst[j] = F16 ? ldexpf(top[b][j], -e_tot[b]) : top[b][j];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < TQ; ++b) flush_tail(b);   // every staged key reaches its stream before the hand-over
 #pragma unroll
@@ -738,6 +771,26 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
             p.seed_frac = frac;
             p.seed_splits = int(std::min<int64_t>(ns, std::max<int64_t>(1, 512 / p.n_qblocks)));
             p.scaled_first = 0;   // every in-loop compaction selects the exact K'-th key: lists are either exact or seeded
+            // Round 3: the pre-pass does not store its keys - tau0 is the r-th largest of the sample, r is small (16 ... 52), and the
+            // sample is split over `bins` = seed workgroups x item waves x 2 lane halves per query: every lane keeps the M largest keys
+            // it sees (registers) and hands over only those; the r-th largest of the bins x M candidates IS the r-th largest sample
+            // key unless some bin holds more than M of the r best - then it is slightly LOWER (the safe side: a few more keys pass
+            // the filter).  With lambda = r / bins <= M / 4 keys of the top r expected per bin that is rare and costs ~1 / r more keys.
+            // The threshold kernel then reads <= 4 096 candidates per query instead of the whole sample row (c4: 80 -> ~8 us and no
+            // 82 MB key matrix; the one-wave pick replaces a 1 024-thread workgroup per query).
+            {
+                const int64_t per_t = cdiv64(ns, p.seed_splits);
+                const int n_sp = int(cdiv64(ns, per_t));               // workgroups per query block the pre-pass really launches
+                const int bins = n_sp * wi * 2;
+                const int rank = std::max(16, int(frac * S + 0.5));
+                const int m = bins * 4 <= 4096 ? 4 : (bins * 2 <= 4096 ? 2 : (bins <= 4096 ? 1 : 0));
+                if (m > 0 && int64_t(bins) * m >= int64_t(4) * rank && !diag_env("HWER_SEED_NO_TOPM")) {
+                    p.seed_top_m = m;
+                    p.seed_rank = rank;
+                    p.seed_cand_ld = ((int64_t(bins) * m + 63) / 64) * 64;
+                    p.seed_cand_n = bins * m;
+                }
+            }
         }
     }
     return p;
@@ -806,9 +859,10 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
     sp.split_items = per;
     sp.n_splits = int(cdiv64(plan.seed_ld, per));
     sp.n_lists = 0;
-    ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
+    // seed_top_m: the lanes keep their M best keys and store only those, (bq, seed_cand_ld) float32; else every key as float16
+    ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_top_m ? plan.seed_cand_ld : plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
                  plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
-                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, 1};
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, plan.seed_top_m ? 0 : 1, plan.seed_top_m};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {
@@ -856,7 +910,7 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !diag_env("HWER_SCREEN_EXACT")) ? 1 : 0, diag_env("HWER_SCREEN_NOFILTER") ? atoi(diag_env("HWER_SCREEN_NOFILTER")) : 0,
                  diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
-                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0};
+                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0, 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

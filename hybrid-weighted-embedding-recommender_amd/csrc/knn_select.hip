@@ -869,72 +869,94 @@ __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(cons
         if (lane >= off) incl += t;
     }
     const int M = __shfl(incl, 63, kWave);
-    if (M > REDW_MAX) {   // wave-uniform: too many keys for the registers - the workgroup kernels take this query
-        if (lane == 0) a.todo[b] = 1;
-        return;
-    }
-    if (lane == 0) a.todo[b] = 0;
+    if (lane == 0) a.todo[b] = 0;   // (round 3: every query is finished here - the workgroup rounds are no longer launched behind this kernel)
     const int excl = incl - n;
-    // coalesced copy of every stream into the wave's LDS array, eight streams' first 64 entries in flight at a time (seeded
-    // streams are short: a stream-by-stream loop is a chain of dependent global-load latencies)
-    for (int s0 = 0; s0 < n_streams; s0 += 8) {
-        uint64_t v[8];
-        int ns[8], os[8];
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    uint64_t* dst = a.cand_out + (b * 2) * CAPH;   // streams 0 and 1 of the output list are contiguous
+    // The query's keys in stream-major order form one sequence of M entries.  It is consumed in windows: the window's keys go to
+    // the wave's LDS array behind the `kept` best keys of the windows before it (none in the first window), then the K' best of
+    // the array are selected - into the output list after the last window, to the front of the array otherwise.  M <= REDW_MAX
+    // (always, but for a sampled threshold that came out far too low: ~1e-4 of the queries at c = 8) is ONE window: the loop
+    // body runs once, exactly the single-pass kernel of round 2.
+    int kept = 0, n_c = 0;
+    for (int w0 = 0; w0 < M || w0 == 0; ) {   // (wave-uniform)
+        const int w1 = min(M, w0 + REDW_MAX - kept);
+        // coalesced copy of every stream's part inside [w0, w1), eight streams' first 64 entries in flight at a time (seeded streams
+        // are short: a stream-by-stream loop is a chain of dependent global-load latencies)
+        for (int s0 = 0; s0 < n_streams; s0 += 8) {
+            uint64_t v[8];
+            int ns[8], os[8], fs[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int s2 = min(s0 + j, n_streams - 1);
-            ns[j] = s0 + j < n_streams ? __shfl(n, s2, kWave) : 0;
-            os[j] = __shfl(excl, s2, kWave);
-            const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH;
-            v[j] = lane < ns[j] ? src[lane] : 0ull;
-        }
+            for (int j = 0; j < 8; ++j) {
+                const int s2 = min(s0 + j, n_streams - 1);
+                const int ex = __shfl(excl, s2, kWave), in = s0 + j < n_streams ? __shfl(incl, s2, kWave) : ex;
+                const int lo = max(ex, w0), hi = min(in, w1);
+                ns[j] = max(hi - lo, 0);       // entries of this stream inside the window
+                fs[j] = lo - ex;               // ... starting at this entry of the stream
+                os[j] = kept + lo - w0;        // ... going to this LDS slot
+                const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH + fs[j];
+                v[j] = lane < ns[j] ? src[lane] : 0ull;
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (lane < ns[j]) lds[os[j] + lane] = v[j];
-            if (ns[j] > 64) {   // wave-uniform, rare: the rest of a long stream
-                const int s2 = s0 + j;
-                const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH;
-                for (int i = 64 + lane; i < ns[j]; i += 64) lds[os[j] + i] = src[i];
+            for (int j = 0; j < 8; ++j) {
+                if (lane < ns[j]) lds[os[j] + lane] = v[j];
+                if (ns[j] > 64) {   // wave-uniform, rare: the rest of a long stream
+                    const int s2 = s0 + j;
+                    const uint64_t* src = a.cand_in + ((int64_t(s2 >> 1) * a.bq + b) * 2 + (s2 & 1)) * CAPH + fs[j];
+                    for (int i = 64 + lane; i < ns[j]; i += 64) lds[os[j] + i] = src[i];
+                }
             }
         }
-    }
-    wave_lds_sync();
-    float sv[REDW_NV];
-#pragma unroll
-    for (int r = 0; r < REDW_NV; ++r) {
-        const int e = 64 * r + lane;
-        const uint64_t kk = e < M ? lds[e] : 0ull;
-        sv[r] = kk != 0ull ? key_score(kk) : -INFINITY;
-    }
-    uint64_t* dst = a.cand_out + (b * 2) * CAPH;   // streams 0 and 1 of the output list are contiguous
-    int n_c = M;
-    if (M > a.kprime) {
-        // exactly the K' best: every key above the K'-th largest score plus as many of the keys equal to it as fit
-        int c_ge;
-        const float t = wave_find_rank<REDW_NV>(sv, a.kprime, 0, c_ge);
-        int c_gt = 0;
-#pragma unroll
-        for (int r = 0; r < REDW_NV; ++r) c_gt += __builtin_popcountll(__ballot(sv[r] > t));
-        const int want_eq = min(c_ge - c_gt, a.kprime - c_gt);
-        const uint64_t lt_mask = (1ull << lane) - 1ull;
-        int eq_seen = 0, out = 0;
-#pragma unroll
-        for (int r = 0; r < REDW_NV; ++r) {
-            const bool gt = sv[r] > t, eq = sv[r] == t;
-            const uint64_t be = __ballot(eq);
-            const bool keep = gt || (eq && eq_seen + __builtin_popcountll(be & lt_mask) < want_eq);
-            const uint64_t bk = __ballot(keep);
-            if (keep) dst[out + __builtin_popcountll(bk & lt_mask)] = lds[64 * r + lane];
-            out += __builtin_popcountll(bk);
-            eq_seen += __builtin_popcountll(be);
-        }
-        n_c = out;   // == K'
-    } else {
+        wave_lds_sync();
+        const int n_now = kept + (w1 - w0);
+        const bool last = w1 >= M;
+        float sv[REDW_NV];
 #pragma unroll
         for (int r = 0; r < REDW_NV; ++r) {
             const int e = 64 * r + lane;
-            if (e < M) dst[e] = lds[e];
+            const uint64_t kk = e < n_now ? lds[e] : 0ull;
+            sv[r] = kk != 0ull ? key_score(kk) : -INFINITY;
         }
+        if (n_now > a.kprime) {
+            // exactly the K' best: every key above the K'-th largest score plus as many of the keys equal to it as fit
+            int c_ge;
+            const float t = wave_find_rank<REDW_NV>(sv, a.kprime, 0, c_ge);
+            int c_gt = 0;
+#pragma unroll
+            for (int r = 0; r < REDW_NV; ++r) c_gt += __builtin_popcountll(__ballot(sv[r] > t));
+            const int want_eq = min(c_ge - c_gt, a.kprime - c_gt);
+            int eq_seen = 0, out = 0;
+#pragma unroll
+            for (int r = 0; r < REDW_NV; ++r) {
+                const bool gt = sv[r] > t, eq = sv[r] == t;
+                const uint64_t be = __ballot(eq);
+                const bool keep = gt || (eq && eq_seen + __builtin_popcountll(be & lt_mask) < want_eq);
+                const uint64_t bk = __ballot(keep);
+                // (in-place compaction to the array's front, not-last windows: a kept key moves DOWN, to a slot whose own key was read in
+                // this or an earlier round - the read of round r precedes its write in program order)
+                const uint64_t kk = lds[64 * r + lane];
+                if (keep) {
+                    if (last) dst[out + __builtin_popcountll(bk & lt_mask)] = kk;
+                    else lds[out + __builtin_popcountll(bk & lt_mask)] = kk;
+                }
+                out += __builtin_popcountll(bk);
+                eq_seen += __builtin_popcountll(be);
+            }
+            n_c = out;   // == K'
+        } else {
+            n_c = n_now;
+            if (last) {
+#pragma unroll
+                for (int r = 0; r < REDW_NV; ++r) {
+                    const int e = 64 * r + lane;
+                    if (e < n_now) dst[e] = lds[e];
+                }
+            }
+        }
+        if (last) break;
+        wave_lds_sync();
+        kept = n_c;
+        w0 = w1;
     }
     if (lane == 0) {
         a.cnt_out[b * 2 + 0] = min(n_c, CAPH) | flags;
@@ -1541,7 +1563,7 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
     off += align256(size_t(p.bq) * 4);
     if (p.seed) {   // seed pre-pass: sample keys (bq, seed_ld), thresholds, a scratch counter row
         w.seed_keys = off;
-        off += align256(size_t(p.bq) * size_t(p.seed_ld) * 2);   // float16 keys
+        off += align256(seed_keys_bytes(p));   // float16 sample keys, or the lanes' best candidates (float32)
         w.seed_tau = off;
         off += align256(size_t(p.bq) * 4);
         w.seed_cnt = off;
@@ -1744,7 +1766,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
             float* seed_keys = reinterpret_cast<float*>(ws + w.seed_keys);
             float* tau = reinterpret_cast<float*>(ws + w.seed_tau);
             if ((rc = launch_seed_screen(plan, X, hnorm, n_items, ldx, qf, B, seed_keys, hdr, st, f16_screen ? &f16 : nullptr))) return rc;
-            if ((rc = launch_seed_threshold(seed_keys, plan.seed_ld, plan.seed_ld, B, plan.seed_frac, tau, reinterpret_cast<int32_t*>(ws + w.seed_cnt), st))) return rc;
+            if ((rc = launch_seed_tau0(plan, seed_keys, B, tau, reinterpret_cast<int32_t*>(ws + w.seed_cnt), st))) return rc;
             tau0 = tau;
         }
         rc = launch_screen(plan, X, hnorm, n_items, ldx, qf, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st,
@@ -1808,7 +1830,12 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_wave_kernel), lds_w, "knn_reduce_wave"))) return rc;
         hipLaunchKernelGGL(reduce_lists_wave_kernel, dim3(unsigned(cdiv64(B, REDW_WAVES))), dim3(64 * REDW_WAVES), lds_w, st, rw);
         if ((rc = check_launch("knn_reduce_wave"))) return rc;
-        todo = todo_w;
+        // the wave kernel finishes every query (windows of 4 096 keys when a threshold came out far too low): the two workgroup
+        // rounds that used to follow it - 2 launches of ~40 us of empty blocks at c4 - are gone
+        cand = cand_final;
+        cnt = cnt_final;
+        n_lists = 1;
+        (void)todo;
     }
     while (n_lists > 1) {   // item splits / shared-query waves: merge the lists of a query into one list of K' keys
         const int groups = int(cdiv64(n_lists, MAX_LISTS_DIRECT));

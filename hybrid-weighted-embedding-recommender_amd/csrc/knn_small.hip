@@ -676,7 +676,7 @@ static SmallLayout small_layout(const SmallPlan& p, const ScreenPlan* seed) {
     size_t off = 0;
     w.qf = off;    off += al256(bq * size_t(p.ng) * 8 * 4);   // queries in fragment order (bq is a multiple of 32); float16 variant: half of it
     w.qexp = off;  off += al256(bq * 4);                      // per-query scale exponents of the float16 variant
-    w.keys = off;  off += al256(seed ? size_t(seed->bq) * size_t(seed->seed_ld) * 2 /* float16 sample keys */ : size_t(p.bq) * size_t(p.ld) * 4);
+    w.keys = off;  off += al256(seed ? seed_keys_bytes(*seed) /* float16 sample keys | the lanes' best candidates */ : size_t(p.bq) * size_t(p.ld) * 4);
     w.thr = off;   off += al256(bq * 4);
     w.count = off; off += al256(bq * 4);
     w.list = off;  off += al256(size_t(p.bq) * SMALL_LIST_CAP * 8);
@@ -754,6 +754,49 @@ int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, d
     return check_launch("knn_seed(threshold)");
 }
 
+// tau0 of one query = the `rank`-th largest of its n <= 64 * PER candidates (the lanes' top-M of the seed pre-pass), one wave per
+// query, four queries per block; fewer finite candidates than `rank` (tiny samples): the smallest of them
+template <int PER>
+__global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict__ cand, int64_t ld, int n, int64_t B, int rank,
+                                                        float* __restrict__ tau0, int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float* row = cand + b * ld;
+    float v[PER];
+    int fin = 0;
+#pragma unroll
+    for (int m = 0; m < PER; ++m) {
+        const int i = lane + 64 * m;
+        v[m] = i < n ? row[i] : -INFINITY;
+        fin += __builtin_popcountll(__ballot(v[m] > -INFINITY));
+    }
+    float t = -INFINITY;   // no finite candidate: open threshold
+    if (fin > 0) {
+        const int rk = min(rank, fin);
+        int c_lo;
+        t = wave_find_rank<PER>(v, rk, rk / HWER_SEED_SLACK_DIV, c_lo);
+    }
+    if (lane == 0) {
+        tau0[b] = t;
+        count[b] = 0;
+    }
+}
+
+size_t seed_keys_bytes(const ScreenPlan& plan) {
+    return plan.seed_top_m ? size_t(plan.bq) * size_t(plan.seed_cand_ld) * 4 : size_t(plan.bq) * size_t(plan.seed_ld) * 2;   // float32 candidates | float16 sample keys
+}
+
+int launch_seed_tau0(const ScreenPlan& plan, const float* seed_keys, int64_t B, float* tau0, int32_t* count_scratch, hipStream_t stream) {
+    if (!plan.seed_top_m) return launch_seed_threshold(seed_keys, plan.seed_ld, plan.seed_ld, B, plan.seed_frac, tau0, count_scratch, stream);
+    const int n = plan.seed_cand_n;
+    const dim3 grid(unsigned(cdiv64(B, 4)));
+    if (n <= 256) hipLaunchKernelGGL(seed_pick_kernel<4>, grid, dim3(256), 0, stream, seed_keys, plan.seed_cand_ld, n, B, plan.seed_rank, tau0, count_scratch);
+    else if (n <= 1024) hipLaunchKernelGGL(seed_pick_kernel<16>, grid, dim3(256), 0, stream, seed_keys, plan.seed_cand_ld, n, B, plan.seed_rank, tau0, count_scratch);
+    else hipLaunchKernelGGL(seed_pick_kernel<64>, grid, dim3(256), 0, stream, seed_keys, plan.seed_cand_ld, n, B, plan.seed_rank, tau0, count_scratch);
+    return check_launch("knn_seed(pick)");
+}
+
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
                  unsigned char* ws, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16, int x_exp, hipStream_t stream,
                  const ScreenPlan* seed) {
@@ -783,7 +826,7 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         ScreenF16 sf{X16, qf, qexp, x_exp};
         if ((rc = launch_seed_screen(*seed, X, hnorm, n_items, ldx, qf, B, seed_keys, hdr, stream, seed16 ? &sf : nullptr))) return rc;
         // the threshold kernel also zeroes count[b] for the queries it handles (b < B)
-        if ((rc = launch_seed_threshold(seed_keys, seed->seed_ld, seed->seed_ld, B, seed->seed_frac, thr, count, stream))) return rc;
+        if ((rc = launch_seed_tau0(*seed, seed_keys, B, thr, count, stream))) return rc;
         sink.tau0 = thr;
     }
     if (f16) {   // float16 storage: half the HBM bytes for the catalogue stream

@@ -100,3 +100,33 @@ def test_blend_search_step_equals_the_separate_calls(hw, layout, U, I, d, T, per
     r_idx2, r_score2 = reference(alpha2)
     assert np.array_equal(idx2, r_idx2) and np.array_equal(score2, r_score2)
     assert not np.array_equal(idx2, idx)
+
+
+# ------------------------------------------------------------------------------------------------- seeded lists longer than one window
+def test_seeded_lists_longer_than_the_merge_window(hw):
+    """reduce_lists_wave_kernel merges ALL lists of a query (round 3: also when they hold more than its 4 096-key window - the
+    workgroup rounds behind it are gone).  Forced here: 6 400 near-duplicates of the queries' neighbourhood sit in rows that the
+    seed pre-pass's strided sample never visits (sample tile p = catalogue tile 35 p at this shape), spread over the 32 item
+    splits so that no single list compacts - every query then carries ~7 000 keys above its seeded threshold into the merge.
+    ids / scores / distances == the oracle's brute force."""
+    from hwer.device_index import DeviceIndex
+    N, d, B, k = 300000, 64, 4096, 200
+    rng = np.random.default_rng(77)
+    X = unit_rows_f32(501, N, d)
+    c = unit_rows_f32(502, 1, d)[0].astype(np.float64)
+    tiles = np.arange(N) // 32
+    rows = np.arange(N)[(tiles % 35 != 0) & (np.arange(N) % 46 == 7)][:6400]
+    assert len(rows) == 6400
+    near = c[None, :] + 0.05 * rng.standard_normal((len(rows), d))
+    X[rows] = (near / np.linalg.norm(near, axis=1, keepdims=True)).astype(np.float32)
+    q = c[None, :] + 0.5 * rng.standard_normal((B, d)) / np.sqrt(d)
+    users = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    V = np.concatenate([users, X]).astype(np.float64)
+    ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all()
+    sel = np.linspace(0, B - 1, 64).astype(np.int64)
+    Qh = np.stack([orc.query_vector(V[:B], int(u)) for u in sel])
+    o_idx, o_score, o_d2 = c_oracle.find_closest_f64(X, Qh, V[sel], k, threads=c_oracle.effective_cpus())
+    assert np.isin(o_idx[:, :50], rows).all()          # the planted rows are the neighbours
+    assert np.array_equal(idx[sel], o_idx + B) and np.array_equal(score[sel], o_score) and np.array_equal(dist[sel], np.sqrt(o_d2))
