@@ -146,6 +146,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define DIAG_STAMPS false
 #endif
 #define STAMP(var) if (DIAG_STAMPS) { var = stamp(); }
+#ifndef HWER_FILTER_V2
+#define HWER_FILTER_V2 1   // float16 streaming screen: max-tree + per-register appends instead of pass masks + LDS park + pop loop (round 3)
+#endif
+constexpr bool FILTER_V2 = HWER_FILTER_V2 != 0;
 #ifndef HWER_F16_MFMA_PRIO
 #define HWER_F16_MFMA_PRIO 0   // wave priority during the float16 MFMA phase ...
 #endif
@@ -271,7 +275,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         const uint32_t xb_addr = xs_addr0 + uint32_t(t & 1) * uint32_t(IB * CH * 16);
         const char* tile_ptr = x_split + uint64_t(uint32_t(ptile)) * tile_bytes;    // wave-uniform
         uint32_t lr = lane_row, lc = lane_chunk;
-        asm volatile("" : "+v"(lr), "+v"(lc));   // opaque: keeps the per-piece offsets from being hoisted into (spilled) registers
+        // float32 kernels: opaque - keeps the per-piece offsets from being hoisted into (spilled) registers.  The float16 kernels
+        // have the registers (229 of 256 at d = 128, TQ = 2): their 1 - 4 piece offsets are loop invariants (round 3: -8 VALU per tile)
+        if constexpr (!F16 || DMA_PER_WAVE > 2) asm volatile("" : "+v"(lr), "+v"(lc));
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
             // piece = wave + 4 i covers rows piece * PIECE_ROWS + lane / CH
@@ -483,6 +489,35 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // (v_alignbit) pushes that sign bit into the mask.  Bit (15 - q) of half-word b <-> accumulator register q of
             // query subtile b.  Both subtiles share ONE park and ONE pop loop: the loop runs max-over-lanes of the lane's
             // total pops, not the sum of the per-subtile maxima.
+            if constexpr (F16 && FILTER_V2) {
+                // Round 3.  With seeded thresholds a passing key is rare (c4: ~1.7 per 32 x 64 tile and wave at c = 4), and what bounds
+                // this loop is the wave's vector-instruction count and its serial chain, not a pipe (SQ counters): the
+                // per-key pass masks (48 VALU per tile), the LDS park of all 32 keys (16 ds_write2st64) and the pop loop (~33 VALU + an
+                // LDS round trip per iteration) are replaced by
+                //   * the lane's maximum of its 16 keys (a v_max3_f32 tree: 8 VALU) and ONE compare with the threshold per subtile;
+                //   * only when some lane passes (wave-uniform branch): one compare per accumulator register, and the append code of a
+                //     register runs under the lanes that pass (s_cbranch_execz skips it otherwise) - the key is still in its register:
+                //     no park, no pop loop, no LDS traffic.
+                if (!ABLATE(4)) {
+                    const uint32_t item0 = uint32_t(i0) + 4 * h;
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b) {
+                        const float m0 = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]), m1 = fmaxf(fmaxf(acc[b][3], acc[b][4]), acc[b][5]);
+                        const float m2 = fmaxf(fmaxf(acc[b][6], acc[b][7]), acc[b][8]), m3 = fmaxf(fmaxf(acc[b][9], acc[b][10]), acc[b][11]);
+                        const float m4 = fmaxf(fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
+                        const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[b][15]));
+                        if (__any(mx > tau[b]) && !ABLATE(1)) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) {
+                                if (acc[b][q] > tau[b])   // back to real units (exact), then straight to the lane's stream
+                                    stage(b, pack_key(ldexpf(acc[b][q], -e_tot[b]), item0 + (q & 3) + 8 * (q >> 2)));
+                            }
+                        }
+                    }
+                } else {
+                    asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15]));
+                }
+            } else {
             uint32_t mask = 0;
             if (ABLATE(4)) asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15]));
             else
@@ -522,6 +557,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     }
                 }
             }
+            }   // !(F16 && FILTER_V2)
             }   // !DENSE
         }
         STAMP(t3);
@@ -748,7 +784,9 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         //        the launch; 2.25 K' stay below the trigger for all but ~2e-4 of the queries (the pre-pass is 9 % of the catalogue;
         //        measured against 2.75: c3's main search 5.27 -> 5.03 ms).
         const bool single_list = p.n_lists == 1 && !small;
-        double c_min = single_list ? 2.25 : (((B <= 4 && small) || (n_items >= 400000 && !small)) ? 8.0 : 4.0);
+        // (round 3: with the candidate pick the pre-pass no longer pays per sample key, and c = 4 beats 8 on the large catalogues
+        // too - same-box sweep, diagnostic build: c4 2.27 -> 2.20 ms per search, c5 4.34 -> 4.30, c4full 13.7 -> 13.5)
+        double c_min = single_list ? 2.25 : ((B <= 4 && small) ? 8.0 : 4.0);
         if (const char* e = diag_env("HWER_SEED_C")) c_min = std::max(1.5, atof(e));   // tuning override (diagnostic builds)
         // sample rank r by c (probabilities above; the threshold kernels never take a rank below 16)
         const double r_min = single_list ? 52.0 : (c_min >= 8.0 ? 16.0 : 28.0);

@@ -105,7 +105,7 @@ def test_blend_search_step_equals_the_separate_calls(hw, layout, U, I, d, T, per
 # ------------------------------------------------------------------------------------------------- seeded lists longer than one window
 def test_seeded_lists_longer_than_the_merge_window(hw):
     """reduce_lists_wave_kernel merges ALL lists of a query (round 3: also when they hold more than its 4 096-key window - the
-    workgroup rounds behind it are gone).  Forced here: 6 400 near-duplicates of the queries' neighbourhood sit in rows that the
+    workgroup rounds behind it are gone).  Forced here: ~6 300 near-duplicates of the queries' neighbourhood sit in rows that the
     seed pre-pass's strided sample never visits (sample tile p = catalogue tile 35 p at this shape), spread over the 32 item
     splits so that no single list compacts - every query then carries ~7 000 keys above its seeded threshold into the merge.
     ids / scores / distances == the oracle's brute force."""
@@ -115,8 +115,8 @@ def test_seeded_lists_longer_than_the_merge_window(hw):
     X = unit_rows_f32(501, N, d)
     c = unit_rows_f32(502, 1, d)[0].astype(np.float64)
     tiles = np.arange(N) // 32
-    rows = np.arange(N)[(tiles % 35 != 0) & (np.arange(N) % 46 == 7)][:6400]
-    assert len(rows) == 6400
+    rows = np.arange(N)[(tiles % 35 != 0) & (np.arange(N) % 46 == 7)]
+    assert len(rows) >= 6000
     near = c[None, :] + 0.05 * rng.standard_normal((len(rows), d))
     X[rows] = (near / np.linalg.norm(near, axis=1, keepdims=True)).astype(np.float32)
     q = c[None, :] + 0.5 * rng.standard_normal((B, d)) / np.sqrt(d)
