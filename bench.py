@@ -202,7 +202,8 @@ def make_workload_class():
                              want_dist=want_dist, sort_by_score=not local_order, f16_screen=False if f32_screen else None, f16_dense=f16_dense,
                              n_sets=n_sets, extra_options=int(env("HWER_BENCH_OPTS", "0")),     # A/B runs: e.g. 16 = HWER_KNN_NO_SEED
                              fused_blend=True if env("HWER_BENCH_FORCE_FUSED_BLEND") else (False if env("HWER_BENCH_NO_FUSED_BLEND") else None),
-                             fused_prologue=False if env("HWER_BENCH_NO_FUSED_PROLOGUE") else None, tail_stream=not env("HWER_BENCH_NO_TAIL_STREAM"))
+                             fused_prologue=False if env("HWER_BENCH_NO_FUSED_PROLOGUE") else None, tail_stream=not env("HWER_BENCH_NO_TAIL_STREAM"),
+                             pipeline=False if env("HWER_BENCH_NO_PIPELINE") else None)
 
         def _alpha_rows(self, seed, lo, hi):
             torch = self.torch
@@ -311,7 +312,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     for _ in range(warmup):
         run_step()
     torch.cuda.synchronize()
-    if graph is None and not w.tail:
+    if graph is None and not w.tail and not w.pipeline:
         lib.hwer_profile_enable(PROFILE_EVERY)   # HIP events around every PROFILE_EVERY-th search (a pair costs ~10 us of stream time)
     # The timed region: EXACTLY `steps` steps between two synchronisations, wall clock (the contract's ms_per_step / value).  Eager
     # steps (>= ~0.2 ms each) also get one HIP event per step boundary inside the region - the per-step distribution
@@ -336,7 +337,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         torch.cuda.synchronize()
     series = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
     del evs
-    if graph is not None or w.tail:    # kernel durations: an eager pass with event brackets after the timed region
+    if graph is not None or w.tail or w.pipeline:    # kernel durations: an eager pass with event brackets after the timed region
         lib.hwer_profile_enable(1)     # (searches one after the other: overlapped searches would stretch each other's brackets)
         w.overlap_tail = False
         for _ in range(10 if graph is not None else 3):

@@ -166,6 +166,8 @@ size_t small_ws_bytes(const SmallPlan& p, const ScreenPlan* seed = nullptr);   /
 int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Q32, int64_t B,
                  unsigned char* ws_after_header, uint64_t** list_out, int32_t** cnt_out, WsHeader* hdr, const void* X16 /*nullable*/,
                  int x_exp, hipStream_t stream, const ScreenPlan* seed = nullptr);
+// where launch_small leaves its candidate lists (for the select stage of a split search)
+void small_outputs(const SmallPlan& p, const ScreenPlan* seed, unsigned char* ws_after_header, uint64_t** list_out, int32_t** cnt_out);
 // float16 storage variant of the small-batch screen (§8f-4): the table scaled by 2^x_exp and rounded to float16
 int f16_scale_exp(float hnorm_max);
 int pack_rows16(const float* X, int64_t n_rows_padded, int64_t ldx, int x_exp, void* X16, hipStream_t stream);

@@ -1680,16 +1680,20 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
                                     id_base, hnorm_max, out_idx, out_score, out_dist2, out_flags, workspace, workspace_bytes, 0, nullptr, 0, stream);
 }
 
-int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
+// stages: 1 = screen (query fragments, seed pre-pass, MFMA screen -> candidate keys in the workspace), 2 = select (candidate keys ->
+// re-rank -> outputs), 3 = both.  The plan and the workspace layout are functions of (B, n_items, d, k, options, X16 != NULL) only,
+// so the two stages of a split search agree on where the candidates live.
+static int knn_search_stages(int stages, const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
                              const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k, int score_mode,
                              int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
                              double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                              size_t workspace_bytes, uint32_t options, const void* X16, int x16_exp, void* stream) {
     if (B == 0) return HWER_OK;
+    const bool do_screen = (stages & 1) != 0, do_select = (stages & 2) != 0;
     const bool conservative = (options & HWER_KNN_EXACT_THRESHOLDS) != 0;
-    if (!X || !hnorm || !Q32 || !Q64 || !out_idx || !out_score || !out_flags || !workspace)
+    if (!X || !workspace || (do_screen && (!hnorm || !Q32)) || (do_select && (!Q64 || !out_idx || !out_score || !out_flags)))
         return fail(HWER_EINVAL, "knn_search: null pointer");
-    if (!out_dist2 && (score_mode == 2 || !sort_by_score))
+    if (do_select && !out_dist2 && (score_mode == 2 || !sort_by_score))
         return fail(HWER_EINVAL, "knn_search: out_dist2 may only be NULL with score_mode 0/1 and sort_by_score");
     const int dp = hwer_knn_padded_dim(d);
     if (dp < 0) return fail(HWER_EINVAL, "knn_search: d=%d unsupported (1..256)", d);
@@ -1697,9 +1701,9 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     if (k < 1 || k > K_MAX) return fail(HWER_EINVAL, "knn_search: k=%d outside 1..%d", k, K_MAX);
     if (k > n_items) return fail(HWER_EINVAL, "knn_search: k must be less than or equal to the number of training points");
     if (n_items >= (int64_t(1) << 32)) return fail(HWER_EINVAL, "knn_search: n_items must be < 2^32 per shard");
-    if (score_mode < 0 || score_mode > 2) return fail(HWER_EINVAL, "knn_search: score_mode must be 0, 1 or 2");
-    if (score_mode != 2 && !A32) return fail(HWER_EINVAL, "knn_search: A32 required for score_mode 0/1");
-    if ((reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Q32) & 15) ||
+    if (do_select && (score_mode < 0 || score_mode > 2)) return fail(HWER_EINVAL, "knn_search: score_mode must be 0, 1 or 2");
+    if (do_select && score_mode != 2 && !A32) return fail(HWER_EINVAL, "knn_search: A32 required for score_mode 0/1");
+    if ((reinterpret_cast<uintptr_t>(X) & 15) || (do_screen && (reinterpret_cast<uintptr_t>(Q32) & 15)) ||
         (reinterpret_cast<uintptr_t>(workspace) & 255))
         return fail(HWER_EINVAL, "knn_search: X/Q32 must be 16-byte and workspace 256-byte aligned");
     hipStream_t st = as_stream(stream);
@@ -1718,13 +1722,15 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         WsHeader* hdr = reinterpret_cast<WsHeader*>(ws);
         uint64_t* list = nullptr;
         int32_t* cnt = nullptr;
-        int rc;
+        int rc = HWER_OK;
         prof_next_call();
-        {
+        if (do_screen) {
             ProfScope ps(0, st);
             rc = launch_small(sp, X, hnorm, n_items, ldx, Q32, B, ws + WS_HEADER_BYTES, &list, &cnt, hdr, X16, x16_exp, st, seed);
+        } else {
+            small_outputs(sp, seed, ws + WS_HEADER_BYTES, &list, &cnt);   // where the screen stage left the lists
         }
-        if (rc) return rc;
+        if (rc || !do_select) return rc;
         ProfScope ps_select(1, st);
         DenseSelectArgs da{};
         da.B = B;
@@ -1754,12 +1760,14 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
     // exponents in the second half (bq ints <= bq * ng * 16 bytes)
     const bool f16_screen = (options & HWER_KNN_F16_SCREEN) != 0 && X16 != nullptr && screen_f16_supported(plan);
     ScreenF16 f16{X16, qf, reinterpret_cast<const int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), x16_exp};
-    if (f16_screen) {
+    if (!do_screen) {
+    } else if (f16_screen) {
         if ((rc = repack_queries16(Q32, B, plan.bq, int(ldx), qf, reinterpret_cast<int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), st))) return rc;
     } else if (!(options & HWER_KNN_QUERIES_READY)) {   // (else: hwer_prepare_search_f32 wrote the fragments already)
         if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) return rc;
     }
-    {
+    rc = HWER_OK;
+    if (do_screen) {
         ProfScope ps(0, st);
         const float* tau0 = nullptr;
         if (plan.seed) {   // sample pre-pass -> per-query initial thresholds
@@ -1772,7 +1780,7 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
         rc = launch_screen(plan, X, hnorm, n_items, ldx, qf, B, cand, cnt, reinterpret_cast<float*>(ws + w.cand_a), hdr, st,
                            f16_screen ? &f16 : nullptr, tau0);
     }
-    if (rc) return rc;
+    if (rc || !do_select) return rc;
     ProfScope ps_select(1, st);
     if (plan.dense) {
         DenseSelectArgs da{};
@@ -1863,6 +1871,29 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
 }
 
 
+
+int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,
+                             const double* Q64, const float* A32, int64_t lda, const int32_t* a_idx, int64_t B, int k, int score_mode,
+                             int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
+                             double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                             size_t workspace_bytes, uint32_t options, const void* X16, int x16_exp, void* stream) {
+    return knn_search_stages(3, X, hnorm, n_items, d, ldx, Q32, Q64, A32, lda, a_idx, B, k, score_mode, sort_by_score, row_ids, id_base, hnorm_max,
+                             out_idx, out_score, out_dist2, out_flags, workspace, workspace_bytes, options, X16, x16_exp, stream);
+}
+
+int hwer_knn_screen_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32, int64_t B, int k,
+                        void* workspace, size_t workspace_bytes, uint32_t options, const void* X16, int x16_exp, void* stream) {
+    return knn_search_stages(1, X, hnorm, n_items, d, ldx, Q32, nullptr, nullptr, 0, nullptr, B, k, 0, 1, nullptr, 0, 0.f, nullptr, nullptr, nullptr,
+                             nullptr, workspace, workspace_bytes, options, X16, x16_exp, stream);
+}
+
+int hwer_knn_select_f32(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32, int64_t lda,
+                        const int32_t* a_idx, int64_t B, int k, int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base,
+                        float hnorm_max, int64_t* out_idx, double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                        size_t workspace_bytes, uint32_t options, const void* X16, void* stream) {
+    return knn_search_stages(2, X, nullptr, n_items, d, ldx, nullptr, Q64, A32, lda, a_idx, B, k, score_mode, sort_by_score, row_ids, id_base,
+                             hnorm_max, out_idx, out_score, out_dist2, out_flags, workspace, workspace_bytes, options, X16, 0, stream);
+}
 
 // Stage-A chunk of the on-device exhaustive pass: about 64 blocks per query on small catalogues (more parallelism, shorter
 // sorts), EX_CHUNK items on large ones; always a power of two >= k so that a block can hand over k entries.

@@ -783,6 +783,12 @@ __global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict_
     }
 }
 
+void small_outputs(const SmallPlan& p, const ScreenPlan* seed, unsigned char* ws, uint64_t** list_out, int32_t** cnt_out) {
+    const SmallLayout w = small_layout(p, seed);
+    *list_out = reinterpret_cast<uint64_t*>(ws + w.list);
+    *cnt_out = reinterpret_cast<int32_t*>(ws + w.count);
+}
+
 size_t seed_keys_bytes(const ScreenPlan& plan) {
     return plan.seed_top_m ? size_t(plan.bq) * size_t(plan.seed_cand_ld) * 4 : size_t(plan.bq) * size_t(plan.seed_ld) * 2;   // float32 candidates | float16 sample keys
 }

@@ -50,6 +50,9 @@ PROTOTYPES = {
     "hwer_knn_workspace_bytes_opts": (c_size_t, [c_int64, c_int64, c_int, c_int, ctypes.c_uint32]),
     "hwer_knn_search_opts_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, c_int64, c_int, c_int,
                                          c_int, _P, c_int64, c_float, _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, c_int, _P]),
+    "hwer_knn_screen_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int64, c_int, _P, c_size_t, ctypes.c_uint32, _P, c_int, _P]),
+    "hwer_knn_select_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, c_int64, c_float,
+                                    _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, _P]),
     "hwer_knn_f16_scale_exp": (c_int, [c_float]),
     "hwer_knn_f16_screen_pays": (c_int, [c_int64, c_int64, c_int]),
     "hwer_pack_rows_f16": (c_int, [_P, c_int64, c_int64, c_int, _P, _P]),

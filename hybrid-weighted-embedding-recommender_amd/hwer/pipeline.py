@@ -29,6 +29,7 @@ from .device_index import roundup
 
 KNN_F16_SCREEN, KNN_QUERIES_READY = 2, 32
 QUERY_CHUNK = 131072       # = DeviceIndex.QUERY_CHUNK: one full round of workgroups per search launch
+PIPE_CHUNK = 65536         # queries per chunk of a pipelined search: one full round of TQ = 1 screen workgroups (512 x 128)
 
 
 class BlendSearchStep:
@@ -44,7 +45,7 @@ class BlendSearchStep:
                  id_base: Optional[int] = None, arith: int = 0, want_dist: bool = False, sort_by_score: bool = True,
                  f16_screen: Optional[bool] = None, f16_dense: bool = False, n_sets: int = 1, extra_options: int = 0,
                  fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = True, eps: float = 1e-4,
-                 search_ids=None, other_ids=None):
+                 search_ids=None, other_ids=None, pipeline: Optional[bool] = None):
         import torch
         lib = self.lib = native.lib()
         self.torch, self.native = torch, native
@@ -138,6 +139,23 @@ class BlendSearchStep:
         self.fused_blend = (self.fused_prologue or (self.d <= 256 and 8 * B <= I)) if fused_blend is None else bool(fused_blend)
         self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) if self.fused_fragments else 0
         self._graph = None
+        # More than PIPE_CHUNK anchors: the search runs as chunks of PIPE_CHUNK queries whose two stages are staggered over two
+        # streams - hwer_knn_screen_f32 of chunk i + 1 (MFMA / issue bound) on the step's stream beside hwer_knn_select_f32 of
+        # chunk i (bound by the gather of the candidates' rows) on a side stream; two workspaces alternate.  Same kernels, same
+        # results as the one-call search.
+        self.pipeline = (B > PIPE_CHUNK) if pipeline is None else bool(pipeline and B > 1)
+        if self.pipeline:
+            with native.device_guard(dev):
+                self.tail = 0
+                ch = min(PIPE_CHUNK, B)
+                self.pipe_chunks = [(b0, min(B, b0 + ch)) for b0 in range(0, B, ch)]
+                wsb = max(lib.hwer_knn_workspace_bytes_opts(b1 - b0, I, d, K, self.opts) for b0, b1 in self.pipe_chunks)
+                self.pipe_ws = [torch.empty(wsb, dtype=torch.uint8, device=dev) for _ in range(min(2, len(self.pipe_chunks)))]
+                for w_ in self.pipe_ws:
+                    native.check(lib.hwer_knn_workspace_init(native.ptr(w_), w_.numel(), self.S()), "knn_workspace_init")
+                self.pipe_side = torch.cuda.Stream(device=dev)
+                self.pipe_ev_screen = [torch.cuda.Event() for _ in self.pipe_chunks]
+                self.pipe_ev_select = [torch.cuda.Event() for _ in self.pipe_chunks]
 
     # ---- stages of a step (S() = the current torch stream of the step's device) -----------------------------------------------
     def S(self):
@@ -178,6 +196,8 @@ class BlendSearchStep:
                 P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
                 self.sort_by_score, P(self.search_ids), self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
                 P(ws), P(self.missed), P(ws_exact), ws_exact.numel(), self.S()), "knn_exact_device")
+        if self.pipeline and U == self.B and self.overlap_tail:
+            return self._search_pipelined(o, opts)
         side_tail = self.tail and U == self.B and self.overlap_tail
         if side_tail:   # the short last search, on the second stream
             torch = self.torch
@@ -189,6 +209,32 @@ class BlendSearchStep:
             search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
         if side_tail:
             cur.wait_stream(self.side)
+
+    def _search_pipelined(self, o, opts):
+        P, lib, K, torch = native.ptr, self.lib, self.k, self.torch
+        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
+        x16 = P(self.X16) if self.f16_screen else None
+        cur = torch.cuda.current_stream(self.dev)
+        for i, (b0, b1) in enumerate(self.pipe_chunks):
+            ws = self.pipe_ws[i % len(self.pipe_ws)]
+            if i >= len(self.pipe_ws):
+                cur.wait_event(self.pipe_ev_select[i - len(self.pipe_ws)])     # the select that read this workspace is done
+            native.check(lib.hwer_knn_screen_f32(P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), b1 - b0, K, P(ws), ws.numel(),
+                                                 opts & ~KNN_QUERIES_READY, x16, self.x16_exp, self.S()), "knn_screen")
+            self.pipe_ev_screen[i].record(cur)
+            with torch.cuda.stream(self.pipe_side):
+                self.pipe_side.wait_event(self.pipe_ev_screen[i])
+                st = ctypes.c_void_p(self.pipe_side.cuda_stream)
+                native.check(lib.hwer_knn_select_f32(
+                    P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), b1 - b0, K, self.arith,
+                    self.sort_by_score, P(self.search_ids), self.id_base, self.hnorm_max, P(oi[b0:b1]), P(osc[b0:b1]),
+                    P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(ws), ws.numel(), opts & ~KNN_QUERIES_READY, x16, st), "knn_select")
+                native.check(lib.hwer_knn_exact_device(
+                    P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
+                    self.sort_by_score, P(self.search_ids), self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None,
+                    P(of[b0:b1]), P(ws), P(self.missed), P(self.ws_exact), self.ws_exact.numel(), st), "knn_exact_device")
+                self.pipe_ev_select[i].record(self.pipe_side)
+        cur.wait_stream(self.pipe_side)
 
     def stage_prepare(self):
         """per-type table + queries (+ the search's float32 query fragments) in ONE launch: hwer_prepare_search_f32"""

@@ -249,6 +249,20 @@ int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items
                              int64_t* out_idx, double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
                              size_t workspace_bytes, uint32_t options, const void* X16 /*nullable*/, int x16_exp, void* stream);
 
+/* The same search as two stream-ordered calls (round 3), for callers that pipeline batches: the screen stage is MFMA / issue bound,
+ * the select stage is bound by the gather of the candidates' rows - with the halves of a large batch staggered on two streams, half
+ * A's select runs beside half B's screen (hwer/pipeline.py does this for more than 65 536 anchors).
+ *   hwer_knn_screen_f32 : query fragments, seed pre-pass, MFMA screen  -> candidate keys in `workspace`
+ *   hwer_knn_select_f32 : candidate keys -> float64 re-rank, certificate, re-score, sort -> outputs (+ uncertified list in the header)
+ * Same arguments, options, X16 (NULL or not) and workspace for both; hwer_knn_screen_f32 + hwer_knn_select_f32 on one stream IS
+ * hwer_knn_search_opts_f32.  Replaces the same reference lines (hwer/recommendation_base.py:78-83, :171-173). */
+int hwer_knn_screen_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32, int64_t B, int k,
+                        void* workspace, size_t workspace_bytes, uint32_t options, const void* X16 /*nullable*/, int x16_exp, void* stream);
+int hwer_knn_select_f32(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const float* A32, int64_t lda,
+                        const int32_t* a_idx, int64_t B, int k, int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base,
+                        float hnorm_max, int64_t* out_idx, double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                        size_t workspace_bytes, uint32_t options, const void* X16 /*nullable: only whether the screen had one*/, void* stream);
+
 /* float16 STORAGE of the item table for the HBM-bound small-batch path.  X16 = the padded float32 table
  * X scaled by 2^x_exp (x_exp = hwer_knn_f16_scale_exp(hnorm_max): no element leaves float16's normal range) and rounded
  * to float16.  When passed to hwer_knn_search_opts_f32, small query batches screen against it with the float16 MFMA (half

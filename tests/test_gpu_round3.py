@@ -130,3 +130,70 @@ def test_seeded_lists_longer_than_the_merge_window(hw):
     o_idx, o_score, o_d2 = c_oracle.find_closest_f64(X, Qh, V[sel], k, threads=c_oracle.effective_cpus())
     assert np.isin(o_idx[:, :50], rows).all()          # the planted rows are the neighbours
     assert np.array_equal(idx[sel], o_idx + B) and np.array_equal(score[sel], o_score) and np.array_equal(dist[sel], np.sqrt(o_d2))
+
+
+# ------------------------------------------------------------------------------------------------- split search = fused search
+@pytest.mark.parametrize("B,N,d,k,opts", [(943, 1682, 64, 200, 0), (3000, 30000, 128, 200, 2), (40, 200000, 128, 100, 0), (1500, 16000, 256, 50, 2),
+                                          (2100, 30000, 128, 200, 16)])
+def test_screen_then_select_equals_the_one_call_search(hw, B, N, d, k, opts):
+    """hwer_knn_screen_f32 + hwer_knn_select_f32 (round 3: the stages of a search as two stream-ordered calls, so that callers can
+    pipeline batches) write exactly what hwer_knn_search_opts_f32 writes - ids, scores, distances, flags - on the dense, streaming
+    (float32 / float16 / unseeded) and small-batch paths; the pipelined BlendSearchStep (three chunks over two streams) equals the
+    one-call step."""
+    import torch
+    from hwer import native
+    from hwer.device_index import DeviceIndex
+    lib = native.lib()
+    V = np.concatenate([unit_rows_f32(31 + d, B, d), unit_rows_f32(32 + d, N, d)]).astype(np.float64)
+    ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    tt = ix.tables["item"]
+    Q64, Q32, a = ix.build_queries(np.arange(B))
+    x16, x16_exp = ix._x16(tt, B) if (opts & 2 or B <= 1024) else (None, 0)
+    P, dev = native.ptr, ix.device
+    wsb = lib.hwer_knn_workspace_bytes_opts(B, N, d, k, opts)
+    out = []
+    for split in (False, True):
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        idx = torch.full((B, k), -7, dtype=torch.int64, device=dev)
+        score = torch.zeros((B, k), dtype=torch.float64, device=dev)
+        d2 = torch.zeros((B, k), dtype=torch.float64, device=dev)
+        flags = torch.full((B,), -7, dtype=torch.int32, device=dev)
+        st = native.stream_ptr(dev)
+        if split:
+            native.check(lib.hwer_knn_screen_f32(P(tt.X), P(tt.hnorm), N, d, ix.ldx, P(Q32), B, k, P(ws), ws.numel(), opts, P(x16), x16_exp, st), "screen")
+            native.check(lib.hwer_knn_select_f32(P(tt.X), N, d, ix.ldx, P(Q64), P(ix.V), ix.ldv, P(a), B, k, 0, 1, P(tt.rows_dev), 0, tt.hnorm_max,
+                                                 P(idx), P(score), P(d2), P(flags), P(ws), ws.numel(), opts, P(x16), st), "select")
+        else:
+            native.check(lib.hwer_knn_search_opts_f32(P(tt.X), P(tt.hnorm), N, d, ix.ldx, P(Q32), P(Q64), P(ix.V), ix.ldv, P(a), B, k, 0, 1,
+                                                      P(tt.rows_dev), 0, tt.hnorm_max, P(idx), P(score), P(d2), P(flags), P(ws), ws.numel(), opts,
+                                                      P(x16), x16_exp, st), "search")
+        torch.cuda.synchronize()
+        out.append([t.cpu().numpy() for t in (idx, score, d2, flags)])
+    for x, y in zip(*out):
+        assert np.array_equal(x, y)
+    assert (out[0][3] > 0).all()
+
+
+def test_pipelined_step_equals_the_one_call_step(hw):
+    import torch
+    from hwer.pipeline import BlendSearchStep
+    dev = torch.device("cuda", 0)
+    U, I, d = 3 * 700 + 55, 20000, 128
+    tabs = [torch.from_numpy(np.concatenate([unit_rows_f32(71 + t, U, d), unit_rows_f32(81 + t, I, d)])).to(dev) for t in range(2)]
+    alpha = torch.tensor([0.5, 0.5], dtype=torch.float32, device=dev)
+    anchors = torch.arange(U, dtype=torch.int32, device=dev)
+    import hwer.pipeline as pl
+    res = []
+    for pipe in (False, True):
+        old = pl.PIPE_CHUNK
+        pl.PIPE_CHUNK = 700 if pipe else old          # three full chunks + a short one over two workspaces
+        try:
+            step = BlendSearchStep(tabs, alpha, U, I, 0, U, anchors, k=200, want_dist=True, pipeline=pipe)
+        finally:
+            pl.PIPE_CHUNK = old
+        assert step.pipeline == pipe and (not pipe or len(step.pipe_chunks) == 4)
+        step.run()
+        step.run()
+        res.append(step.results())
+    for x, y in zip(*res):
+        assert np.array_equal(x, y)

@@ -31,7 +31,11 @@ def unit_rows(seed, n, d, clustered=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--watchdog", type=int, default=0, help="seconds after which the Python stacks are dumped and the process exits")
     args = ap.parse_args()
+    if args.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
     from hwer.device_index import DeviceIndex
     from oracle import c_oracle
     from oracle import hwer_oracle as orc
