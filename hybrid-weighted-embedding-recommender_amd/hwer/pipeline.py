@@ -139,11 +139,14 @@ class BlendSearchStep:
         self.fused_blend = (self.fused_prologue or (self.d <= 256 and 8 * B <= I)) if fused_blend is None else bool(fused_blend)
         self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) if self.fused_fragments else 0
         self._graph = None
-        # More than PIPE_CHUNK anchors: the search runs as chunks of PIPE_CHUNK queries whose two stages are staggered over two
+        # pipeline=True: the search runs as chunks of PIPE_CHUNK queries whose two stages are staggered over two
         # streams - hwer_knn_screen_f32 of chunk i + 1 (MFMA / issue bound) on the step's stream beside hwer_knn_select_f32 of
         # chunk i (bound by the gather of the candidates' rows) on a side stream; two workspaces alternate.  Same kernels, same
         # results as the one-call search.
-        self.pipeline = (B > PIPE_CHUNK) if pipeline is None else bool(pipeline and B > 1)
+        # MEASURED (round 3, c3 = 138 493 anchors x 26 744 rows, same box): 6.97 ms pipelined vs 5.72 ms as one search + tail stream -
+        # the select needs four waves per SIMD in flight to saturate the Infinity-Cache gather and finds one free slot beside a
+        # resident screen, and 65 536-query chunks run the screen at TQ = 1 (twice the per-tile overhead per query).  Off by default.
+        self.pipeline = bool(pipeline) and B > 1
         if self.pipeline:
             with native.device_guard(dev):
                 self.tail = 0
