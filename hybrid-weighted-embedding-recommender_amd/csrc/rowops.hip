@@ -556,8 +556,10 @@ __global__ __launch_bounds__(256) void audit_reduce_kernel(const float* __restri
 // K3+K4 query construction (hwer/recommendation_base.py:153-155,164-170), T = arithmetic type.
 // 8 lanes per query; lane k owns columns j = k, k+8, ...  LDS per query: vec[d], sq[d], q[d] of T.
 // =====================================================================================================
+// (V64 != NULL: the rows come from the float64 table - the true float64 flavour of round 3, hwer_query_mix_f64rows; ldv is then ITS stride)
 template <typename T>
-__device__ __forceinline__ T load_elem(const float* V, int64_t ldv, int32_t idx, int j) {
+__device__ __forceinline__ T load_elem(const float* V, int64_t ldv, int32_t idx, int j, const double* V64 = nullptr) {
+    if (V64) return idx < 0 ? clip_unknown<T>(T(V64[j])) : T(V64[int64_t(idx) * ldv + j]);
     if (idx < 0) return clip_unknown<T>(T(V[j]));
     return T(V[int64_t(idx) * ldv + j]);
 }
@@ -565,14 +567,14 @@ __device__ __forceinline__ T load_elem(const float* V, int64_t ldv, int32_t idx,
 // vec <- unit(mean of the listed rows); returns nothing, result in `vec`
 template <typename T>
 __device__ __forceinline__ void unit_mean_rows(const float* V, int64_t ldv, int d, const int32_t* idx, int64_t n,
-                                               int32_t single, T* vec, T* sq, int k) {
+                                               int32_t single, T* vec, T* sq, int k, const double* V64 = nullptr) {
     for (int j = k; j < d; j += 8) {
         T acc;
         if (idx == nullptr) {
-            acc = load_elem<T>(V, ldv, single, j);  // mean of one row = row / 1
+            acc = load_elem<T>(V, ldv, single, j, V64);  // mean of one row = row / 1
         } else {
-            acc = load_elem<T>(V, ldv, idx[0], j);
-            for (int64_t m = 1; m < n; ++m) acc = acc + load_elem<T>(V, ldv, idx[m], j);
+            acc = load_elem<T>(V, ldv, idx[0], j, V64);
+            for (int64_t m = 1; m < n; ++m) acc = acc + load_elem<T>(V, ldv, idx[m], j, V64);
             acc = acc / T(double(n));
         }
         vec[j] = acc;
@@ -601,6 +603,7 @@ struct QueryMixArgs {
     //   Qf[((b / 32) * (ldq32 / 8) + j / 8) * 64 + (b % 32) + 32 * ((j % 8) / 4)][j % 4] = q_b[j], zero for b >= B and j >= d
     float* Qf;
     int64_t bq;
+    const double* V64;   // nullable: read the rows from this float64 table (stride ldv) instead of V
 };
 template <typename T>
 __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb) {
@@ -640,19 +643,19 @@ __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned c
         // every lane of the wave runs the same control flow; dead groups compute on anchor 0 and skip the store
         const int64_t bb = live ? b : 0;
         int cnt = 1;
-        unit_mean_rows<T>(V, ldv, d, nullptr, 1, anchor[bb], vec, sq, k);
+        unit_mean_rows<T>(V, ldv, d, nullptr, 1, anchor[bb], vec, sq, k, a.V64);
         for (int j = k; j < d; j += 8) q[j] = vec[j];
         const int64_t np_ = pos_ptr ? pos_ptr[bb + 1] - pos_ptr[bb] : 0;
         const int64_t nn_ = neg_ptr ? neg_ptr[bb + 1] - neg_ptr[bb] : 0;
         // the two branches below are taken per 8-lane group; wave_lds_sync inside is a wave-level fence only
         // (no s_barrier), so divergence between groups is legal.
         if (np_ > 0) {
-            unit_mean_rows<T>(V, ldv, d, pos_idx + pos_ptr[bb], np_, 0, vec, sq, k);
+            unit_mean_rows<T>(V, ldv, d, pos_idx + pos_ptr[bb], np_, 0, vec, sq, k, a.V64);
             for (int j = k; j < d; j += 8) q[j] = q[j] + vec[j];
             ++cnt;
         }
         if (nn_ > 0) {
-            unit_mean_rows<T>(V, ldv, d, neg_idx + neg_ptr[bb], nn_, 0, vec, sq, k);
+            unit_mean_rows<T>(V, ldv, d, neg_idx + neg_ptr[bb], nn_, 0, vec, sq, k, a.V64);
             for (int j = k; j < d; j += 8) q[j] = q[j] + (T(-1) * vec[j]);
             ++cnt;
         }
@@ -1227,6 +1230,21 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
     if (arith == 0) hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     else hipLaunchKernelGGL(query_mix_kernel<float>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     return check_launch("query_mix");
+}
+
+int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                           const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
+                           int64_t ldq32, void* stream) {
+    if (B == 0) return HWER_OK;
+    if (!V64 || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "query_mix_f64rows: null pointer");
+    if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix_f64rows: bad shape");
+    if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix_f64rows: ptr without idx");
+    const size_t per_wave = size_t(8) * 3 * d * sizeof(double);
+    const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, 8 * wpb), kMaxStreamBlocks * 4)));
+    const QueryMixArgs qa{nullptr, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0, V64};
+    hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
+    return check_launch("query_mix_f64rows");
 }
 
 int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids, int64_t n_rows, float* X, int64_t ldx,

@@ -82,14 +82,24 @@ class DeviceIndex:
         with native.device_guard(self.device):
             self._init(vectors, type_rows, arith, audit)
 
+    #: keep genuine float64 rows on the device and answer from them (False: the stage-wise contract of rounds 1-2 - rows are rounded
+    #: to float32 at upload, results are exact for the rounded table)
+    keep_f64 = True
+
     def _init(self, vectors, type_rows, arith, audit):
         torch = _torch()
+        self.V64 = None
         if isinstance(vectors, np.ndarray):
             if arith is None:
                 arith = 0 if vectors.dtype == np.float64 else 1
             host = np.ascontiguousarray(vectors, dtype=np.float32)
             N, d = host.shape
             src = torch.from_numpy(host).to(self.device)
+            # Genuine float64 rows (not float32 values widened): the reference's KD-tree and predict work on them as they are
+            # (hwer/recommendation_base.py:74,79,109,135-144).  The float64 table stays resident beside its float32 rounding: the MFMA
+            # screen runs on the rounding (a superset is all it has to keep), values come from the float64 rows (_search_candidates).
+            if vectors.dtype == np.float64 and self.keep_f64 and not np.array_equal(host.astype(np.float64), vectors, equal_nan=True):
+                self.V64 = torch.from_numpy(np.ascontiguousarray(vectors)).to(self.device)
         else:
             if arith is None:
                 arith = 1
@@ -153,6 +163,11 @@ class DeviceIndex:
         s = torch.from_numpy(np.ascontiguousarray(src, dtype=np.int32)).to(self.device)
         t = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.int32)).to(self.device)
         P = s.numel()
+        if arith == 0 and self.V64 is not None:     # float64 rows: the reference's float64 products
+            out = torch.empty(P, dtype=torch.float64, device=self.device)
+            native.check(self.lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(s), native.ptr(t), P,
+                                                          native.ptr(out), native.stream_ptr(self.device)), "pair_score_f64rows")
+            return out.cpu().numpy()
         if arith == 0:
             out = torch.empty(P, dtype=torch.float64, device=self.device)
             fn = self.lib.hwer_pair_score_f64
@@ -190,6 +205,11 @@ class DeviceIndex:
         np_, ni = csr(negative)
         Q64 = torch.empty((B, self.d), dtype=torch.float64, device=self.device)
         Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=self.device)
+        if self.V64 is not None and self.arith == 0:
+            native.check(self.lib.hwer_query_mix_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(a), native.ptr(pp), native.ptr(pi),
+                                                         native.ptr(np_), native.ptr(ni), B, native.ptr(Q64), native.ptr(Q32), self.ldx,
+                                                         native.stream_ptr(self.device)), "query_mix_f64rows")
+            return Q64, Q32, a
         native.check(self.lib.hwer_query_mix(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(a), native.ptr(pp),
                                              native.ptr(pi), native.ptr(np_), native.ptr(ni), B, self.arith,
                                              native.ptr(Q64), native.ptr(Q32), self.ldx, native.stream_ptr(self.device)), "query_mix")
@@ -262,9 +282,20 @@ class DeviceIndex:
             # anchor row of query b defaults to row b of the table - materialised ONCE, so that every chunk and every
             # fallback tier scores query b against V[b] (a NULL a_idx means "chunk-local index" inside the library)
             anchors_dev = torch.arange(B, dtype=torch.int32, device=self.device)
-        if k > self.lib.hwer_knn_max_k() or self.wide:
-            self._search_exhaustive(tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags)
+        if self.V64 is not None or k > self.lib.hwer_knn_max_k() or self.wide:
+            if os.environ.get("HWER_FORCE_EXHAUSTIVE") and self.V64 is None:     # tests: the certified fallback on its own
+                self._search_exhaustive(tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags)
+            else:
+                self._search_candidates(tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags)
             return idx, score, dist2, flags
+        self._search_f32(tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags)
+        return idx, score, dist2, flags
+
+    def _search_f32(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags):
+        """the HIP search on the float32 table (d <= 256, k <= 392): MFMA screen -> float64 re-rank -> certificate, then the
+        exhaustive tiers for uncertified queries; fills idx / score / dist2 / flags."""
+        torch = _torch()
+        B = Q64.shape[0]
         path_opt = self._path_options()
         for b0 in range(0, B, self.QUERY_CHUNK):
             b1 = min(B, b0 + self.QUERY_CHUNK)
@@ -306,7 +337,105 @@ class DeviceIndex:
             if bad.numel():
                 self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
                                      dist2, flags)
-        return idx, score, dist2, flags
+
+    #: extra candidates asked of the screen by _search_candidates (the certificate needs a gap between the k-th exact distance and
+    #: the bound on everything that was not a candidate)
+    CAND_MARGIN = 32
+
+    def _search_candidates(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
+        """Exact k-NN as "screen a superset, re-rank it exactly, certify" for the shapes the fused HIP search does not take:
+          * genuine float64 `vectors` (V64): the HIP search on the float32 rounding of the table returns the k + 32 nearest ROUNDED rows
+            (exact for the rounded table); rounding moves a squared distance by at most eps(D) = 2 sqrt(D) delta + delta^2, delta =
+            2^-24 ||x||max, so every row outside the candidates has a true squared distance >= T - eps(T), T = the largest candidate's
+            rounded squared distance;
+          * tables wider than hwer_knn_max_dim() or k above hwer_knn_max_k(): the screen is ONE library GEMM (float32 Q X^T - half
+            norms: a plain matrix product - rocBLAS / hipBLASLt on the MFMA units), top-(k + 32) keys by torch.topk; a float32 key is off
+            by at most E = (2 d + 32) 2^-24 (||q|| ||x||max + ||x||max^2) whatever the summation order, so every row outside the
+            candidates has a true squared distance >= ||q||^2 - 2 (kmin + E).
+        The candidates' exact squared distances come from hwer_knn_cand_dist2 (scikit-learn's summation order, on the float64 rows when
+        there are any), stable device sorts give the (distance, id) order, hwer_pair_score* the scores.  A query is certified when its
+        k-th exact distance lies strictly below the bound (or every row was a candidate); the others - near-ties across the bound -
+        are recomputed over ALL rows.  Same values and order as the reference; replaces the all-pairs float64 pass of rounds 1-2
+        (`_search_exhaustive`, kept as the certified fallback)."""
+        torch = _torch()
+        lib, dev = self.lib, self.device
+        B, n = Q64.shape[0], tt.n
+        stream = native.stream_ptr(dev)
+        kc = min(n, k + self.CAND_MARGIN)
+        use_hip = self.V64 is not None and not self.wide and kc <= lib.hwer_knn_max_k()
+        table, is64, ld = (self.V64, 1, self.d) if self.V64 is not None else (self.V, 0, self.ldv)
+        xmax = float(np.sqrt(2.0 * max(tt.hnorm_max, 0.0))) * (1.0 + 1e-6)
+        per = max(1, min(B, 65535, (1 << 28) // max(n if not use_hip else kc, 1)))       # <= 1 GiB of float32 keys at a time
+        for b0 in range(0, B, per):
+            b1 = min(B, b0 + per)
+            nb = b1 - b0
+            q64 = Q64[b0:b1]
+            if use_hip:
+                c_idx = torch.empty((nb, kc), dtype=torch.int64, device=dev)
+                c_sc = torch.empty((nb, kc), dtype=torch.float64, device=dev)
+                c_d2 = torch.empty((nb, kc), dtype=torch.float64, device=dev)
+                c_fl = torch.empty(nb, dtype=torch.int32, device=dev)
+                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, c_idx, c_sc, c_d2, c_fl)   # ids = local rows
+                local = c_idx
+                T = c_d2[:, kc - 1]
+                delta = (2.0 ** -24) * xmax
+                bound = T - 2.0 * torch.sqrt(T) * delta - delta * delta - 1e-12
+            else:
+                keys = torch.matmul(Q32[b0:b1, :self.d], tt.X[:n, :self.d].t())
+                keys -= tt.hnorm[:n].unsqueeze(0)
+                kv, local = torch.topk(keys, kc, dim=1)
+                del keys
+                qn2 = (q64 * q64).sum(1)
+                E = (2.0 * self.d + 32.0) * (2.0 ** -24) * (torch.sqrt(qn2) * xmax + xmax * xmax)
+                bound = qn2 - 2.0 * (kv[:, kc - 1].to(torch.float64) + E) - 1e-12 * torch.clamp(qn2, min=1.0)
+            # exact squared distances of the candidates, then (distance asc, row asc)
+            local, _ = torch.sort(local, dim=1)
+            rows = tt.rows_dev[local]
+            D = torch.empty((nb, kc), dtype=torch.float64, device=dev)
+            native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(rows), kc, nb, kc, native.ptr(q64),
+                                                 native.ptr(D), stream), "knn_cand_dist2")
+            D, p2 = torch.sort(D, dim=1, stable=True)
+            local = local.gather(1, p2)
+            cert = (D[:, k - 1] < bound) if kc < n else torch.ones(nb, dtype=torch.bool, device=dev)
+            fl = torch.where(cert, 1, 2).to(torch.int32)
+            d2 = D[:, :k].contiguous()
+            local = local[:, :k].contiguous()
+            bad = torch.nonzero(~cert).flatten()
+            if bad.numel():     # near-ties across the bound: all rows of the type, a few queries at a time
+                step = max(1, (1 << 26) // n)
+                for c0 in range(0, int(bad.numel()), step):
+                    sel = bad[c0:c0 + step]
+                    allrows = tt.rows_dev.unsqueeze(0).expand(sel.numel(), n).contiguous()
+                    Da = torch.empty((sel.numel(), n), dtype=torch.float64, device=dev)
+                    native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(allrows), n, sel.numel(), n,
+                                                         native.ptr(q64.index_select(0, sel).contiguous()), native.ptr(Da), stream), "knn_cand_dist2(all)")
+                    Da, pa = torch.sort(Da, dim=1, stable=True)       # ties keep the row (= id) order
+                    d2[sel] = Da[:, :k]
+                    local[sel] = pa[:, :k]
+            rows = tt.rows_dev[local]                                      # rows of the vector table (pair scoring)
+            ids = rows if use_rows else local + int(id_base)             # reported ids
+            if score_mode == 2:
+                sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
+            else:
+                a = anchors_dev[b0:b1].to(torch.int32)
+                src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
+                dst = rows.to(torch.int32).contiguous().view(-1)
+                if score_mode == 0 and self.V64 is not None:
+                    out = torch.empty(nb * k, dtype=torch.float64, device=dev)
+                    native.check(lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(src), native.ptr(dst), nb * k,
+                                                             native.ptr(out), stream), "pair_score_f64rows")
+                else:
+                    out = torch.empty(nb * k, dtype=torch.float64 if score_mode == 0 else torch.float32, device=dev)
+                    fn = lib.hwer_pair_score_f64 if score_mode == 0 else lib.hwer_pair_score_f32
+                    native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(src), native.ptr(dst), nb * k, native.ptr(out), stream),
+                                 "pair_score")
+                sc = out.view(nb, k).to(torch.float64)
+            if sort_by_score:
+                sc, o2 = torch.sort(sc, dim=1, descending=True, stable=True)
+                ids, d2 = ids.gather(1, o2), d2.gather(1, o2)
+            idx[b0:b1], score[b0:b1], flags[b0:b1] = ids, sc, fl
+            if dist2 is not None:
+                dist2[b0:b1] = d2
 
     def _search_exhaustive(self, tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
         """Shapes outside the selection kernels' limits - k above hwer_knn_max_k() or d above hwer_knn_max_dim(); the reference

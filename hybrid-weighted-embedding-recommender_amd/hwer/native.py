@@ -53,6 +53,9 @@ PROTOTYPES = {
     "hwer_knn_screen_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int64, c_int, _P, c_size_t, ctypes.c_uint32, _P, c_int, _P]),
     "hwer_knn_select_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, c_int64, c_float,
                                     _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, _P]),
+    "hwer_query_mix_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P]),
+    "hwer_pair_score_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),
+    "hwer_knn_cand_dist2": (c_int, [_P, c_int, c_int64, c_int, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P]),
     "hwer_knn_f16_scale_exp": (c_int, [c_float]),
     "hwer_knn_f16_screen_pays": (c_int, [c_int64, c_int64, c_int]),
     "hwer_pack_rows_f16": (c_int, [_P, c_int64, c_int64, c_int, _P, _P]),

@@ -310,6 +310,26 @@ int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, 
                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * F64    true float64 `vectors` (round 3).  The reference keeps ContentRecommendation's rows in float64
+ *        (hwer/content_recommender.py:96, hwer/recommendation_base.py:109); its KD-tree (:74, :79) and predict (:135-144) work on
+ *        them.  The MFMA screen runs on float32 / float16 roundings of the rows - a screen only has to keep a superset - and these
+ *        entry points produce the reference's VALUES from the float64 table:
+ *   hwer_query_mix_f64rows  : hwer_query_mix over a float64 table (float64 arithmetic; Q32 = the float32 rounding for the screen)
+ *   hwer_pair_score_f64rows : hwer_pair_score_f64 over a float64 table
+ *   hwer_knn_cand_dist2     : out[b][c] = ||Q64[b] - table[cand[b][c]]||^2 in scikit-learn's summation order for listed candidate
+ *                             rows of a float32 (table_is_f64 = 0) or float64 table; cand < 0 -> +inf.  The exact re-rank behind a
+ *                             candidate set: the float32 search asked for k + 32 (float64 flavour), or a library GEMM screen for
+ *                             tables wider than hwer_knn_max_dim() / k above hwer_knn_max_k() (hwer/device_index.py).  B <= 65535.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                           const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
+                           int64_t ldq32, void* stream);
+int hwer_pair_score_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst, int64_t P,
+                            double* out, void* stream);
+int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int d, int64_t ld, const int64_t* cand, int64_t ld_cand,
+                        int64_t B, int64_t kc, const double* Q64, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K12    seen-item filter + cuts of the Recall@K evaluation — replaces the per-user list comprehensions of
  *        validation.extraction_efficiency (hwer/validation.py:133-141):
  *          unseen = [i for i in ranked[b] if i not in seen(b)][:cut_max]

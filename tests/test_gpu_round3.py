@@ -197,3 +197,70 @@ def test_pipelined_step_equals_the_one_call_step(hw):
         res.append(step.results())
     for x, y in zip(*res):
         assert np.array_equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------------- true float64 flavour (G14)
+def g14_inputs():
+    U, I, d = 64, 4096, 64
+    x = np.random.default_rng(1400).standard_normal((U + I, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x, U, I, d
+
+
+def test_float64_rows_g14(golden, hw):
+    """north_star's "neighbour indices exactly" for the reference's float64 flavour with GENUINE float64 rows (G14, captured from the
+    reference: hwer/content_recommender.py:96, hwer/recommendation_base.py:74,79,109,135-174): the float64 table stays resident beside
+    its float32 rounding, the HIP search screens the rounding for k + 32 candidates, hwer_knn_cand_dist2 / hwer_pair_score_f64rows /
+    hwer_query_mix_f64rows produce the values from the float64 rows.  ids ==, scores == (bit for bit), KD-tree distances ==, predict
+    ==, positive / negative-list queries ==."""
+    import hashlib
+    from hwer import Node, VectorIndex
+    g = golden("g14_float64_rows")
+    V, U, I, d = g14_inputs()
+    assert hashlib.sha256(np.ascontiguousarray(V).tobytes()).hexdigest() == str(g["input_sha256"])
+    users, items = [Node("user", i) for i in range(U)], [Node("item", i) for i in range(I)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=d)
+    m.fit(users + items, V)
+    assert m.knn.index.V64 is not None and m.knn.index.arith == 0
+    k = int(g["k"])
+    idx, score = m.find_closest_neighbours_batch("item", users, k=k)
+    assert np.array_equal(idx - U, g["idx"].astype(np.int64))
+    assert np.array_equal(score, g["score"])
+    one = m.find_closest_neighbours("item", users[5], k=k)
+    assert [m.nodes_to_idx[n] - U for n, _ in one] == g["idx"][5].tolist() and [s for _, s in one] == g["score"][5].tolist()
+    for u in range(8):
+        res = m.knn.query(m.get_average_embeddings([users[u]]), "item", k=k)
+        assert [m.nodes_to_idx[n] for n, _ in res] == g["query_idx"][u].tolist()
+        assert np.array_equal(np.asarray([dd for _, dd in res]), g["query_dist"][u])
+    assert np.array_equal(m.predict_indices(g["pair_src"], g["pair_dst"]), g["pair_score"])
+    po, no = np.r_[0, np.cumsum(g["pn_pos_len"])], np.r_[0, np.cumsum(g["pn_neg_len"])]
+    table = m.knn.idx_to_node()
+    pos = [[table[int(j)] for j in g["pn_pos"][po[a]:po[a + 1]]] for a in range(16)]
+    neg = [[table[int(j)] for j in g["pn_neg"][no[a]:no[a + 1]]] for a in range(16)]
+    idx_pn, sc_pn = m.find_closest_neighbours_batch("item", users[:16], k=50, positive=pos, negative=neg)
+    assert np.array_equal(idx_pn, g["pn_idx"]) and np.array_equal(sc_pn, g["pn_score"])
+
+
+@pytest.mark.parametrize("N,d,k,B", [(20000, 96, 200, 300), (3000, 300, 393, 64), (1200, 64, 1200, 40)])
+def test_float64_rows_vs_oracle(hw, N, d, k, B):
+    """genuine float64 rows at other shapes, all against the numpy oracle on the float64 rows: a streaming-size catalogue, a wide
+    table with k above the select kernels' limit (library-GEMM screen), and k = every row; near-duplicate rows (differing below
+    float32 resolution) included - their order is decided by the float64 distances."""
+    from hwer.device_index import DeviceIndex
+    rng = np.random.default_rng(90 + d)
+    X = rng.standard_normal((B + N, d))
+    X /= np.linalg.norm(X, axis=1, keepdims=True)
+    X[B + 11] = X[B + 10] * (1.0 + 3e-9)            # the same float32 row, different float64 rows
+    X[B + 12] = X[B + 10] * (1.0 - 2e-9)
+    ix = DeviceIndex(X, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    assert ix.V64 is not None
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all()
+    rows = np.arange(B, B + N)
+    for u in list(range(0, B, max(1, B // 12))) + [B - 1]:
+        o_idx, o_score, o_dist = orc.find_closest(X, rows, u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist), u
+    # a query right at the planted rows
+    q_near = np.where(np.arange(B) == 0, 0, 0)
+    src, dst = rng.integers(-1, B + N, 500), rng.integers(-1, B + N, 500)
+    assert np.array_equal(ix.pair_score(src, dst), orc.pair_score(X, src, dst))

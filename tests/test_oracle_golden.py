@@ -301,3 +301,34 @@ def test_g12_pca_errors():
         orc.incremental_pca_fit_transform(X, 5)          # more components than columns
     with pytest.raises(ValueError):
         orc.incremental_pca_fit_transform(X[:3], 4)      # more components than rows of the first batch
+
+
+def g14_inputs():
+    """tools/capture_goldens.py g14_inputs: genuine float64 unit rows regenerated from the seed"""
+    U, I, d = 64, 4096, 64
+    x = np.random.default_rng(1400).standard_normal((U + I, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x, U, I, d
+
+
+def test_g14_float64_rows(golden):
+    """The reference fed GENUINE float64 rows (not float32 values widened): the oracle restatement reproduces its neighbours,
+    scores, KD-tree distances, predict values and positive / negative-list queries bit for bit."""
+    import hashlib
+    g = golden("g14_float64_rows")
+    V, U, I, d = g14_inputs()
+    assert hashlib.sha256(np.ascontiguousarray(V).tobytes()).hexdigest() == str(g["input_sha256"])
+    k = int(g["k"])
+    rows = np.arange(U, U + I)
+    for u in (0, 1, 17, 63):
+        idx, sc, _ = orc.find_closest(V, rows, u, k=k)
+        assert np.array_equal(idx - U, g["idx"][u].astype(np.int64)) and np.array_equal(sc, g["score"][u])
+    for u in range(8):
+        q = orc.query_vector(V, u)
+        local, dist = orc.knn_bruteforce(q, V[rows], k)
+        assert np.array_equal(rows[local], g["query_idx"][u]) and np.array_equal(dist, g["query_dist"][u])
+    assert np.array_equal(orc.pair_score(V, g["pair_src"], g["pair_dst"]), g["pair_score"])
+    po, no = np.r_[0, np.cumsum(g["pn_pos_len"])], np.r_[0, np.cumsum(g["pn_neg_len"])]
+    for a in range(16):
+        idx, sc, _ = orc.find_closest(V, rows, a, positive=g["pn_pos"][po[a]:po[a + 1]], negative=g["pn_neg"][no[a]:no[a + 1]], k=50)
+        assert np.array_equal(idx, g["pn_idx"][a]) and np.array_equal(sc, g["pn_score"][a])

@@ -532,6 +532,48 @@ def g13(pkg):
     np.savez_compressed(os.path.join(OUT, "g13_eval_callers.npz"), **out)
 
 
+def g14_inputs():
+    """genuine float64 unit rows (NOT float32-representable): 64 users + 4 096 items, d = 64 - regenerated by the tests from the
+    seed; the fixture carries their SHA-256"""
+    U, I, d = 64, 4096, 64
+    x = np.random.default_rng(1400).standard_normal((U + I, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x, U, I, d
+
+
+def g14(pkg):
+    """True float64 flavour: the reference fed genuine float64 rows - find_closest_neighbours ids / scores,
+    MultiKNN.query distances, predict, and anchors with positive / negative lists."""
+    V, U, I, d = g14_inputs()
+    assert not np.array_equal(V.astype(np.float32).astype(np.float64), V)
+    m, users, items = make_model(pkg, V, U, I)
+    k = 200
+    idx, sc = run_knn(m, users, k)
+    q_nodes, q_dist = [], []
+    for u in range(8):
+        res = m.knn.query(m.get_average_embeddings([users[u]]), "item", k=k)
+        q_nodes.append([m.nodes_to_idx[nd] for nd, _ in res])
+        q_dist.append([dd for _, dd in res])
+    rng = np.random.default_rng(1401)
+    ps, pd = rng.integers(-1, U + I, 2000), rng.integers(-1, U + I, 2000)
+    Node = Concrete(pkg).rb.Node
+    ghost = Node("item", "ghost")
+
+    def node(i):
+        return ghost if i < 0 else (users[i] if i < U else items[i - U])
+    pred = m.predict([(node(int(a)), node(int(b))) for a, b in zip(ps, pd)])
+    pos = [[items[int(j)] for j in rng.integers(0, I, int(n))] for n in rng.integers(0, 4, 16)]
+    neg = [[items[int(j)] for j in rng.integers(0, I, int(n))] for n in rng.integers(0, 3, 16)]
+    idx_pn, sc_pn = run_knn(m, users[:16], 50, positive=pos, negative=neg)
+    lens = lambda ll: np.asarray([len(x) for x in ll], dtype=np.int32)   # noqa: E731
+    flat = lambda ll: np.asarray([m.nodes_to_idx[nd] for x in ll for nd in x], dtype=np.int64)   # noqa: E731
+    np.savez_compressed(os.path.join(OUT, "g14_float64_rows.npz"), seed=1400, n_users=U, n_items=I, d=d, k=k, input_sha256=sha(V),
+                        idx=(idx - U).astype(np.int16), score=sc.astype(np.float64), query_idx=np.asarray(q_nodes, dtype=np.int64),
+                        query_dist=np.asarray(q_dist, dtype=np.float64), pair_src=ps.astype(np.int32), pair_dst=pd.astype(np.int32),
+                        pair_score=np.asarray(pred, dtype=np.float64), pn_pos_len=lens(pos), pn_pos=flat(pos), pn_neg_len=lens(neg),
+                        pn_neg=flat(neg), pn_idx=idx_pn, pn_score=sc_pn.astype(np.float64))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     pkg = ref_shims.install()
@@ -550,6 +592,7 @@ def main():
     g11(pkg)
     g12(pkg)
     g13(pkg)
+    g14(pkg)
     for f in sorted(os.listdir(OUT)):
         print("%-32s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))
 
