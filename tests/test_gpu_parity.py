@@ -685,10 +685,15 @@ def test_pack_exchange_kernel_matches_host_packing(hw, B, k, G):
     assert torch.equal(dev.cpu(), host)
 
 
+@pytest.mark.parametrize("path", ["candidates", "exhaustive"])
 @pytest.mark.parametrize("k,flavour", [(393, "f64"), (600, "f64"), (1500, "f64"), (500, "f32"), (500, "gcn")])
-def test_large_k_path_matches_oracle(hw, k, flavour):
-    """k above the selection kernels' limit (392): all-distances kernel + stable device sorts; the reference takes any
-    k <= N_t (hwer/recommendation_base.py:79).  Same indices, scores and distances as the oracle, ties included."""
+def test_large_k_path_matches_oracle(hw, monkeypatch, k, flavour, path):
+    """k above the selection kernels' limit (392); the reference takes any k <= N_t (hwer/recommendation_base.py:79).  Round 3: a
+    library-GEMM screen + exact re-rank of k + 32 candidates + certificate (`_search_candidates`, flags 1; 2 for queries whose k-th
+    distance ties across the bound); the all-pairs float64 pass of rounds 1-2 stays as the certified fallback (forced here by
+    HWER_FORCE_EXHAUSTIVE: flags 2).  Same indices, scores and distances as the oracle on both, ties included."""
+    if path == "exhaustive":
+        monkeypatch.setenv("HWER_FORCE_EXHAUSTIVE", "1")
     d, N, B = 48, 1500, 9
     V32 = np.concatenate([unit_rows_f32(801, B, d), unit_rows_f32(802, N, d)])
     V32[B + 7] = V32[B + 3]            # duplicate rows: an exact distance tie
@@ -699,7 +704,7 @@ def test_large_k_path_matches_oracle(hw, k, flavour):
         idx, sc, dist, fl = ix.search("item", np.arange(B), k=k, scoring="gcn")
     else:
         idx, sc, dist, fl = ix.search("item", np.arange(B), k=k)
-    assert (fl == 2).all()
+    assert (fl == 2).all() if path == "exhaustive" else (fl > 0).all()
     for b in range(B):
         o_idx, o_sc, o_dist = orc.find_closest(V, np.arange(B, B + N), b, k=k, scoring="gcn" if flavour == "gcn" else "base")
         assert np.array_equal(idx[b], o_idx), (k, flavour, b)

@@ -159,16 +159,20 @@ def test_index_on_a_device_that_is_not_current(hw):
 
 
 # ------------------------------------------------------------------------------------------------- wide tables / large k
-@pytest.mark.parametrize("d,flav", [(300, "f64"), (515, "f64"), (515, "f32"), (257, "gcn")])
-def test_knn_wide_tables(hw, d, flav):
+@pytest.mark.parametrize("path", ["candidates", "exhaustive"])
+@pytest.mark.parametrize("d,flav", [(300, "f64"), (515, "f64"), (515, "f32"), (257, "gcn"), (1024, "f64")])
+def test_knn_wide_tables(hw, monkeypatch, d, flav, path):
     """The reference has no width limit (hwer/recommendation_base.py:74; n_dims can exceed 256, content_recommender.py:67).
-    d > 256 takes the exhaustive float64 path: same ids, scores and distances as the oracle, bit for bit."""
+    d > 256: library-GEMM screen + exact re-rank of the candidates + certificate (round 3), or - forced - the all-pairs float64
+    fallback: same ids, scores and distances as the oracle, bit for bit."""
+    if path == "exhaustive":
+        monkeypatch.setenv("HWER_FORCE_EXHAUSTIVE", "1")
     U, N, k = 23, 4000, 200
     V32 = np.concatenate([unit_rows_f32(7, U, d), unit_rows_f32(8, N, d)])
     V = V32 if flav in ("f32", "gcn") else V32.astype(np.float64)
     ix = make_index(V, U, N)
     idx, score, dist, flags = ix.search("item", np.arange(U), k=k, scoring="gcn" if flav == "gcn" else "base")
-    assert (flags == 2).all()
+    assert (flags == 2).all() if path == "exhaustive" else (flags == 1).all()
     for u in range(U):
         o_idx, o_score, o_dist = orc.find_closest(V, np.arange(U, U + N), u, k=k, scoring="gcn" if flav == "gcn" else "base")
         assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist)
