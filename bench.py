@@ -648,6 +648,32 @@ def api_latency(torch, Vh, U, I, d, arrays_only=False):
 # ====================================================================================================================
 # N = 1
 # ====================================================================================================================
+def wide_probe(torch, dev):
+    """Shapes outside the fused HIP search through the host mirror (results left on the device): a 515-column table (ML-20M-sized
+    catalogue, 4 096 anchors, k = 200) and k = 1 000 on a 128-column one - the library-GEMM screen + exact candidate re-rank of
+    round 3 (`DeviceIndex._search_candidates`) next to the all-pairs float64 pass it replaced (`_search_exhaustive`, forced)."""
+    from hwer.device_index import DeviceIndex
+    out = {}
+    for tag, d, k, B, N in (("d515_k200", 515, 200, 4096, 26744), ("d128_k1000", 128, 1000, 4096, 26744)):
+        V = gen_unit_rows(torch, 7000 + d, 0, B + N, d, dev)
+        ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}, device=dev, arith=0, audit=False)
+        Q64, Q32, a = ix.build_queries(np.arange(B))
+        ent = {"users": B, "items": N, "d": d, "k": k}
+        for name, force in (("candidates_ms", None), ("exhaustive_ms", "1")):
+            if force:
+                os.environ["HWER_FORCE_EXHAUSTIVE"] = force
+            try:
+                fn = lambda: ix.search_queries("item", Q64, Q32, k, a)       # noqa: E731
+                ent[name] = cuda_time(torch, fn, 3, warm=1)
+            finally:
+                os.environ.pop("HWER_FORCE_EXHAUSTIVE", None)
+        ent["speedup"] = ent["exhaustive_ms"] / ent["candidates_ms"]
+        out[tag] = ent
+        del ix, V
+        torch.cuda.empty_cache()
+    return out
+
+
 def run_single(args):
     import torch
     from hwer import native
@@ -676,6 +702,7 @@ def run_single(args):
                                  "use this value as the N = 1 point of the scaling curve")
     out = finish_line(base, top)
     out["configs"] = configs
+    out["wide_or_large_k"] = wide_probe(torch, dev)
     out["strong_scaling_headroom"] = {"c4full_over_c4_median": configs["c4full"]["ms_median"] / configs["c4"]["ms_median"],
                                       "note": "one GPU's step on the whole 10M-row catalogue / its step on one 1.25M-row shard: the 8-GPU speedup before exchange effects"}
     out["bench_wall_s"] = time.perf_counter() - t_start
@@ -753,6 +780,8 @@ def compact_line(full, detail_path):
         cfgs[name] = e
     if cfgs:
         out["configs"] = cfgs
+    if "wide_or_large_k" in full:
+        out["wide_or_large_k"] = {t: {"ms": _r(e["candidates_ms"], 4), "exhaustive_ms": _r(e["exhaustive_ms"], 4)} for t, e in full["wide_or_large_k"].items()}
     for k_ in ("strong_scaling_headroom", "emulated_shards"):
         if k_ in full:
             v = full[k_]

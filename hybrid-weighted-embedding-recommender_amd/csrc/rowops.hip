@@ -604,6 +604,8 @@ struct QueryMixArgs {
     float* Qf;
     int64_t bq;
     const double* V64;   // nullable: read the rows from this float64 table (stride ldv) instead of V
+    int gq;              // queries a wave builds per trip: 0 = 8 (one per group of 8 lanes); 4 / 2 / 1 for rows so wide that 8 x 3 d values
+                         // do not fit the CU's LDS (float64 arithmetic above d = 853) - the other lane groups sit out
 };
 template <typename T>
 __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb) {
@@ -620,12 +622,14 @@ __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned c
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave >= wpb) return;          // fused launches run 256-thread blocks whatever wpb is
     const int g8 = lane >> 3, k = lane & 7;
-    T* base = reinterpret_cast<T*>(smem_raw) + size_t(wave * 8 + g8) * 3 * d;
+    const int gq = a.gq ? a.gq : 8;
+    if (g8 >= gq) return;             // (no workgroup barrier below; the 8-lane groups never exchange data with each other)
+    T* base = reinterpret_cast<T*>(smem_raw) + size_t(wave * gq + g8) * 3 * d;
     T* vec = base;
     T* sq = base + d;
     T* q = base + 2 * d;
-    const int64_t q0 = (blk * wpb + wave) * 8;
-    const int64_t qstride = nblk * wpb * 8;
+    const int64_t q0 = (blk * wpb + wave) * gq;
+    const int64_t qstride = nblk * wpb * gq;
     const int ngq = int(ldq32 / 8);
     auto frag_at = [&](int64_t b, int j) -> float& {
         return a.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)];
@@ -1223,10 +1227,12 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
     if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix: bad shape");
     if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix: ptr without idx");
     if (arith != 0 && arith != 1) return fail(HWER_EINVAL, "query_mix: arith must be 0 (float64) or 1 (float32)");
-    const size_t per_wave = size_t(8) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));
+    int gq = 8;
+    while (gq > 1 && size_t(gq) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float)) > size_t(128) * 1024) gq >>= 1;
+    const size_t per_wave = size_t(gq) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));
     const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
-    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, 8 * wpb), kMaxStreamBlocks * 4)));
-    const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0};
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, gq * wpb), kMaxStreamBlocks * 4)));
+    const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0, nullptr, gq == 8 ? 0 : gq};
     if (arith == 0) hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     else hipLaunchKernelGGL(query_mix_kernel<float>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     return check_launch("query_mix");
@@ -1239,10 +1245,12 @@ int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, con
     if (!V64 || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "query_mix_f64rows: null pointer");
     if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix_f64rows: bad shape");
     if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix_f64rows: ptr without idx");
-    const size_t per_wave = size_t(8) * 3 * d * sizeof(double);
+    int gq = 8;
+    while (gq > 1 && size_t(gq) * 3 * d * sizeof(double) > size_t(128) * 1024) gq >>= 1;
+    const size_t per_wave = size_t(gq) * 3 * d * sizeof(double);
     const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
-    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, 8 * wpb), kMaxStreamBlocks * 4)));
-    const QueryMixArgs qa{nullptr, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0, V64};
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, gq * wpb), kMaxStreamBlocks * 4)));
+    const QueryMixArgs qa{nullptr, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0, V64, gq == 8 ? 0 : gq};
     hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     return check_launch("query_mix_f64rows");
 }
