@@ -59,6 +59,7 @@ struct ScreenArgs {
     const float* tau0;   // streaming mode: per-query initial threshold from the seed pre-pass (NULL: open thresholds)
     int tile_stride;     // 1; the seed pre-pass visits every tile_stride-th tile of the catalogue (its items are sample-local)
     int dense_f16;       // DENSE mode: `dense` holds float16 keys (the seed pre-pass: its keys only place a threshold - half the bytes)
+    int sparse_hits;     // streaming float16 mode: fewer than ~0.6 passing keys expected per tile and wave -> the max-tree filter (FILTER_V2)
     int seed_m;          // DENSE mode, seed pre-pass (round 3): 0 = store every key; M in {1, 2, 4} = every lane keeps the M largest keys it
                          // sees for its query and stores only those: dense[q * ld_dense + bin * M + j], bin = (split * wi + wave_i) * 2 + lane half
 };
@@ -489,15 +490,18 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // (v_alignbit) pushes that sign bit into the mask.  Bit (15 - q) of half-word b <-> accumulator register q of
             // query subtile b.  Both subtiles share ONE park and ONE pop loop: the loop runs max-over-lanes of the lane's
             // total pops, not the sum of the per-subtile maxima.
-            if constexpr (F16 && FILTER_V2) {
-                // Round 3.  With seeded thresholds a passing key is rare (c4: ~1.7 per 32 x 64 tile and wave at c = 4), and what bounds
-                // this loop is the wave's vector-instruction count and its serial chain, not a pipe (SQ counters): the
-                // per-key pass masks (48 VALU per tile), the LDS park of all 32 keys (16 ds_write2st64) and the pop loop (~33 VALU + an
-                // LDS round trip per iteration) are replaced by
+            if (F16 && FILTER_V2 && a.sparse_hits) {   // (wave-uniform)
+                // Round 3, catalogues so large that most tiles of a wave hold NO passing key (seeded thresholds let c K' keys of a query
+                // through whatever the catalogue size: 0.2 per 32 x 64 tile and wave on 10 M rows, 1.7 on 1.25 M).  What bounds this loop
+                // is the wave's serial chain and instruction count, not a pipe (SQ counters): the per-key pass masks (48
+                // VALU per tile) are replaced by
                 //   * the lane's maximum of its 16 keys (a v_max3_f32 tree: 8 VALU) and ONE compare with the threshold per subtile;
                 //   * only when some lane passes (wave-uniform branch): one compare per accumulator register, and the append code of a
                 //     register runs under the lanes that pass (s_cbranch_execz skips it otherwise) - the key is still in its register:
-                //     no park, no pop loop, no LDS traffic.
+                //     no park, no pop loop, no LDS traffic.  The 16 compare / branch pairs are a ~600-cycle chain, so this variant only
+                //     pays while hit tiles are the exception: same-box A/B (rocprofv3 kernel durations) 10.62 -> 10.27 ms on the 10 M-row
+                //     catalogue, but 1.65 -> 1.71 ms on the 1.25 M-row shard and 2.91 -> 2.95 at d = 256 - the plan switches it on
+                //     (sparse_hits) below 0.6 expected passing keys per tile and wave.
                 if (!ABLATE(4)) {
                     const uint32_t item0 = uint32_t(i0) + 4 * h;
 #pragma unroll
@@ -900,7 +904,7 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
     // seed_top_m: the lanes keep their M best keys and store only those, (bq, seed_cand_ld) float32; else every key as float16
     ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_top_m ? plan.seed_cand_ld : plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
                  plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
-                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, plan.seed_top_m ? 0 : 1, plan.seed_top_m};
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, plan.seed_top_m ? 0 : 1, 0, plan.seed_top_m};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {
@@ -948,7 +952,9 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !diag_env("HWER_SCREEN_EXACT")) ? 1 : 0, diag_env("HWER_SCREEN_NOFILTER") ? atoi(diag_env("HWER_SCREEN_NOFILTER")) : 0,
                  diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
-                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0, 0};
+                 f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0,
+                 // expected passing keys per 32-row tile and wave (32 tq queries) under the seeded thresholds
+                 (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < 0.6 && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ? 1 : 0, 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

@@ -833,6 +833,10 @@ __device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRan
     const int64_t group_global = (blk * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = nblk * 4 * g.groups_per_wave;
     const int64_t n_out = PACK ? ((rg.n + 31) / 32) * 32 : rg.n;   // PACK: pad rows (zeros, half norm +inf)
+    // The searched type's table IS a slice of V when its rows are contiguous, as wide as the padded table and the caller passed
+    // X = V + row0 * ldv (V then has the <= 31 pad rows behind its last row): the row just stored in V is the table row - no second
+    // 4 d-byte store per row (round 3: 22 % of the bytes this launch moves at d = 128, T = 2)
+    const bool x_is_v = PACK && rg.ids == nullptr && pk.ldx == a.ldv && a.d == int(pk.ldx) && pk.X == a.V + rg.row0 * a.ldv;
     for (int64_t rb = group_global - g.sub; rb < n_out; rb += group_stride * U) {
         int64_t pos[U], rr[U];
         bool live[U];
@@ -869,7 +873,7 @@ __device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRan
                     }
                     ss = w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
                     if (c < pk.x4) {
-                        *reinterpret_cast<float4*>(pk.X + r * pk.ldx + 4 * c) = w;
+                        if (!x_is_v) *reinterpret_cast<float4*>(pk.X + r * pk.ldx + 4 * c) = w;
                         if (pk.X16)
                             pk.X16[(r * pk.ldx) / 4 + c] = half4_rt{(_Float16)ldexpf(w.x, pk.x_exp), (_Float16)ldexpf(w.y, pk.x_exp), (_Float16)ldexpf(w.z, pk.x_exp), (_Float16)ldexpf(w.w, pk.x_exp)};
                     }

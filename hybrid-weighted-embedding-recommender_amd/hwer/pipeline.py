@@ -83,12 +83,17 @@ class BlendSearchStep:
         with native.device_guard(dev):
             self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
             self.item_rows = search_ids if search_ids is not None else torch.arange(self.search_row0, self.search_row0 + I, dtype=torch.int64, device=dev)
-            self.V = torch.zeros((N, self.ldv), dtype=torch.float32, device=dev)
+            I_pad = self.I_pad = lib.hwer_knn_padded_rows(I)
+            # The searched type's padded table X is a SLICE of V when that type's rows are the last rows of V and the padded width
+            # equals the row stride (d = 32 / 64 / 128 / 256): V is allocated with the <= 31 pad rows behind it, and the fused prologue
+            # stores each such row once (hwer_blend_prepare_search_f32 recognises X == V + row0 * ldv) - 22 % fewer bytes at d = 128.
+            self.x_in_v = search_ids is None and self.search_row0 + I == N and self.ldv == self.ldx and not os.environ.get("HWER_NO_X_IN_V")
+            self._Vbuf = torch.zeros((N + (I_pad - I if self.x_in_v else 0), self.ldv), dtype=torch.float32, device=dev)
+            self.V = self._Vbuf[:N]
             self.audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)     # counts[4] | sum |norm-1| (f64) | pad
             self.audit_counts = self.audit_buf[:4]
             self.audit_dev = self.audit_buf[4:5].view(torch.float64)
-            I_pad = self.I_pad = lib.hwer_knn_padded_rows(I)
-            self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
+            self.X = self._Vbuf[self.search_row0:self.search_row0 + I_pad] if self.x_in_v else torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
             self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
             # float16 screen wherever it pays (hwer_knn_f16_screen_pays: every streamed catalogue, dense ones from ~1e9 multiply-adds)
             if f16_screen is None:

@@ -29,6 +29,9 @@ def main():
                             env[k] = v
                         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lat_probe.py"), B, "20"], env=env, capture_output=True, text=True, timeout=300)
                         line = "%s rep%d [%s]: %s" % (c, rep, e, (r.stdout.strip().splitlines() or ["FAILED " + r.stderr[-300:]])[-1])
+                        stamps = [l for l in r.stderr.splitlines() if l.startswith("[stamps]") or l.startswith("[select stamps]")]
+                        if stamps:      # (a launch's stamps are printed by the NEXT launch: the last line is the steady state)
+                            line += "\n    " + stamps[-1]
                         print(line, flush=True)
                         fh.write(line + "\n")
                         fh.flush()
