@@ -84,6 +84,31 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
 
     for (int64_t b = wave_global; b < n_batches; b += wave_stride) {
         const int64_t p0 = b * 8;
+        if (d4 <= 64) {
+            // rows of up to 256 columns: one float4 per lane and row - ALL row loads of the 8 pairs are issued before the first product
+            // is formed (round 3: the loop below had one pair of row loads in flight per lane)
+            float4 av[8], bv[8];
+            bool us[8], ut[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t p = p0 + j * rows_per_instr + sub;
+                const bool on = j * rows_per_instr < 8 && p < P && c0 < d4;
+                const int32_t s = on ? src[p] : 0, t = on ? dst[p] : 0;
+                us[j] = s < 0; ut[j] = t < 0;
+                av[j] = on ? load_row4(V, ldv, s, c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bv[j] = on ? load_row4(V, ldv, t, c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j * rows_per_instr < 8 && p0 + j * rows_per_instr + sub < P && c0 < d4) {
+                    T* w = slab + (j * rows_per_instr + sub) * stride + 4 * c0;
+                    w[0] = widen<T>(av[j].x, us[j]) * widen<T>(bv[j].x, ut[j]);
+                    w[1] = widen<T>(av[j].y, us[j]) * widen<T>(bv[j].y, ut[j]);
+                    w[2] = widen<T>(av[j].z, us[j]) * widen<T>(bv[j].z, ut[j]);
+                    w[3] = widen<T>(av[j].w, us[j]) * widen<T>(bv[j].w, ut[j]);
+                }
+            }
+        } else
         for (int pb = 0; pb < 8; pb += rows_per_instr) {
             const int64_t p = p0 + pb + sub;
             if (p < P) {
@@ -143,8 +168,29 @@ static int launch_pair_score(const float* V, int64_t N, int d, int64_t ldv, cons
 // =====================================================================================================
 constexpr int MAXC = 4;  // d <= 1024
 
+// butterfly sum over the L (power of two) lanes of a row group, result in every lane.  The exchanges are DPP / permlane moves
+// (lane_xor32: one or two VALU instructions, ~10 cycles of latency) instead of ds_bpermute round trips through the LDS pipe (~100
+// cycles each): a row kernel's trip is load -> reduce -> normalise -> store, and with 5-6 dependent exchanges per reduction and two
+// or three reductions per row the bpermute chain was most of the time a wave spent with no load in flight (round 3).  Same lanes
+// paired in the same order: bit-identical sums.
+__device__ __forceinline__ float xor_lane_f(float v, int m) {
+    const uint32_t u = __float_as_uint(v);
+    switch (m) {
+        case 1: return __uint_as_float(lane_xor32<1>(u));
+        case 2: return __uint_as_float(lane_xor32<2>(u));
+        case 4: return __uint_as_float(lane_xor32<4>(u));
+        case 8: return __uint_as_float(lane_xor32<8>(u));
+        case 16: return __uint_as_float(lane_xor32<16>(u));
+        default: return __uint_as_float(lane_xor32<32>(u));
+    }
+}
 __device__ __forceinline__ float group_sum(float v, int L) {
-    for (int m = 1; m < L; m <<= 1) v += __shfl_xor(v, m, kWave);
+    if (L > 1) v += xor_lane_f(v, 1);
+    if (L > 2) v += xor_lane_f(v, 2);
+    if (L > 4) v += xor_lane_f(v, 4);
+    if (L > 8) v += xor_lane_f(v, 8);
+    if (L > 16) v += xor_lane_f(v, 16);
+    if (L > 32) v += xor_lane_f(v, 32);
     return v;
 }
 
