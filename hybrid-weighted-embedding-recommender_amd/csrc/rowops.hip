@@ -84,31 +84,8 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
 
     for (int64_t b = wave_global; b < n_batches; b += wave_stride) {
         const int64_t p0 = b * 8;
-        if (d4 <= 64) {
-            // rows of up to 256 columns: one float4 per lane and row - ALL row loads of the 8 pairs are issued before the first product
-            // is formed (round 3: the loop below had one pair of row loads in flight per lane)
-            float4 av[8], bv[8];
-            bool us[8], ut[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int64_t p = p0 + j * rows_per_instr + sub;
-                const bool on = j * rows_per_instr < 8 && p < P && c0 < d4;
-                const int32_t s = on ? src[p] : 0, t = on ? dst[p] : 0;
-                us[j] = s < 0; ut[j] = t < 0;
-                av[j] = on ? load_row4(V, ldv, s, c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-                bv[j] = on ? load_row4(V, ldv, t, c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j * rows_per_instr < 8 && p0 + j * rows_per_instr + sub < P && c0 < d4) {
-                    T* w = slab + (j * rows_per_instr + sub) * stride + 4 * c0;
-                    w[0] = widen<T>(av[j].x, us[j]) * widen<T>(bv[j].x, ut[j]);
-                    w[1] = widen<T>(av[j].y, us[j]) * widen<T>(bv[j].y, ut[j]);
-                    w[2] = widen<T>(av[j].z, us[j]) * widen<T>(bv[j].z, ut[j]);
-                    w[3] = widen<T>(av[j].w, us[j]) * widen<T>(bv[j].w, ut[j]);
-                }
-            }
-        } else
+        // (round 3: issuing all 16 row loads of a step before the first product - 64 more VGPRs - measured SLOWER: 0.72 -> 0.50 of the
+        // HBM roofline on the 1.25 M-row table, 0.40 -> 0.38 at d = 256; the loop below already keeps several waves' loads in flight)
         for (int pb = 0; pb < 8; pb += rows_per_instr) {
             const int64_t p = p0 + pb + sub;
             if (p < P) {
