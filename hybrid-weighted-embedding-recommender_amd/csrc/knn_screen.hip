@@ -821,6 +821,9 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
             // The threshold kernel then reads <= 4 096 candidates per query instead of the whole sample row (c4: 80 -> ~8 us and no
             // 82 MB key matrix; the one-wave pick replaces a 1 024-thread workgroup per query).
             {
+                // (a handful of queries: hundreds of pre-pass workgroups per query block would hand the one-wave pick thousands of
+                // candidates - 2 488 for one query on 1.25 M rows: 19 us of pick; at most 1 024 of them: 128 workgroups of ~3 tiles)
+                if (int64_t(p.seed_splits) * wi * 2 > 1024) p.seed_splits = std::max(1, 1024 / (wi * 2));
                 const int64_t per_t = cdiv64(ns, p.seed_splits);
                 const int n_sp = int(cdiv64(ns, per_t));               // workgroups per query block the pre-pass really launches
                 const int bins = n_sp * wi * 2;
