@@ -828,7 +828,8 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
                 const int n_sp = int(cdiv64(ns, per_t));               // workgroups per query block the pre-pass really launches
                 const int bins = n_sp * wi * 2;
                 const int rank = std::max(16, int(frac * S + 0.5));
-                const int m = bins * 4 <= 4096 ? 4 : (bins * 2 <= 4096 ? 2 : (bins <= 4096 ? 1 : 0));
+                // M: as many as keep the pick within 1 024 candidates (16 keys per lane of its wave), at most 4
+                const int m = bins * 4 <= 1024 ? 4 : (bins * 2 <= 1024 ? 2 : (bins <= 4096 ? 1 : 0));
                 if (m > 0 && int64_t(bins) * m >= int64_t(4) * rank && !diag_env("HWER_SEED_NO_TOPM")) {
                     p.seed_top_m = m;
                     p.seed_rank = rank;
