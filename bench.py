@@ -268,7 +268,7 @@ def load_traffic(config):
     """HBM-side bytes of the screen stage per launch from the committed rocprofv3 PMC passes of THIS command
     ((2 * FETCH_SIZE + WRITE_SIZE) * 1024; gfx950 counts wide reads at half their bytes - MI355X_MICROARCH.md §HBM).  The
     counters cannot be read from inside the run: the value is labelled with the file it comes from."""
-    for fn in ("r2_pmc_traffic.json", "r1_pmc_traffic.json"):
+    for fn in ("r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 ent = json.load(fh).get(config)

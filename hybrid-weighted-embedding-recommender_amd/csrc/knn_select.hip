@@ -910,49 +910,57 @@ __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(cons
         wave_lds_sync();
         const int n_now = kept + (w1 - w0);
         const bool last = w1 >= M;
-        float sv[REDW_NV];
+        // the selection over the array's n_now keys with NV keys per lane: 16 when they fit (seeded lists at c = 4: ~1 000 keys per
+        // query - a counting probe is then 16 compares per lane instead of 64), else 32 or 64
+        auto select_window = [&](auto nv_tag) {
+            constexpr int NV = decltype(nv_tag)::value;
+            float sv[NV];
 #pragma unroll
-        for (int r = 0; r < REDW_NV; ++r) {
-            const int e = 64 * r + lane;
-            const uint64_t kk = e < n_now ? lds[e] : 0ull;
-            sv[r] = kk != 0ull ? key_score(kk) : -INFINITY;
-        }
-        if (n_now > a.kprime) {
-            // exactly the K' best: every key above the K'-th largest score plus as many of the keys equal to it as fit
-            int c_ge;
-            const float t = wave_find_rank<REDW_NV>(sv, a.kprime, 0, c_ge);
-            int c_gt = 0;
-#pragma unroll
-            for (int r = 0; r < REDW_NV; ++r) c_gt += __builtin_popcountll(__ballot(sv[r] > t));
-            const int want_eq = min(c_ge - c_gt, a.kprime - c_gt);
-            int eq_seen = 0, out = 0;
-#pragma unroll
-            for (int r = 0; r < REDW_NV; ++r) {
-                const bool gt = sv[r] > t, eq = sv[r] == t;
-                const uint64_t be = __ballot(eq);
-                const bool keep = gt || (eq && eq_seen + __builtin_popcountll(be & lt_mask) < want_eq);
-                const uint64_t bk = __ballot(keep);
-                // (in-place compaction to the array's front, not-last windows: a kept key moves DOWN, to a slot whose own key was read in
-                // this or an earlier round - the read of round r precedes its write in program order)
-                const uint64_t kk = lds[64 * r + lane];
-                if (keep) {
-                    if (last) dst[out + __builtin_popcountll(bk & lt_mask)] = kk;
-                    else lds[out + __builtin_popcountll(bk & lt_mask)] = kk;
-                }
-                out += __builtin_popcountll(bk);
-                eq_seen += __builtin_popcountll(be);
+            for (int r = 0; r < NV; ++r) {
+                const int e = 64 * r + lane;
+                const uint64_t kk = e < n_now ? lds[e] : 0ull;
+                sv[r] = kk != 0ull ? key_score(kk) : -INFINITY;
             }
-            n_c = out;   // == K'
-        } else {
-            n_c = n_now;
-            if (last) {
+            if (n_now > a.kprime) {
+                // exactly the K' best: every key above the K'-th largest score plus as many of the keys equal to it as fit
+                int c_ge;
+                const float t = wave_find_rank<NV>(sv, a.kprime, 0, c_ge);
+                int c_gt = 0;
 #pragma unroll
-                for (int r = 0; r < REDW_NV; ++r) {
-                    const int e = 64 * r + lane;
-                    if (e < n_now) dst[e] = lds[e];
+                for (int r = 0; r < NV; ++r) c_gt += __builtin_popcountll(__ballot(sv[r] > t));
+                const int want_eq = min(c_ge - c_gt, a.kprime - c_gt);
+                int eq_seen = 0, out = 0;
+#pragma unroll
+                for (int r = 0; r < NV; ++r) {
+                    const bool gt = sv[r] > t, eq = sv[r] == t;
+                    const uint64_t be = __ballot(eq);
+                    const bool keep = gt || (eq && eq_seen + __builtin_popcountll(be & lt_mask) < want_eq);
+                    const uint64_t bk = __ballot(keep);
+                    // (in-place compaction to the array's front, not-last windows: a kept key moves DOWN, to a slot whose own key was read in
+                    // this or an earlier round - the read of round r precedes its write in program order)
+                    const uint64_t kk = lds[64 * r + lane];
+                    if (keep) {
+                        if (last) dst[out + __builtin_popcountll(bk & lt_mask)] = kk;
+                        else lds[out + __builtin_popcountll(bk & lt_mask)] = kk;
+                    }
+                    out += __builtin_popcountll(bk);
+                    eq_seen += __builtin_popcountll(be);
+                }
+                n_c = out;   // == K'
+            } else {
+                n_c = n_now;
+                if (last) {
+#pragma unroll
+                    for (int r = 0; r < NV; ++r) {
+                        const int e = 64 * r + lane;
+                        if (e < n_now) dst[e] = lds[e];
+                    }
                 }
             }
-        }
+        };
+        if (n_now <= 16 * 64) select_window(std::integral_constant<int, 16>{});
+        else if (n_now <= 32 * 64) select_window(std::integral_constant<int, 32>{});
+        else select_window(std::integral_constant<int, REDW_NV>{});
         if (last) break;
         wave_lds_sync();
         kept = n_c;
