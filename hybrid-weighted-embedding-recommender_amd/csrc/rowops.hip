@@ -777,29 +777,54 @@ __device__ __forceinline__ void blend_unit_rows(const BlendArgs& a, const RowGro
             acc[u].w = fmaf(al[u], v[u].w, acc[u].w);
         }
     }
+    float ssv[U], inv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        float ss = acc[u].x * acc[u].x + acc[u].y * acc[u].y + acc[u].z * acc[u].z + acc[u].w * acc[u].w;
-        ss = group_sum(ss, g.L);      // lanes past d4 hold exact zeros: the sum is that of the pow2ceil(d4)-lane group
-        const float inv = 1.0f / sqrtf(ss);
-        o[u] = make_float4(acc[u].x * inv, acc[u].y * inv, acc[u].z * inv, acc[u].w * inv);
+        const float ss = acc[u].x * acc[u].x + acc[u].y * acc[u].y + acc[u].z * acc[u].z + acc[u].w * acc[u].w;
+        ssv[u] = group_sum(ss, g.L);  // lanes past d4 hold exact zeros: the sum is that of the pow2ceil(d4)-lane group
     }
+    // An IEEE square root + division is ~45 vector instructions whatever the lanes hold, and this kernel is not far from
+    // VALU-bound (SQ counters: ~830 wave-instructions per trip of 8 rows).  Every lane of a row group holds all four sums: lane
+    // (lane & 3) == u takes row u's, ONE sqrt / division sequence serves the four rows, quad broadcasts hand the results back
+    // (round 3).  Same operations on the same values: bit-identical rows.
+    if (U == 4 && g.L >= 4) {
+        const int l3 = int(threadIdx.x) & 3;
+        const float sp = l3 == 0 ? ssv[0] : (l3 == 1 ? ssv[1] : (l3 == 2 ? ssv[2] : ssv[U - 1]));
+        const float ip = 1.0f / sqrtf(sp);
+        const int ipb = __float_as_int(ip);
+        inv[0] = __int_as_float(__builtin_amdgcn_update_dpp(ipb, ipb, 0x00, 0xF, 0xF, true));   // quad_perm [0,0,0,0]
+        if (U > 1) inv[1 % U] = __int_as_float(__builtin_amdgcn_update_dpp(ipb, ipb, 0x55, 0xF, 0xF, true));   // [1,1,1,1]
+        if (U > 2) inv[2 % U] = __int_as_float(__builtin_amdgcn_update_dpp(ipb, ipb, 0xAA, 0xF, 0xF, true));   // [2,2,2,2]
+        if (U > 3) inv[3 % U] = __int_as_float(__builtin_amdgcn_update_dpp(ipb, ipb, 0xFF, 0xF, 0xF, true));   // [3,3,3,3]
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) inv[u] = 1.0f / sqrtf(ssv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) o[u] = make_float4(acc[u].x * inv[u], acc[u].y * inv[u], acc[u].z * inv[u], acc[u].w * inv[u]);
 }
-// store the row in V and audit its norm AS STORED
-__device__ __forceinline__ void store_audit_row(const BlendArgs& a, const RowGroup& g, int64_t r, bool live, const float4& o, AuditAcc& au) {
+// store the row in V; returns the squared norm of the row AS STORED (every lane of the row group)
+__device__ __forceinline__ float store_row(const BlendArgs& a, const RowGroup& g, int64_t r, bool live, const float4& o) {
     float s2 = 0.f;
     if (live && g.c0 < a.d4) {
         *reinterpret_cast<float4*>(a.V + r * a.ldv + 4 * g.c0) = o;
         s2 = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
     }
-    s2 = group_sum(s2, g.L);
-    if (live && g.c0 == 0) {
-        const float n = sqrtf(s2);
+    return group_sum(s2, g.L);
+}
+__device__ __forceinline__ void audit_norm(const BlendArgs& a, float s2, bool count, AuditAcc& au) {
+    const float n = sqrtf(s2);
+    if (count) {
         au.pos += double(n) > 1.0 + double(a.audit_eps);
         au.neg += double(n) < 1.0 - double(a.audit_eps);
         au.nan += (n != n);
         au.dev += fabs(double(n) - 1.0);
     }
+}
+// store the row in V and audit its norm AS STORED
+__device__ __forceinline__ void store_audit_row(const BlendArgs& a, const RowGroup& g, int64_t r, bool live, const float4& o, AuditAcc& au) {
+    const float s2 = store_row(a, g, r, live, o);
+    audit_norm(a, s2, live && g.c0 == 0, au);
 }
 // block partials -> header accumulators; the last PACK / OTHER block moves the totals out and re-zeroes the accumulators
 __device__ __forceinline__ void audit_finish(const BlendArgs& a, AuditAcc au) {
@@ -871,10 +896,19 @@ __device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRan
             rr[u] = live[u] ? (rg.ids ? rg.ids[pos[u]] : rg.row0 + pos[u]) : 0;
         }
         blend_unit_rows<U>(a, g, rr, live, o);
+        if (U == 4 && g.L >= 4) {   // the four rows' audits through ONE square root: lane (c0 & 3) == u of a group audits row u
+            float s2v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) s2v[u] = (rb + int64_t(u) * group_stride < n_out) ? store_row(a, g, rr[u], live[u], o[u]) : 0.f;   // (wave-uniform guard)
+            const int l3 = g.c0 & 3;
+            const float sp = l3 == 0 ? s2v[0] : (l3 == 1 ? s2v[1] : (l3 == 2 ? s2v[2] : s2v[U - 1]));
+            const bool lv = l3 == 0 ? live[0] : (l3 == 1 ? live[1] : (l3 == 2 ? live[2] : live[U - 1]));
+            audit_norm(a, sp, lv && g.c0 < 4, au);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (rb + int64_t(u) * group_stride >= n_out) break;   // wave-uniform
-            store_audit_row(a, g, rr[u], live[u], o[u], au);
+            if (!(U == 4 && g.L >= 4)) store_audit_row(a, g, rr[u], live[u], o[u], au);
             if constexpr (PACK) {
                 const int64_t r = pos[u];
                 const int c = g.c0;
