@@ -21,6 +21,11 @@ constexpr int K_MAX = KPRIME_MAX - SLACK;
 #endif
 constexpr bool STAGE_APPENDS = HWER_STAGE_APPENDS != 0;
 constexpr int SCREEN_IB = 32;        // item rows per LDS tile (one 32-row MFMA subtile)
+#ifndef HWER_SCREEN16_IB
+#define HWER_SCREEN16_IB 64
+#endif
+constexpr int SCREEN16_IB = HWER_SCREEN16_IB;   // ... of the float16 streaming screen: two subtiles per tile barrier / LDS-DMA phase (32: round 2's tiles)
+constexpr int ROW_PAD = 64;          // tables are allocated and padded (zero rows, half norm +inf) to whole ROW_PAD-row tiles
 constexpr int DENSE_MAX_ITEMS = 8192; // catalogues up to this size take the dense path
 constexpr int MAX_LISTS_DIRECT = 8;  // lists the select kernel can take in one pass (8 * 1024 keys = 64 KB LDS)
 

@@ -177,7 +177,11 @@ __device__ __forceinline__ void make_opaque(half8_t& f) { asm volatile("" : "+v"
 // dense mode (its keys are unscaled when they are stored).
 template <int NG, int TQ, bool DENSE, bool F16 = false>
 __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
-    constexpr int IB = 32;                         // item rows per tile = one 32-row MFMA subtile
+    // item rows per tile: one 32-row MFMA subtile; the float16 streaming screen takes TWO per tile (round 3) - the tile barrier, the
+    // LDS-DMA issue phase (~150 cycles per 1-KiB piece in the wave's chain), the capacity check and the loop control are ~1 000 of a
+    // 32-row tile's ~2 100 cycles and amortise over twice the MFMAs
+    constexpr int IB = (F16 && !DENSE) ? SCREEN16_IB : 32;
+    constexpr int NSUB = IB / 32;
     constexpr int CH = F16 ? NG : 2 * NG;          // 16-byte chunks per row
     constexpr int TILE_CHUNKS = IB * CH;
     constexpr int DMA_PER_WAVE = TILE_CHUNKS / 256 > 0 ? TILE_CHUNKS / 256 : 1;   // 1-KiB LDS-DMA pieces per wave and tile
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         uint32_t lr = lane_row, lc = lane_chunk;
         // float32 kernels: opaque - keeps the per-piece offsets from being hoisted into (spilled) registers.  The float16 kernels
         // have the registers (229 of 256 at d = 128, TQ = 2): their 1 - 4 piece offsets are loop invariants (round 3: -8 VALU per tile)
-        if constexpr (!F16 || DMA_PER_WAVE > 2) asm volatile("" : "+v"(lr), "+v"(lc));
+        if constexpr (!F16 || DMA_PER_WAVE > 4) asm volatile("" : "+v"(lr), "+v"(lc));
 #pragma unroll
         for (int i = 0; i < DMA_PER_WAVE; ++i) {
             // piece = wave + 4 i covers rows piece * PIECE_ROWS + lane / CH
@@ -356,11 +360,16 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_pre = 0, acc_mfma = 0, acc_epi = 0, acc_wait = 0, acc_post = 0, acc_flush = 0, acc_dma = 0;
     for (int t = 0; t < n_tiles; ++t) {
         STAMP(t0);
-        const float* xb = xs + (t & 1) * IB * CH * 4;
-        const float* hb = hn + (t & 1) * IB;
-        const int64_t i0 = i_begin + int64_t(p_cur) * IB;
+        const float* xb_tile = xs + (t & 1) * IB * CH * 4;
+        const float* hb_tile = hn + (t & 1) * IB;
+        const int64_t i0_tile = i_begin + int64_t(p_cur) * IB;
         p_cur = perm_next(p_cur);
         if ((t & wi_mask) == wii) {   // wave-uniform: tiles are dealt round-robin over the wi waves that share these queries
+#pragma unroll
+          for (int sub = 0; sub < NSUB; ++sub) {   // the 32-row MFMA subtiles of this tile (same swizzle: (row + 32) & 15 == row & 15)
+            const float* xb = xb_tile + sub * 32 * CH * 4;
+            const float* hb = hb_tile + sub * 32;
+            const int64_t i0 = i0_tile + 32 * sub;
             f32x16 acc[TQ];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
@@ -436,7 +445,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // Streaming mode: outstanding VMEM here = the DMA of tile t+1 (issued a whole MFMA phase ago) and the appends
             // of the previous tile (a whole tile ago): this wait is free, and it lets this tile's appends go straight to
             // HBM and stay in flight across the barrier below (no LDS staging of the appends, no flush).
-            if constexpr (!DENSE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (second subtile of a 64-row tile: no wait - it would only stall on the appends the first one has just issued)
+            if constexpr (!DENSE) { if (sub == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             if constexpr (DENSE) {
                 if (a.seed_m) {   // (wave-uniform) seed pre-pass: the lane's running top-4 per query subtile, sorted descending
 #pragma unroll
@@ -563,6 +573,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
             }   // !(F16 && FILTER_V2)
             }   // !DENSE
+          }   // sub
         }
         STAMP(t3);
         // ---- tile boundary ---------------------------------------------------------------------------------------------
@@ -593,9 +604,10 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         if (t + 2 < n_tiles && !ABLATE(16)) tile_dma(t + 2, p_dma);      // refill the ring slot every wave has just finished reading
         p_dma = perm_next(p_dma);
         STAMP(t4b);
-        // ---- stream capacity: a lane appends at most 16 keys per tile, so checking every SECOND tile against CAPH - 32
-        // keeps every stream within its CAPH slots; a compaction leaves at most K' <= 448 <= CAPH - 32 keys in a stream.
-        if (t & 1) {
+        // ---- stream capacity: a lane appends at most 16 keys per 32-row subtile, so checking every 64 rows (every SECOND 32-row tile,
+        // every 64-row tile) against CAPH - 32 keeps every stream within its CAPH slots; a compaction leaves at most K' <= 448 <=
+        // CAPH - 32 keys in a stream.
+        if ((t & 1) || NSUB == 2) {
 #pragma unroll
         for (int b = 0; b < TQ; ++b) {
             uint64_t need = __ballot(cnt[b] > CAPH - 32);
@@ -746,7 +758,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     if (const char* e = diag_env("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
     const int64_t max_splits = std::max<int64_t>(1, n_items / (min_list * wi));
     splits = std::min(splits, max_splits);
-    const int ib = 32;
+    const int ib = (options & HWER_KNN_F16_SCREEN) ? SCREEN16_IB : 32;   // item splits start on tile boundaries of the kernel that will run
     int64_t per = cdiv64(cdiv64(n_items, splits), ib) * ib;
     splits = cdiv64(n_items, per);
     p.n_splits = int(splits);
@@ -869,7 +881,8 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 template <int NG, int TQ>
 static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     const size_t lds_dense = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
-    const size_t lds_stream = lds_dense + (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);   // + append staging
+    const size_t lds_stream = size_t(2) * SCREEN16_IB * NG * 16 + size_t(2) * SCREEN16_IB * 4 + size_t(4) * 64 * 16 * TQ * 4 +
+                              (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);   // 64-row tiles (+ append staging)
     static uint64_t attr_done = 0, attr_done_d = 0;   // per device
     int dev;
     const int grid = plan.n_qblocks * plan.n_splits;

@@ -468,7 +468,7 @@ __device__ __forceinline__ void row_norm_body(const RowNormArgs& a, int64_t blk,
     const RowGroup g(PACK ? x4 : d4);
     const int64_t group_global = (blk * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = nblk * 4 * g.groups_per_wave;
-    const int64_t n_out = PACK ? ((n_rows + 31) / 32) * 32 : n_rows;   // PACK: pad rows (zeros, half norm +inf)
+    const int64_t n_out = PACK ? ((n_rows + ROW_PAD - 1) / ROW_PAD) * ROW_PAD : n_rows;   // PACK: pad rows (zeros, half norm +inf)
     for (int64_t rb = group_global - g.sub; rb < n_out; rb += group_stride * U) {
         float4 v[U][NC];
         int64_t rr[U];
@@ -880,7 +880,7 @@ __device__ __forceinline__ void blend_rows_body(const BlendArgs& a, const RowRan
     const RowGroup g(PACK ? pk.x4 : a.d4);
     const int64_t group_global = (blk * 4 + (threadIdx.x >> 6)) * g.groups_per_wave + g.sub;
     const int64_t group_stride = nblk * 4 * g.groups_per_wave;
-    const int64_t n_out = PACK ? ((rg.n + 31) / 32) * 32 : rg.n;   // PACK: pad rows (zeros, half norm +inf)
+    const int64_t n_out = PACK ? ((rg.n + ROW_PAD - 1) / ROW_PAD) * ROW_PAD : rg.n;   // PACK: pad rows (zeros, half norm +inf)
     // The searched type's table IS a slice of V when its rows are contiguous, as wide as the padded table and the caller passed
     // X = V + row0 * ldv (V then has the <= 31 pad rows behind its last row): the row just stored in V is the table row - no second
     // 4 d-byte store per row (round 3: 22 % of the bytes this launch moves at d = 128, T = 2)
@@ -1246,7 +1246,7 @@ int hwer_unit_audit_f32(const float* V, int64_t N, int d, int64_t ldv, float eps
     return check_launch("unit_audit(reduce)");
 }
 
-int64_t hwer_knn_padded_rows(int64_t n_rows) { return ((n_rows + 31) / 32) * 32; }
+int64_t hwer_knn_padded_rows(int64_t n_rows) { return ((n_rows + ROW_PAD - 1) / ROW_PAD) * ROW_PAD; }
 
 int hwer_knn_padded_dim(int d) {
     if (d < 1 || d > 256) return -1;
