@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // item rows per tile: one 32-row MFMA subtile; the float16 streaming screen takes TWO per tile (round 3) - the tile barrier, the
     // LDS-DMA issue phase (~150 cycles per 1-KiB piece in the wave's chain), the capacity check and the loop control are ~1 000 of a
     // 32-row tile's ~2 100 cycles and amortise over twice the MFMAs
-    constexpr int IB = (F16 && !DENSE) ? SCREEN16_IB : 32;
+    // (d = 256: a 64-row ring is 64 KB and leaves ONE workgroup per CU - measured 3.09 -> 3.96 ms at c5: 32-row tiles there)
+    constexpr int IB = (F16 && !DENSE && NG <= 16) ? SCREEN16_IB : 32;
     constexpr int NSUB = IB / 32;
     constexpr int CH = F16 ? NG : 2 * NG;          // 16-byte chunks per row
     constexpr int TILE_CHUNKS = IB * CH;
@@ -758,7 +759,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     if (const char* e = diag_env("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
     const int64_t max_splits = std::max<int64_t>(1, n_items / (min_list * wi));
     splits = std::min(splits, max_splits);
-    const int ib = (options & HWER_KNN_F16_SCREEN) ? SCREEN16_IB : 32;   // item splits start on tile boundaries of the kernel that will run
+    const int ib = ((options & HWER_KNN_F16_SCREEN) && p.ng <= 16) ? SCREEN16_IB : 32;   // item splits start on tile boundaries of the kernel that will run
     int64_t per = cdiv64(cdiv64(n_items, splits), ib) * ib;
     splits = cdiv64(n_items, per);
     p.n_splits = int(splits);
@@ -881,7 +882,8 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 template <int NG, int TQ>
 static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     const size_t lds_dense = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
-    const size_t lds_stream = size_t(2) * SCREEN16_IB * NG * 16 + size_t(2) * SCREEN16_IB * 4 + size_t(4) * 64 * 16 * TQ * 4 +
+    constexpr int IBS = NG <= 16 ? SCREEN16_IB : 32;
+    const size_t lds_stream = size_t(2) * IBS * NG * 16 + size_t(2) * IBS * 4 + size_t(4) * 64 * 16 * TQ * 4 +
                               (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);   // 64-row tiles (+ append staging)
     static uint64_t attr_done = 0, attr_done_d = 0;   // per device
     int dev;
