@@ -850,6 +850,8 @@ struct ReduceWaveArgs {
     int64_t B;
     int kprime;
     int32_t* todo;
+    int win;        // keys of the wave's LDS array (1 024 ... REDW_MAX): sized for the lists the seeded thresholds are EXPECTED to leave (c K' keys
+                    // per query), so that more waves fit a CU - the kernel is a chain of load latencies (round 3: 4 -> 10 resident waves per CU at c4)
 };
 
 __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(const ReduceWaveArgs a) {
@@ -857,7 +859,7 @@ __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(cons
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = int64_t(blockIdx.x) * REDW_WAVES + wave;
     if (b >= a.B) return;   // no workgroup barrier below
-    uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw) + size_t(wave) * REDW_MAX;
+    uint64_t* lds = reinterpret_cast<uint64_t*>(smem_raw) + size_t(wave) * a.win;
     const int n_streams = 2 * a.n_lists;   // <= 64: lane s owns stream s = (list s / 2, half s % 2)
     const int craw = lane < n_streams ? a.cnt_in[(int64_t(lane >> 1) * a.bq + b) * 2 + (lane & 1)] : 0;
     const int n = craw & ~CNT_FLAGS;
@@ -880,7 +882,7 @@ __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(cons
     // body runs once, exactly the single-pass kernel of round 2.
     int kept = 0, n_c = 0;
     for (int w0 = 0; w0 < M || w0 == 0; ) {   // (wave-uniform)
-        const int w1 = min(M, w0 + REDW_MAX - kept);
+        const int w1 = min(M, w0 + a.win - kept);
         // coalesced copy of every stream's part inside [w0, w1), eight streams' first 64 entries in flight at a time (seeded streams
         // are short: a stream-by-stream loop is a chain of dependent global-load latencies)
         for (int s0 = 0; s0 < n_streams; s0 += 8) {
@@ -1841,8 +1843,11 @@ static int knn_search_stages(int stages, const float* X, const float* hnorm, int
         uint64_t* cand_final = (rounds & 1) ? cand_other : cand;
         int32_t* cnt_final = (rounds & 1) ? cnt_other : cnt;
         int32_t* todo_w = reinterpret_cast<int32_t*>(ws + w.todo);
-        ReduceWaveArgs rw{cand, cnt, n_lists, cand_final, cnt_final, plan.bq, B, plan.kprime, todo_w};
-        const size_t lds_w = size_t(REDW_WAVES) * REDW_MAX * 8;
+        // window: twice the keys the seeded thresholds are expected to leave a query (c K' = seed_frac x n_items), 1 024 ... 4 096
+        int win = 1024;
+        while (win < REDW_MAX && double(win) < 2.0 * plan.seed_frac * double(n_items)) win <<= 1;
+        ReduceWaveArgs rw{cand, cnt, n_lists, cand_final, cnt_final, plan.bq, B, plan.kprime, todo_w, win};
+        const size_t lds_w = size_t(REDW_WAVES) * size_t(win) * 8;
         if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_wave_kernel), lds_w, "knn_reduce_wave"))) return rc;
         hipLaunchKernelGGL(reduce_lists_wave_kernel, dim3(unsigned(cdiv64(B, REDW_WAVES))), dim3(64 * REDW_WAVES), lds_w, st, rw);
         if ((rc = check_launch("knn_reduce_wave"))) return rc;
