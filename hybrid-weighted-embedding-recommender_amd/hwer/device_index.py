@@ -244,6 +244,9 @@ class DeviceIndex:
         torch = _torch()
         if self._ws is None or self._ws.numel() < nbytes:
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            # every (re)allocation: zero the header once (the fused prologue keeps its audit accumulators there and fails loudly on a
+            # workspace that never went through this call)
+            native.check(self.lib.hwer_knn_workspace_init(native.ptr(self._ws), self._ws.numel(), native.stream_ptr(self.device)), "knn_workspace_init")
         return self._ws
 
     def _exact_workspace(self, nbytes):
