@@ -1063,6 +1063,20 @@ int hwer_pair_score_f64(const float* V, int64_t N, int d, int64_t ldv, const int
     return launch_pair_score<double>(V, N, d, ldv, src, dst, P, out, stream);
 }
 
+// compute units of the current device (cached per device)
+static int device_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 static int rows_grid(int64_t rows, int d4) {
     int L = 1;
     while (L < d4 && L < 64) L <<= 1;
@@ -1395,9 +1409,25 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     const int wpb = 4;
     const int64_t q_rows = bq ? std::max(B, bq) : B;
     // about 32 rows per PACK / OTHER block, at least ... at most the streaming grid (every such block ends with one set of atomics)
-    const int n_pack = int(std::min<int64_t>(rows_grid(n_rows, x4), std::max<int64_t>(64, cdiv64(n_rows, 32))));
-    const int n_oth = n_other ? int(std::min<int64_t>(rows_grid(n_other, d4), std::max<int64_t>(64, cdiv64(n_other, 32)))) : 0;
+    int n_pack = int(std::min<int64_t>(rows_grid(n_rows, x4), std::max<int64_t>(64, cdiv64(n_rows, 32))));
+    int n_oth = n_other ? int(std::min<int64_t>(rows_grid(n_other, d4), std::max<int64_t>(64, cdiv64(n_other, 32)))) : 0;
     const int n_mix = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, gq * wpb), kMaxStreamBlocks * 4)));
+    // Large tables: ONE round of resident workgroups (4 per CU at this kernel's 111 VGPRs), every block a grid-stride loop over an
+    // equal share of the rows - with 2 048 + 2 048 blocks the kernel ran 2.6 rounds and its last, 60 % filled round was a tail of
+    // ~10 % (round 3, same-box sweep of the PACK blocks 2 048 -> 768 ... 1 024: c4 0.54 -> 0.49 ms, c5 1.65 -> 1.5 ms, c4full +-0).
+    // The row-streaming blocks share what the QUERY blocks leave, in proportion to their rows.
+    if (!diag_env("HWER_ROW_BLOCKS")) {
+        const int64_t slots = int64_t(4) * device_cu_count();
+        const int64_t budget = slots - std::min<int64_t>(n_mix, slots / 4);
+        if (int64_t(n_pack) + n_oth > budget) {
+            const double share = double(n_rows) / double(n_rows + n_other);
+            int64_t np = std::max<int64_t>(1, std::min<int64_t>(n_pack, int64_t(share * double(budget) + 0.5)));
+            int64_t no = n_other ? std::max<int64_t>(1, std::min<int64_t>(n_oth, budget - np)) : 0;
+            np = std::max<int64_t>(1, std::min<int64_t>(n_pack, budget - no));
+            n_pack = int(np);
+            n_oth = int(no);
+        }
+    }
     WsHeader* hdr = static_cast<WsHeader*>(knn_workspace);
     const BlendArgs ba{tables, ld_tables, row_idx, alpha, alpha_per_row, T, d, d4, V, ldv, eps, hdr,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, unsigned(n_pack + n_oth)};
