@@ -747,6 +747,7 @@ int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, d
     SmallSelectArgs sa{keys, ld, n, B, 0, tau0, count_scratch, nullptr, want_frac};
     if (n <= 1024) hipLaunchKernelGGL((small_threshold_wave_kernel<16, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
     else if (n <= 2048) hipLaunchKernelGGL((small_threshold_wave_kernel<32, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
+    else if (n <= 3072) hipLaunchKernelGGL((small_threshold_wave_kernel<48, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);   // (c3: 2 464 sample keys per query)
     else if (n <= 4096) hipLaunchKernelGGL((small_threshold_wave_kernel<64, H>), dim3(unsigned(cdiv64(B, 4))), dim3(256), 0, stream, sa);
     else if (n <= 16384) hipLaunchKernelGGL((small_threshold_kernel<16, H>), dim3(unsigned(B)), dim3(1024), 0, stream, sa);
     else if (n <= 32768) hipLaunchKernelGGL((small_threshold_kernel<32, H>), dim3(unsigned(B)), dim3(1024), 0, stream, sa);
