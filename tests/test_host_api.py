@@ -233,6 +233,14 @@ def test_lazy_rows_mapping_api():
     assert len(m) == 3 and list(m) == ["a", "b", "c"] and "b" in m and "z" not in m
     assert m["b"] == [1, 2] and m["b"] is m["b"] and built == [1]      # built once, on demand
     assert dict(m.items()) == {"a": [0, 1], "b": [1, 2], "c": [2, 3]}
-    assert m.get("z") is None
+    assert m.get("z") is None and "z" not in m                       # dict.get does not insert
+    # the reference hands out a defaultdict(list) (hwer/validation.py:30-35): an unknown key reads as - and becomes - an empty list,
+    # and the mapping is writable
+    assert m["z"] == [] and "z" in m and len(m) == 4
+    m["y"] = [7]
+    m.update({"a": [9]})
+    assert m["y"] == [7] and m["a"] == [9] and m.pop("y") == [7] and "y" not in m
+    del m["z"]
     with pytest.raises(KeyError):
-        m["z"]
+        del m["z"]
+    assert list(m) == ["a", "b", "c"]
