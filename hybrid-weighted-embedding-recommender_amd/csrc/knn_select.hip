@@ -854,7 +854,11 @@ struct ReduceWaveArgs {
                     // per query), so that more waves fit a CU - the kernel is a chain of load latencies (round 3: 4 -> 10 resident waves per CU at c4)
 };
 
-__global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(const ReduceWaveArgs a) {
+// NVMAX = keys per lane of the largest selection the launch can need (window / 64): 32 for windows up to 2 048 keys - the usual case,
+// and the one that must not carry the 64-key variant's registers: compiled together the kernel took 256 VGPRs + 90 AGPRs = ONE wave per
+// SIMD, and its ~24 us per query ran in five rounds (round 3: 120 -> 70 us at c4, 91 -> 57 at c5 with three waves per SIMD)
+template <int NVMAX>
+__global__ __launch_bounds__(64 * REDW_WAVES, NVMAX <= 32 ? 3 : 1) void reduce_lists_wave_kernel(const ReduceWaveArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b = int64_t(blockIdx.x) * REDW_WAVES + wave;
@@ -961,8 +965,8 @@ __global__ __launch_bounds__(64 * REDW_WAVES) void reduce_lists_wave_kernel(cons
             }
         };
         if (n_now <= 16 * 64) select_window(std::integral_constant<int, 16>{});
-        else if (n_now <= 32 * 64) select_window(std::integral_constant<int, 32>{});
-        else select_window(std::integral_constant<int, REDW_NV>{});
+        else if (NVMAX <= 32 || n_now <= 32 * 64) select_window(std::integral_constant<int, 32>{});
+        else select_window(std::integral_constant<int, NVMAX>{});
         if (last) break;
         wave_lds_sync();
         kept = n_c;
@@ -1843,13 +1847,18 @@ static int knn_search_stages(int stages, const float* X, const float* hnorm, int
         uint64_t* cand_final = (rounds & 1) ? cand_other : cand;
         int32_t* cnt_final = (rounds & 1) ? cnt_other : cnt;
         int32_t* todo_w = reinterpret_cast<int32_t*>(ws + w.todo);
-        // window: twice the keys the seeded thresholds are expected to leave a query (c K' = seed_frac x n_items), 1 024 ... 4 096
+        // window: 1.5x the keys the seeded thresholds are expected to leave a query (c K' = seed_frac x n_items; a query with more takes
+        // further windows), 1 024 ... 4 096
         int win = 1024;
-        while (win < REDW_MAX && double(win) < 2.0 * plan.seed_frac * double(n_items)) win <<= 1;
+        while (win < REDW_MAX && double(win) < 1.5 * plan.seed_frac * double(n_items)) win <<= 1;
         ReduceWaveArgs rw{cand, cnt, n_lists, cand_final, cnt_final, plan.bq, B, plan.kprime, todo_w, win};
         const size_t lds_w = size_t(REDW_WAVES) * size_t(win) * 8;
-        if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_wave_kernel), lds_w, "knn_reduce_wave"))) return rc;
-        hipLaunchKernelGGL(reduce_lists_wave_kernel, dim3(unsigned(cdiv64(B, REDW_WAVES))), dim3(64 * REDW_WAVES), lds_w, st, rw);
+        if (win <= 2048) {
+            hipLaunchKernelGGL(reduce_lists_wave_kernel<32>, dim3(unsigned(cdiv64(B, REDW_WAVES))), dim3(64 * REDW_WAVES), lds_w, st, rw);
+        } else {
+            if ((rc = set_max_lds(reinterpret_cast<const void*>(&reduce_lists_wave_kernel<REDW_NV>), lds_w, "knn_reduce_wave"))) return rc;
+            hipLaunchKernelGGL(reduce_lists_wave_kernel<REDW_NV>, dim3(unsigned(cdiv64(B, REDW_WAVES))), dim3(64 * REDW_WAVES), lds_w, st, rw);
+        }
         if ((rc = check_launch("knn_reduce_wave"))) return rc;
         // the wave kernel finishes every query (windows of 4 096 keys when a threshold came out far too low): the two workgroup
         // rounds that used to follow it - 2 launches of ~40 us of empty blocks at c4 - are gone
