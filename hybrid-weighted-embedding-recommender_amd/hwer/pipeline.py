@@ -44,7 +44,7 @@ class BlendSearchStep:
     def __init__(self, tables: Sequence, alpha, search_row0: int, n_search: int, other_row0: int, n_other: int, anchors, k: int = 200,
                  id_base: Optional[int] = None, arith: int = 0, want_dist: bool = False, sort_by_score: bool = True,
                  f16_screen: Optional[bool] = None, f16_dense: bool = False, n_sets: int = 1, extra_options: int = 0,
-                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = True, eps: float = 1e-4,
+                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = False, eps: float = 1e-4,
                  search_ids=None, other_ids=None, pipeline: Optional[bool] = None):
         import torch
         lib = self.lib = native.lib()
@@ -119,13 +119,20 @@ class BlendSearchStep:
             native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws), self.ws.numel(), self.S()), "knn_workspace_init")   # once per allocation
             self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
             self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
-            # More anchors than one search takes (ML-20M shape: 131 072 + 7 421): the short last search runs on a second stream with its
-            # own workspaces, beside the first one - its MFMA-bound screen fills the issue slots the first search's gather-bound
-            # select leaves idle.
+            # More anchors than one search takes (ML-20M shape: 131 072 + 7 421).  tail_stream=True runs the short last search on a
+            # second stream with its own workspaces, beside the first one (round 2: 6.02 -> 5.76 ms).  OFF by default since round 3: the
+            # main screen is ONE round of 512 workgroups that need two 241-VGPR waves per SIMD, and any wave of the tail's kernels
+            # sitting on a SIMD keeps the second one out - a workgroup that starts late still needs its full 2.1 ms, so the step was
+            # bimodal (rocprofv3: the main screen 2.19 ... 3.97 ms; steps of 4.96 or 6.2 ms, with or without stream priorities).
+            # One search after the other: 5.05 ms, every step.
             self.tail = B % self.CH if (B > self.CH and tail_stream) else 0
             self.overlap_tail = True
             if self.tail:
-                self.side = torch.cuda.Stream(device=dev)
+                # the tail search runs BESIDE the main one, at a lower stream priority: without it the two searches' kernels compete for
+                # the CUs in whatever order the queues drain, and a c3 step was bimodal (4.96 or 6.2 ms: the main screen's 241-VGPR waves
+                # waiting for register space behind the tail's list-merge waves)
+                self.side = torch.cuda.Stream(device=dev, priority=0)
+                self.main_hi = torch.cuda.Stream(device=dev, priority=-1)
                 self.ws_tail = torch.empty(lib.hwer_knn_workspace_bytes_opts(self.tail, I, d, K, self.opts), dtype=torch.uint8, device=dev)
                 self.ws_exact_tail = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
         # rows pass the eps unit-norm audit (checked by `check()` after the step) => 0.5||x||^2 <= 0.5 (1 + eps)^2
@@ -213,10 +220,16 @@ class BlendSearchStep:
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
                 search(U - self.tail, U, self.ws_tail, self.ws_exact_tail)
-        for b0 in range(0, U - (self.tail if side_tail else 0), self.CH):
-            search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
-        if side_tail:
+        if side_tail:     # the main chunks on the high-priority stream
+            self.main_hi.wait_stream(cur)
+            with self.torch.cuda.stream(self.main_hi):
+                for b0 in range(0, U - self.tail, self.CH):
+                    search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
+            cur.wait_stream(self.main_hi)
             cur.wait_stream(self.side)
+        else:
+            for b0 in range(0, U, self.CH):
+                search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
 
     def _search_pipelined(self, o, opts):
         P, lib, K, torch = native.ptr, self.lib, self.k, self.torch
