@@ -256,6 +256,20 @@ def cuda_time(torch, fn, reps, warm=2):
     return e0.elapsed_time(e1) / reps
 
 
+def cuda_time_median(torch, fn, reps, warm=2):
+    """median of per-repetition HIP-event intervals (latencies: one hiccup must not move the number)"""
+    for _ in range(warm):
+        fn()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for i in range(reps):
+        fn()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    return float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]))
+
+
 def read_profile(lib):
     tot, cnt = ctypes.c_double(), ctypes.c_int64()
     lib.hwer_profile_read(0, ctypes.byref(tot), ctypes.byref(cnt))
@@ -462,7 +476,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
             continue
         ob = dict(idx=o["idx"][:B], score=o["score"][:B], dist2=None, flags=o["flags"][:B])
         opts_b = w.opts if B > 1024 else 0       # small batches take the HBM-bound path, which reads the float16 copy when there is one
-        ms = cuda_time(torch, lambda: w.stage_search(ob, B=B, opts=opts_b), 20 if B <= 64 else 5, warm=2)
+        ms = cuda_time_median(torch, lambda: w.stage_search(ob, B=B, opts=opts_b), 21 if B <= 64 else 7, warm=2)
         row_bytes = (2.0 if w.X16 is not None else 4.0) * w.ldx
         ent = {"batch": B, "ms": ms, "pairs_per_s": float(B) * I / ms * 1e3}
         if B <= 64:
