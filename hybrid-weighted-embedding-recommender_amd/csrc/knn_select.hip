@@ -578,7 +578,7 @@ struct DenseSelectArgs {
     EmitArgs emit;
     // LIST variant (small-batch path): the "row" of query b is its candidate list of packed keys
     const uint64_t* list;        // (B, list_cap)
-    const int32_t* list_count;   // (B) appended keys (may exceed the capacity: overflow)
+    const int32_t* list_count;   // (B x COUNT_STRIDE) appended keys of query b at [b * COUNT_STRIDE] (may exceed the capacity: overflow)
     int list_cap;
     int list_min;                // K': a list shorter than this came from a threshold that was too high
     float key_rel_err;           // extra |key error| / (||q|| ||x||max) of the screen that produced the keys (float16 screen: ~2^-10)
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     int n_list = 0, cnt_raw = 0;
     if constexpr (LIST) {
         lst = a.list + b * a.list_cap;
-        cnt_raw = a.list_count[b];
+        cnt_raw = a.list_count[b * COUNT_STRIDE];
         n_list = min(cnt_raw, a.list_cap);
 #pragma unroll
         for (int mm = 0; mm < MV; ++mm) {
@@ -1581,7 +1581,7 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
         w.seed_tau = off;
         off += align256(size_t(p.bq) * 4);
         w.seed_cnt = off;
-        off += align256(size_t(p.bq) * 4);
+        off += align256(size_t(p.bq) * 4 * COUNT_STRIDE);   // (the threshold kernels zero a strided counter per query: knn_small.hip)
     }
     w.total = off;
     return w;

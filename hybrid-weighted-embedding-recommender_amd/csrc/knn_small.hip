@@ -35,7 +35,7 @@ __device__ __forceinline__ void small_park_flush(const SmallSink& sk, const uint
     const int lane = threadIdx.x & 63;
     for (int i = lane; i < n; i += 64) {
         const int32_t q = pq[i];
-        const int pos = atomicAdd(&sk.count[q], 1);
+        const int pos = atomicAdd(&sk.count[int64_t(q) * COUNT_STRIDE], 1);
         if (pos < SMALL_LIST_CAP) sk.list[int64_t(q) * SMALL_LIST_CAP + pos] = pk[i];
     }
 }
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelect
     const float t = wave_find_rank_fn(count_ge, vmin, vmax, rank, a.want_frac > 0.0 ? rank / HWER_SEED_SLACK_DIV : rank / 8, c_lo);
     if (threadIdx.x == 0) {
         a.thr[b] = seed_margin<KT>(t);
-        a.count[b] = 0;
+        a.count[b * COUNT_STRIDE] = 0;
     }
 }
 
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(256) void small_threshold_wave_kernel(const SmallSe
     const float t = wave_find_rank<PER>(v, rank, a.want_frac > 0.0 ? rank / HWER_SEED_SLACK_DIV : rank / 8, c_lo);
     if (lane == 0) {
         a.thr[b] = seed_margin<KT>(t);
-        a.count[b] = 0;
+        a.count[b * COUNT_STRIDE] = 0;
     }
 }
 
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void small_collect_kernel(const SmallSelectArg
                     if (pos < LCAP) {
                         s_keys[pos] = key;
                     } else {   // staging full (massive ties): append directly
-                        const int g = atomicAdd(&a.count[b], 1);
+                        const int g = atomicAdd(&a.count[b * COUNT_STRIDE], 1);
                         if (g < SMALL_LIST_CAP) list[g] = key;
                     }
                 }
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(256) void small_collect_kernel(const SmallSelectArg
     }
     __syncthreads();
     const int n = min(s_n, LCAP);
-    if (threadIdx.x == 0) s_base = n > 0 ? atomicAdd(&a.count[b], n) : 0;
+    if (threadIdx.x == 0) s_base = n > 0 ? atomicAdd(&a.count[b * COUNT_STRIDE], n) : 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256)
         if (s_base + i < SMALL_LIST_CAP) list[s_base + i] = s_keys[i];
@@ -678,7 +678,7 @@ static SmallLayout small_layout(const SmallPlan& p, const ScreenPlan* seed) {
     w.qexp = off;  off += al256(bq * 4);                      // per-query scale exponents of the float16 variant
     w.keys = off;  off += al256(seed ? seed_keys_bytes(*seed) /* float16 sample keys | the lanes' best candidates */ : size_t(p.bq) * size_t(p.ld) * 4);
     w.thr = off;   off += al256(bq * 4);
-    w.count = off; off += al256(bq * 4);
+    w.count = off; off += al256(bq * 4 * COUNT_STRIDE);   // one counter per 128 bytes
     w.list = off;  off += al256(size_t(p.bq) * SMALL_LIST_CAP * 8);
     w.total = off;
     return w;
@@ -780,7 +780,7 @@ __global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict_
     }
     if (lane == 0) {
         tau0[b] = t;
-        count[b] = 0;
+        count[b * COUNT_STRIDE] = 0;
     }
 }
 
