@@ -172,7 +172,7 @@ def make_workload_class():
         GPU holds (the whole catalogue at N = 1); ids reported by the search are global: users 0..U-1, then the items."""
 
         def __init__(self, torch, lib, cfg, dev, lo=None, hi=None, f32_screen=False, f16_dense=False, want_dist=False, local_order=False,
-                     n_sets=1):
+                     n_sets=1, k=None):
             self.torch, self.cfg, self.dev = torch, cfg, dev
             U, I_total, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
             lo = 0 if lo is None else lo
@@ -198,7 +198,7 @@ def make_workload_class():
                 alpha = torch.full((T,), 1.0 / T, dtype=torch.float32, device=dev)
             env = os.environ.get
             super().__init__(tables, alpha, search_row0=U, n_search=I, other_row0=0, n_other=U,
-                             anchors=torch.arange(0, B, dtype=torch.int32, device=dev), k=K, id_base=U + lo, arith=0,   # float64 score flavour
+                             anchors=torch.arange(0, B, dtype=torch.int32, device=dev), k=K if k is None else k, id_base=U + lo, arith=0,   # float64 score flavour
                              want_dist=want_dist, sort_by_score=not local_order, f16_screen=False if f32_screen else None, f16_dense=f16_dense,
                              n_sets=n_sets, extra_options=int(env("HWER_BENCH_OPTS", "0")),     # A/B runs: e.g. 16 = HWER_KNN_NO_SEED
                              fused_blend=True if env("HWER_BENCH_FORCE_FUSED_BLEND") else (False if env("HWER_BENCH_NO_FUSED_BLEND") else None),
@@ -820,15 +820,17 @@ def write_detail(full, path):
 # ====================================================================================================================
 # one GPU rehearses the G-GPU job (--emulate-shards G): same shards, same pack / merge kernels, same buffer layout - no collective
 # ====================================================================================================================
-def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_screen=False, log=None):
+def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_screen=False, log=None, list_len=None):
     """-> dict.  The catalogue of `cfg` on ONE GPU, three ways: (1) as a single table (the N = 1 job); (2) cut into the G
     `shard_bounds` ranges, each searched with ids = id_base + local row exactly as rank g of `bench.py --gpus G` does (its own blend,
     its own per-type table, local (distance, id) order), packed by hwer_pack_exchange into slice g of ONE (G, 3, B, k) int64 buffer -
     the layout `all_gather_into_tensor` gives the receive buffer - and merged in place by hwer_merge_topk_strided; (3) the oracle's
     brute force over the whole catalogue on `n_oracle` sampled queries.  Asserts (2) == (1) for every query (ids, scores, squared
-    distances) and (2) == (3) on the sample."""
+    distances) and (2) == (3) on the sample.
+    Round 3: the shards send shortened lists (list_len entries, default hwer.distributed.local_list_len(K, G); K = full lists) and
+    hwer_merge_topk_lists proves per query that none ran out; if one did the rehearsal is repeated with full lists, as the job would."""
     from hwer import native
-    from hwer.distributed import merge_on_device, pack_send_buffer, shard_bounds
+    from hwer.distributed import local_list_len, merge_on_device, pack_send_buffer, shard_bounds
     from oracle import c_oracle
     from oracle import hwer_oracle as orc
     I_total, d = cfg["I"], cfg["d"]
@@ -853,11 +855,12 @@ def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_
     torch.cuda.empty_cache()
     say("single table: %.3f ms / step" % single_ms)
     # (2) the G shards, one after the other, into the all-gather's receive layout
-    recv = torch.empty((G, 3, B, K), dtype=torch.int64, device=dev)
+    k_in = local_list_len(K, G) if list_len is None else max(min(int(list_len), K), -(-K // G))
+    recv = torch.empty((G, 3, B, k_in), dtype=torch.int64, device=dev)
     shard_ms, n_exh = [], 0
     for g in range(G):
         lo, hi = shard_bounds(I_total, G, g)
-        w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=f32_screen, want_dist=True, local_order=True)
+        w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=f32_screen, want_dist=True, local_order=True, k=k_in)
         for _ in range(warmup):
             w.step()
         e[0].record()
@@ -872,9 +875,16 @@ def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_
         say("shard %d rows [%d, %d): %.3f ms / step" % (g, lo, hi, shard_ms[-1]))
         del w, o
         torch.cuda.empty_cache()
-    views = (recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64))     # strided: list stride 3 B k
-    m = merge_on_device(*views, True)
-    merge_ms = cuda_time(torch, lambda: merge_on_device(*views, True), 5, warm=1)
+    views = (recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64))     # strided: list stride 3 B k_in
+    *m, ran_out = merge_on_device(*views, True, k=K, want_exhausted=True)
+    n_ran_out = int(ran_out.sum().item())
+    if n_ran_out and k_in < K:   # a list ran out: the job repeats with full lists - so does the rehearsal (its numbers are then the full-list ones)
+        say("%d queries saw a %d-entry list run out: repeating with full lists" % (n_ran_out, k_in))
+        del recv, views, m
+        r = emulate_shards(torch, lib, cfg, dev, G, steps, warmup, n_oracle, f32_screen, log, list_len=K)
+        r["lists_ran_out_first_pass"] = n_ran_out
+        return r
+    merge_ms = cuda_time(torch, lambda: merge_on_device(*views, True, k=K, want_exhausted=True), 5, warm=1)
     m_idx, m_score, m_d2 = (t.cpu().numpy() for t in m)
     same = {"idx": bool(np.array_equal(m_idx, one["idx"].cpu().numpy())), "score": bool(np.array_equal(m_score, one["score"].cpu().numpy())),
             "dist2": bool(np.array_equal(m_d2, one["dist2"].cpu().numpy()))}
@@ -893,7 +903,8 @@ def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_
     return {"shards": G, "queries": B, "items_total": I_total, "single_table_ms": single_ms, "shard_ms": shard_ms, "shard_ms_max": max(shard_ms),
             "merge_ms": merge_ms, "speedup_before_exchange": single_ms / (max(shard_ms) + merge_ms), "merged_equals_single_table": True,
             "queries_compared": B, "oracle_checked_queries": n_par, "exhaustive_fallback_queries": {"single": n_exh_single, "shards": n_exh},
-            "recv_layout": "(G, 3, B, k) int64 = all_gather_into_tensor's receive buffer; merged in place (list stride 3*B*k)"}
+            "local_list_len": k_in, "lists_ran_out_first_pass": 0, "exchange_bytes_per_rank": 24 * B * k_in,
+            "recv_layout": "(G, 3, B, k_in) int64 = all_gather_into_tensor's receive buffer; merged in place by hwer_merge_topk_lists (list stride 3*B*k_in)"}
 
 
 def run_emulated_shards(args):
@@ -909,7 +920,8 @@ def run_emulated_shards(args):
         cfg["name"] += " [catalogue cut to %d items]" % cfg["I"]
     t0 = time.perf_counter()
     r = emulate_shards(torch, lib, cfg, dev, args.emulate_shards, steps=max(3, min(args.steps, 10)), warmup=max(2, min(args.warmup, 3)),
-                       f32_screen=args.f32_screen, log=lambda m: sys.stderr.write("[emulate] %s\n" % m))
+                       f32_screen=args.f32_screen, log=lambda m: sys.stderr.write("[emulate] %s\n" % m),
+                       list_len=K if os.environ.get("HWER_BENCH_FULL_LISTS") else (int(os.environ["HWER_BENCH_LIST_LEN"]) if os.environ.get("HWER_BENCH_LIST_LEN") else None))
     B, I = r["queries"], r["items_total"]
     step_ms = r["shard_ms_max"] + r["merge_ms"]
     return {"metric": METRIC, "value": float(B) * I / (step_ms * 1e-3), "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -928,7 +940,7 @@ def run_sharded(args, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     from hwer import native
-    from hwer.distributed import all_gather_results, exchange_by_query, merge_on_device, shard_bounds
+    from hwer.distributed import all_gather_results, exchange_by_query, local_list_len, merge_on_device, shard_bounds
     backend = os.environ.get("HWER_BENCH_BACKEND", "nccl")     # "gloo" only to exercise the N > 1 code path on a 1-GPU box
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
@@ -948,7 +960,14 @@ def run_sharded(args, rank, local_rank, world):
     I_total, U, d = cfg["I"], cfg["U"], cfg["d"]
     assert cfg.get("B", U) == U, "the strong-scaling job expects every user row to be a query (c4full, c4)"
     lo, hi = shard_bounds(I_total, world, rank)
-    w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2)
+    # Shortened local lists (hwer.distributed.local_list_len): a shard sends its k_in < K nearest - ~K / N of a query's K nearest live on
+    # it - and the merge proves per query that no list ran out (hwer_merge_topk_lists: out_exhausted).  A run in which any did is
+    # repeated as a whole with full lists (below); HWER_BENCH_FULL_LISTS=1 forces full lists.
+    k_in = K if os.environ.get("HWER_BENCH_FULL_LISTS") else local_list_len(K, world)
+    if os.environ.get("HWER_BENCH_LIST_LEN"):     # rehearsals: force a list length (a 2-rank job keeps full lists by itself)
+        k_in = max(min(int(os.environ["HWER_BENCH_LIST_LEN"]), K), -(-K // world))
+    w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2, k=k_in)
+    ex_accum = torch.zeros((U,), dtype=torch.int32, device=dev)   # queries whose merge saw a list run out, over every step of the job
     comm = torch.cuda.Stream(device=dev)
     ev_searched = [torch.cuda.Event() for _ in range(2)]
     ev_merged = [torch.cuda.Event() for _ in range(2)]
@@ -974,7 +993,12 @@ def run_sharded(args, rank, local_rank, world):
                 e0.record(comm)
                 g = exchange_by_query(o["idx"], o["score"], o["dist2"]) if exchange == "by_query" else all_gather_results(o["idx"], o["score"], o["dist2"])
                 e1.record(comm)
-                merged[s] = merge_on_device(*g, True)
+                if k_in < K:
+                    *m3, ex = merge_on_device(*g, True, k=K, want_exhausted=True)
+                    merged[s] = tuple(m3)
+                    ex_accum[:ex.numel()] |= ex
+                else:
+                    merged[s] = merge_on_device(*g, True)
                 e2.record(comm)
                 ev_merged[s].record(comm)
             ev_log.append((e0, e1, e2))
@@ -1010,9 +1034,27 @@ def run_sharded(args, rank, local_rank, world):
     screen_ms, select_ms, _ = read_profile(lib)
     last = w.sets[(step_no[0] - 1) & 1]
     n_exhaustive = w.checks(last)
-    idx_h, score_h = res[0].cpu().numpy(), res[1].cpu().numpy()
     other = "by_query" if main_exchange == "all_gather" else "all_gather"
     el2, _, xs2 = timed(make_step(other), args.steps, min(args.warmup, 2))
+    # any list that ran out, on any rank, in any step of either variant: the shortened lists are not valid for this catalogue -
+    # the whole measurement is repeated with full lists (every rank takes the same branch: the count is all-reduced)
+    n_ran_out = torch.tensor([int(ex_accum.sum().item())], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(n_ran_out, op=dist.ReduceOp.MAX)
+    lists_ran_out = int(n_ran_out.item())
+    if lists_ran_out and k_in < K:
+        if rank == 0:
+            sys.stderr.write("[bench] %d queries saw a local list of %d run out: repeating the job with full lists\n" % (lists_ran_out, k_in))
+        del w
+        torch.cuda.empty_cache()
+        k_in = K
+        w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2, k=k_in)
+        step_no[0] = 0
+        elapsed, res, xs = timed(make_step(main_exchange), args.steps, args.warmup, profile=True)
+        screen_ms, select_ms, _ = read_profile(lib)
+        last = w.sets[(step_no[0] - 1) & 1]
+        n_exhaustive = w.checks(last)
+        el2, _, xs2 = timed(make_step(other), args.steps, min(args.warmup, 2))
+    idx_h, score_h = res[0].cpu().numpy(), res[1].cpu().numpy()
 
     # ---- parity: rank 0 collects every rank's blended item rows (rank order = global id order) and checks the merged lists of
     # sampled users against the oracle's brute force over the WHOLE catalogue ----------------------------------------------
@@ -1086,7 +1128,8 @@ def run_sharded(args, rank, local_rank, world):
         "roofline": {"kernel": "knn_screen on this rank's shard", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": screen_ms},
         "kernels_ms": {"knn_screen": screen_ms, "knn_select_rerank": select_ms},
-        "exchange": {"kind": main_exchange, "bytes_sent_per_rank_per_step": 24 * U * K if main_exchange == "all_gather" else 24 * U * K * (world - 1) // world,
+        "exchange": {"kind": main_exchange, "bytes_sent_per_rank_per_step": 24 * U * k_in if main_exchange == "all_gather" else 24 * U * k_in * (world - 1) // world,
+                     "local_list_len": k_in, "lists_ran_out_first_pass": lists_ran_out,
                      "collective_ms": float(xa[:, 0].mean()) if len(xa) else None, "merge_ms": float(xa[:, 1].mean()) if len(xa) else None,
                      "note": "side-stream times (HIP events around the collective and around the merge kernel), overlapped with the next step's search"},
         "variants": {other: {"ms_per_step": el2 / args.steps * 1e3, "value": float(U) * I_total / (el2 / args.steps),

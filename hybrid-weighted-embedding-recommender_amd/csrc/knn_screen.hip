@@ -151,6 +151,9 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define HWER_FILTER_V2 1   // float16 streaming screen: max-tree + per-register appends instead of pass masks + LDS park + pop loop (round 3)
 #endif
 constexpr bool FILTER_V2 = HWER_FILTER_V2 != 0;
+#ifndef HWER_F16_PREFETCH
+#define HWER_F16_PREFETCH 1    // float16 tile product: A fragments requested this many k-steps ahead of their MFMAs
+#endif
 #ifndef HWER_F16_MFMA_PRIO
 #define HWER_F16_MFMA_PRIO 0   // wave priority during the float16 MFMA phase ...
 #endif
@@ -352,12 +355,22 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     if (n_tiles > 1) tile_dma(1, p_dma);
     p_dma = perm_next(p_dma);
 
+#if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
+    // phase experiment (HWER_SCREEN_NOFILTER = n << 16): the workgroup in the CU's odd threadgroup slot starts its tile loop n x ~64 cycles late
+    if (!DENSE && (a.debug_nofilter >> 16) != 0) {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        if ((hwid >> 16) & 1u)
+            for (int i = 0; i < (a.debug_nofilter >> 16); ++i) __builtin_amdgcn_s_sleep(1);
+    }
+#endif
     float top[DENSE ? TQ : 1][4];   // seed pre-pass (seed_m): the lane's best keys per query subtile (scaled units when F16)
 #pragma unroll
     for (int b = 0; b < (DENSE ? TQ : 1); ++b) top[b][0] = top[b][1] = top[b][2] = top[b][3] = -INFINITY;
     const bool getenv_calib = a.debug_nofilter == 2;
     unsigned long long clk0 = 0, rt0 = 0;
     if (DIAG_STAMPS) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long rt_m0 = 0, rt_n0 = 0, rt_m2 = 0;   // phase marks of tile 64 / 66 (10-ns ticks): are the two workgroups of a CU in step?
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, acc_pre = 0, acc_mfma = 0, acc_epi = 0, acc_wait = 0, acc_post = 0, acc_flush = 0, acc_dma = 0;
     for (int t = 0; t < n_tiles; ++t) {
         STAMP(t0);
@@ -399,13 +412,19 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 asm volatile("" : "+v"(sw));
                 const unsigned char* abase = reinterpret_cast<const unsigned char*>(xb) + r * (NG * 16);
                 auto a_ptr = [&](int g) { return abase + 16 * ((2 * g + h) ^ sw); };
-                half8_t av_next = *reinterpret_cast<const half8_t*>(a_ptr(0));
+                // fragment look-ahead: PF ds_read_b128 in flight ahead of the MFMAs that consume them (two MFMAs = 64 matrix-pipe cycles per
+                // k-step cover less than one LDS round trip)
+                constexpr int PF = HWER_F16_PREFETCH < NQF ? HWER_F16_PREFETCH : NQF;
+                half8_t avq[PF];
+#pragma unroll
+                for (int g = 0; g < PF; ++g) avq[g] = *reinterpret_cast<const half8_t*>(a_ptr(g));
                 __builtin_amdgcn_s_setprio(HWER_F16_MFMA_PRIO);
                 STAMP(t1);
+                if (DIAG_STAMPS && sub == 0 && (t == 64 || t == 66)) { if (t == 64) rt_m0 = __builtin_amdgcn_s_memrealtime(); else rt_m2 = __builtin_amdgcn_s_memrealtime(); }
 #pragma unroll
                 for (int g = 0; g < NQF; ++g) {
-                    const half8_t av = av_next;
-                    if (g + 1 < NQF && !ABLATE(32)) av_next = *reinterpret_cast<const half8_t*>(a_ptr(g + 1));
+                    const half8_t av = avq[g % PF];
+                    if (g + PF < NQF && !ABLATE(32)) avq[g % PF] = *reinterpret_cast<const half8_t*>(a_ptr(g + PF));
                     if (ABLATE(128)) continue;
 #pragma unroll
                     for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, qf[b][g], acc[b], 0, 0, 0);
@@ -442,7 +461,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             }
             }
             if constexpr (F16) __builtin_amdgcn_s_setprio(HWER_F16_REST_PRIO); else __builtin_amdgcn_s_setprio(3);
-            if (DIAG_STAMPS) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); }
+            if (DIAG_STAMPS) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); t2 = stamp(); if (t == 64 && sub == NSUB - 1) rt_n0 = __builtin_amdgcn_s_memrealtime(); }
             // Streaming mode: outstanding VMEM here = the DMA of tile t+1 (issued a whole MFMA phase ago) and the appends
             // of the previous tile (a whole tile ago): this wait is free, and it lets this tile's appends go straight to
             // HBM and stay in flight across the barrier below (no LDS staging of the appends, no flush).
@@ -652,6 +671,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     }
     if (DIAG_STAMPS && lane == 0) {
         unsigned long long* o = a.debug_stamps + (size_t(blockIdx.x) * 4 + wave) * 8;
+        {
+            uint32_t hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* o2 = a.debug_stamps + size_t(gridDim.x) * 32 + (size_t(blockIdx.x) * 4 + wave) * 4;
+            o2[0] = (static_cast<unsigned long long>(xcc) << 32) | hwid; o2[1] = rt_m0; o2[2] = rt_n0; o2[3] = rt_m2;
+        }
         o[0] = rt0 - rt_entry; o[1] = acc_mfma; o[2] = acc_epi; o[3] = acc_wait; o[4] = acc_post; o[5] = n_tiles;   // o[0]: prologue in 10-ns ticks
         o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel clock = o[6] / o[7] x 100 MHz
     }
@@ -957,8 +983,11 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
 #endif
     if (diag_env("HWER_SCREEN_STAMPS")) {
         if (dbg) {   // print the previous launch's stamps
-            std::vector<unsigned long long> h(size_t(dbg_grid) * 32);
+            std::vector<unsigned long long> h(size_t(dbg_grid) * 48);
             (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+            if (const char* raw = diag_env("HWER_SCREEN_STAMPS_RAW")) {   // (hw id, phase marks) per wave behind the phase sums: tools/phase_marks.py
+                if (FILE* f = fopen(raw, "wb")) { int g = dbg_grid; fwrite(&g, 4, 1, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            }
             double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}; double tiles = 0; int n = 0;
             for (int w = 0; w < dbg_grid * 4; ++w) { if (h[w * 8 + 5] == 0) continue; for (int c = 0; c < 8; ++c) sum[c] += double(h[w * 8 + c]); tiles += double(h[w * 8 + 5]); ++n; }
             fprintf(stderr, "[stamps] waves=%d tiles/wave=%.0f prologue=%.1f us; cycles/tile: mfma=%.0f epilogue=%.0f wait+barrier=%.0f post=%.0f; loop %.0f cycles in %.1f us -> in-kernel clock %.2f GHz\n", n, tiles / n,
@@ -966,7 +995,7 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
             (void)hipFree(dbg);
         }
         dbg_grid = plan.n_qblocks * plan.n_splits;
-        if (hipMalloc(&dbg, size_t(dbg_grid) * 32 * 8) != hipSuccess || hipMemset(dbg, 0, size_t(dbg_grid) * 32 * 8) != hipSuccess) dbg = nullptr;
+        if (hipMalloc(&dbg, size_t(dbg_grid) * 48 * 8) != hipSuccess || hipMemset(dbg, 0, size_t(dbg_grid) * 48 * 8) != hipSuccess) dbg = nullptr;
     }
     ScreenArgs a{X, hnorm, n_items, ldx, Q32, B, dense, plan.ld_dense, cand, cand_cnt, plan.n_qblocks, plan.wq, plan.split_items, plan.bq,
                  plan.kprime, (plan.scaled_first && !diag_env("HWER_SCREEN_EXACT")) ? 1 : 0, diag_env("HWER_SCREEN_NOFILTER") ? atoi(diag_env("HWER_SCREEN_NOFILTER")) : 0,

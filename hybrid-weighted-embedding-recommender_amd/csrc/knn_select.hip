@@ -190,6 +190,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         const float* src3 = a.X + int64_t(min(cand[min(g0 + 48 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
         float* dst = stage + srow * RR_RS + scol;
         // software pipeline: the gathers of chunk c + 1 are in flight while chunk c is reduced in float64
+        // (round 3: a second chunk of look-ahead - +16 VGPRs, 128 with a few spilled - measured slower: c2 search 0.155 -> 0.160 ms, c3 4.80 -> 4.99)
         float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
         float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
 #pragma unroll 1
@@ -292,7 +293,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     const uint64_t* s_sorted = nullptr;
     if constexpr (COOP) {   // all four waves' rounds are in the shared tables
         __syncthreads();
-        if (lazy && n_b <= 64 && n_r <= 256 && !(a.debug_skip & 2)) {   // block-uniform
+        if (lazy && n_b <= 64 && n_r <= 256 && !(a.debug_skip & 6)) {   // block-uniform
             uint64_t* skeys = reinterpret_cast<uint64_t*>(cand + kp);     // the four staging areas (20 KB) are free now
             uint64_t* sfinal = skeys + 256;
             const int i = 64 * coop_wave + lane;
@@ -682,6 +683,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     int c_lo;
     const bool lazy_ok = a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2;
     float t_hi;   // count(key32 >= t_hi) < k (and >= k - 12 when lazy_ok)
+    // (round 3, measured and not kept: three thresholds per workgroup exchange in the COOP form - 9.5 -> 4.3 barrier rounds at c1, the same
+    // ~9.7 K cycles of rank search: what a probe costs there is its compares / scalar counts under four waves per SIMD, not the barrier)
     const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo, &t_hi, lazy_ok);   // <= k-th largest key, at most c_lo - k extra keys above it
     SEL_STAMP(2);
     double Q2 = 0.0;
@@ -1162,7 +1165,10 @@ struct MergeArgs {
     int64_t* out_idx;
     double* out_score;
     double* out_dist2;
-    int64_t list_stride;   // elements between list l and l + 1 of the same array (B * k when the lists are packed)
+    int64_t list_stride;   // elements between list l and l + 1 of the same array (B * kin when the lists are packed)
+    int kin;               // entries per input list (<= k: shortened local lists, hwer_merge_topk_lists); n_lists * kin >= k
+    int32_t* out_exhausted;   // nullable (B): 1 when some list gave ALL its kin (real) entries to the k winners - the shard behind it may
+                              // hold more that belong (only meaningful when kin < k); 0 otherwise
 };
 
 // Stable order of the k winners by score, descending, by ONE wave: win_key[r] = ~orderable(score of the winner of rank r).
@@ -1217,10 +1223,10 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
     __shared__ int s_count;
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int k = a.k, G = a.n_lists;
-    const int64_t row = b * k;
+    const int k = a.k, kin = a.kin, G = a.n_lists;   // kin entries per list in, k winners out
+    const int64_t row = b * k, row_in = b * kin;
     auto load_ent = [&](int l, int j) {
-        const int64_t src = int64_t(l) * a.list_stride + row + j;
+        const int64_t src = int64_t(l) * a.list_stride + row_in + j;
         Ent e;
         e.hi = f64_orderable(a.dist2[src]);
         e.lo = (uint64_t(a.idx[src]) << MERGE_POS_BITS) | uint64_t(uint32_t((l << MERGE_J_BITS) | j));
@@ -1249,26 +1255,28 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
     const uint64_t lt_mask = (1ull << lane) - 1ull;
     const uint32_t pos_mask = (1u << MERGE_POS_BITS) - 1u;
     auto src_of_pos = [&](uint32_t pos) {
-        return int64_t(pos >> MERGE_J_BITS) * a.list_stride + row + int64_t(pos & ((1u << MERGE_J_BITS) - 1u));
+        return int64_t(pos >> MERGE_J_BITS) * a.list_stride + row_in + int64_t(pos & ((1u << MERGE_J_BITS) - 1u));
     };
     if (G <= MERGE_RANK_LISTS) {
         __shared__ int s_cnt[MERGE_RANK_LISTS];
-        uint64_t* win_key = reinterpret_cast<uint64_t*>(ent + size_t(G) * k);
+        __shared__ int s_win[MERGE_RANK_LISTS];   // winners per list (out_exhausted)
+        if (tid < MERGE_RANK_LISTS) s_win[tid] = 0;
+        uint64_t* win_key = reinterpret_cast<uint64_t*>(ent + size_t(G) * kin);
         uint32_t* win_pos = reinterpret_cast<uint32_t*>(win_key + 512);
         uint32_t* ord = win_pos + 512;
         // ---- 2a. survivors stay at their list position; s_cnt[l] = length of list l's surviving prefix ---------------------
         for (int l = wave; l < G; l += 4) {
             int c = 0;
-            for (int j0 = 0; j0 < k; j0 += 64) {
+            for (int j0 = 0; j0 < kin; j0 += 64) {
                 const int j = j0 + lane;
                 bool keep = false;
                 Ent e{};
-                if (j < k) {
+                if (j < kin) {
                     e = load_ent(l, j);
                     keep = !ent_less(t, e);
                 }
                 const uint64_t bal = __ballot(keep);
-                if (keep) ent[l * k + j] = e;
+                if (keep) ent[l * kin + j] = e;
                 c += __builtin_popcountll(bal);
                 if (bal != ~0ull) break;   // sorted list: the survivors are a prefix, and it ended inside this piece
             }
@@ -1285,11 +1293,11 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
                 if (j < c) break;
                 j -= c;
             }
-            const Ent e = ent[l * k + j];
+            const Ent e = ent[l * kin + j];
             int rank = j;
             for (int l2 = 0; l2 < G && rank < k; ++l2) {
                 if (l2 == l) continue;
-                const Ent* lst = ent + l2 * k;
+                const Ent* lst = ent + l2 * kin;
                 int lo = 0, hi = s_cnt[l2];
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
@@ -1301,6 +1309,7 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
             if (rank < k) {
                 const uint32_t pos = uint32_t(e.lo) & pos_mask;
                 const int64_t src = src_of_pos(pos);
+                if (a.out_exhausted && a.idx[src] >= 0) atomicAdd(&s_win[l], 1);   // (padding rows carry id -1)
                 if (a.sort_by_score) {
                     win_key[rank] = ~f64_orderable(a.score[src]);
                     win_pos[rank] = pos;
@@ -1309,6 +1318,14 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
                     a.out_score[row + rank] = a.score[src];
                     a.out_dist2[row + rank] = a.dist2[src];
                 }
+            }
+        }
+        if (a.out_exhausted) {   // a list whose kin entries ALL made it: its shard may hold further members (kin < k only)
+            __syncthreads();
+            if (tid == 0) {
+                int ex = 0;
+                for (int l = 0; l < G; ++l) ex |= (kin < k && s_win[l] >= kin) ? 1 : 0;
+                a.out_exhausted[b] = ex;
             }
         }
         if (!a.sort_by_score) return;
@@ -1330,11 +1347,11 @@ __global__ __launch_bounds__(256) void merge_topk_kernel(const MergeArgs a) {
     }
     // ---- 2. survivors -> LDS ------------------------------------------------------------------------------------------
     for (int l = wave; l < G; l += 4) {
-        for (int j0 = 0; j0 < k; j0 += 64) {
+        for (int j0 = 0; j0 < kin; j0 += 64) {
             const int j = j0 + lane;
             bool keep = false;
             Ent e{};
-            if (j < k) {
+            if (j < kin) {
                 e = load_ent(l, j);
                 keep = !ent_less(t, e);
             }
@@ -2014,22 +2031,35 @@ int hwer_knn_exact_f64(const float* X, int64_t n_items, int d, int64_t ldx, cons
 
 int hwer_merge_topk(const int64_t* idx, const double* score, const double* dist2, int n_lists, int64_t B, int k,
                     int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2, void* stream) {
-    return hwer_merge_topk_strided(idx, score, dist2, B * k, n_lists, B, k, sort_by_score, out_idx, out_score, out_dist2, stream);
+    return hwer_merge_topk_lists(idx, score, dist2, B * k, n_lists, B, k, k, sort_by_score, out_idx, out_score, out_dist2, nullptr, stream);
 }
 
 int hwer_merge_topk_strided(const int64_t* idx, const double* score, const double* dist2, int64_t list_stride, int n_lists,
                             int64_t B, int k, int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2,
                             void* stream) {
+    return hwer_merge_topk_lists(idx, score, dist2, list_stride, n_lists, B, k, k, sort_by_score, out_idx, out_score, out_dist2, nullptr, stream);
+}
+
+int hwer_merge_topk_lists(const int64_t* idx, const double* score, const double* dist2, int64_t list_stride, int n_lists,
+                          int64_t B, int k_in, int k, int sort_by_score, int64_t* out_idx, double* out_score, double* out_dist2,
+                          int32_t* out_exhausted, void* stream) {
     if (B == 0) return HWER_OK;
-    if (list_stride < B * k) return fail(HWER_EINVAL, "merge_topk: list_stride %lld < B * k", (long long)list_stride);
     if (!idx || !score || !dist2 || !out_idx || !out_score || !out_dist2) return fail(HWER_EINVAL, "merge_topk: null pointer");
     if (n_lists < 1 || k < 1 || k > 512) return fail(HWER_EINVAL, "merge_topk: need n_lists >= 1 and 1 <= k <= 512");
-    const int64_t total = int64_t(n_lists) * k;
-    if (total > 8192) return fail(HWER_EINVAL, "merge_topk: n_lists * k = %lld > 8192", (long long)total);
-    const size_t lds = merge_lds_bytes(n_lists, k);
+    if (k_in < 1 || k_in > k) return fail(HWER_EINVAL, "merge_topk: need 1 <= k_in <= k (got k_in=%d, k=%d)", k_in, k);
+    if (int64_t(n_lists) * k_in < k) return fail(HWER_EINVAL, "merge_topk: n_lists * k_in = %lld < k = %d", (long long)(int64_t(n_lists) * k_in), k);
+    if (list_stride < B * k_in) return fail(HWER_EINVAL, "merge_topk: list_stride %lld < B * k_in", (long long)list_stride);
+    if (k_in != k && n_lists > MERGE_RANK_LISTS) return fail(HWER_EINVAL, "merge_topk: shortened lists (k_in < k) need n_lists <= %d", MERGE_RANK_LISTS);
+    const int64_t total = int64_t(n_lists) * k_in;
+    if (total > 8192) return fail(HWER_EINVAL, "merge_topk: n_lists * k_in = %lld > 8192", (long long)total);
+    const size_t lds = merge_lds_bytes(n_lists, k);   // (sized for full lists: covers k_in <= k)
     int rc;
     if ((rc = set_max_lds(reinterpret_cast<const void*>(&merge_topk_kernel), lds, "merge_topk"))) return rc;
-    MergeArgs ma{idx, score, dist2, n_lists, B, k, sort_by_score, out_idx, out_score, out_dist2, list_stride};
+    if (out_exhausted && n_lists > MERGE_RANK_LISTS) {   // the sort path merges full lists only: nothing can be exhausted
+        hipError_t e = hipMemsetAsync(out_exhausted, 0, size_t(B) * 4, as_stream(stream));
+        if (e != hipSuccess) return fail(HWER_ELAUNCH, "merge_topk: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    MergeArgs ma{idx, score, dist2, n_lists, B, k, sort_by_score, out_idx, out_score, out_dist2, list_stride, k_in, out_exhausted};
     hipLaunchKernelGGL(merge_topk_kernel, dim3(unsigned(B)), dim3(256), lds, as_stream(stream), ma);
     return check_launch("merge_topk");
 }

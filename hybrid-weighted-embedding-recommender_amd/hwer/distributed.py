@@ -22,6 +22,27 @@ def shard_bounds(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, min(lo + per, n_rows)
 
 
+KPRIME_SLACK = 56   # csrc/knn_internal.h SLACK: a local search keeps K' = roundup64(k + 56) keys per query
+
+
+def local_list_len(k: int, world_size: int) -> int:
+    """Entries per query a shard sends when the catalogue is split over `world_size` shards (round 3: shortened local lists).
+    A shard holds ~k / G of a query's k nearest (Binomial(k, 1/G) for rows dealt at random): k_in = the largest list length
+    with the same K' = roundup64(k_in + 56) as mean + 6 sigma + 4, capped at k.  Exactness never rests on that estimate - the
+    merge reports every query for which a list ran out (hwer_merge_topk_lists: out_exhausted) and ShardedSearch.search repeats
+    those with full lists - it only decides how often that happens.  G = 8, k = 200: 72 (K' = 128 instead of 256); G = 4: 136;
+    G <= 2: k."""
+    G = max(int(world_size), 1)
+    if G <= 1 or k <= 8:
+        return k
+    mean = k / G
+    need = mean + 6.0 * (mean * (1.0 - 1.0 / G)) ** 0.5 + 4.0
+    kp = -(-(int(need + 0.999999) + KPRIME_SLACK) // 64) * 64          # K' that `need` entries cost
+    k_in = kp - KPRIME_SLACK                                            # ... and the longest list of that cost
+    k_in = max(k_in, -(-k // G))                                        # G * k_in >= k
+    return k if k_in >= k else k_in
+
+
 def all_gather_results(idx, score, dist2, group=None):
     """ONE all_gather_into_tensor of the three (B, k) result arrays -> three (G, B, k) views of the receive buffer.
     Every rank packs (idx | score bits | dist2 bits) into one (3, B, k) int64 buffer (device tensors: one hwer_pack_exchange
@@ -122,35 +143,40 @@ def exchange_by_query(idx, score, dist2, group=None):
     return recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64)
 
 
-def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True):
-    """hwer_merge_topk over gathered (G, B, k) tensors -> (idx, score, dist2) (B, k) tensors."""
+def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True, k=None, want_exhausted=False):
+    """hwer_merge_topk_lists over gathered (G, B, k_in) tensors -> (idx, score, dist2) (B, k) tensors, k >= k_in (default k_in);
+    with want_exhausted a fourth (B,) int32 tensor: 1 where some list gave all its k_in entries to the winners (k_in < k only:
+    that query has to be repeated with full lists)."""
     import torch
     from . import native
     lib = native.lib()
-    G, B, k = g_idx.shape
+    G, B, k_in = g_idx.shape
+    k = k_in if k is None else int(k)
     strides = {t.stride() for t in (g_idx, g_score, g_dist2)}
-    if len(strides) != 1 or g_idx.stride()[1:] != (k, 1) or (G > 1 and g_idx.stride(0) < B * k):
+    if len(strides) != 1 or g_idx.stride()[1:] != (k_in, 1) or (G > 1 and g_idx.stride(0) < B * k_in):
         g_idx, g_score, g_dist2 = g_idx.contiguous(), g_score.contiguous(), g_dist2.contiguous()
-    list_stride = g_idx.stride(0) if G > 1 else B * k
+    list_stride = g_idx.stride(0) if G > 1 else B * k_in
     o_idx = torch.empty((B, k), dtype=torch.int64, device=g_idx.device)
     o_score = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
     o_dist2 = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
+    o_ex = torch.zeros((B,), dtype=torch.int32, device=g_idx.device) if want_exhausted else None
     with native.device_guard(g_idx.device):
-        native.check(lib.hwer_merge_topk_strided(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), list_stride, G, B, k,
-                                                 1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
-                                                 native.ptr(o_dist2), native.stream_ptr(g_idx.device)), "merge_topk")
-    return o_idx, o_score, o_dist2
+        native.check(lib.hwer_merge_topk_lists(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), list_stride, G, B, k_in, k,
+                                               1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
+                                               native.ptr(o_dist2), native.ptr(o_ex) if o_ex is not None else None,
+                                               native.stream_ptr(g_idx.device)), "merge_topk")
+    return (o_idx, o_score, o_dist2, o_ex) if want_exhausted else (o_idx, o_score, o_dist2)
 
 
 class ShardedSearch:
     """k-NN over a row-sharded catalogue.
 
-    local_search(Q64, Q32, k_local) -> (idx, score, dist2) (B, k_local) tensors of the LOCAL shard in ascending
-    (dist2, global id) order with GLOBAL ids; merge(g_idx, g_score, g_dist2, sort_by_score) -> merged tensors.
+    local_search(Q64, Q32, k_local[, rows=positions]) -> (idx, score, dist2) (B, k_local) tensors of the LOCAL shard in ascending
+    (dist2, global id) order with GLOBAL ids (`rows` only when a subset of the batch is repeated with full lists); merge(g_idx, g_score, g_dist2, sort_by_score) -> merged tensors.
     Both are injectable so that the collective plumbing is testable on CPU (gloo) without a GPU."""
 
     def __init__(self, n_rows: int, local_search: Callable, merge: Callable = merge_on_device, group=None,
-                 pad_value: float = float("inf"), exchange: str = "all_gather"):
+                 pad_value: float = float("inf"), exchange: str = "all_gather", list_len: Optional[int] = None):
         import torch.distributed as dist
         self.group = group
         self.world = dist.get_world_size(group)
@@ -161,19 +187,33 @@ class ShardedSearch:
         self.pad_value = pad_value
         assert exchange in ("all_gather", "by_query")
         self.exchange = exchange   # "by_query": every rank ends up with the merged result of ITS query slice only
+        # Shortened local lists (all-gather exchange only: every rank sees every list, so all ranks agree on the queries to repeat
+        # without another collective).  None: local_list_len(k, world) when the merge is the device kernel, full lists for an
+        # injected merge; an int forces that length (the merge must then accept k= / want_exhausted= like merge_on_device).
+        self.list_len = list_len
+        self.repeated_queries = 0   # queries of the last search() that were repeated with full lists
 
-    def search(self, Q64, Q32, k: int, sort_by_score: bool = True):
+    def _list_len(self, k: int) -> int:
+        if self.exchange != "all_gather" or self.world > 16:
+            return k
+        if self.list_len is not None:
+            return max(min(int(self.list_len), k), -(-k // self.world))
+        return local_list_len(k, self.world) if self.merge is merge_on_device else k
+
+    def search(self, Q64, Q32, k: int, sort_by_score: bool = True, _full: bool = False, _rows=None):
         import torch
         if k > self.n_rows:
             raise ValueError("k must be less than or equal to the number of training points")
         n_local = self.hi - self.lo
-        k_local = min(k, n_local)
+        k_in = k if _full else self._list_len(k)
+        k_local = min(k_in, n_local)
         B = Q64.shape[0]
-        idx = torch.full((B, k), -1, dtype=torch.int64, device=Q64.device)
-        score = torch.zeros((B, k), dtype=torch.float64, device=Q64.device)
-        dist2 = torch.full((B, k), self.pad_value, dtype=torch.float64, device=Q64.device)  # short shards pad with +inf
+        idx = torch.full((B, k_in), -1, dtype=torch.int64, device=Q64.device)
+        score = torch.zeros((B, k_in), dtype=torch.float64, device=Q64.device)
+        dist2 = torch.full((B, k_in), self.pad_value, dtype=torch.float64, device=Q64.device)  # short shards pad with +inf
         if k_local > 0:
-            li, ls, ld = self.local_search(Q64, Q32, k_local)
+            # (a repeat passes the positions of its queries in the caller's batch: per-query state of the local search - anchors - follows)
+            li, ls, ld = self.local_search(Q64, Q32, k_local) if _rows is None else self.local_search(Q64, Q32, k_local, rows=_rows)
             idx[:, :k_local], score[:, :k_local], dist2[:, :k_local] = li, ls, ld
         if self.exchange == "by_query":
             g = exchange_by_query(idx, score, dist2, self.group)
@@ -181,14 +221,27 @@ class ShardedSearch:
             lo, hi = query_slice(B, self.world, self.rank)
             return m_idx[:hi - lo], m_score[:hi - lo], m_dist2[:hi - lo]   # rows of queries [lo, hi)
         g = all_gather_results(idx, score, dist2, self.group)
-        return self.merge(*g, sort_by_score)
+        if k_in == k:
+            if not _full:
+                self.repeated_queries = 0
+            return self.merge(*g, sort_by_score)
+        m_idx, m_score, m_dist2, exhausted = self.merge(*g, sort_by_score, k=k, want_exhausted=True)
+        # Every rank merged the same gathered lists with the same kernel: `exhausted` is identical on all ranks, so they all take (or
+        # skip) the repeat - a second, full-list exchange for those queries only - together.
+        again = torch.nonzero(exhausted, as_tuple=False).flatten()
+        self.repeated_queries = int(again.numel())
+        if self.repeated_queries:
+            r_idx, r_score, r_dist2 = self.search(Q64[again], Q32[again] if Q32 is not None else None, k, sort_by_score, _full=True, _rows=again)
+            m_idx[again], m_score[again], m_dist2[again] = r_idx, r_score, r_dist2
+        return m_idx, m_score, m_dist2
 
 
 def sharded_index_search(index, node_type: str, shard: ShardedSearch, Q64, Q32, k, anchors_dev=None, score_mode=None,
                          sort_by_score=True):
     """Convenience: DeviceIndex whose `node_type` table holds only this rank's rows [shard.lo, shard.hi)."""
-    def local(q64, q32, kl):
-        i, s, d2, _ = index.search_queries(node_type, q64, q32, kl, anchors_dev, score_mode, sort_by_score=False,
+    def local(q64, q32, kl, rows=None):   # rows: positions of a repeated subset of the batch (shortened lists that ran out)
+        an = anchors_dev if (rows is None or anchors_dev is None) else anchors_dev[rows]
+        i, s, d2, _ = index.search_queries(node_type, q64, q32, kl, an, score_mode, sort_by_score=False,
                                            id_base=shard.lo)
         return i, s, d2
     shard.local_search = local

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "hwer_pca_project_unit_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int, _P, c_int, c_int, _P, c_int64,
                                           _P, c_int64, _P]),
     "hwer_merge_topk_strided": (c_int, [_P, _P, _P, c_int64, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "hwer_merge_topk_lists": (c_int, [_P, _P, _P, c_int64, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

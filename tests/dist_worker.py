@@ -70,8 +70,20 @@ def main():
     idx, score, dist2 = sharded_index_search(ix, "item", sh, Q64, Q32, k, anchors_dev=a_dev, sort_by_score=False)
     r_idx, _, r_d2 = c_oracle.find_closest_f64(items, Qh, V64[:U], k, sort_by_score=False, threads=4)
     assert np.array_equal(idx.cpu().numpy(), r_idx) and np.array_equal(dist2.cpu().numpy(), r_d2)
+    # shortened local lists (round 3): every shard sends list_len < k entries, hwer_merge_topk_lists flags the queries for which a list
+    # ran out, those - and only those - are repeated with full lists (a second, smaller exchange): same result, both orders
+    repeated = []
+    for list_len in sorted({-(-k // world), min(k, -(-k // world) + max(2, k // 10)), min(k, (3 * k) // 4)}):
+        sh = ShardedSearch(n_items, None, exchange="all_gather", list_len=list_len)
+        idx, score, dist2 = sharded_index_search(ix, "item", sh, Q64, Q32, k, anchors_dev=a_dev)
+        assert np.array_equal(idx.cpu().numpy(), o_idx) and np.array_equal(score.cpu().numpy(), o_score) and np.array_equal(dist2.cpu().numpy(), o_d2), (rank, list_len)
+        repeated.append((list_len, sh.repeated_queries))
+        idx, score, dist2 = sharded_index_search(ix, "item", sh, Q64, Q32, k, anchors_dev=a_dev, sort_by_score=False)
+        assert np.array_equal(idx.cpu().numpy(), r_idx) and np.array_equal(dist2.cpu().numpy(), r_d2), (rank, list_len)
+    if k * world <= n_items and k >= 8:
+        assert repeated[0][1] > 0, repeated   # lists of k / world entries: a list runs out unless the k nearest split exactly evenly
     with open(os.path.join(out_dir, "ok%d" % rank), "w") as fh:
-        fh.write("%s world=%d shard=[%d,%d)\n" % (backend, world, lo, hi))
+        fh.write("%s world=%d shard=[%d,%d) short lists (len, repeated queries): %s\n" % (backend, world, lo, hi, repeated))
     dist.barrier()
     dist.destroy_process_group()
 

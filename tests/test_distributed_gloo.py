@@ -23,7 +23,7 @@ def _unit_rows(seed, n, d):
     return x.astype(np.float32)
 
 
-def _worker(rank, world, port, n_items, k, out_dir):
+def _worker(rank, world, port, n_items, k, out_dir, list_len=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from hwer.distributed import ShardedSearch, shard_bounds
@@ -33,31 +33,38 @@ def _worker(rank, world, port, n_items, k, out_dir):
     Q = np.stack([orc.query_vector(V, u) for u in range(U)])
     lo, hi = shard_bounds(n_items, world, rank)
 
-    def local_search(Q64, Q32, kl):   # stand-in for DeviceIndex.search_queries(sort_by_score=False, id_base=U + lo)
-        idx = np.empty((B, kl), np.int64); sc = np.empty((B, kl)); d2 = np.empty((B, kl))
-        for b in range(B):
+    def local_search(Q64, Q32, kl, rows=None):   # stand-in for DeviceIndex.search_queries(sort_by_score=False, id_base=U + lo)
+        nb = Q64.shape[0]
+        anchors = np.arange(nb) if rows is None else rows.numpy()   # query b of the batch is user b
+        idx = np.empty((nb, kl), np.int64); sc = np.empty((nb, kl)); d2 = np.empty((nb, kl))
+        for b in range(nb):
             loc, dist_ = orc.knn_bruteforce(Q64[b].numpy(), V[U + lo:U + hi], kl)
             idx[b] = loc + U + lo
             d2[b] = orc.dist2_sequential(Q64[b].numpy(), V[U + lo:U + hi])[loc]
-            sc[b] = orc.pair_score(V, np.full(kl, b), idx[b])
+            sc[b] = orc.pair_score(V, np.full(kl, anchors[b]), idx[b])
         return torch.from_numpy(idx), torch.from_numpy(sc), torch.from_numpy(d2)
 
-    def merge(g_idx, g_score, g_dist2, sort_by_score):   # stand-in for hwer_merge_topk
-        G, B = g_idx.shape[0], g_idx.shape[1]
-        o_i = np.empty((B, k), np.int64); o_s = np.empty((B, k)); o_d = np.empty((B, k))
+    def merge(g_idx, g_score, g_dist2, sort_by_score, k=k, want_exhausted=False):   # stand-in for hwer_merge_topk_lists
+        G, B, k_in = g_idx.shape
+        o_i = np.empty((B, k), np.int64); o_s = np.empty((B, k)); o_d = np.empty((B, k)); ex = np.zeros(B, np.int32)
         for b in range(B):
             dd = np.concatenate([g_dist2[g, b].numpy() for g in range(G)])
             ii = np.concatenate([g_idx[g, b].numpy() for g in range(G)])
             ss = np.concatenate([g_score[g, b].numpy() for g in range(G)])
             order = np.lexsort((ii, dd))[:k]
+            taken = np.bincount(order // k_in, weights=(ii[order] >= 0), minlength=G)   # real entries each list gave to the winners
+            ex[b] = int(k_in < k and (taken >= k_in).any())
             if sort_by_score:
                 order = order[np.argsort(-ss[order], kind="stable")]
             o_i[b], o_s[b], o_d[b] = ii[order], ss[order], dd[order]
-        return torch.from_numpy(o_i), torch.from_numpy(o_s), torch.from_numpy(o_d)
+        out = (torch.from_numpy(o_i), torch.from_numpy(o_s), torch.from_numpy(o_d))
+        return out + (torch.from_numpy(ex),) if want_exhausted else out
 
-    sh = ShardedSearch(n_items, local_search, merge)
+    sh = ShardedSearch(n_items, local_search, merge, list_len=list_len)
     assert (sh.lo, sh.hi) == (lo, hi)
     idx, score, dist2 = sh.search(torch.from_numpy(Q), torch.from_numpy(Q.astype(np.float32)), k)
+    if list_len is not None:   # shortened local lists: same result; the lists that ran out were repeated with full lists
+        open(os.path.join(out_dir, "rep%d" % rank), "w").write(str(sh.repeated_queries))
     # every rank must hold the single-process result
     for b in range(B):
         o_idx, o_score, o_dist = orc.find_closest(V, np.arange(U, U + n_items), b, k=k)
@@ -83,6 +90,30 @@ def test_sharded_search_world2_gloo(tmp_path, n_items, k):
     port = 29500 + (os.getpid() + n_items) % 2000
     mp.spawn(_worker, args=(2, port, n_items, k, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+@pytest.mark.parametrize("n_items,k,list_len", [(101, 20, 12), (101, 20, 10), (40, 30, 16)])
+def test_sharded_search_short_lists_world2_gloo(tmp_path, n_items, k, list_len):
+    """Shortened local lists (hwer.distributed.local_list_len / hwer_merge_topk_lists): every shard sends list_len < k entries, the
+    merge flags the queries for which a list ran out, those are repeated with full lists - the result equals the single-process one
+    (asserted inside the worker) and both ranks repeat the same number of queries."""
+    port = 31500 + (os.getpid() + n_items + list_len) % 2000
+    mp.spawn(_worker, args=(2, port, n_items, k, str(tmp_path), list_len), nprocs=2, join=True)
+    assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+    rep = [int((tmp_path / ("rep%d" % r)).read_text()) for r in range(2)]
+    assert rep[0] == rep[1]
+    if list_len * 2 == k:
+        assert rep[0] > 0   # 2 x 10 = 20: a list is exhausted unless the two shards hold exactly 10 each
+
+
+def test_local_list_len_rule():
+    from hwer.distributed import local_list_len
+    assert local_list_len(200, 1) == 200 and local_list_len(200, 2) == 200
+    assert local_list_len(200, 8) == 72 and local_list_len(200, 4) == 136
+    for k in (1, 7, 20, 200, 392):
+        for g in (1, 2, 3, 4, 8, 16):
+            kin = local_list_len(k, g)
+            assert 1 <= kin <= k and kin * g >= k
 
 
 def test_shard_bounds_cover_and_order():

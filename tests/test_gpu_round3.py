@@ -48,6 +48,65 @@ def test_emulated_shards_equal_single_table(hw, bench_mod, name, items, G):
     r = bench_mod.emulate_shards(torch, native.lib(), cfg, dev, G, steps=1, warmup=1, n_oracle=32)
     assert r["merged_equals_single_table"] and r["queries_compared"] == 4096 and r["oracle_checked_queries"] == 32
     assert len(r["shard_ms"]) == G
+    # round 3: the shards sent shortened lists (72 of 200 entries for 8 shards, 136 for 3) and no list ran out
+    from hwer.distributed import local_list_len
+    assert r["local_list_len"] == local_list_len(200, G) < 200 and r["lists_ran_out_first_pass"] == 0
+
+
+def _merge_lists_numpy(g_idx, g_score, g_d2, k, sort_by_score):
+    G, B, k_in = g_idx.shape
+    o_i = np.empty((B, k), np.int64); o_s = np.empty((B, k)); o_d = np.empty((B, k)); ex = np.zeros(B, np.int32)
+    for b in range(B):
+        dd, ii, ss = g_d2[:, b].reshape(-1), g_idx[:, b].reshape(-1), g_score[:, b].reshape(-1)
+        order = np.lexsort((np.arange(G * k_in), ii, dd))[:k]      # (dist2, id), source position last (padding rows share id -1)
+        taken = np.bincount(order // k_in, weights=(ii[order] >= 0), minlength=G)
+        ex[b] = int(k_in < k and (taken >= k_in).any())
+        if sort_by_score:
+            order = order[np.argsort(-ss[order], kind="stable")]
+        o_i[b], o_s[b], o_d[b] = ii[order], ss[order], dd[order]
+    return o_i, o_s, o_d, ex
+
+
+@pytest.mark.parametrize("G,B,k_in,k,skew", [(8, 300, 72, 200, 0.0), (8, 64, 25, 200, 0.0), (4, 257, 136, 200, 0.5), (2, 33, 100, 200, 0.0),
+                                              (16, 40, 13, 200, 0.9), (3, 50, 7, 20, 0.0), (8, 31, 200, 200, 0.0), (5, 17, 1, 5, 0.0)])
+def test_merge_topk_lists_shortened(hw, G, B, k_in, k, skew):
+    """hwer_merge_topk_lists: G sorted lists of k_in <= k entries -> the k nearest + the per-query flag `a list ran out` - against a
+    numpy merge of the same lists (ids, scores, distances ==, flags ==), both output orders; duplicate distances across lists (ties broken
+    by id), padded tails (id -1, +inf) in a third of the lists, and `skew` = share of queries whose nearest all sit in list 0."""
+    import torch
+    from hwer.distributed import merge_on_device
+    rng = np.random.default_rng(G * 1000 + k_in)
+    g_idx = np.empty((G, B, k_in), np.int64); g_d2 = np.empty((G, B, k_in)); g_sc = np.empty((G, B, k_in))
+    for g in range(G):
+        for b in range(B):
+            n_real = k_in if (g + b) % 3 else int(rng.integers(0, k_in + 1))
+            d2 = np.round(rng.random(n_real) * 50) / 50.0 + 1.0              # few distinct values: ties within and across lists
+            if g == 0 and rng.random() < skew:
+                d2 = d2 * 1e-3                                                # list 0 holds this query's nearest
+            ids = rng.choice(1000000, n_real, replace=False) * G + g          # distinct ids across lists
+            o = np.lexsort((ids, d2))
+            g_d2[g, b, :n_real], g_idx[g, b, :n_real] = d2[o], ids[o]
+            g_d2[g, b, n_real:], g_idx[g, b, n_real:] = np.inf, -1
+            g_sc[g, b] = rng.random(k_in)
+            g_sc[g, b, n_real:] = 0.0
+    dev = torch.device("cuda", 0)
+    t = [torch.from_numpy(x).to(dev) for x in (g_idx, g_sc, g_d2)]
+    total_real = (g_idx >= 0).sum(axis=(0, 2))
+    for sort_by_score in (True, False):
+        m_i, m_s, m_d, ex = merge_on_device(*t, sort_by_score, k=k, want_exhausted=True)
+        r_i, r_s, r_d, r_ex = _merge_lists_numpy(g_idx, g_sc, g_d2, k, sort_by_score)
+        ok = total_real >= k        # (queries with fewer than k real entries in all lists end in padding rows: only the real part is compared)
+        assert np.array_equal(ex.cpu().numpy(), r_ex)
+        assert np.array_equal(m_i.cpu().numpy()[ok], r_i[ok]) and np.array_equal(m_s.cpu().numpy()[ok], r_s[ok]) and np.array_equal(m_d.cpu().numpy()[ok], r_d[ok])
+        if not sort_by_score:
+            short = ~ok
+            for b in np.nonzero(short)[0]:
+                n = int(total_real[b])
+                assert np.array_equal(m_i.cpu().numpy()[b, :n], r_i[b, :n]) and np.array_equal(m_d.cpu().numpy()[b, :n], r_d[b, :n])
+    if k_in < k and skew > 0:
+        assert r_ex.sum() > 0
+    if k_in == k:
+        assert r_ex.sum() == 0
 
 
 # ------------------------------------------------------------------------------------------------- the step as library code

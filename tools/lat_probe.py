@@ -18,6 +18,8 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     from hwer import native
+    if os.environ.get("HWER_PROBE_K"):       # experiment: neighbours per query (bench.K is read when the workload is built)
+        bench.K = int(os.environ["HWER_PROBE_K"])
     lib = native.lib()
     dev = torch.device("cuda", 0)
     w = bench.Workload(torch, lib, bench.CONFIGS[os.environ.get("HWER_PROBE_CFG", "c4")], dev)
