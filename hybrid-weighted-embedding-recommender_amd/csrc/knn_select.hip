@@ -6,6 +6,7 @@
 //   dist2 : scikit-learn `euclidean_rdist64`  -> sequential  d += (q_j - x_j)^2, separate mul and add roundings
 //   score : numpy `(a * b).sum(1)`             -> pairwise summation of the rounded products
 #include <algorithm>
+#include <string>
 #include <cstdlib>
 #include <type_traits>
 
@@ -96,7 +97,8 @@ struct EmitArgs {
     unsigned long long* stamps;   // diagnostic build only (HWER_SELECT_STAMPS=1): per-query phase cycle counts, 8 per query
 };
 #ifdef HWER_DIAG_STAMPS
-#define SEL_STAMP(slot) do { if (a_stamps && (threadIdx.x & 63) == 0) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); a_stamps[(slot)] = t_; } } while (0)
+#define SEL_STAMP(slot) do { if (a_stamps && (threadIdx.x & 63) == 0) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); a_stamps[(slot)] = t_; \
+    if ((slot) == 0) a_stamps[10] = __builtin_amdgcn_s_memrealtime(); if ((slot) == 6) a_stamps[11] = __builtin_amdgcn_s_memrealtime(); } } while (0)   /* 10 / 11: start / end in 10-ns ticks (one clock for the whole chip) */
 #else
 #define SEL_STAMP(slot) do { } while (0)
 #endif
@@ -683,8 +685,10 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     int c_lo;
     const bool lazy_ok = a.emit.out_dist2 == nullptr && a.emit.sort_by_score && a.emit.score_mode != 2;
     float t_hi;   // count(key32 >= t_hi) < k (and >= k - 12 when lazy_ok)
-    // (round 3, measured and not kept: three thresholds per workgroup exchange in the COOP form - 9.5 -> 4.3 barrier rounds at c1, the same
-    // ~9.7 K cycles of rank search: what a probe costs there is its compares / scalar counts under four waves per SIMD, not the barrier)
+    // (round 3, measured and not kept, c1 = 943 queries x 1 682 keys in the one-query-per-workgroup form, phase stamps + same-box step times:
+    //  three thresholds per workgroup exchange - 9.5 -> 4.3 barrier rounds, the same ~9.7 K cycles of rank search; the whole search by ONE
+    //  wave on the whole row in its registers, ballot counts 13.0 K cycles, per-lane VALU counts + one wave reduction per probe ~ the same
+    //  step time; a probe's cost follows the compares a SIMD has to issue for its four resident workgroups, not the barrier)
     const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo, &t_hi, lazy_ok);   // <= k-th largest key, at most c_lo - k extra keys above it
     SEL_STAMP(2);
     double Q2 = 0.0;
@@ -1549,6 +1553,42 @@ static unsigned long long* sel_stamps_buffer(int64_t B) {
             for (int c = 0; c < 6; ++c) sum[c] += double(t[c + 1] - t[c]);
             if (t[7] && t[8] && t[9]) { tail[0] += double(t[7] - t[4]); tail[1] += double(t[8] - t[7]); tail[2] += double(t[9] - t[8]); tail[3] += double(t[5] - t[9]); ++nt; }
             ++n;
+        }
+        {   // when do the workgroups of the launch start and end? (100-MHz clock)
+            std::vector<double> st, en;
+            for (int64_t q = 0; q < buf_B; ++q) {
+                const unsigned long long* t = &h[size_t(q) * 16];
+                if (t[10] && t[11] > t[10]) { st.push_back(double(t[10])); en.push_back(double(t[11])); }
+            }
+            if (!st.empty()) {
+                const double t0 = *std::min_element(st.begin(), st.end());
+                std::vector<double> s2(st), e2(en);
+                std::sort(s2.begin(), s2.end());
+                std::sort(e2.begin(), e2.end());
+                auto pc = [&](const std::vector<double>& v, double f) { return (v[size_t(f * double(v.size() - 1))] - t0) * 0.01; };
+                double life = 0;
+                for (size_t i = 0; i < st.size(); ++i) life += en[i] - st[i];
+                fprintf(stderr, "[select stamps]   launch timeline, us after the first start: starts p50 %.2f p90 %.2f max %.2f | ends p10 %.2f p50 %.2f p90 %.2f max %.2f | mean lifetime %.2f us\n",
+                        pc(s2, 0.5), pc(s2, 0.9), pc(s2, 1.0), pc(e2, 0.1), pc(e2, 0.5), pc(e2, 0.9), pc(e2, 1.0), life / double(st.size()) * 0.01);
+            }
+        }
+        {   // spread of every phase over the queries
+            static const char* names[6] = {"load+minmax", "rank-search", "collect", "rerank-rounds", "sorts", "emit"};
+            std::string line = "[select stamps]   phase cycles p10 / p50 / p90 / max:";
+            for (int c = 0; c < 6; ++c) {
+                std::vector<double> v;
+                for (int64_t q = 0; q < buf_B; ++q) {
+                    const unsigned long long* t = &h[size_t(q) * 16];
+                    if (t[6] <= t[0] || t[0] == 0) continue;
+                    v.push_back(double(t[c + 1] - t[c]));
+                }
+                if (v.empty()) break;
+                std::sort(v.begin(), v.end());
+                char b[160];
+                snprintf(b, sizeof b, " %s %.0f / %.0f / %.0f / %.0f;", names[c], v[v.size() / 10], v[v.size() / 2], v[(v.size() * 9) / 10], v.back());
+                line += b;
+            }
+            fprintf(stderr, "%s\n", line.c_str());
         }
         if (nt) fprintf(stderr, "[select stamps]   tail of %lld lazy queries: boundary-rank=%.0f keys=%.0f sort=%.0f fixup=%.0f\n", (long long)nt, tail[0] / nt, tail[1] / nt, tail[2] / nt, tail[3] / nt);
         if (n) fprintf(stderr, "[select stamps] queries=%lld cycles/query: load+minmax=%.0f rank-search=%.0f collect=%.0f rerank-rounds=%.0f sorts=%.0f emit=%.0f total=%.0f\n",
