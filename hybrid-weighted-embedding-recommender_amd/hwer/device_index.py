@@ -45,8 +45,14 @@ def _on_device(fn):
 
     @functools.wraps(fn)
     def wrapped(self, *a, **kw):
-        with native.device_guard(self.device):
+        if getattr(self, "_guarded", False):      # already inside one of this index's guarded methods: the device is current
             return fn(self, *a, **kw)
+        self._guarded = True
+        try:
+            with native.device_guard(self.device):
+                return fn(self, *a, **kw)
+        finally:
+            self._guarded = False
     return wrapped
 
 
@@ -184,7 +190,15 @@ class DeviceIndex:
                       negative: Optional[Sequence[Sequence[int]]] = None):
         """-> (Q64 (B, d) float64, Q32 (B, ldx) float32, anchors_dev int32) on the device."""
         torch = _torch()
-        a = torch.from_numpy(np.ascontiguousarray(anchors, dtype=np.int32)).to(self.device)
+        anchors = np.ascontiguousarray(anchors, dtype=np.int32)
+        if anchors.size == 1 and 0 <= int(anchors.flat[0]) < self.N:
+            # one anchor (the reference-shaped per-anchor loop): a one-element VIEW of a resident arange - no host-to-device copy
+            if getattr(self, "_row_ids_dev", None) is None:
+                self._row_ids_dev = torch.arange(self.N, dtype=torch.int32, device=self.device)
+            a0 = int(anchors.flat[0])
+            a = self._row_ids_dev[a0:a0 + 1]
+        else:
+            a = torch.from_numpy(anchors).to(self.device)
         B = a.numel()
 
         def csr(lists):
@@ -300,10 +314,15 @@ class DeviceIndex:
         torch = _torch()
         B = Q64.shape[0]
         path_opt = self._path_options()
+        st = native.stream_ptr(self.device)       # one stream lookup per call (torch.cuda.current_stream costs ~4 us)
+        sizes = self.__dict__.setdefault("_ws_sizes", {})
         for b0 in range(0, B, self.QUERY_CHUNK):
             b1 = min(B, b0 + self.QUERY_CHUNK)
             nb = b1 - b0
-            wsb = self.lib.hwer_knn_workspace_bytes_opts(nb, tt.n, self.d, k, path_opt)
+            key = (nb, tt.n, k, path_opt)
+            if key not in sizes:
+                sizes[key] = (self.lib.hwer_knn_workspace_bytes_opts(nb, tt.n, self.d, k, path_opt), self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
+            wsb, wseb = sizes[key]
             if wsb == 0:
                 raise native.HwerNativeError("knn: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" %
                                              (nb, tt.n, self.d, k, self.lib.hwer_knn_max_k()))
@@ -317,19 +336,27 @@ class DeviceIndex:
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,
                 1 if sort_by_score else 0, native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
                 tt.hnorm_max, native.ptr(idx[b0:b1]), native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None,
-                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), opt, native.ptr(x16), x16_exp, native.stream_ptr(self.device)), "knn_search")
+                native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), opt, native.ptr(x16), x16_exp, st), "knn_search")
             # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
             # to 8 per call; anything beyond that is picked up by the host-driven pass below
-            wse = self._exact_workspace(self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
+            wse = self._exact_workspace(wseb)
             native.check(self.lib.hwer_knn_exact_device(
                 native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64[b0:b1]), native.ptr(self.V) if score_mode != 2 else None,
                 self.ldv, native.ptr(a_sub), k, score_mode, 1 if sort_by_score else 0,
                 native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), native.ptr(idx[b0:b1]),
                 native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None, native.ptr(flags[b0:b1]), native.ptr(ws), None,
-                native.ptr(wse), wse.numel(), native.stream_ptr(self.device)), "knn_exact_device")
-        n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
-        native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), native.stream_ptr(self.device)), "count_uncertified")
-        if int(n_bad.item()):
+                native.ptr(wse), wse.numel(), st), "knn_exact_device")
+        if B <= 4096:
+            # small batches: the flags themselves come to the host (one copy; `search` reuses it) instead of a count kernel + its result
+            flags_host = flags.cpu()
+            self._flags_host = (flags, flags_host)
+            n_bad_host = int((flags_host == 0).sum())
+        else:
+            n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+            native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), st), "count_uncertified")
+            n_bad_host = int(n_bad.item())
+        if n_bad_host:
+            self._flags_host = None
             bad = torch.nonzero(flags == 0).flatten()
             if bad.numel() > self.RETRY_MIN:
                 # many uncertified queries = the sampled thresholds were defeated (e.g. a catalogue sorted by cluster): run
@@ -542,4 +569,7 @@ class DeviceIndex:
         sc = score.cpu().numpy()
         if mode == 1:
             sc = sc.astype(np.float32)  # exact: the kernel widened float32 values
-        return idx.cpu().numpy(), sc, (np.sqrt(dist2.cpu().numpy()) if dist2 is not None else None), flags.cpu().numpy()
+        fh = getattr(self, "_flags_host", None)
+        flags_np = fh[1].numpy() if (fh is not None and fh[0] is flags) else flags.cpu().numpy()   # (_search_f32 already fetched them)
+        self._flags_host = None
+        return idx.cpu().numpy(), sc, (np.sqrt(dist2.cpu().numpy()) if dist2 is not None else None), flags_np

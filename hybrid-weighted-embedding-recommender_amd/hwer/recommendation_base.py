@@ -264,8 +264,11 @@ class RecommendationBase(metaclass=abc.ABCMeta):
         if anchor not in self.nodes_to_idx:
             raise NodeNotFoundException("Node = %s, was not provided in training" % anchor)
         idx, score = self.find_closest_neighbours_batch(node_type, [anchor], k, [positive], [negative])
+        from operator import itemgetter
         table = self.knn.idx_to_node()
-        return list(zip((table[i] for i in idx[0].tolist()), score[0].tolist()))
+        ids = idx[0].tolist()
+        nodes = itemgetter(*ids)(table) if len(ids) > 1 else (table[ids[0]],)     # one C-level gather instead of a generator per node
+        return list(zip(nodes, score[0].tolist()))
 
     def find_items_for_user(self, user: Node, k=200, item_type: str = "item"):
         """Alias named in BASELINE.json's north_star."""
