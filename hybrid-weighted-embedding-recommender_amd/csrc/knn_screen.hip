@@ -151,6 +151,10 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define HWER_FILTER_V2 1   // float16 streaming screen: max-tree + per-register appends instead of pass masks + LDS park + pop loop (round 3)
 #endif
 constexpr bool FILTER_V2 = HWER_FILTER_V2 != 0;
+#ifndef HWER_WIDE64
+#define HWER_WIDE64 1   // d = 256 (NG = 32): 64-row tiles too - with the park-free filter (sparse_hits forced) the 2 x 32 KB ring leaves two workgroups per CU
+#endif
+constexpr bool WIDE64 = HWER_WIDE64 != 0;
 #ifndef HWER_F16_PREFETCH
 #define HWER_F16_PREFETCH 1    // float16 tile product: A fragments requested this many k-steps ahead of their MFMAs
 #endif
@@ -184,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     // LDS-DMA issue phase (~150 cycles per 1-KiB piece in the wave's chain), the capacity check and the loop control are ~1 000 of a
     // 32-row tile's ~2 100 cycles and amortise over twice the MFMAs
     // (d = 256: a 64-row ring is 64 KB and leaves ONE workgroup per CU - measured 3.09 -> 3.96 ms at c5: 32-row tiles there)
-    constexpr int IB = (F16 && !DENSE && NG <= 16) ? SCREEN16_IB : 32;
+    constexpr int IB = (F16 && !DENSE && (NG <= 16 || WIDE64)) ? SCREEN16_IB : 32;
+    static_assert(IB == 32 || IB == 64, "the half-norm request (one per lane of wave 0) and the capacity check cover at most 64 rows per tile");
     constexpr int NSUB = IB / 32;
     constexpr int CH = F16 ? NG : 2 * NG;          // 16-byte chunks per row
     constexpr int TILE_CHUNKS = IB * CH;
@@ -785,7 +790,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     if (const char* e = diag_env("HWER_SCREEN_MINLIST")) min_list = std::max(32, atoi(e));
     const int64_t max_splits = std::max<int64_t>(1, n_items / (min_list * wi));
     splits = std::min(splits, max_splits);
-    const int ib = ((options & HWER_KNN_F16_SCREEN) && p.ng <= 16) ? SCREEN16_IB : 32;   // item splits start on tile boundaries of the kernel that will run
+    const int ib = ((options & HWER_KNN_F16_SCREEN) && (p.ng <= 16 || WIDE64)) ? SCREEN16_IB : 32;   // item splits start on tile boundaries of the kernel that will run
     int64_t per = cdiv64(cdiv64(n_items, splits), ib) * ib;
     splits = cdiv64(n_items, per);
     p.n_splits = int(splits);
@@ -908,9 +913,12 @@ static int launch_screen_t(const ScreenPlan& plan, const ScreenArgs& a, hipStrea
 template <int NG, int TQ>
 static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
     const size_t lds_dense = size_t(2) * 32 * NG * 16 + size_t(2) * 32 * 4 + size_t(4) * 64 * 16 * TQ * 4;
-    constexpr int IBS = NG <= 16 ? SCREEN16_IB : 32;
-    const size_t lds_stream = size_t(2) * IBS * NG * 16 + size_t(2) * IBS * 4 + size_t(4) * 64 * 16 * TQ * 4 +
-                              (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);   // 64-row tiles (+ append staging)
+    constexpr int IBS = (NG <= 16 || WIDE64) ? SCREEN16_IB : 32;
+    // 64-row tiles (+ append staging).  d = 256: no key park - that launch always filters with the max-tree variant (launch_screen sets
+    // sparse_hits), and 2 x 32 KB of ring + 16 KB of park would leave one workgroup per CU
+    constexpr bool NO_PARK = NG > 16 && WIDE64;
+    const size_t lds_stream = size_t(2) * IBS * NG * 16 + size_t(2) * IBS * 4 + (NO_PARK ? 0 : size_t(4) * 64 * 16 * TQ * 4) +
+                              (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);
     static uint64_t attr_done = 0, attr_done_d = 0;   // per device
     int dev;
     const int grid = plan.n_qblocks * plan.n_splits;
@@ -1002,7 +1010,8 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
                  diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
                  f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0,
                  // expected passing keys per 32-row tile and wave (32 tq queries) under the seeded thresholds
-                 (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < 0.6 && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ? 1 : 0, 0};
+                 (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < 0.6 && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ||
+                 (f16 && WIDE64 && plan.ng > 16 && !plan.dense) ? 1 : 0, 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

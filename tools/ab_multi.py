@@ -17,6 +17,7 @@ def main():
     prod, keep = os.path.join(L, "libhwer_hip.so"), os.path.join(L, "libhwer_hip_keep.so")
     shutil.copy(prod, keep)
     try:
+        os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
         with open(out, "a") as fh:
             for rep in range(int(os.environ.get("AB_REPS", "3"))):
                 for c in cfgs:

@@ -18,6 +18,7 @@ def main():
     shutil.copy(prod, keep)
     shutil.copy(diag, prod)
     try:
+        os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
         with open(out, "a") as fh:
             for rep in range(int(os.environ.get("AB_REPS", "2"))):
                 for c in cfgs:
