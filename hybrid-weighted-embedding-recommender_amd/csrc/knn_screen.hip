@@ -917,8 +917,9 @@ static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStr
     // 64-row tiles (+ append staging).  d = 256: no key park - that launch always filters with the max-tree variant (launch_screen sets
     // sparse_hits), and 2 x 32 KB of ring + 16 KB of park would leave one workgroup per CU
     constexpr bool NO_PARK = NG > 16 && WIDE64;
-    const size_t lds_stream = size_t(2) * IBS * NG * 16 + size_t(2) * IBS * 4 + (NO_PARK ? 0 : size_t(4) * 64 * 16 * TQ * 4) +
-                              (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);
+    size_t lds_stream = size_t(2) * IBS * NG * 16 + size_t(2) * IBS * 4 + (NO_PARK ? 0 : size_t(4) * 64 * 16 * TQ * 4) +
+                        (STAGE_APPENDS ? size_t(4) * 8 * TQ * 64 * 8 : 0);
+    if (const char* e = diag_env("HWER_SCREEN_LDS_PAD_KB")) lds_stream += size_t(atoi(e)) * 1024;   // occupancy experiments (diagnostic builds)
     static uint64_t attr_done = 0, attr_done_d = 0;   // per device
     int dev;
     const int grid = plan.n_qblocks * plan.n_splits;
@@ -932,7 +933,7 @@ static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStr
         hipLaunchKernelGGL((screen_kernel<NG, TQ, true, true>), dim3(grid), dim3(256), lds_dense, stream, a);
         return check_launch("knn_screen16(dense)");
     }
-    if (attr_pending(attr_done, &dev)) {
+    if (attr_pending(attr_done, &dev) || diag_env("HWER_SCREEN_LDS_PAD_KB")) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen_kernel<NG, TQ, false, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, int(lds_stream));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16: hipFuncSetAttribute: %s", hipGetErrorString(e));
