@@ -323,3 +323,28 @@ def test_float64_rows_vs_oracle(hw, N, d, k, B):
     q_near = np.where(np.arange(B) == 0, 0, 0)
     src, dst = rng.integers(-1, B + N, 500), rng.integers(-1, B + N, 500)
     assert np.array_equal(ix.pair_score(src, dst), orc.pair_score(X, src, dst))
+
+
+# ------------------------------------------------------------------------------------------------- extreme shapes through the index
+@pytest.mark.parametrize("U,I,d,k", [(1, 1, 1, 1), (3, 2, 2, 2), (5, 33, 3, 1), (5, 33, 3, 33), (2, 64, 64, 64), (7, 65, 17, 65), (1, 392, 8, 392),
+                                      (4, 8193, 5, 1), (3, 300, 256, 299)])
+def test_extreme_shapes_vs_oracle(hw, U, I, d, k):
+    """Degenerate corners of the hot path through DeviceIndex.search (the call behind find_closest_neighbours_batch): a one-row catalogue, k = 1,
+    k = every row of the type, d = 1, one column short of / one row past the tile and path thresholds (64-row tiles, 8 192-row dense limit,
+    k = 392 = the fused search's largest) - ids, scores and distances == the oracle; an EMPTY anchor batch returns empty arrays."""
+    from hwer.device_index import DeviceIndex
+    rng = np.random.default_rng(U * 1000 + I + d)
+    V = rng.standard_normal((U + I, d))
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    V = V.astype(np.float32)
+    ix = DeviceIndex(V, {"user": np.arange(U), "item": np.arange(U, U + I)}, arith=0)
+    idx, score, dist, flags = ix.search("item", np.arange(U), k=k)
+    assert idx.shape == (U, k) and (flags > 0).all()
+    V64 = V.astype(np.float64)
+    Qh = np.stack([orc.query_vector(V64, u) for u in range(U)])
+    o_idx, o_score, o_d2 = c_oracle.find_closest_f64(V[U:], Qh, V64[:U], k, threads=2)
+    assert np.array_equal(idx, o_idx + U) and np.array_equal(score, o_score) and np.array_equal(dist, np.sqrt(o_d2))
+    e_idx, e_score, e_dist, e_flags = ix.search("item", np.zeros(0, dtype=np.int64), k=k)
+    assert e_idx.shape == (0, k) and e_score.shape == (0, k) and e_flags.shape == (0,)
+    with pytest.raises(ValueError):
+        ix.search("item", np.arange(U), k=I + 1)
