@@ -348,3 +348,30 @@ def test_extreme_shapes_vs_oracle(hw, U, I, d, k):
     assert e_idx.shape == (0, k) and e_score.shape == (0, k) and e_flags.shape == (0,)
     with pytest.raises(ValueError):
         ix.search("item", np.arange(U), k=I + 1)
+
+
+# ------------------------------------------------------------------------------------------------- BASELINE configs at full size, as the bench runs them
+@pytest.mark.parametrize("name,n_check", [("c1", 943), ("c2", 128), ("c3", 64), ("c5", 32)])
+def test_bench_step_at_full_size_vs_oracle(hw, bench_mod, name, n_check):
+    """The step bench.py times (hwer.pipeline.BlendSearchStep on the synthetic tables of BASELINE.json's configs, full size: c1 943 x 1 682,
+    c2 6 040 x 3 706, c3 138 493 x 26 744, c5 four tables / per-row alpha / d = 256 / 131 072 + 1.25 M blended rows / 4 096 queries): unit-norm
+    audit clean, every query certified or recomputed, and `n_check` evenly spaced queries == the oracle's brute force over the blended rows the step
+    produced (ids and scores bit for bit; the blend itself is held to the oracle by ::test_blend_search_step_equals_the_separate_calls and
+    test_gpu_round2.py::test_c5_blend_and_search_shard_size).  c4 / c4full at full size: ::test_emulated_shards_equal_single_table."""
+    import torch
+    from hwer import native
+    cfg = dict(bench_mod.CONFIGS[name])
+    dev = torch.device("cuda", 0)
+    w = bench_mod.Workload(torch, native.lib(), cfg, dev)
+    w.step()
+    torch.cuda.synchronize()
+    idx, score = w.results()[:2]
+    U, B = w.U, w.B
+    assert idx.shape == (B, bench_mod.K)
+    Vh = w.V[:, :w.d].cpu().numpy()
+    V64u = Vh[:U].astype(np.float64)
+    sel = np.unique(np.linspace(0, B - 1, n_check).astype(np.int64))
+    Qh = np.stack([orc.query_vector(V64u, int(q)) for q in sel])
+    o_idx, o_score, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64u[sel], bench_mod.K, threads=c_oracle.effective_cpus())
+    assert np.array_equal(idx[sel], o_idx + U)
+    assert np.array_equal(score[sel], o_score)
