@@ -351,6 +351,20 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         torch.cuda.synchronize()
     series = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
     del evs
+    in_step = None
+    if graph is None and not w.tail and not w.pipeline:
+        # Eager steps: the two parts of a step measured IN the step (an event between the prologue and the search of real steps, right behind
+        # the timed region: same clocks, same cache state).  A stage repeated on its own runs in another cache state - the search of c4 reads
+        # the table the prologue has just written (the last ~256 MB of it still in the Infinity Cache) and is ~10 % faster there than back
+        # to back with itself.
+        n_split = max(5, min(steps, 10))
+        marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_split)]
+        for e0, e1, e2 in marks:
+            e0.record()
+            w.step(mark=e1)
+            e2.record()
+        torch.cuda.synchronize()
+        in_step = (float(np.median([e0.elapsed_time(e1) for e0, e1, _ in marks])), float(np.median([e1.elapsed_time(e2) for _, e1, e2 in marks])), n_split)
     if graph is not None or w.tail or w.pipeline:    # kernel durations: an eager pass with event brackets after the timed region
         lib.hwer_profile_enable(1)     # (searches one after the other: overlapped searches would stretch each other's brackets)
         w.overlap_tail = False
@@ -453,6 +467,13 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
                            "share_of_step": (screen_step_ms + select_step_ms) / ms_per_step}
     prologue = "blend_prepare_search" if w.fused_blend else None
     res["stage_sum_ms"] = (stages[prologue] if prologue else (stages["blend_normalize_audit"] + (stages["prepare_search"] if w.fused_prologue else stages["pack_rows"] + stages["query_mix"]))) + stages["knn_search"]
+    res["stage_sum_note"] = "prologue + search, each timed on its own (back-to-back repetitions of one stage)"
+    if in_step is not None:
+        pro, sea, n_split = in_step
+        res["stages_in_step_ms"] = {"prologue": pro, "search": sea}
+        res["stage_sum_separate_ms"] = res["stage_sum_ms"]
+        res["stage_sum_ms"] = pro + sea
+        res["stage_sum_note"] = "prologue + search inside real steps (median of %d steps, one HIP event between the two); stage_sum_separate_ms: each stage repeated on its own" % n_split
 
     # ---- the same step with the float32 screen, beside the float16 number (streaming configurations) -------------------------
     if f32_beside and f16:
@@ -730,7 +751,7 @@ def finish_line(base, r):
                 "config": {"workload": r["workload"], "users": r["users"], "items_per_gpu": r["items"], "items_total": r["items"], "d": r["d"],
                            "k": r["k"], "tables": r["tables"], "alpha": r["alpha"], "f16_screen": r["f16_screen"], "sharding": "none"}})
     for k_ in ("ms_median", "ms_min", "ms_max", "ms_mean_events", "ms_series", "ms_series_note", "roofline", "dominant_kernel", "stage_frac", "stage_frac_note",
-               "kernels", "stages_ms", "stage_sum_ms", "certified_queries", "exhaustive_fallback_queries",
+               "kernels", "stages_ms", "stage_sum_ms", "stage_sum_note", "stages_in_step_ms", "stage_sum_separate_ms", "certified_queries", "exhaustive_fallback_queries",
                "parity_checked_queries", "hip_graph", "f32_screen", "query_latency_ms", "pair_score", "cpu_baseline", "speedup_vs_cpu",
                "speedup_vs_reference_shaped_loop", "api_latency_ms"):
         if k_ in r:

@@ -274,21 +274,22 @@ class BlendSearchStep:
             P(self.X16) if self.f16_screen else None, self.x16_exp, P(self.anchors), self.B, self.arith, P(self.Q64), P(self.Q32), self.ldx,
             P(self.ws), self.bq_frag, self.S()), "blend_prepare_search")
 
-    def step(self, o=None):
-        """launch one whole step on the current stream into result set `o` (default: set 0); returns the result set"""
+    def step(self, o=None, mark=None):
+        """launch one whole step on the current stream into result set `o` (default: set 0); returns the result set.
+        mark: optional torch.cuda.Event recorded between the prologue and the search (measurement: the two parts of a step IN the step)"""
         o = self.sets[0] if o is None else o
         if self.fused_blend:          # the whole prologue is one launch
             self.stage_blend_prepare()
-            self.stage_search(o, opts=self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0))
         elif self.fused_prologue:     # blend, then the fused table + queries launch
             self.stage_blend()
             self.stage_prepare()
-            self.stage_search(o, opts=self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0))
         else:
             self.stage_blend()
             self.stage_pack()
             self.stage_queries()
-            self.stage_search(o)
+        if mark is not None:
+            mark.record()
+        self.stage_search(o, opts=self.opts | (KNN_QUERIES_READY if (self.fused_fragments and (self.fused_blend or self.fused_prologue)) else 0))
         return o
 
     # ---- library-facing helpers -------------------------------------------------------------------------------------------------
