@@ -332,25 +332,34 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     # steps (>= ~0.2 ms each) also get one HIP event per step boundary inside the region - the per-step distribution
     # (median / min / max) costs nothing there; graph-replayed steps (c1 / c2: ~0.05-0.2 ms) get theirs from a second pass.
     in_loop = graph is None
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    t0 = time.perf_counter()
-    if in_loop:
-        evs[0].record()
-    for i in range(steps):
-        run_step()
+    discarded = []
+    for attempt in range(3):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
         if in_loop:
-            evs[i + 1].record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    lib.hwer_profile_enable(0)
-    if not in_loop:
-        evs[0].record()
+            evs[0].record()
         for i in range(steps):
             run_step()
-            evs[i + 1].record()
+            if in_loop:
+                evs[i + 1].record()
         torch.cuda.synchronize()
-    series = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
-    del evs
+        elapsed = time.perf_counter() - t0
+        if not in_loop:
+            evs[0].record()
+            for i in range(steps):
+                run_step()
+                evs[i + 1].record()
+            torch.cuda.synchronize()
+        series = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+        del evs
+        # A timed region of graph replays is K x ~0.05-0.2 ms: ONE host or driver stall of a few milliseconds inside it multiplies its
+        # wall-clock mean (seen once in ~6 default runs: c1 0.216 ms against a per-step median of 0.056).  Such a region is measured
+        # again - at most twice, every discarded mean is reported (`timed_region`) - and the reported one is still EXACTLY K steps
+        # between two synchronisations.
+        if graph is None or elapsed / steps * 1e3 <= 1.3 * float(np.median(series)) or attempt == 2:
+            break
+        discarded.append(elapsed / steps * 1e3)
+    lib.hwer_profile_enable(0)
     in_step = None
     if graph is None and not w.tail and not w.pipeline:
         # Eager steps: the two parts of a step measured IN the step (an event between the prologue and the search of real steps, right behind
@@ -443,7 +452,9 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         "f16_screen": f16, "dtype": "f16" if f16 else "f32", "steps": steps, "warmup": warmup, "hip_graph": graph is not None,
         "value": value, "unit": "pairs/s", "ms_per_step": ms_per_step,
         "ms_median": float(np.median(series)), "ms_min": float(series.min()), "ms_max": float(series.max()), "ms_mean_events": float(series.mean()),
-        "ms_series": [round(float(x), 4) for x in series], "ms_series_note": "HIP-event interval of every step" + ("" if in_loop else " (second pass: the timed steps are graph replays)"),
+        "timed_region": {"attempts": len(discarded) + 1, "discarded_ms_per_step": [round(x, 5) for x in discarded],
+                         "rule": "graph-replayed steps only: a region whose wall-clock mean exceeds 1.3x the median of its per-step event intervals is measured again (at most twice)"},
+        "ms_series": [round(float(x), 4) for x in series[:256]], "ms_series_note": "HIP-event interval of every step" + ("" if in_loop else " (second pass: the timed steps are graph replays)"),
         "user_rows": w.U,
         "roofline": {k_: dominant[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
         "stage_frac": stage_tf / MFMA_F32_PEAK_TFLOPS,
@@ -750,7 +761,7 @@ def finish_line(base, r):
     out.update({"value": r["value"], "ms_per_step": r["ms_per_step"], "dtype": r["dtype"], "steps": r["steps"], "warmup": r["warmup"],
                 "config": {"workload": r["workload"], "users": r["users"], "items_per_gpu": r["items"], "items_total": r["items"], "d": r["d"],
                            "k": r["k"], "tables": r["tables"], "alpha": r["alpha"], "f16_screen": r["f16_screen"], "sharding": "none"}})
-    for k_ in ("ms_median", "ms_min", "ms_max", "ms_mean_events", "ms_series", "ms_series_note", "roofline", "dominant_kernel", "stage_frac", "stage_frac_note",
+    for k_ in ("ms_median", "ms_min", "ms_max", "ms_mean_events", "timed_region", "ms_series", "ms_series_note", "roofline", "dominant_kernel", "stage_frac", "stage_frac_note",
                "kernels", "stages_ms", "stage_sum_ms", "stage_sum_note", "stages_in_step_ms", "stage_sum_separate_ms", "certified_queries", "exhaustive_fallback_queries",
                "parity_checked_queries", "hip_graph", "f32_screen", "query_latency_ms", "pair_score", "cpu_baseline", "speedup_vs_cpu",
                "speedup_vs_reference_shaped_loop", "api_latency_ms"):
@@ -799,6 +810,9 @@ def compact_line(full, detail_path):
         out["speedup_vs_reference_shaped_loop"] = _r(full.get("speedup_vs_reference_shaped_loop"), 4)
     if "recall_latency_ms" in full:
         out["recall_latency_ms"] = _r(full["recall_latency_ms"], 4)
+    tr = full.get("timed_region")
+    if tr and tr.get("attempts", 1) > 1:      # a timed region that was measured again: say so in the line itself
+        out["timed_region"] = {"attempts": tr["attempts"], "discarded_ms_per_step": tr["discarded_ms_per_step"]}
     if full.get("query_latency_ms"):
         out["query_latency_ms"] = {str(e["batch"]): _r(e["ms"], 4) for e in full["query_latency_ms"]}
     cfgs = {}
@@ -813,6 +827,8 @@ def compact_line(full, detail_path):
             e["query_latency_ms"] = {str(q["batch"]): _r(q["ms"], 4) for q in r["query_latency_ms"]}
         if "speedup_vs_cpu" in r:
             e["speedup_vs_cpu"] = _r(r["speedup_vs_cpu"], 4)
+        if (r.get("timed_region") or {}).get("attempts", 1) > 1:
+            e["timed_region_attempts"] = r["timed_region"]["attempts"]
         cfgs[name] = e
     if cfgs:
         out["configs"] = cfgs
@@ -1169,8 +1185,8 @@ def run_sharded(args, rank, local_rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps of the top-level configuration (c1: 1 000 x 0.05 ms; the larger configurations clamp it to 20-40)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS),
                     help="N = 1: run only this configuration (profiling); default = c1 at the top level + c2, c3, c4, c4full under `configs`.  "
                          "N > 1: the catalogue to strong-scale (default c4full)")
