@@ -410,10 +410,10 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     sbytes = w.stage_bytes()
     if w.fused_prologue:   # what the step actually runs instead of pack_rows + query_mix (+ the search's repacking launch)
         stages["prepare_search"] = cuda_time(torch, w.stage_prepare, stage_reps)
-        sbytes["prepare_search"] = sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
+        sbytes["prepare_search"] = sbytes["pack_rows"] + sbytes["query_mix"] + (2.0 if w.bq_frag < 0 else 4.0) * abs(w.bq_frag) * w.ldx
     if w.fused_blend:      # ... and the blend with them: the step's whole prologue
         stages["blend_prepare_search"] = cuda_time(torch, w.stage_blend_prepare, stage_reps)
-        sbytes["blend_prepare_search"] = (sbytes["blend_normalize_audit"] + sbytes["pack_rows"] + sbytes["query_mix"] + 4.0 * w.bq_frag * w.ldx
+        sbytes["blend_prepare_search"] = (sbytes["blend_normalize_audit"] + sbytes["pack_rows"] + sbytes["query_mix"] + (2.0 if w.bq_frag < 0 else 4.0) * abs(w.bq_frag) * w.ldx
                                           - 4.0 * d * (I + w.B)    # the table pass and the queries read registers, not V
                                           - (4.0 * w.ldx * I if w.x_in_v else 0.0))   # ... and the table IS a slice of V: one store per row
     f16 = w.f16_screen

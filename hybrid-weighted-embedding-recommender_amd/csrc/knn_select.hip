@@ -1833,6 +1833,8 @@ static int knn_search_stages(int stages, const float* X, const float* hnorm, int
     ScreenF16 f16{X16, qf, reinterpret_cast<const int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), x16_exp};
     if (!do_screen) {
     } else if (f16_screen) {
+        // (HWER_KNN_QUERIES_READY: the prologue - hwer_prepare_search_f32 / hwer_blend_prepare_search_f32 with bq < 0 - wrote the float16 fragments and exponents)
+        if (!(options & HWER_KNN_QUERIES_READY))
         if ((rc = repack_queries16(Q32, B, plan.bq, int(ldx), qf, reinterpret_cast<int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), st))) return rc;
     } else if (!(options & HWER_KNN_QUERIES_READY)) {   // (else: hwer_prepare_search_f32 wrote the fragments already)
         if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) return rc;

@@ -629,7 +629,41 @@ struct QueryMixArgs {
     const double* V64;   // nullable: read the rows from this float64 table (stride ldv) instead of V
     int gq;              // queries a wave builds per trip: 0 = 8 (one per group of 8 lanes); 4 / 2 / 1 for rows so wide that 8 x 3 d values
                          // do not fit the CU's LDS (float64 arithmetic above d = 853) - the other lane groups sit out
+    int frag16;          // Qf holds the FLOAT16 fragments of the float16 screen instead (knn_small.hip: repack_queries16 layout): half8
+                         // Qf16[((b / 32) * (ldq32 / 16) + j / 16) * 64 + (b % 32) + 32 * ((j % 16) / 8)][j % 8] = half(q_b[j] * 2^e_b), e_b = the power of
+                         // two that puts the row's largest |element| in [2^13, 2^14), and behind them (byte offset bq * ldq32 * 2) the bq exponents
 };
+
+// One query row's fragments (float32 or float16 form), by the 8 lanes (k = 0 .. 7) that built the row: value(j) = float32 element j (j < d) of a LIVE
+// row; dead / padding rows (b < bq) and the padding columns are zero-filled.  Same values as repack_queries / repack_queries16 produce from Q32.
+template <class Value>
+__device__ __forceinline__ void store_query_fragments(const QueryMixArgs& a, int64_t b, bool live, int k, Value value) {
+    if (!a.Qf || b >= a.bq) return;
+    const int ldq = int(a.ldq32), d = a.d;
+    if (!a.frag16) {
+        const int ngq = ldq / 8;
+        for (int j = k; j < ldq; j += 8)
+            a.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)] = (live && j < d) ? value(j) : 0.f;
+        return;
+    }
+    float m = 0.f;
+    if (live)
+        for (int j = k; j < d; j += 8) m = fmaxf(m, fabsf(value(j)));
+    m = fmaxf(m, __shfl_xor(m, 1, kWave));   // the 8 lanes of the row's group
+    m = fmaxf(m, __shfl_xor(m, 2, kWave));
+    m = fmaxf(m, __shfl_xor(m, 4, kWave));
+    int e = 0;
+    if (m > 0.f && m < INFINITY) {
+        int me;
+        frexpf(m, &me);        // m = f * 2^me, f in [0.5, 1)  ->  m * 2^(14 - me) in [2^13, 2^14)
+        e = 14 - me;
+    }
+    _Float16* Qh = reinterpret_cast<_Float16*>(a.Qf);
+    const int ks = ldq / 16;
+    for (int j = k; j < ldq; j += 8)
+        Qh[(((b >> 5) * ks + (j >> 4)) * 64 + (b & 31) + 32 * ((j & 15) >> 3)) * 8 + (j & 7)] = (live && j < d) ? (_Float16)ldexpf(value(j), e) : (_Float16)0.f;
+    if (k == 0) reinterpret_cast<int32_t*>(reinterpret_cast<unsigned char*>(a.Qf) + size_t(a.bq) * size_t(ldq) * 2)[b] = e;
+}
 template <typename T>
 __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned char* smem_raw, int64_t blk, int64_t nblk, int wpb) {
     const float* __restrict__ V = a.V;
@@ -653,16 +687,10 @@ __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned c
     T* q = base + 2 * d;
     const int64_t q0 = (blk * wpb + wave) * gq;
     const int64_t qstride = nblk * wpb * gq;
-    const int ngq = int(ldq32 / 8);
-    auto frag_at = [&](int64_t b, int j) -> float& {
-        return a.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)];
-    };
     const int64_t n_rows_all = a.Qf ? (a.bq > B ? a.bq : B) : B;
     for (int64_t qb = q0; qb < n_rows_all; qb += qstride) {  // qb wave-uniform
         if (qb >= B) {   // wave-uniform: only fragment padding rows are left in this group of 8
-            const int64_t b = qb + g8;
-            if (b < a.bq)
-                for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+            store_query_fragments(a, qb + g8, false, k, [](int) { return 0.f; });
             continue;
         }
         const int64_t b = qb + g8;
@@ -691,15 +719,10 @@ __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned c
                 const T v = q[j] / T(double(cnt));
                 Q64[b * d + j] = double(v);
                 Q32[b * ldq32 + j] = float(v);
-                if (a.Qf) frag_at(b, j) = float(v);
             }
-            for (int j = d + k; j < ldq32; j += 8) {
-                Q32[b * ldq32 + j] = 0.f;
-                if (a.Qf) frag_at(b, j) = 0.f;
-            }
-        } else if (a.Qf && b < a.bq) {
-            for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+            for (int j = d + k; j < ldq32; j += 8) Q32[b * ldq32 + j] = 0.f;
         }
+        store_query_fragments(a, b, live, k, [&](int j) { return float(q[j] / T(double(cnt))); });
         wave_lds_sync();
     }
 }
@@ -963,16 +986,10 @@ __device__ __forceinline__ void blend_query_body(const BlendArgs& a, const Query
     const RowGroup g(a.d4);
     const int64_t q0 = (blk * wpb + wave) * G;
     const int64_t qstride = nblk * wpb * G;
-    const int ngq = int(ldq32 / 8);
-    auto frag_at = [&](int64_t b, int j) -> float& {
-        return qa.Qf[(((b >> 5) * ngq + (j >> 3)) * 64 + (b & 31) + 32 * ((j & 7) >> 2)) * 4 + (j & 3)];
-    };
     const int64_t n_rows_all = qa.Qf ? (qa.bq > B ? qa.bq : B) : B;
     for (int64_t qb = q0; qb < n_rows_all; qb += qstride) {  // qb wave-uniform
         if (qb >= B) {   // only fragment padding rows are left in this group
-            const int64_t b = qb + g8;
-            if (grp && b < qa.bq)
-                for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+            if (grp) store_query_fragments(qa, qb + g8, false, k, [](int) { return 0.f; });
             continue;
         }
         // the G anchor rows of this trip, blended exactly as the PACK / OTHER blocks blend them, into LDS
@@ -1008,15 +1025,10 @@ __device__ __forceinline__ void blend_query_body(const BlendArgs& a, const Query
                 const T v = (vec[j] / nrm) / T(1.0);
                 qa.Q64[b * d + j] = double(v);
                 qa.Q32[b * ldq32 + j] = float(v);
-                if (qa.Qf) frag_at(b, j) = float(v);
             }
-            for (int j = d + k; j < ldq32; j += 8) {
-                qa.Q32[b * ldq32 + j] = 0.f;
-                if (qa.Qf) frag_at(b, j) = 0.f;
-            }
-        } else if (grp && qa.Qf && b < qa.bq) {
-            for (int j = k; j < ldq32; j += 8) frag_at(b, j) = 0.f;
+            for (int j = d + k; j < ldq32; j += 8) qa.Q32[b * ldq32 + j] = 0.f;
         }
+        if (grp) store_query_fragments(qa, b, live, k, [&](int j) { return float((vec[j] / nrm) / T(1.0)); });
         wave_lds_sync();
     }
 }
@@ -1348,8 +1360,11 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
     if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "prepare_search: ptr without idx");
     if (arith != 0 && arith != 1) return fail(HWER_EINVAL, "prepare_search: arith must be 0 (float64) or 1 (float32)");
     if (X16 && (reinterpret_cast<uintptr_t>(X16) & 7) != 0) return fail(HWER_EINVAL, "prepare_search: X16 must be 8-byte aligned");
+    const int frag16 = bq < 0 ? 1 : 0;   // bq < 0: float16 fragments (the search then runs with HWER_KNN_F16_SCREEN | HWER_KNN_QUERIES_READY) for -bq rows
+    if (frag16) bq = -bq;
     if (knn_workspace && ((reinterpret_cast<uintptr_t>(knn_workspace) & 255) != 0 || bq < B || bq % 32 != 0))
-        return fail(HWER_EINVAL, "prepare_search: workspace must be 256-byte aligned and bq = hwer_knn_query_padding(...) >= B");
+        return fail(HWER_EINVAL, "prepare_search: workspace must be 256-byte aligned and |bq| = hwer_knn_query_padding(...) >= B");
+    if (frag16 && ldq32 % 16 != 0) return fail(HWER_EINVAL, "prepare_search: float16 fragments need ldq32 to be a multiple of 16");
     const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
     if (x4 > 64) return fail(HWER_EINVAL, "prepare_search: d <= 256 only");
     const size_t per_wave = size_t(8) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));
@@ -1360,7 +1375,7 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
     const RowNormArgs pa{V, ldv, d, d4, row_ids, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
     // right behind the workspace header: where hwer_knn_search_opts_f32 keeps its query fragments (ws_layout: w.qf)
     float* qf = knn_workspace ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
-    const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, qf, bq};
+    const QueryMixArgs qa{V, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, qf, bq, nullptr, 0, frag16};
     if (arith == 0)
         hipLaunchKernelGGL((prepare_search_kernel<double, 1, 4>), dim3(n_pack + n_mix), dim3(256), per_wave * wpb, as_stream(stream), pa, qa, n_pack, wpb);
     else
@@ -1397,7 +1412,10 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     if (X16 && (reinterpret_cast<uintptr_t>(X16) & 7) != 0) return fail(HWER_EINVAL, "blend_prepare_search: X16 must be 8-byte aligned");
     if (!knn_workspace || (reinterpret_cast<uintptr_t>(knn_workspace) & 255) != 0)
         return fail(HWER_EINVAL, "blend_prepare_search: needs the (256-byte aligned, hwer_knn_workspace_init-ed) search workspace");
-    if (bq != 0 && (bq < B || bq % 32 != 0)) return fail(HWER_EINVAL, "blend_prepare_search: bq must be 0 (no fragments) or hwer_knn_query_padding(...) >= B");
+    const int frag16 = bq < 0 ? 1 : 0;   // bq < 0: float16 fragments for -bq rows (see hwer_prepare_search_f32)
+    if (frag16) bq = -bq;
+    if (bq != 0 && (bq < B || bq % 32 != 0)) return fail(HWER_EINVAL, "blend_prepare_search: |bq| must be 0 (no fragments) or hwer_knn_query_padding(...) >= B");
+    if (frag16 && ldq32 % 16 != 0) return fail(HWER_EINVAL, "blend_prepare_search: float16 fragments need ldq32 to be a multiple of 16");
     const int d4 = (d + 3) / 4, x4 = int(ldx / 4);
     if (x4 > 64) return fail(HWER_EINVAL, "blend_prepare_search: d <= 256 only");
     // query staging: G queries per wave and trip, as many as keep the block's LDS (4 waves) within 32 KB - the same launch streams
@@ -1434,7 +1452,7 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     const RowRange pack{pack_ids, pack_row0, n_rows}, other{other_ids, other_row0, n_other};
     const RowNormArgs pk{V, ldv, d, d4, nullptr, n_rows, X, ldx, x4, hnorm, reinterpret_cast<half4_rt*>(X16), x_exp};
     float* qf = bq ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
-    const QueryMixArgs qa{V, ldv, d, anchor, nullptr, nullptr, nullptr, nullptr, B, Q64, Q32, ldq32, qf, bq};
+    const QueryMixArgs qa{V, ldv, d, anchor, nullptr, nullptr, nullptr, nullptr, B, Q64, Q32, ldq32, qf, bq, nullptr, 0, frag16};
     const dim3 grid(n_pack + n_oth + n_mix);
     // four rows in flight per row group whatever T is (measured at T = 4, d = 256: 1.63 ms, against 2.38 with one row in flight and
     // 1.84 for the three separate launches - the stand-alone blend kernel prefers one row there, this one does not)

@@ -143,13 +143,19 @@ class BlendSearchStep:
         # Small catalogues (dense path): the prologue's two latency-floor kernels run as ONE launch that also writes the search's
         # query fragments (hwer_prepare_search_f32 + HWER_KNN_QUERIES_READY); one search call per step only.
         self.fused_prologue = (I <= 8192 and B <= self.CH) if fused_prologue is None else bool(fused_prologue)
-        self.fused_fragments = self.fused_prologue and not self.f16_screen
+        self.fused_fragments = self.fused_prologue     # (re-decided below once fused_blend is known)
         # ... and the blend + audit with them (hwer_blend_prepare_search_f32: the whole prologue of the step is one kernel).  Large
         # catalogues too: the per-type table and its float16 copy are written from the blended row in registers instead of being
         # re-read from V - one pass over the rows less.  NOT where the anchors outnumber the rows (every anchor row is blended a
         # second time for its query): that shape keeps the separate launches.
         self.fused_blend = (self.fused_prologue or (self.d <= 256 and 8 * B <= I)) if fused_blend is None else bool(fused_blend)
+        # The search's query fragments come out of the prologue launch whenever the step is ONE search call behind a fused prologue
+        # (float32 fragments, or - round 3 - the float16 ones with their per-query exponents: bq < 0 in the prologue call); the search
+        # then skips its repacking launch (HWER_KNN_QUERIES_READY).
+        self.fused_fragments = (self.fused_prologue or self.fused_blend) and B <= self.CH and not os.environ.get("HWER_NO_FUSED_FRAGMENTS")
         self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) if self.fused_fragments else 0
+        if self.f16_screen:
+            self.bq_frag = -self.bq_frag
         self._graph = None
         # pipeline=True: the search runs as chunks of PIPE_CHUNK queries whose two stages are staggered over two
         # streams - hwer_knn_screen_f32 of chunk i + 1 (MFMA / issue bound) on the step's stream beside hwer_knn_select_f32 of

@@ -153,7 +153,9 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
 /* Fused search prologue for small, latency-bound searches: hwer_pack_rows_f32_f16 and hwer_query_mix in ONE launch (both read only
  * the vector table), and - when `knn_workspace` is given - the float32 query fragments of the search that follows, written straight
  * into that workspace: pass the same workspace to hwer_knn_search_opts_f32 with HWER_KNN_QUERIES_READY and it skips its own repacking
- * launch.  bq = hwer_knn_query_padding(B, n_items, d, k, options) of that search.  Same arguments as the two functions; d <= 256. */
+ * launch.  bq = hwer_knn_query_padding(B, n_items, d, k, options) of that search.  Same arguments as the two functions; d <= 256.
+ * Round 3: bq < 0 asks for the FLOAT16 fragments of a search that will run with HWER_KNN_F16_SCREEN (|bq| rows; per-query
+ * power-of-two scales behind them - exactly what the search's own repacking launch would write; ldq32 must be a multiple of 16). */
 int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const int64_t* row_ids /*nullable*/, int64_t n_rows, float* X,
                             int64_t ldx, float* hnorm, void* X16 /*nullable*/, int x_exp, const int32_t* anchor, const int64_t* pos_ptr,
                             const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, int arith, double* Q64,
@@ -174,7 +176,7 @@ int hwer_prepare_search_f32(const float* V, int64_t N, int d, int64_t ldv, const
  *                        are accumulated in its header and handed to audit_counts / audit_absdev_sum by the last block; on a
  *                        workspace that was never initialised the audit counts come back as all-ones: the audit fails loudly);
  *                        bq = hwer_knn_query_padding(...) to also write the float32 query fragments (then search with
- *                        HWER_KNN_QUERIES_READY), 0 to skip them.
+ *                        HWER_KNN_QUERIES_READY), -bq for the float16 fragments of an HWER_KNN_F16_SCREEN search, 0 to skip them.
  * d <= 256. */
 int hwer_knn_workspace_init(void* workspace, size_t workspace_bytes, void* stream);
 int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables, const int32_t* const* row_idx /*nullable*/, const float* alpha,
@@ -238,8 +240,10 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
 /* HWER_KNN_NO_SEED: the streaming screen starts every candidate list with an open threshold (collect, then select) instead of the
  * per-query threshold seeded from a sample pre-pass.  Same results; kept for A/B measurements and path coverage in the tests. */
 #define HWER_KNN_NO_SEED 16u
-/* HWER_KNN_QUERIES_READY: the float32 query fragments are already in the workspace (hwer_prepare_search_f32 wrote them for
- * hwer_knn_query_padding(...) rows); honoured by the float32 dense / streaming screens, ignored (the search repacks) elsewhere. */
+/* HWER_KNN_QUERIES_READY: the query fragments (float32, or float16 + scales with HWER_KNN_F16_SCREEN: prologue called with bq < 0)
+ * are already in the workspace (hwer_prepare_search_f32 wrote them for
+ * hwer_knn_query_padding(...) rows); honoured by the dense / streaming screens (float32 and float16), ignored (the search repacks)
+ * on the small-batch path. */
 #define HWER_KNN_QUERIES_READY 32u
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
 int64_t hwer_knn_query_padding(int64_t B, int64_t n_items, int d, int k, uint32_t options); /* rows of query fragments the search reads (>= B) */
