@@ -355,6 +355,132 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Up to four queries (round 3): the filtering pass as a plain matrix-vector product.  With one query a 32 x 32 MFMA tile uses
+// one column in 32 and the tile ring costs 9 LDS-DMA requests + a ring wait per 8 KB - the pass ran at 4.4 TB/s (73 us for the
+// 320 MB of a 1.25 M x 128 float16 table).  Here every lane loads 16 bytes (8 float16 columns) of a row straight into registers
+// - NG lanes per row, 64 / NG rows per load instruction, 32 rows = NG / 2 loads in flight per wave while the previous 32 are
+// reduced (v_dot2_f32_f16 on the lane's 8 columns, a butterfly over the row's lanes), many waves per CU.  Keys are in the same
+// scaled units as the MFMA kernels' (query scaled by 2^qexp, table by 2^x_exp, float32 accumulation) and are unscaled when parked.
+// Same sink as small_screen16_kernel<.., FILTER = true>: keys above tau0[b] go to the query's list.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Gemv16Args {
+    const _Float16* X16;   // (Np, ldx) float16, scaled by 2^x_exp; Np a multiple of 64 (pad rows: zeros, half norm +inf)
+    const float* hnorm;
+    int64_t ldx;
+    const float* Q32;      // (B, ldx) float32 queries
+    const int32_t* qexp;   // (>= B) per-query scale exponents (repack_queries16)
+    int x_exp;
+    int B;                 // 1 .. NB
+    int64_t n_blocks;      // 32-row blocks of the padded table
+    WsHeader* hdr;
+    SmallSink sink;
+};
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#ifndef HWER_GEMV_DOUBLE_BUFFER
+#define HWER_GEMV_DOUBLE_BUFFER 0
+#endif
+constexpr bool GEMV_DOUBLE_BUFFER = HWER_GEMV_DOUBLE_BUFFER != 0;
+#ifndef HWER_GEMV_MAX_B
+#define HWER_GEMV_MAX_B 1   // queries up to which the matrix-vector pass is taken (measured on 1.25 M x 128: 1 query 0.121 -> 0.114 ms; 2 .. 4 queries slower than the MFMA ring)
+#endif
+#ifndef HWER_GEMV_WAVES_PER_CU
+#define HWER_GEMV_WAVES_PER_CU 48
+#endif
+template <int NG, int NB>
+__global__ __launch_bounds__(256) void small_gemv16_kernel(const Gemv16Args a) {
+    constexpr int NL = NG / 2;          // 1-KiB loads per 32-row block
+    constexpr int RPL = 64 / NG;        // rows per load instruction
+    static_assert(NG == 8 || NG == 16 || NG == 32, "rows of 128 / 256 / 512 bytes");
+    __shared__ uint64_t s_pk[4][SMALL_PARK];
+    __shared__ int32_t s_pq[4][SMALL_PARK];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0) hdr_reset(a.hdr, tid, 256);   // empty uncertified list, idle tickets
+    uint64_t* pk = s_pk[wave];
+    int32_t* pq = s_pq[wave];
+    int n_park = 0;
+    const int c = lane % NG, rl = lane / NG;   // the lane's 16-byte chunk of a row, its row within a load
+    // the lane's 8 columns of every query, scaled and rounded exactly as repack_queries16 does
+    half2_t qh[NB][4];
+    float tau[NB], nscale[NB];
+    int e_tot[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const bool live = b < a.B;
+        const int e = live ? a.qexp[b] : 0;
+        e_tot[b] = a.x_exp + e;
+        nscale[b] = -ldexpf(1.0f, e_tot[b]);
+        tau[b] = live ? ldexpf(a.sink.tau0[b], e_tot[b]) : INFINITY;   // the filter compares in the query's scaled units
+        const float* qrow = a.Q32 + int64_t(live ? b : 0) * a.ldx + 8 * c;
+        const float4 x = *reinterpret_cast<const float4*>(qrow), y = *reinterpret_cast<const float4*>(qrow + 4);
+        qh[b][0] = half2_t{(_Float16)ldexpf(x.x, e), (_Float16)ldexpf(x.y, e)};
+        qh[b][1] = half2_t{(_Float16)ldexpf(x.z, e), (_Float16)ldexpf(x.w, e)};
+        qh[b][2] = half2_t{(_Float16)ldexpf(y.x, e), (_Float16)ldexpf(y.y, e)};
+        qh[b][3] = half2_t{(_Float16)ldexpf(y.z, e), (_Float16)ldexpf(y.w, e)};
+    }
+    const int64_t n_waves = int64_t(gridDim.x) * 4;
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
+    const uint32_t row_bytes = uint32_t(a.ldx) * 2u;
+    auto load_block = [&](int64_t blk, uint4 (&v)[NL], float& hn) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.X16) + blk * 32 * int64_t(row_bytes);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) v[i] = *reinterpret_cast<const uint4*>(base + uint32_t(i * RPL + rl) * row_bytes + uint32_t(c) * 16u);
+        hn = a.hnorm[blk * 32 + (lane & 31)];
+    };
+    int64_t blk = int64_t(blockIdx.x) * 4 + wave;
+    uint4 cur[NL], nxt[GEMV_DOUBLE_BUFFER ? NL : 1];
+    float hn_cur = 0.f, hn_nxt = 0.f;
+    if (GEMV_DOUBLE_BUFFER && blk < a.n_blocks) load_block(blk, cur, hn_cur);
+    for (; blk < a.n_blocks; blk += n_waves) {
+        const int64_t nb = blk + n_waves;
+        if constexpr (GEMV_DOUBLE_BUFFER) {
+            if (nb < a.n_blocks) load_block(nb, nxt, hn_nxt);
+        } else {
+            load_block(blk, cur, hn_cur);
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int row = i * RPL + rl;                       // row of this lane within the block
+            const float hn = __shfl(hn_cur, row, kWave);
+            const half2_t* xv = reinterpret_cast<const half2_t*>(&cur[i]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float dot = __builtin_amdgcn_fdot2(xv[0], qh[b][0], 0.f, false);
+                dot = __builtin_amdgcn_fdot2(xv[1], qh[b][1], dot, false);
+                dot = __builtin_amdgcn_fdot2(xv[2], qh[b][2], dot, false);
+                dot = __builtin_amdgcn_fdot2(xv[3], qh[b][3], dot, false);
+#pragma unroll
+                for (int off = 1; off < NG; off <<= 1) dot += __shfl_xor(dot, off, kWave);   // the row's NG lanes
+                const float key_s = fmaf(hn, nscale[b], dot);
+                const bool pass = c == 0 && key_s > tau[b];      // one lane per row decides (pad rows: half norm +inf -> -inf)
+                const uint64_t bal = __ballot(pass);
+                if (bal != 0ull) {                                // wave-uniform, rare
+                    if (n_park + 64 > SMALL_PARK) {
+                        wave_lds_sync();
+                        small_park_flush(a.sink, pk, pq, n_park);
+                        wave_lds_sync();
+                        n_park = 0;
+                    }
+                    if (pass) {
+                        const int pos = n_park + __builtin_popcountll(bal & lt_mask);
+                        pk[pos] = pack_key(ldexpf(key_s, -e_tot[b]), uint32_t(blk * 32 + row));
+                        pq[pos] = b;
+                    }
+                    n_park += __builtin_popcountll(bal);
+                }
+            }
+        }
+        if constexpr (GEMV_DOUBLE_BUFFER) {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) cur[i] = nxt[i];
+            hn_cur = hn_nxt;
+        }
+    }
+    wave_lds_sync();
+    small_park_flush(a.sink, pk, pq, n_park);
+}
+
 // queries -> float16 MFMA fragments, each query scaled by the power of two that puts its largest element in
 // [2^13, 2^14).  One 256-thread block per 32-query subtile: 8 threads scan a query row for its maximum.
 __global__ __launch_bounds__(256) void repack_queries16_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, half8_t* __restrict__ Qf16,
@@ -836,7 +962,25 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         if ((rc = launch_seed_tau0(*seed, seed_keys, B, thr, count, stream))) return rc;
         sink.tau0 = thr;
     }
-    if (f16) {   // float16 storage: half the HBM bytes for the catalogue stream
+    if (f16 && seed && B <= HWER_GEMV_MAX_B && (p.ng == 8 || p.ng == 16 || p.ng == 32) && !diag_env("HWER_SMALL_NO_GEMV")) {
+        // a handful of queries: the filtering pass as a matrix-vector product (small_gemv16_kernel)
+        const int64_t n_pad = ((n_items + ROW_PAD - 1) / ROW_PAD) * ROW_PAD;
+        Gemv16Args ga{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, Q32, qexp, x_exp, int(B), n_pad / 32, hdr, sink};
+        // 4 waves per block, ~16 waves per CU: every wave keeps NG / 2 KiB in flight
+        const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(ga.n_blocks, 4), int64_t(HWER_GEMV_WAVES_PER_CU / 4) * 256)));
+        auto go = [&](auto ng, auto nb) {
+            hipLaunchKernelGGL((small_gemv16_kernel<decltype(ng)::value, decltype(nb)::value>), dim3(grid), dim3(256), 0, stream, ga);
+        };
+        auto by_b = [&](auto ng) {
+            if (B == 1) go(ng, std::integral_constant<int, 1>{});
+            else if (B == 2) go(ng, std::integral_constant<int, 2>{});
+            else go(ng, std::integral_constant<int, 4>{});
+        };
+        if (p.ng == 8) by_b(std::integral_constant<int, 8>{});
+        else if (p.ng == 16) by_b(std::integral_constant<int, 16>{});
+        else by_b(std::integral_constant<int, 32>{});
+        if ((rc = check_launch("knn_small(gemv16)"))) return rc;
+    } else if (f16) {   // float16 storage: half the HBM bytes for the catalogue stream
         Small16Args a16{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, reinterpret_cast<const half8_t*>(qf), qexp, x_exp, B,
                         reinterpret_cast<float*>(ws + w.keys), p.ld, int(p.ld / 32), hdr, sink};
         // waves x ring slots per CU.  A wave's tile is a serial chain (LDS-DMA requests ~150 cycles each, MFMAs, filter), so the
