@@ -481,6 +481,72 @@ __global__ __launch_bounds__(256) void small_gemv16_kernel(const Gemv16Args a) {
     small_park_flush(a.sink, pk, pq, n_park);
 }
 
+// ONE query, seed pre-pass (round 3): the sample keys by the same matrix-vector product, straight from Q32 - the kernel derives the query's
+// float16 scale itself (and leaves it in qexp[0] for the filtering pass), so the repacking launch in front of the pre-pass is gone.
+// keys[j] (float32, real units) = key of sample row j; sample tile p (32 rows) = catalogue tile p * tile_stride.
+struct SeedGemvArgs {
+    const _Float16* X16;
+    const float* hnorm;
+    int64_t ldx;
+    const float* Q32;
+    int x_exp;
+    int64_t n_tiles;       // sample tiles
+    int64_t tile_stride;
+    float* keys;           // (n_tiles * 32)
+    int32_t* qexp;         // [0] <- the query's scale exponent
+    WsHeader* hdr;
+};
+template <int NG>
+__global__ __launch_bounds__(256) void small_seedgemv_kernel(const SeedGemvArgs a) {
+    constexpr int NL = NG / 2, RPL = 64 / NG;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (blockIdx.x == 0) hdr_reset(a.hdr, tid, 256);
+    const int c = lane % NG, rl = lane / NG;
+    const float* qrow = a.Q32 + 8 * c;
+    const float4 x = *reinterpret_cast<const float4*>(qrow), y = *reinterpret_cast<const float4*>(qrow + 4);
+    float m = fmaxf(fmaxf(fmaxf(fabsf(x.x), fabsf(x.y)), fmaxf(fabsf(x.z), fabsf(x.w))), fmaxf(fmaxf(fabsf(y.x), fabsf(y.y)), fmaxf(fabsf(y.z), fabsf(y.w))));
+#pragma unroll
+    for (int off = 1; off < NG; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));   // the row's NG lanes: the whole (padded) query
+    int e = 0;
+    if (m > 0.f && m < INFINITY) {   // as repack_queries16
+        int me;
+        frexpf(m, &me);
+        e = 14 - me;
+    }
+    if (blockIdx.x == 0 && tid == 0) a.qexp[0] = e;
+    const int e_tot = a.x_exp + e;
+    const float nscale = -ldexpf(1.0f, e_tot);
+    half2_t qh[4];
+    qh[0] = half2_t{(_Float16)ldexpf(x.x, e), (_Float16)ldexpf(x.y, e)};
+    qh[1] = half2_t{(_Float16)ldexpf(x.z, e), (_Float16)ldexpf(x.w, e)};
+    qh[2] = half2_t{(_Float16)ldexpf(y.x, e), (_Float16)ldexpf(y.y, e)};
+    qh[3] = half2_t{(_Float16)ldexpf(y.z, e), (_Float16)ldexpf(y.w, e)};
+    const uint32_t row_bytes = uint32_t(a.ldx) * 2u;
+    const int64_t n_waves = int64_t(gridDim.x) * 4;
+    for (int64_t p = int64_t(blockIdx.x) * 4 + wave; p < a.n_tiles; p += n_waves) {
+        const int64_t row0 = p * a.tile_stride * 32;
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(a.X16) + row0 * int64_t(row_bytes);
+        uint4 v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) v[i] = *reinterpret_cast<const uint4*>(base + uint32_t(i * RPL + rl) * row_bytes + uint32_t(c) * 16u);
+        const float hn_l = a.hnorm[row0 + (lane & 31)];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int row = i * RPL + rl;
+            const float hn = __shfl(hn_l, row, kWave);
+            const half2_t* xv = reinterpret_cast<const half2_t*>(&v[i]);
+            float dot = __builtin_amdgcn_fdot2(xv[0], qh[0], 0.f, false);
+            dot = __builtin_amdgcn_fdot2(xv[1], qh[1], dot, false);
+            dot = __builtin_amdgcn_fdot2(xv[2], qh[2], dot, false);
+            dot = __builtin_amdgcn_fdot2(xv[3], qh[3], dot, false);
+#pragma unroll
+            for (int off = 1; off < NG; off <<= 1) dot += __shfl_xor(dot, off, kWave);
+            if (c == 0) a.keys[p * 32 + row] = ldexpf(fmaf(hn, nscale, dot), -e_tot);   // (pad rows: -inf)
+        }
+    }
+}
+
 // queries -> float16 MFMA fragments, each query scaled by the power of two that puts its largest element in
 // [2^13, 2^14).  One 256-thread block per 32-query subtile: 8 threads scan a query row for its maximum.
 __global__ __launch_bounds__(256) void repack_queries16_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, half8_t* __restrict__ Qf16,
@@ -561,9 +627,9 @@ __device__ __forceinline__ float seed_margin(float t) {
     if constexpr (std::is_same<KT, float>::value) return t;
     else return t - fabsf(t) * 0x1p-10f - 1e-7f;
 }
-template <int PER, typename KT = float>   // samples per thread: 16 (16 384-key sample), 32 or 64 (65 536): a probe is PER compares + one block reduction
-__global__ __launch_bounds__(1024) void small_threshold_kernel(const SmallSelectArgs a) {
-    constexpr int NT = 1024, NWV = NT / 64;
+template <int PER, typename KT = float, int NT_ = 1024>   // samples per thread: 16 (16 384-key sample), 32 or 64 (65 536): a probe is PER compares + one block reduction
+__global__ __launch_bounds__(NT_) void small_threshold_kernel(const SmallSelectArgs a) {   // (NT_ = 256: one query's ~10 K sample keys - four waves reduce faster than sixteen)
+    constexpr int NT = NT_, NWV = NT / 64;
     __shared__ int s_cnt[NWV];
     __shared__ float s_mm[2 * NWV];
     const int64_t b = blockIdx.x;
@@ -944,14 +1010,35 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
     const bool seed16 = f16 && seed && screen_f16_supported(*seed);   // the seed pre-pass reads the float16 copy when its kernel can
     float* qf = reinterpret_cast<float*>(ws + w.qf);
     int32_t* qexp = reinterpret_cast<int32_t*>(ws + w.qexp);
-    if (f16) {
+    // one query (matrix-vector passes, round 3): the pre-pass reads Q32 itself and leaves the query's scale in qexp[0] - no repacking launch;
+    // its sample keys are float32, one row of seed_ld keys, and the block threshold kernel picks tau0 from them
+    const bool gemv = f16 && seed && B <= HWER_GEMV_MAX_B && B == 1 && (p.ng == 8 || p.ng == 16 || p.ng == 32) && seed->seed_ld <= 65536 &&
+                      size_t(seed->seed_ld) * 4 <= seed_keys_bytes(*seed) && !diag_env("HWER_SMALL_NO_GEMV");
+    if (gemv) {
+        float* seed_keys = reinterpret_cast<float*>(ws + w.keys);   // (>= 32 rows x seed_ld float16 were provisioned: one float32 row fits)
+        SeedGemvArgs sg{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, Q32, x_exp, seed->seed_tiles, seed->seed_stride, seed_keys, qexp, hdr};
+        const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(seed->seed_tiles, 4), 512)));
+        if (p.ng == 8) hipLaunchKernelGGL(small_seedgemv_kernel<8>, dim3(grid), dim3(256), 0, stream, sg);
+        else if (p.ng == 16) hipLaunchKernelGGL(small_seedgemv_kernel<16>, dim3(grid), dim3(256), 0, stream, sg);
+        else hipLaunchKernelGGL(small_seedgemv_kernel<32>, dim3(grid), dim3(256), 0, stream, sg);
+        if ((rc = check_launch("knn_small(seed gemv)"))) return rc;
+        const int64_t S = seed->seed_ld;
+        SmallSelectArgs sa{seed_keys, S, S, 1, 0, thr, count, nullptr, seed->seed_frac};
+        if (S <= 1024) hipLaunchKernelGGL((small_threshold_wave_kernel<16, float>), dim3(1), dim3(256), 0, stream, sa);
+        else if (S <= 4096) hipLaunchKernelGGL((small_threshold_wave_kernel<64, float>), dim3(1), dim3(256), 0, stream, sa);
+        else if (S <= 16384) hipLaunchKernelGGL((small_threshold_kernel<16, float>), dim3(1), dim3(1024), 0, stream, sa);   // (256 threads x 64 keys: 14.9 vs 10.7 us on 9 766 keys)
+        else if (S <= 32768) hipLaunchKernelGGL((small_threshold_kernel<32, float>), dim3(1), dim3(1024), 0, stream, sa);
+        else hipLaunchKernelGGL((small_threshold_kernel<64, float>), dim3(1), dim3(1024), 0, stream, sa);
+        if ((rc = check_launch("knn_small(seed threshold)"))) return rc;
+        sink.tau0 = thr;
+    } else if (f16) {
         hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(bq_all / 32)), dim3(256), 0, stream, Q32, B, int(ldx), p.ng,
                            reinterpret_cast<half8_t*>(qf), qexp);
         if ((rc = check_launch("knn_small(repack16)"))) return rc;
     } else if ((rc = repack_queries(Q32, B, bq_all, int(ldx), qf, stream))) {
         return rc;
     }
-    if (seed) {
+    if (seed && !gemv) {
         // Seeded mode: sample pre-pass (the dense mode of the streaming screen over every seed_stride-th tile) -> tau0 per query
         // -> ONE pass over the catalogue that keeps only the keys above tau0.  No key matrix, no collect pass.
         float* seed_keys = reinterpret_cast<float*>(ws + w.keys);
@@ -962,7 +1049,7 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         if ((rc = launch_seed_tau0(*seed, seed_keys, B, thr, count, stream))) return rc;
         sink.tau0 = thr;
     }
-    if (f16 && seed && B <= HWER_GEMV_MAX_B && (p.ng == 8 || p.ng == 16 || p.ng == 32) && !diag_env("HWER_SMALL_NO_GEMV")) {
+    if (gemv || (f16 && seed && B <= HWER_GEMV_MAX_B && (p.ng == 8 || p.ng == 16 || p.ng == 32) && !diag_env("HWER_SMALL_NO_GEMV"))) {
         // a handful of queries: the filtering pass as a matrix-vector product (small_gemv16_kernel)
         const int64_t n_pad = ((n_items + ROW_PAD - 1) / ROW_PAD) * ROW_PAD;
         Gemv16Args ga{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, Q32, qexp, x_exp, int(B), n_pad / 32, hdr, sink};
