@@ -375,3 +375,28 @@ def test_bench_step_at_full_size_vs_oracle(hw, bench_mod, name, n_check):
     o_idx, o_score, _ = c_oracle.find_closest_f64(Vh[U:], Qh, V64u[sel], bench_mod.K, threads=c_oracle.effective_cpus())
     assert np.array_equal(idx[sel], o_idx + U)
     assert np.array_equal(score[sel], o_score)
+
+
+# ------------------------------------------------------------------------------------------------- one query: matrix-vector passes
+@pytest.mark.parametrize("I,d,k", [(50000, 40, 200), (50000, 64, 1), (70001, 100, 200), (33000, 128, 50), (20000, 200, 200), (20000, 256, 392)])
+def test_one_query_matrix_vector_passes(hw, I, d, k):
+    """B = 1 on a catalogue beyond the dense limit (csrc/knn_small.hip: small_seedgemv_kernel + small_gemv16_kernel, every padded width 64 /
+    128 / 256, a row count that is not a multiple of the 64-row padding): ids, scores and distances == the oracle for several anchors, one search
+    each; two and three anchors at once (the MFMA ring) agree as well."""
+    from hwer.device_index import DeviceIndex
+    rng = np.random.default_rng(I + d)
+    U = 5
+    V = rng.standard_normal((U + I, d)).astype(np.float32)
+    V /= np.linalg.norm(V.astype(np.float64), axis=1, keepdims=True)
+    V = V.astype(np.float32)
+    ix = DeviceIndex(V, {"user": np.arange(U), "item": np.arange(U, U + I)}, arith=0)
+    V64 = V.astype(np.float64)
+    Qh = np.stack([orc.query_vector(V64, u) for u in range(U)])
+    o_idx, o_score, o_d2 = c_oracle.find_closest_f64(V[U:], Qh, V64[:U], k, threads=c_oracle.effective_cpus())
+    for u in range(U):
+        idx, score, dist, flags = ix.search("item", np.asarray([u]), k=k)
+        assert flags[0] > 0
+        assert np.array_equal(idx[0], o_idx[u] + U) and np.array_equal(score[0], o_score[u]) and np.array_equal(dist[0], np.sqrt(o_d2[u]))
+    for sel in ([0, 3], [1, 2, 4]):
+        idx, score, dist, flags = ix.search("item", np.asarray(sel), k=k)
+        assert np.array_equal(idx, o_idx[sel] + U) and np.array_equal(score, o_score[sel])
