@@ -834,7 +834,7 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
         const bool single_list = p.n_lists == 1 && !small;
         // (round 3: with the candidate pick the pre-pass no longer pays per sample key, and c = 4 beats 8 on the large catalogues
         // too - same-box sweep, diagnostic build: c4 2.27 -> 2.20 ms per search, c5 4.34 -> 4.30, c4full 13.7 -> 13.5)
-        double c_min = single_list ? 2.25 : ((B <= 4 && small) ? 8.0 : 4.0);
+        double c_min = single_list ? 2.25 : ((B <= 2 && small) ? 8.0 : 4.0);   // (3 - 4 queries: 0.127 ms at c = 8, 0.112 - 0.115 at c = 4 on 1.25 M rows)
         if (const char* e = diag_env("HWER_SEED_C")) c_min = std::max(1.5, atof(e));   // tuning override (diagnostic builds)
         // sample rank r by c (probabilities above; the threshold kernels never take a rank below 16)
         const double r_min = single_list ? 52.0 : (c_min >= 8.0 ? 16.0 : 28.0);

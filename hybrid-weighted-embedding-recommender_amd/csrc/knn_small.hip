@@ -364,6 +364,16 @@ __global__ __launch_bounds__(64 * NW, 1) void small_screen16_kernel(const Small1
 // scaled units as the MFMA kernels' (query scaled by 2^qexp, table by 2^x_exp, float32 accumulation) and are unscaled when parked.
 // Same sink as small_screen16_kernel<.., FILTER = true>: keys above tau0[b] go to the query's list.
 // ---------------------------------------------------------------------------------------------------------------------
+// sum over the NG (8 / 16 / 32) consecutive lanes that hold one row, result in every one of them
+template <int NG>
+__device__ __forceinline__ float row_lanes_sum(float v) {
+    v += __uint_as_float(lane_xor32<1>(__float_as_uint(v)));
+    v += __uint_as_float(lane_xor32<2>(__float_as_uint(v)));
+    v += __uint_as_float(lane_xor32<4>(__float_as_uint(v)));
+    if constexpr (NG >= 16) v += __uint_as_float(lane_xor32<8>(__float_as_uint(v)));
+    if constexpr (NG >= 32) v += __uint_as_float(lane_xor32<16>(__float_as_uint(v)));
+    return v;
+}
 struct Gemv16Args {
     const _Float16* X16;   // (Np, ldx) float16, scaled by 2^x_exp; Np a multiple of 64 (pad rows: zeros, half norm +inf)
     const float* hnorm;
@@ -382,7 +392,7 @@ typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 #endif
 constexpr bool GEMV_DOUBLE_BUFFER = HWER_GEMV_DOUBLE_BUFFER != 0;
 #ifndef HWER_GEMV_MAX_B
-#define HWER_GEMV_MAX_B 1   // queries up to which the matrix-vector pass is taken (measured on 1.25 M x 128: 1 query 0.121 -> 0.114 ms; 2 .. 4 queries slower than the MFMA ring)
+#define HWER_GEMV_MAX_B 2   // queries up to which the matrix-vector filtering pass is taken (1.25 M x 128, ms per search vs the MFMA ring: 1 query 0.121 -> 0.098, 2 queries 0.123 -> 0.110; 3 - 4 queries 0.123 - 0.125, the ring 0.112 - 0.115)
 #endif
 #ifndef HWER_GEMV_WAVES_PER_CU
 #define HWER_GEMV_WAVES_PER_CU 48
@@ -450,8 +460,7 @@ __global__ __launch_bounds__(256) void small_gemv16_kernel(const Gemv16Args a) {
                 dot = __builtin_amdgcn_fdot2(xv[1], qh[b][1], dot, false);
                 dot = __builtin_amdgcn_fdot2(xv[2], qh[b][2], dot, false);
                 dot = __builtin_amdgcn_fdot2(xv[3], qh[b][3], dot, false);
-#pragma unroll
-                for (int off = 1; off < NG; off <<= 1) dot += __shfl_xor(dot, off, kWave);   // the row's NG lanes
+                dot = row_lanes_sum<NG>(dot);   // the row's NG lanes (DPP / permlane exchanges: no LDS round trips)
                 const float key_s = fmaf(hn, nscale[b], dot);
                 const bool pass = c == 0 && key_s > tau[b];      // one lane per row decides (pad rows: half norm +inf -> -inf)
                 const uint64_t bal = __ballot(pass);
@@ -540,8 +549,7 @@ __global__ __launch_bounds__(256) void small_seedgemv_kernel(const SeedGemvArgs 
             dot = __builtin_amdgcn_fdot2(xv[1], qh[1], dot, false);
             dot = __builtin_amdgcn_fdot2(xv[2], qh[2], dot, false);
             dot = __builtin_amdgcn_fdot2(xv[3], qh[3], dot, false);
-#pragma unroll
-            for (int off = 1; off < NG; off <<= 1) dot += __shfl_xor(dot, off, kWave);
+            dot = row_lanes_sum<NG>(dot);
             if (c == 0) a.keys[p * 32 + row] = ldexpf(fmaf(hn, nscale, dot), -e_tot);   // (pad rows: -inf)
         }
     }
