@@ -501,7 +501,9 @@ struct SeedGemvArgs {
     int x_exp;
     int64_t n_tiles;       // sample tiles
     int64_t tile_stride;
-    float* keys;           // (n_tiles * 32)
+    float* keys;           // (waves x rows-per-load) candidates: every row slot of every wave hands over the largest sample key it saw (the
+                           // seed pre-pass's top-M scheme with M = 1: the r-th largest candidate is the r-th largest sample key unless two of the r best
+                           // share a slot - then it is slightly lower, the safe side)
     int32_t* qexp;         // [0] <- the query's scale exponent
     WsHeader* hdr;
 };
@@ -533,6 +535,7 @@ __global__ __launch_bounds__(256) void small_seedgemv_kernel(const SeedGemvArgs 
     qh[3] = half2_t{(_Float16)ldexpf(y.z, e), (_Float16)ldexpf(y.w, e)};
     const uint32_t row_bytes = uint32_t(a.ldx) * 2u;
     const int64_t n_waves = int64_t(gridDim.x) * 4;
+    float best = -INFINITY;
     for (int64_t p = int64_t(blockIdx.x) * 4 + wave; p < a.n_tiles; p += n_waves) {
         const int64_t row0 = p * a.tile_stride * 32;
         const unsigned char* base = reinterpret_cast<const unsigned char*>(a.X16) + row0 * int64_t(row_bytes);
@@ -550,9 +553,10 @@ __global__ __launch_bounds__(256) void small_seedgemv_kernel(const SeedGemvArgs 
             dot = __builtin_amdgcn_fdot2(xv[2], qh[2], dot, false);
             dot = __builtin_amdgcn_fdot2(xv[3], qh[3], dot, false);
             dot = row_lanes_sum<NG>(dot);
-            if (c == 0) a.keys[p * 32 + row] = ldexpf(fmaf(hn, nscale, dot), -e_tot);   // (pad rows: -inf)
+            best = fmaxf(best, fmaf(hn, nscale, dot));   // (pad rows: -inf; scaled units: one power of two for the whole query)
         }
     }
+    if (c == 0) a.keys[(int64_t(blockIdx.x) * 4 + wave) * RPL + rl] = ldexpf(best, -e_tot);
 }
 
 // queries -> float16 MFMA fragments, each query scaled by the power of two that puts its largest element in
@@ -1020,24 +1024,25 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
     int32_t* qexp = reinterpret_cast<int32_t*>(ws + w.qexp);
     // one query (matrix-vector passes, round 3): the pre-pass reads Q32 itself and leaves the query's scale in qexp[0] - no repacking launch;
     // its sample keys are float32, one row of seed_ld keys, and the block threshold kernel picks tau0 from them
-    const bool gemv = f16 && seed && B <= HWER_GEMV_MAX_B && B == 1 && (p.ng == 8 || p.ng == 16 || p.ng == 32) && seed->seed_ld <= 65536 &&
-                      size_t(seed->seed_ld) * 4 <= seed_keys_bytes(*seed) && !diag_env("HWER_SMALL_NO_GEMV");
+    const bool gemv = f16 && seed && B <= HWER_GEMV_MAX_B && B == 1 && (p.ng == 8 || p.ng == 16 || p.ng == 32) && seed_keys_bytes(*seed) >= 4096 && !diag_env("HWER_SMALL_NO_GEMV");
     if (gemv) {
         float* seed_keys = reinterpret_cast<float*>(ws + w.keys);   // (>= 32 rows x seed_ld float16 were provisioned: one float32 row fits)
         SeedGemvArgs sg{reinterpret_cast<const _Float16*>(X16), hnorm, ldx, Q32, x_exp, seed->seed_tiles, seed->seed_stride, seed_keys, qexp, hdr};
-        const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(seed->seed_tiles, 4), 512)));
+        // at most 1 024 candidates (one wave picks tau0 from 16 per lane): waves x (64 / NG) row slots
+        const int rpl = 64 / p.ng;
+        const int n_wv = int(std::max<int64_t>(4, std::min<int64_t>(seed->seed_tiles, 1024 / rpl)));
+        const int grid = (n_wv + 3) / 4;
+        const int n_cand = grid * 4 * rpl;
         if (p.ng == 8) hipLaunchKernelGGL(small_seedgemv_kernel<8>, dim3(grid), dim3(256), 0, stream, sg);
         else if (p.ng == 16) hipLaunchKernelGGL(small_seedgemv_kernel<16>, dim3(grid), dim3(256), 0, stream, sg);
         else hipLaunchKernelGGL(small_seedgemv_kernel<32>, dim3(grid), dim3(256), 0, stream, sg);
         if ((rc = check_launch("knn_small(seed gemv)"))) return rc;
-        const int64_t S = seed->seed_ld;
-        SmallSelectArgs sa{seed_keys, S, S, 1, 0, thr, count, nullptr, seed->seed_frac};
-        if (S <= 1024) hipLaunchKernelGGL((small_threshold_wave_kernel<16, float>), dim3(1), dim3(256), 0, stream, sa);
-        else if (S <= 4096) hipLaunchKernelGGL((small_threshold_wave_kernel<64, float>), dim3(1), dim3(256), 0, stream, sa);
-        else if (S <= 16384) hipLaunchKernelGGL((small_threshold_kernel<16, float>), dim3(1), dim3(1024), 0, stream, sa);   // (256 threads x 64 keys: 14.9 vs 10.7 us on 9 766 keys)
-        else if (S <= 32768) hipLaunchKernelGGL((small_threshold_kernel<32, float>), dim3(1), dim3(1024), 0, stream, sa);
-        else hipLaunchKernelGGL((small_threshold_kernel<64, float>), dim3(1), dim3(1024), 0, stream, sa);
-        if ((rc = check_launch("knn_small(seed threshold)"))) return rc;
+        // tau0 = the rank-th largest candidate, rank = the sample rank of the plan (the threshold kernel of the full sample took 10.7 us for
+        // 9 766 keys; this pick 6)
+        const int rank = std::max(16, int(seed->seed_frac * double(seed->seed_ld) + 0.5));
+        if (n_cand <= 256) hipLaunchKernelGGL(seed_pick_kernel<4>, dim3(1), dim3(256), 0, stream, seed_keys, int64_t(n_cand), n_cand, int64_t(1), rank, thr, count);
+        else hipLaunchKernelGGL(seed_pick_kernel<16>, dim3(1), dim3(256), 0, stream, seed_keys, int64_t(n_cand), n_cand, int64_t(1), rank, thr, count);
+        if ((rc = check_launch("knn_small(seed pick)"))) return rc;
         sink.tau0 = thr;
     } else if (f16) {
         hipLaunchKernelGGL(repack_queries16_kernel, dim3(unsigned(bq_all / 32)), dim3(256), 0, stream, Q32, B, int(ldx), p.ng,
