@@ -525,7 +525,8 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // (v_alignbit) pushes that sign bit into the mask.  Bit (15 - q) of half-word b <-> accumulator register q of
             // query subtile b.  Both subtiles share ONE park and ONE pop loop: the loop runs max-over-lanes of the lane's
             // total pops, not the sum of the per-subtile maxima.
-            if (F16 && FILTER_V2 && a.sparse_hits) {   // (wave-uniform)
+            constexpr bool ALWAYS_SPARSE = F16 && FILTER_V2 && NG > 16 && WIDE64;   // d = 256: the park-free filter only (no park in its LDS, launch_screen16_t)
+            if (ALWAYS_SPARSE || (F16 && FILTER_V2 && a.sparse_hits)) {   // (wave-uniform)
                 // Round 3, catalogues so large that most tiles of a wave hold NO passing key (seeded thresholds let c K' keys of a query
                 // through whatever the catalogue size: 0.2 per 32 x 64 tile and wave on 10 M rows, 1.7 on 1.25 M).  What bounds this loop
                 // is the wave's serial chain and instruction count, not a pipe (SQ counters): the per-key pass masks (48
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                 } else {
                     asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15]));
                 }
-            } else {
+            } else if constexpr (!ALWAYS_SPARSE) {
             uint32_t mask = 0;
             if (ABLATE(4)) asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15]));
             else
