@@ -32,9 +32,17 @@ class LazyRows(MutableMapping):
     iteration, keys / values / items, get, assignment, `del`, pop, update."""
 
     def __init__(self, keys, build_row):
-        self._pos = {k: j for j, k in enumerate(keys)}   # keys whose list still lives in the arrays (or in the cache)
+        self._keys = keys        # the key -> row dictionary is built on first use (one hash per key: as much host time as resolving the anchors)
+        self._pos_dict = None
         self._build = build_row
         self._cache = {}
+
+    @property
+    def _pos(self):              # keys whose list still lives in the arrays (or in the cache)
+        if self._pos_dict is None:
+            self._pos_dict = {k: j for j, k in enumerate(self._keys)}
+            self._keys = None
+        return self._pos_dict
 
     def __getitem__(self, key):
         got = self._cache.get(key)
