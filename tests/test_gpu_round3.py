@@ -400,3 +400,29 @@ def test_one_query_matrix_vector_passes(hw, I, d, k):
     for sel in ([0, 3], [1, 2, 4]):
         idx, score, dist, flags = ix.search("item", np.asarray(sel), k=k)
         assert np.array_equal(idx, o_idx[sel] + U) and np.array_equal(score, o_score[sel])
+
+
+# ------------------------------------------------------------------------------------------------- float16 fragments out of the prologue
+@pytest.mark.parametrize("U,I,d,T,per_row", [(3000, 20000, 128, 2, False), (2500, 30000, 256, 3, True), (4096, 9000, 64, 2, False), (600, 3000, 128, 2, False)])
+def test_fused_float16_fragments_equal_the_repacking_launch(hw, bench_mod, monkeypatch, U, I, d, T, per_row):
+    """hwer_blend_prepare_search_f32 / hwer_prepare_search_f32 with bq < 0 write the float16 query fragments + per-query scales of the float16 screen;
+    the search then runs with HWER_KNN_QUERIES_READY.  Same ids / scores / flags as the step whose search repacks the queries itself
+    (HWER_NO_FUSED_FRAGMENTS=1), streaming and dense float16 shapes, d = 64 / 128 / 256."""
+    import torch
+    from hwer import native
+    cfg = dict(U=U, I=I, d=d, T=T, per_row=per_row, name="test")
+    dev = torch.device("cuda", 0)
+    res = []
+    for no_frag in ("", "1"):
+        if no_frag:
+            monkeypatch.setenv("HWER_NO_FUSED_FRAGMENTS", "1")
+        else:
+            monkeypatch.delenv("HWER_NO_FUSED_FRAGMENTS", raising=False)
+        w = bench_mod.Workload(torch, native.lib(), cfg, dev, f16_dense=True)
+        assert w.f16_screen
+        assert bool(w.fused_fragments) == (not no_frag and (w.fused_blend or w.fused_prologue))
+        w.step()
+        torch.cuda.synchronize()
+        res.append(w.results()[:2] + (w.sets[0]["flags"].cpu().numpy(),))
+        del w
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
