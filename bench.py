@@ -356,7 +356,10 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         # wall-clock mean (seen once in ~6 default runs: c1 0.216 ms against a per-step median of 0.056).  Such a region is measured
         # again - at most twice, every discarded mean is reported (`timed_region`) - and the reported one is still EXACTLY K steps
         # between two synchronisations.
-        if graph is None or elapsed / steps * 1e3 <= 1.3 * float(np.median(series)) or attempt == 2:
+        # (eager steps - 2 .. 14 ms each, 20 - 40 per region - carry their events inside the region: there a mean more than 15 % above the
+        # median is the same kind of stall; the round-2 driver run caught one at c4: 4.41 ms against a 3.04 ms stage sum)
+        limit = 1.3 if graph is not None else 1.15
+        if elapsed / steps * 1e3 <= limit * float(np.median(series)) or attempt == 2:
             break
         discarded.append(elapsed / steps * 1e3)
     lib.hwer_profile_enable(0)
@@ -453,7 +456,7 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         "value": value, "unit": "pairs/s", "ms_per_step": ms_per_step,
         "ms_median": float(np.median(series)), "ms_min": float(series.min()), "ms_max": float(series.max()), "ms_mean_events": float(series.mean()),
         "timed_region": {"attempts": len(discarded) + 1, "discarded_ms_per_step": [round(x, 5) for x in discarded],
-                         "rule": "graph-replayed steps only: a region whose wall-clock mean exceeds 1.3x the median of its per-step event intervals is measured again (at most twice)"},
+                         "rule": "a timed region whose wall-clock mean exceeds 1.3x (graph-replayed steps) / 1.15x (eager steps) the median of its per-step event intervals is measured again (at most twice)"},
         "ms_series": [round(float(x), 4) for x in series[:256]], "ms_series_note": "HIP-event interval of every step" + ("" if in_loop else " (second pass: the timed steps are graph replays)"),
         "user_rows": w.U,
         "roofline": {k_: dominant[k_] for k_ in ("kernel", "bound", "achieved", "peak", "unit", "frac")},
