@@ -1836,7 +1836,10 @@ static int knn_search_stages(int stages, const float* X, const float* hnorm, int
         // (HWER_KNN_QUERIES_READY: the prologue - hwer_prepare_search_f32 / hwer_blend_prepare_search_f32 with bq < 0 - wrote the float16 fragments and exponents)
         if (!(options & HWER_KNN_QUERIES_READY))
         if ((rc = repack_queries16(Q32, B, plan.bq, int(ldx), qf, reinterpret_cast<int32_t*>(ws + w.qf + size_t(plan.bq) * size_t(plan.ng) * 16), st))) return rc;
-    } else if (!(options & HWER_KNN_QUERIES_READY)) {   // (else: hwer_prepare_search_f32 wrote the fragments already)
+    } else if (!(options & HWER_KNN_QUERIES_READY) || (options & HWER_KNN_F16_SCREEN)) {
+        // (QUERIES_READY alone: hwer_prepare_search_f32 wrote the float32 fragments already.  QUERIES_READY together with F16_SCREEN when
+        // the float16 screen does NOT run here - no X16, or a padded width below 64 - means the prologue may have left float16
+        // fragments where this screen reads float32 ones: repack from Q32 rather than trust them)
         if ((rc = repack_queries(Q32, B, plan.bq, int(ldx), qf, st))) return rc;
     }
     rc = HWER_OK;

@@ -31,7 +31,8 @@ def _require_gpu(device):
     if not torch.cuda.is_available():
         raise native.HwerNativeError("hwer (MI355X build) needs a ROCm GPU: torch.cuda.is_available() is False; "
                                      "there is no CPU fallback for the retrieval path")
-    return torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    dev = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+    return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
 
 
 def roundup(x, m):
@@ -40,19 +41,18 @@ def roundup(x, m):
 
 def _on_device(fn):
     """Run a DeviceIndex method with the index's device current (native launches go to the CURRENT HIP device and to its
-    current torch stream - an index on cuda:1 used while cuda:0 is current would otherwise launch on the wrong GPU)."""
+    current torch stream - an index on cuda:1 used while cuda:0 is current would otherwise launch on the wrong GPU).
+    Re-entrant calls skip the guard when the device IS current (a query of the runtime, not a flag on the instance: a second
+    thread entering while the first is inside must not inherit the first one's guard)."""
     import functools
 
     @functools.wraps(fn)
     def wrapped(self, *a, **kw):
-        if getattr(self, "_guarded", False):      # already inside one of this index's guarded methods: the device is current
+        torch = _torch()
+        if torch.cuda.current_device() == self.device.index:
             return fn(self, *a, **kw)
-        self._guarded = True
-        try:
-            with native.device_guard(self.device):
-                return fn(self, *a, **kw)
-        finally:
-            self._guarded = False
+        with native.device_guard(self.device):
+            return fn(self, *a, **kw)
     return wrapped
 
 
@@ -277,7 +277,7 @@ class DeviceIndex:
 
     @_on_device
     def search_queries(self, node_type: str, Q64, Q32, k: int, anchors_dev=None, score_mode: Optional[int] = None,
-                       sort_by_score: bool = True, id_base: Optional[int] = None, want_dist: bool = True):
+                       sort_by_score: bool = True, id_base: Optional[int] = None, want_dist: bool = True, _flags_host_out: Optional[list] = None):
         """Exact k nearest rows of `node_type` for B query vectors already on the device.
         -> torch tensors (idx (B,k) int64 global ids, score (B,k) f64, dist2 (B,k) f64 or None, flags (B) int32).
         want_dist=False (score order, base scoring only) skips the distances the result does not depend on."""
@@ -305,12 +305,15 @@ class DeviceIndex:
             else:
                 self._search_candidates(tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags)
             return idx, score, dist2, flags
-        self._search_f32(tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags)
+        fh = self._search_f32(tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags)
+        if _flags_host_out is not None:
+            _flags_host_out.append(fh)      # the host copy of `flags` the small-batch path already fetched (None otherwise)
         return idx, score, dist2, flags
 
     def _search_f32(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags):
         """the HIP search on the float32 table (d <= 256, k <= 392): MFMA screen -> float64 re-rank -> certificate, then the
-        exhaustive tiers for uncertified queries; fills idx / score / dist2 / flags."""
+        exhaustive tiers for uncertified queries; fills idx / score / dist2 / flags.  -> the host copy of the final flags when the
+        small-batch branch fetched one and nothing changed them afterwards (else None)."""
         torch = _torch()
         B = Q64.shape[0]
         path_opt = self._path_options()
@@ -349,14 +352,14 @@ class DeviceIndex:
         if B <= 4096:
             # small batches: the flags themselves come to the host (one copy; `search` reuses it) instead of a count kernel + its result
             flags_host = flags.cpu()
-            self._flags_host = (flags, flags_host)
             n_bad_host = int((flags_host == 0).sum())
         else:
+            flags_host = None
             n_bad = torch.zeros(1, dtype=torch.int32, device=self.device)
             native.check(self.lib.hwer_knn_count_uncertified(native.ptr(flags), B, native.ptr(n_bad), st), "count_uncertified")
             n_bad_host = int(n_bad.item())
         if n_bad_host:
-            self._flags_host = None
+            flags_host = None
             bad = torch.nonzero(flags == 0).flatten()
             if bad.numel() > self.RETRY_MIN:
                 # many uncertified queries = the sampled thresholds were defeated (e.g. a catalogue sorted by cluster): run
@@ -367,6 +370,7 @@ class DeviceIndex:
             if bad.numel():
                 self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
                                      dist2, flags)
+        return flags_host
 
     #: extra candidates asked of the screen by _search_candidates (the certificate needs a gap between the k-th exact distance and
     #: the bound on everything that was not a candidate)
@@ -565,11 +569,10 @@ class DeviceIndex:
         -> numpy (idx (B,k) int64, score (B,k) in the reference's dtype, dist (B,k) float64 or None, flags (B))."""
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
         mode = 2 if scoring == "gcn" else self.arith
-        idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist)
+        fh = []
+        idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist, _flags_host_out=fh)
         sc = score.cpu().numpy()
         if mode == 1:
             sc = sc.astype(np.float32)  # exact: the kernel widened float32 values
-        fh = getattr(self, "_flags_host", None)
-        flags_np = fh[1].numpy() if (fh is not None and fh[0] is flags) else flags.cpu().numpy()   # (_search_f32 already fetched them)
-        self._flags_host = None
+        flags_np = fh[0].numpy() if (fh and fh[0] is not None) else flags.cpu().numpy()   # (_search_f32 already fetched them)
         return idx.cpu().numpy(), sc, (np.sqrt(dist2.cpu().numpy()) if dist2 is not None else None), flags_np

@@ -172,7 +172,10 @@ class ShardedSearch:
     """k-NN over a row-sharded catalogue.
 
     local_search(Q64, Q32, k_local[, rows=positions]) -> (idx, score, dist2) (B, k_local) tensors of the LOCAL shard in ascending
-    (dist2, global id) order with GLOBAL ids (`rows` only when a subset of the batch is repeated with full lists); merge(g_idx, g_score, g_dist2, sort_by_score) -> merged tensors.
+    (dist2, global id) order with GLOBAL ids.  `rows` is passed only when a subset of the batch is repeated with full lists (the
+    positions of those queries in the caller's batch, so that per-query state - anchors - follows); a callable WITHOUT a `rows`
+    parameter is still accepted: the search then keeps full lists (no shortened lists, hence no repeat).
+    merge(g_idx, g_score, g_dist2, sort_by_score) -> merged tensors.
     Both are injectable so that the collective plumbing is testable on CPU (gloo) without a GPU."""
 
     def __init__(self, n_rows: int, local_search: Callable, merge: Callable = merge_on_device, group=None,
@@ -193,8 +196,19 @@ class ShardedSearch:
         self.list_len = list_len
         self.repeated_queries = 0   # queries of the last search() that were repeated with full lists
 
+    @staticmethod
+    def _takes_rows(fn) -> bool:
+        """does the injected local_search accept `rows=` (the positions of a repeated subset)?  A 3-argument callable written against
+        the rounds-1/2 contract does not: such a search keeps full lists (no data-dependent repeat can reach it)."""
+        import inspect
+        try:
+            ps = inspect.signature(fn).parameters
+        except (TypeError, ValueError):
+            return False
+        return "rows" in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
+
     def _list_len(self, k: int) -> int:
-        if self.exchange != "all_gather" or self.world > 16:
+        if self.exchange != "all_gather" or self.world > 16 or not self._takes_rows(self.local_search):
             return k
         if self.list_len is not None:
             return max(min(int(self.list_len), k), -(-k // self.world))

@@ -98,7 +98,8 @@ class BlendSearchStep:
             # float16 screen wherever it pays (hwer_knn_f16_screen_pays: every streamed catalogue, dense ones from ~1e9 multiply-adds)
             if f16_screen is None:
                 f16_screen = bool(lib.hwer_knn_f16_screen_pays(min(B, QUERY_CHUNK), I, d))
-            self.f16_screen = bool(f16_screen and lib.hwer_knn_padded_dim(d) >= 64) or (f16_dense and I <= 8192)
+            # (both ways in: the float16 MFMA tiles start at a padded width of 64 - below that the library screens in float32)
+            self.f16_screen = bool((f16_screen or (f16_dense and I <= 8192)) and lib.hwer_knn_padded_dim(d) >= 64)
             self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
             self.Q64 = torch.empty((B, d), dtype=torch.float64, device=dev)
             self.Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=dev)

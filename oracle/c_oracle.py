@@ -26,6 +26,8 @@ def lib():
         P, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         L.orc_find_closest_f64.restype = i32
         L.orc_find_closest_f64.argtypes = [P, i64, i32, P, P, i64, i32, i32, i32, P, P, P]
+        L.orc_find_closest_f64_scalar.restype = i32
+        L.orc_find_closest_f64_scalar.argtypes = L.orc_find_closest_f64.argtypes
         L.orc_pair_score_f64.restype = i32
         L.orc_pair_score_f64.argtypes = [P, i64, i32, P, P, i64, i32, P]
         L.orc_num_threads.restype = i32
@@ -37,9 +39,10 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
-def find_closest_f64(X32, Q64, A64, k, sort_by_score=True, threads=1):
+def find_closest_f64(X32, Q64, A64, k, sort_by_score=True, threads=1, scalar=False):
     """X32 (N,d) float32 item rows; Q64 (B,d) queries; A64 (B,d) anchor rows or None (GcnNCF scoring).
-    -> (local idx (B,k) int64, score (B,k) f64, dist2 (B,k) f64)"""
+    -> (local idx (B,k) int64, score (B,k) f64, dist2 (B,k) f64).  scalar=True: the one-pair-at-a-time restatement
+    (orc_find_closest_f64_scalar) instead of the row-blocked loop - same values, bit for bit."""
     X32 = np.ascontiguousarray(X32, dtype=np.float32)
     Q64 = np.ascontiguousarray(Q64, dtype=np.float64)
     A = None if A64 is None else np.ascontiguousarray(A64, dtype=np.float64)
@@ -47,7 +50,8 @@ def find_closest_f64(X32, Q64, A64, k, sort_by_score=True, threads=1):
     idx = np.empty((B, k), np.int64)
     sc = np.empty((B, k), np.float64)
     d2 = np.empty((B, k), np.float64)
-    rc = lib().orc_find_closest_f64(_p(X32), X32.shape[0], d, _p(Q64), None if A is None else _p(A), B, k,
+    fn = lib().orc_find_closest_f64_scalar if scalar else lib().orc_find_closest_f64
+    rc = fn(_p(X32), X32.shape[0], d, _p(Q64), None if A is None else _p(A), B, k,
                                     1 if sort_by_score else 0, threads, _p(idx), _p(sc), _p(d2))
     if rc != 0:
         raise ValueError("k must be less than or equal to the number of training points")

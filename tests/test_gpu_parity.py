@@ -295,7 +295,8 @@ def test_knn_small_batch_path(hw, d, N, B, k):
 @pytest.mark.parametrize("d,N,B,k", [(128, 50000, 5, 200), (64, 20000, 64, 100), (256, 12000, 33, 200), (32, 40000, 200, 50)])
 def test_knn_small_batch_f16_storage_is_invisible(hw, d, N, B, k):
     """the float16 storage of the small-batch screen (half the bytes streamed) must not change a single bit of the result:
-    same ids / scores / distances with and without it, both certified; non-unit row norms included."""
+    same ids / scores / distances with and without it, both certified.  Unit rows here; rows with a wide dynamic range and mixed
+    norms: tests/test_gpu_round4.py::test_f16_screen_adversarial_rows."""
     from hwer.device_index import DeviceIndex
     X = unit_rows_f32(35 + d, N, d)
     users = unit_rows_f32(36 + d, B, d)
@@ -973,7 +974,8 @@ def test_fit_feature_table_vs_oracle_shapes(hw, case):
 ])
 def test_knn_f16_streaming_screen_is_invisible(hw, monkeypatch, d, N, B, k, splits):
     """HWER_KNN_F16_SCREEN: the streaming screen on the float16 copy of the table (v_mfma_f32_32x32x16_f16) must return the
-    same ids / scores / distances as the float32 screen and the oracle - bit for bit; non-unit row norms included.
+    same ids / scores / distances as the float32 screen and the oracle - bit for bit.  Row norms here are off 1 by at most 4e-5 (inside
+    the audit); rows with a wide dynamic range and norms 1e-3 ... 1: tests/test_gpu_round4.py::test_f16_screen_adversarial_rows.
     (All five shapes hold more than 1 024 queries and therefore stream anyway; HWER_NO_SMALL - read by the host mirror,
     DeviceIndex._path_options -> HWER_KNN_NO_SMALL - only pins that choice against future changes of the path rule.)"""
     from hwer.device_index import DeviceIndex

@@ -39,14 +39,14 @@ def test_emulated_shards_equal_single_table(hw, bench_mod, name, items, G):
     shard searched like rank g of the 8-GPU job (own blend, own table, ids = id_base + local row, (distance, id) order), packed
     by hwer_pack_exchange into slice g of a (8, 3, B, k) buffer laid out like the all-gather's receive buffer, merged in place by
     hwer_merge_topk_strided: ids, scores and squared distances must EQUAL the single-table result for all 4 096 queries and the
-    oracle's brute force over the whole catalogue on 32 of them.  (A ragged 3-shard cut of 1 000 003 rows as well.)"""
+    oracle's brute force over the whole catalogue on 256 of them (round 4; 32 before).  (A ragged 3-shard cut of 1 000 003 rows as well.)"""
     import torch
     from hwer import native
     cfg = dict(bench_mod.CONFIGS[name])
     cfg["I"] = items
     dev = torch.device("cuda", 0)
-    r = bench_mod.emulate_shards(torch, native.lib(), cfg, dev, G, steps=1, warmup=1, n_oracle=32)
-    assert r["merged_equals_single_table"] and r["queries_compared"] == 4096 and r["oracle_checked_queries"] == 32
+    r = bench_mod.emulate_shards(torch, native.lib(), cfg, dev, G, steps=1, warmup=1, n_oracle=256)
+    assert r["merged_equals_single_table"] and r["queries_compared"] == 4096 and r["oracle_checked_queries"] == 256
     assert len(r["shard_ms"]) == G
     # round 3: the shards sent shortened lists (72 of 200 entries for 8 shards, 136 for 3) and no list ran out
     from hwer.distributed import local_list_len
@@ -351,11 +351,12 @@ def test_extreme_shapes_vs_oracle(hw, U, I, d, k):
 
 
 # ------------------------------------------------------------------------------------------------- BASELINE configs at full size, as the bench runs them
-@pytest.mark.parametrize("name,n_check", [("c1", 943), ("c2", 128), ("c3", 64), ("c5", 32)])
+@pytest.mark.parametrize("name,n_check", [("c1", 943), ("c2", 6040), ("c3", 2048), ("c5", 4096)])
 def test_bench_step_at_full_size_vs_oracle(hw, bench_mod, name, n_check):
     """The step bench.py times (hwer.pipeline.BlendSearchStep on the synthetic tables of BASELINE.json's configs, full size: c1 943 x 1 682,
     c2 6 040 x 3 706, c3 138 493 x 26 744, c5 four tables / per-row alpha / d = 256 / 131 072 + 1.25 M blended rows / 4 096 queries): unit-norm
-    audit clean, every query certified or recomputed, and `n_check` evenly spaced queries == the oracle's brute force over the blended rows the step
+    audit clean, every query certified or recomputed, and `n_check` evenly spaced queries - round 4: ALL of c1 / c2 / c5, 2 048 of c3 - == the oracle's
+    brute force (oracle/hwer_oracle.c, row-blocked loop) over the blended rows the step
     produced (ids and scores bit for bit; the blend itself is held to the oracle by ::test_blend_search_step_equals_the_separate_calls and
     test_gpu_round2.py::test_c5_blend_and_search_shard_size).  c4 / c4full at full size: ::test_emulated_shards_equal_single_table."""
     import torch

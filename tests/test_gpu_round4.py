@@ -1,0 +1,157 @@
+"""GPU parity tests added in round 4: a seeded slice of tools/fuzz_parity.py inside the driver-run suite, adversarial rows for the
+float16 screens (wide dynamic range, mixed norms, duplicates at the cut), the RCCL branch of hwer/distributed.py executed on one GPU
+(backend nccl, world size 1).  Bit-exact for ids / scores / distances unless an assert states a tolerance."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import unit_rows_f32
+from oracle import c_oracle
+from oracle import hwer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hw():
+    import hwer
+    from hwer import native
+    native.lib()
+    return hwer
+
+
+# ------------------------------------------------------------------------------------------------- seeded fuzz slice
+def _fuzz_cases(n=48, seed=2026):
+    """Deterministic (B, N, d, k, arith, scoring, want_dist, nonunit) cases around the thresholds between the search paths: 8 192 / 8 193
+    rows (dense | streaming), 32 / 33 and 1 024 / 1 025 queries (cooperative select | wave per query; small-batch | streaming screen),
+    k at both ends (1, 392 = the fused search's largest), widths that are not multiples of anything.  Work per case is bounded
+    (B N d <= 1.2e9) so that the slice stays within seconds."""
+    rng = np.random.default_rng(seed)
+    Bs = [1, 2, 31, 32, 33, 64, 65, 255, 256, 257, 1000, 1024, 1025, 2100]
+    Ns = [1, 5, 31, 32, 33, 64, 65, 1000, 4095, 8191, 8192, 8193, 8300, 12000, 20000, 40000]
+    ds = [1, 3, 8, 17, 31, 32, 33, 64, 66, 100, 128, 129, 200, 256]
+    ks = [1, 2, 10, 64, 100, 200, 256, 392]
+    pinned = [(32, 8192, 64, 392), (33, 8193, 128, 1), (1024, 8192, 33, 200), (1025, 8193, 31, 392), (1, 8193, 256, 392), (33, 8192, 1, 1),
+              (1025, 8192, 128, 1), (32, 8193, 17, 200), (1024, 8193, 64, 392), (1025, 8192, 200, 200)]
+    cases = []
+    for i in range(n):
+        if i < len(pinned):
+            B, N, d, k = pinned[i]
+        else:
+            while True:
+                B, N, d = int(rng.choice(Bs)), int(rng.choice(Ns)), int(rng.choice(ds))
+                if float(B) * N * d <= 1.2e9:
+                    break
+            k = int(rng.choice([x for x in ks if x <= N]))
+        arith = int(rng.integers(0, 2))
+        scoring = "gcn" if rng.random() < 0.2 else "base"
+        want = bool(rng.integers(0, 2)) or scoring == "gcn"
+        cases.append((B, N, d, k, arith, scoring, want, bool(d > 1 and rng.random() < 0.3), int(rng.integers(1 << 30))))
+    return cases
+
+
+@pytest.mark.parametrize("B,N,d,k,arith,scoring,want,nonunit,seed", _fuzz_cases())
+def test_fuzz_slice_vs_oracle(hw, B, N, d, k, arith, scoring, want, nonunit, seed):
+    """tools/fuzz_parity.py's check, one seeded case: every query of DeviceIndex.search against the C oracle's brute force - ids, scores
+    (float64 flavour: bit for bit; float32 flavour: neighbour sets on every query, order and scores against the numpy oracle on three),
+    distances where they were asked for; every query certified (1) or recomputed exhaustively (2)."""
+    from hwer.device_index import DeviceIndex
+    rng = np.random.default_rng(seed)
+
+    def unit(n):
+        x = rng.standard_normal((n, d), dtype=np.float32).astype(np.float64)
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        return x.astype(np.float32)
+    V32 = np.concatenate([unit(B), unit(N)])
+    if nonunit:      # non-unit rows are legal for the k-NN itself (MultiKNN.query on arbitrary vectors, recommendation_base.py:74-83)
+        V32[B:] *= rng.uniform(0.5, 3.0, size=(N, 1)).astype(np.float32)
+    V = V32.astype(np.float64) if arith == 0 else V32
+    ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}, arith=arith, audit=False)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k, scoring=scoring, want_dist=want)
+    assert ((flags == 1) | (flags == 2)).all()
+    Q64, _, _ = ix.build_queries(np.arange(B))
+    A = V32[:B].astype(np.float64)
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(V32[B:], Q64.cpu().numpy(), None if scoring == "gcn" else A, k, threads=c_oracle.effective_cpus())
+    if arith == 0 or scoring == "gcn":
+        assert np.array_equal(idx, o_idx + B)
+    else:
+        assert np.array_equal(np.sort(idx, axis=1), np.sort(o_idx + B, axis=1))
+        for u in rng.choice(B, size=min(B, 3), replace=False).tolist():
+            n_idx, n_sc, _ = orc.find_closest(V, np.arange(B, B + N), int(u), k=k)
+            assert np.array_equal(idx[u], n_idx) and np.array_equal(score[u], n_sc)
+    if scoring == "gcn" and arith == 0:
+        assert np.array_equal(score, (2.0 - np.sqrt(o_d2)) / 2.0)
+    elif scoring != "gcn" and arith == 0:
+        assert np.array_equal(score, o_sc)
+    if want and (arith == 0 or scoring == "gcn"):
+        assert np.array_equal(dist, np.sqrt(o_d2))
+
+
+# ------------------------------------------------------------------------------------------------- adversarial rows for the float16 screens
+def _heavy_tailed_rows(rng, n, d, norm_lo=1e-3, norm_hi=1.0):
+    """rows whose elements span 30 binades (sign * 2^-U(0, 30)), row norms log-uniform in [norm_lo, norm_hi]"""
+    x = np.exp2(-rng.uniform(0.0, 30.0, size=(n, d))) * rng.choice([-1.0, 1.0], size=(n, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    x *= np.exp(rng.uniform(np.log(norm_lo), np.log(norm_hi), size=(n, 1)))
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("B,N,d,k,tag", [(40, 12000, 128, 200, "small-batch float16 storage"), (1, 12000, 64, 100, "one query: matrix-vector passes"),
+                                          (1500, 9000, 128, 200, "streaming float16 screen"), (1200, 10000, 256, 50, "streaming float16 screen, d = 256"),
+                                          (3, 9000, 100, 392, "ring, padded width")])
+def test_f16_screen_adversarial_rows(hw, B, N, d, k, tag):
+    """The float16 screens' error bound (knn_select.hip: 1.02 * 2^-10 * ||q|| * ||x||max on top of the float32 bound) under rows the unit-norm
+    suites never produce: elements spread over 30 binades (most of a row sits in float16's subnormal range after the table-wide scaling),
+    row norms from 1e-3 to 1 in one table (the reference's MultiKNN takes any vectors, hwer/recommendation_base.py:64-83: the audit belongs to
+    __build_knn__), heavy-tailed queries, and exact duplicates planted at every checked query's cut (rank k - 2 ... k + 2).  Through
+    MultiKNN(nodes_to_idx, vectors) directly; ids, scores and distances == the oracle for every query, flags in {1, 2}, and the same
+    bits with the float16 copies switched off."""
+    from hwer import MultiKNN, Node
+    rng = np.random.default_rng(B * 31 + N + d)
+    items = _heavy_tailed_rows(rng, N, d)
+    users = _heavy_tailed_rows(rng, B, d, 0.5, 1.0)
+    # duplicates near the cut: for a few queries, copy the row at rank k-1 over rows chosen far down the ranking (exact ties at the cut)
+    Xd, Ud = items.astype(np.float64), users.astype(np.float64)
+    for b in range(0, B, max(1, B // 6)):
+        q = Ud[b] / np.linalg.norm(Ud[b])
+        d2 = ((Xd - q) ** 2).sum(1)
+        order = np.argsort(d2, kind="stable")
+        victims = order[N // 2 + 5 * b: N // 2 + 5 * b + 4]
+        items[victims] = items[order[k - 1]]
+        Xd[victims] = Xd[order[k - 1]]
+    V = np.concatenate([users, items]).astype(np.float64)      # float32-representable float64 rows: stored as float32, float64 flavour
+    nodes = [Node("user", i) for i in range(B)] + [Node("item", i) for i in range(N)]
+    nodes_to_idx = {n: i for i, n in enumerate(nodes)}
+    res = []
+    for f16 in (True, False):
+        m = MultiKNN(nodes_to_idx, V)
+        m.index.use_f16_storage = f16
+        m.index.f16_screen = f16
+        res.append(m.index.search("item", np.arange(B), k=k))
+        assert (m.index.tables["item"].X16 is not None) == f16, tag
+    idx, score, dist, flags = res[0]
+    assert ((flags == 1) | (flags == 2)).all(), tag
+    for a, b_ in zip(res[0][:3], res[1][:3]):
+        assert np.array_equal(a, b_), tag
+    Qh = np.stack([orc.query_vector(V, u) for u in range(B)])
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(items, Qh, V[:B], k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(idx, o_idx + B), tag
+    assert np.array_equal(score, o_sc) and np.array_equal(dist, np.sqrt(o_d2)), tag
+    # MultiKNN.query (arbitrary vector, ascending distance) on the same table
+    got = m.query(Qh[0], "item", k=min(k, 50))
+    r_idx, _, r_d2 = c_oracle.find_closest_f64(items, Qh[:1], None, min(k, 50), sort_by_score=False)
+    assert [nodes_to_idx[n] for n, _ in got] == (r_idx[0] + B).tolist() and [x for _, x in got] == np.sqrt(r_d2[0]).tolist()
+
+
+# ------------------------------------------------------------------------------------------------- RCCL, world size 1
+def test_sharded_search_rccl_world1(hw, tmp_path):
+    """The `nccl` branch of hwer/distributed.py on the one GPU of this box: RCCL initialised (backend nccl, world size 1),
+    all_gather_into_tensor and all_to_all_single on DEVICE buffers (no host staging), hwer_pack_exchange -> the receive layout ->
+    hwer_merge_topk_lists in place, results == the oracle - the same worker the two-rank tests run (tests/dist_worker.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_round2 import _run_workers
+    _run_workers("nccl", 1, tmp_path, (20011, 64, 97, 200))
+    assert "nccl world=1" in (tmp_path / "ok0").read_text()

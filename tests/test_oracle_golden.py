@@ -231,6 +231,9 @@ def test_c_oracle_matches_golden_and_numpy(golden):
         idx, sc, d2 = c_oracle.find_closest_f64(V32[U:], Q, V[:U], k, threads=2)
         assert np.array_equal(idx + U, g[f"idx_f64_k{k}"])
         assert np.array_equal(sc, g[f"score_f64_k{k}"])
+        # the row-blocked loop (default) and the one-pair-at-a-time restatement: the same bits
+        for a, b in zip((idx, sc, d2), c_oracle.find_closest_f64(V32[U:], Q, V[:U], k, threads=2, scalar=True)):
+            assert np.array_equal(a, b)
     idx, sc, d2 = c_oracle.find_closest_f64(V32[U:], Q, None, 10, sort_by_score=False)
     assert np.array_equal(idx + U, g["knnq_idx_f64_k10"]) and np.array_equal(np.sqrt(d2), g["knnq_dist_f64_k10"])
     g4 = golden("g4_predict")
@@ -332,3 +335,21 @@ def test_g14_float64_rows(golden):
     for a in range(16):
         idx, sc, _ = orc.find_closest(V, rows, a, positive=g["pn_pos"][po[a]:po[a + 1]], negative=g["pn_neg"][no[a]:no[a + 1]], k=50)
         assert np.array_equal(idx, g["pn_idx"][a]) and np.array_equal(sc, g["pn_score"][a])
+
+
+@pytest.mark.parametrize("B,N,d,k", [(70, 3001, 128, 200), (33, 1000, 37, 10), (5, 31, 1, 31), (3, 33, 300, 33), (65, 97, 64, 97)])
+def test_c_oracle_blocked_equals_scalar(B, N, d, k):
+    """orc_find_closest_f64 (32 rows x 32 queries in flight, SIMD lanes) against orc_find_closest_f64_scalar (one pair at a time): ids,
+    scores, squared distances bit for bit - ragged row blocks and query groups, duplicate rows (ties -> ascending row id), both output
+    orders, both score flavours."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(B * 7 + N)
+    X = rng.standard_normal((N, d)).astype(np.float32)
+    X[N // 2] = X[N // 3]
+    X[-1] = X[0]
+    Q, A = rng.standard_normal((B, d)), rng.standard_normal((B, d))
+    for anchors in (A, None):
+        for sbs in (True, False):
+            a = c_oracle.find_closest_f64(X, Q, anchors, k, sbs, threads=3)
+            b = c_oracle.find_closest_f64(X, Q, anchors, k, sbs, threads=2, scalar=True)
+            assert all(np.array_equal(x, y) for x, y in zip(a, b))

@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round-3 profiles: rocprofv3 kernel stats + timeline + FETCH_SIZE / WRITE_SIZE passes of `bench.py --config <c> --no-cpu-baseline
+# Per-round profiles: rocprofv3 kernel stats + timeline + FETCH_SIZE / WRITE_SIZE passes of `bench.py --config <c> --no-cpu-baseline
 # --sweep-only --no-graph` for the configurations of the bench line (c1, c2, c3, c4), SQ counters of the c3 / c4 screen.
-# usage (on the GPU box, from the repo root):  tools/profile_round3.sh gpurun_out/prof2 "c1 c2 c3 c4"
+# usage (on the GPU box, from the repo root):  tools/profile_round.sh gpurun_out/prof "c1 c2 c3 c4"
 set -u
-out=${1:-gpurun_out/prof2}; cfgs=${2:-"c1 c2 c3 c4"}; mkdir -p $out
+out=${1:-gpurun_out/prof}; cfgs=${2:-"c1 c2 c3 c4"}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+python3 -c "import sys; sys.path.insert(0, 'hybrid-weighted-embedding-recommender_amd/csrc'); import build; print(build._digest())" > $out/library_digest.txt
 for c in $cfgs; do
   steps=20; [ $c = c3 ] && steps=10; [ $c = c4 ] && steps=10; [ $c = c4full ] && steps=5
   echo "rocprof stats $c" >> $out/progress.log
