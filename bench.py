@@ -725,8 +725,9 @@ def api_latency(torch, Vh, U, I, d, arrays_only=False):
 # ====================================================================================================================
 def wide_probe(torch, dev):
     """Shapes outside the fused HIP search through the host mirror (results left on the device): a 515-column table (ML-20M-sized
-    catalogue, 4 096 anchors, k = 200) and k = 1 000 on a 128-column one - the library-GEMM screen + exact candidate re-rank of
-    round 3 (`DeviceIndex._search_candidates`) next to the all-pairs float64 pass it replaced (`_search_exhaustive`, forced)."""
+    catalogue, 4 096 anchors, k = 200) and k = 1 000 on a 128-column one - round 4: hwer_knn_keys_f32 (float32 MFMA, 16-column slabs) +
+    hwer_knn_topk_rows_f32 + exact candidate re-rank + hwer_knn_order_rows_f64 (`DeviceIndex._search_candidates`; rounds 1-3: a library
+    GEMM / top-k / sorts) next to the all-pairs float64 pass it replaced (`_search_exhaustive`, forced)."""
     from hwer.device_index import DeviceIndex
     out = {}
     for tag, d, k, B, N in (("d515_k200", 515, 200, 4096, 26744), ("d128_k1000", 128, 1000, 4096, 26744)):

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
 LIB = os.path.join(LIBDIR, "libhwer_hip.so")
-SOURCES = ["rowops.hip", "knn_screen.hip", "knn_small.hip", "knn_select.hip", "fit_pca.hip", "rows_f64.hip"]
+SOURCES = ["rowops.hip", "knn_screen.hip", "knn_small.hip", "knn_select.hip", "fit_pca.hip", "rows_f64.hip", "knn_wide.hip"]
 HEADERS = ["hwer_common.h", "knn_internal.h", os.path.join(ROOT, "include", "hwer_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-I" + os.path.join(ROOT, "include"), "-I" + HERE, "-Wno-unused-result"] + os.environ.get("HIPCC_EXTRA", "").split()

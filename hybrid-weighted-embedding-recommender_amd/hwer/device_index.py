@@ -376,21 +376,86 @@ class DeviceIndex:
     #: the bound on everything that was not a candidate)
     CAND_MARGIN = 32
 
+    def _order_rows(self, values, n_in, n_out, descending=False, gather=None, ids=None, id_add=0, id_map=None, payload_i64=None, payload_f64=None,
+                    bound=None, every_row=False, want_flags=False):
+        """hwer_knn_order_rows_f64 over the rows of `values`: -> (out_values (B, n_out), out_ids (B, n_out) int64, out_payload_i64, out_payload_f64,
+        flags) (None where not asked).  Rows longer than the LDS network get the rank-sort workspace."""
+        torch = _torch()
+        lib, dev = self.lib, self.device
+        B = values.shape[0]
+        o_val = torch.empty((B, n_out), dtype=torch.float64, device=dev)
+        o_ids = torch.empty((B, n_out), dtype=torch.int64, device=dev)
+        o_pi = torch.empty((B, n_out), dtype=torch.int64, device=dev) if payload_i64 is not None else None
+        o_pf = torch.empty((B, n_out), dtype=torch.float64, device=dev) if payload_f64 is not None else None
+        fl = torch.empty(B, dtype=torch.int32, device=dev) if want_flags else None
+        wsb = lib.hwer_knn_order_rows_workspace_bytes(B, n_in)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev) if wsb else None
+        native.check(lib.hwer_knn_order_rows_f64(
+            native.ptr(values), values.stride(0), native.ptr(gather), gather.stride(0) if gather is not None else 0, native.ptr(ids),
+            ids.stride(0) if ids is not None else 0, B, n_in, n_out, 1 if descending else 0, native.ptr(o_val), native.ptr(o_ids), int(id_add),
+            native.ptr(id_map), native.ptr(payload_i64), native.ptr(o_pi), native.ptr(payload_f64), native.ptr(o_pf), native.ptr(bound), native.ptr(fl),
+            1 if every_row else 0, native.ptr(ws), wsb, native.stream_ptr(dev)), "knn_order_rows")
+        return o_val, o_ids, o_pi, o_pf, fl
+
+    def _nearest_of_all(self, D, n, k):
+        """(nq, n) float64 squared distances -> the k smallest per row in (distance, row) order: (d2 (nq, k), local rows (nq, k)).
+        hwer_knn_topk_rows_f64 (exact radix select + ordered compaction) then hwer_knn_order_rows_f64 on the k selected."""
+        torch = _torch()
+        nq = D.shape[0]
+        sel = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        native.check(self.lib.hwer_knn_topk_rows_f64(native.ptr(D), D.stride(0), n, nq, k, native.ptr(sel), k, native.stream_ptr(self.device)), "knn_topk_rows_f64")
+        d2, local, _, _, _ = self._order_rows(D, k, k, gather=sel)
+        return d2, local
+
+    def _score_and_emit(self, b0, b1, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2):
+        """scores of the k nearest (hwer_pair_score*: numpy's pairwise order; GcnNCF flavour: from the distance), then the reference's final
+        order - a stable sort by score descending (hwer/recommendation_base.py:172-173) = hwer_knn_order_rows_f64 on (score desc, position asc)
+        with the ids and distances as payloads - into rows b0:b1 of the outputs."""
+        torch = _torch()
+        lib, dev = self.lib, self.device
+        stream = native.stream_ptr(dev)
+        nb = b1 - b0
+        rows = tt.rows_dev[local]                                      # rows of the vector table (pair scoring)
+        ids = rows if use_rows else local + int(id_base)             # reported ids
+        if score_mode == 2:
+            sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
+        else:
+            a = anchors_dev[b0:b1].to(torch.int32)
+            src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
+            dst = rows.to(torch.int32).contiguous().view(-1)
+            if score_mode == 0 and self.V64 is not None:
+                out = torch.empty(nb * k, dtype=torch.float64, device=dev)
+                native.check(lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(src), native.ptr(dst), nb * k,
+                                                         native.ptr(out), stream), "pair_score_f64rows")
+            else:
+                out = torch.empty(nb * k, dtype=torch.float64 if score_mode == 0 else torch.float32, device=dev)
+                fn = lib.hwer_pair_score_f64 if score_mode == 0 else lib.hwer_pair_score_f32
+                native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(src), native.ptr(dst), nb * k, native.ptr(out), stream),
+                             "pair_score")
+            sc = out.view(nb, k).to(torch.float64)
+        if sort_by_score:
+            sc, _, ids, d2, _ = self._order_rows(sc.contiguous(), k, k, descending=True, payload_i64=ids.contiguous(), payload_f64=d2.contiguous())
+        idx[b0:b1], score[b0:b1] = ids, sc
+        if dist2 is not None:
+            dist2[b0:b1] = d2
+
     def _search_candidates(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
         """Exact k-NN as "screen a superset, re-rank it exactly, certify" for the shapes the fused HIP search does not take:
           * genuine float64 `vectors` (V64): the HIP search on the float32 rounding of the table returns the k + 32 nearest ROUNDED rows
             (exact for the rounded table); rounding moves a squared distance by at most eps(D) = 2 sqrt(D) delta + delta^2, delta =
             2^-24 ||x||max, so every row outside the candidates has a true squared distance >= T - eps(T), T = the largest candidate's
             rounded squared distance;
-          * tables wider than hwer_knn_max_dim() or k above hwer_knn_max_k(): the screen is ONE library GEMM (float32 Q X^T - half
-            norms: a plain matrix product - rocBLAS / hipBLASLt on the MFMA units), top-(k + 32) keys by torch.topk; a float32 key is off
-            by at most E = (2 d + 32) 2^-24 (||q|| ||x||max + ||x||max^2) whatever the summation order, so every row outside the
-            candidates has a true squared distance >= ||q||^2 - 2 (kmin + E).
+          * tables wider than hwer_knn_max_dim() or k above hwer_knn_max_k(): the screen is hwer_knn_keys_f32 - float32 MFMA keys
+            Q X^T - half norms, the columns consumed in 16-column slabs (csrc/knn_wide.hip) - and hwer_knn_topk_rows_f32 keeps the k + 32
+            largest keys of every query (exact radix select; ids ascending).  A float32 key is off by at most E = (2 d + 32) 2^-24
+            (||q|| ||x||max + ||x||max^2) whatever the summation order, so every row outside the candidates has a true squared
+            distance >= ||q||^2 - 2 (kmin + E).
         The candidates' exact squared distances come from hwer_knn_cand_dist2 (scikit-learn's summation order, on the float64 rows when
-        there are any), stable device sorts give the (distance, id) order, hwer_pair_score* the scores.  A query is certified when its
-        k-th exact distance lies strictly below the bound (or every row was a candidate); the others - near-ties across the bound -
-        are recomputed over ALL rows.  Same values and order as the reference; replaces the all-pairs float64 pass of rounds 1-2
-        (`_search_exhaustive`, kept as the certified fallback)."""
+        there are any), hwer_knn_order_rows_f64 puts them in (distance, id) order, cuts to k and evaluates the certificate - the k-th exact
+        distance strictly below the bound, or every row a candidate; the others - near-ties across the bound - are recomputed over ALL
+        rows (hwer_knn_topk_rows_f64 + the same ordering).  hwer_pair_score* give the scores, one more hwer_knn_order_rows_f64 the
+        reference's stable order by score.  Same values and order as the reference; every step is a kernel of libhwer_hip.so (rounds
+        1-3: a library GEMM and library top-k / sorts)."""
         torch = _torch()
         lib, dev = self.lib, self.device
         B, n = Q64.shape[0], tt.n
@@ -399,42 +464,41 @@ class DeviceIndex:
         use_hip = self.V64 is not None and not self.wide and kc <= lib.hwer_knn_max_k()
         table, is64, ld = (self.V64, 1, self.d) if self.V64 is not None else (self.V, 0, self.ldv)
         xmax = float(np.sqrt(2.0 * max(tt.hnorm_max, 0.0))) * (1.0 + 1e-6)
-        per = max(1, min(B, 65535, (1 << 28) // max(n if not use_hip else kc, 1)))       # <= 1 GiB of float32 keys at a time
+        n_pad = tt.X.shape[0]
+        per = max(1, min(B, 65535, (1 << 28) // max(n_pad if not use_hip else kc, 1)))       # <= 1 GiB of float32 keys at a time
         for b0 in range(0, B, per):
             b1 = min(B, b0 + per)
             nb = b1 - b0
             q64 = Q64[b0:b1]
             if use_hip:
-                c_idx = torch.empty((nb, kc), dtype=torch.int64, device=dev)
+                local = torch.empty((nb, kc), dtype=torch.int64, device=dev)
                 c_sc = torch.empty((nb, kc), dtype=torch.float64, device=dev)
                 c_d2 = torch.empty((nb, kc), dtype=torch.float64, device=dev)
                 c_fl = torch.empty(nb, dtype=torch.int32, device=dev)
-                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, c_idx, c_sc, c_d2, c_fl)   # ids = local rows
-                local = c_idx
+                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, local, c_sc, c_d2, c_fl)   # ids = local rows
                 T = c_d2[:, kc - 1]
                 delta = (2.0 ** -24) * xmax
-                bound = T - 2.0 * torch.sqrt(T) * delta - delta * delta - 1e-12
+                bound = T - 2.0 * torch.sqrt(T) * delta - delta * delta - 1e-12 * torch.clamp(T, min=1.0)
             else:
-                keys = torch.matmul(Q32[b0:b1, :self.d], tt.X[:n, :self.d].t())
-                keys -= tt.hnorm[:n].unsqueeze(0)
-                kv, local = torch.topk(keys, kc, dim=1)
+                q32 = Q32[b0:b1]
+                keys = torch.empty((nb, n_pad), dtype=torch.float32, device=dev)
+                native.check(lib.hwer_knn_keys_f32(native.ptr(tt.X), native.ptr(tt.hnorm), n_pad, n, self.ldx, native.ptr(q32), q32.stride(0), nb,
+                                                   native.ptr(keys), n_pad, stream), "knn_keys")
+                local = torch.empty((nb, kc), dtype=torch.int64, device=dev)
+                kmin = torch.empty(nb, dtype=torch.float32, device=dev)
+                native.check(lib.hwer_knn_topk_rows_f32(native.ptr(keys), n_pad, n, nb, kc, native.ptr(local), kc, native.ptr(kmin), stream), "knn_topk_rows_f32")
                 del keys
                 qn2 = (q64 * q64).sum(1)
                 E = (2.0 * self.d + 32.0) * (2.0 ** -24) * (torch.sqrt(qn2) * xmax + xmax * xmax)
-                bound = qn2 - 2.0 * (kv[:, kc - 1].to(torch.float64) + E) - 1e-12 * torch.clamp(qn2, min=1.0)
-            # exact squared distances of the candidates, then (distance asc, row asc)
-            local, _ = torch.sort(local, dim=1)
+                bound = qn2 - 2.0 * (kmin.to(torch.float64) + E) - 1e-12 * torch.clamp(qn2, min=1.0)
+            # exact squared distances of the candidates, then (distance asc, row asc), cut to k, certificate
             rows = tt.rows_dev[local]
             D = torch.empty((nb, kc), dtype=torch.float64, device=dev)
             native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(rows), kc, nb, kc, native.ptr(q64),
                                                  native.ptr(D), stream), "knn_cand_dist2")
-            D, p2 = torch.sort(D, dim=1, stable=True)
-            local = local.gather(1, p2)
-            cert = (D[:, k - 1] < bound) if kc < n else torch.ones(nb, dtype=torch.bool, device=dev)
-            fl = torch.where(cert, 1, 2).to(torch.int32)
-            d2 = D[:, :k].contiguous()
-            local = local[:, :k].contiguous()
-            bad = torch.nonzero(~cert).flatten()
+            d2, local, _, _, cert = self._order_rows(D, kc, k, ids=local, bound=bound.contiguous(), every_row=(kc >= n), want_flags=True)
+            fl = torch.where(cert == 1, 1, 2).to(torch.int32)
+            bad = torch.nonzero(cert == 0).flatten()
             if bad.numel():     # near-ties across the bound: all rows of the type, a few queries at a time
                 step = max(1, (1 << 26) // n)
                 for c0 in range(0, int(bad.numel()), step):
@@ -443,40 +507,16 @@ class DeviceIndex:
                     Da = torch.empty((sel.numel(), n), dtype=torch.float64, device=dev)
                     native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(allrows), n, sel.numel(), n,
                                                          native.ptr(q64.index_select(0, sel).contiguous()), native.ptr(Da), stream), "knn_cand_dist2(all)")
-                    Da, pa = torch.sort(Da, dim=1, stable=True)       # ties keep the row (= id) order
-                    d2[sel] = Da[:, :k]
-                    local[sel] = pa[:, :k]
-            rows = tt.rows_dev[local]                                      # rows of the vector table (pair scoring)
-            ids = rows if use_rows else local + int(id_base)             # reported ids
-            if score_mode == 2:
-                sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
-            else:
-                a = anchors_dev[b0:b1].to(torch.int32)
-                src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
-                dst = rows.to(torch.int32).contiguous().view(-1)
-                if score_mode == 0 and self.V64 is not None:
-                    out = torch.empty(nb * k, dtype=torch.float64, device=dev)
-                    native.check(lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(src), native.ptr(dst), nb * k,
-                                                             native.ptr(out), stream), "pair_score_f64rows")
-                else:
-                    out = torch.empty(nb * k, dtype=torch.float64 if score_mode == 0 else torch.float32, device=dev)
-                    fn = lib.hwer_pair_score_f64 if score_mode == 0 else lib.hwer_pair_score_f32
-                    native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(src), native.ptr(dst), nb * k, native.ptr(out), stream),
-                                 "pair_score")
-                sc = out.view(nb, k).to(torch.float64)
-            if sort_by_score:
-                sc, o2 = torch.sort(sc, dim=1, descending=True, stable=True)
-                ids, d2 = ids.gather(1, o2), d2.gather(1, o2)
-            idx[b0:b1], score[b0:b1], flags[b0:b1] = ids, sc, fl
-            if dist2 is not None:
-                dist2[b0:b1] = d2
+                    d2[sel], local[sel] = self._nearest_of_all(Da, n, k)       # ties keep the row (= id) order
+            self._score_and_emit(b0, b1, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
+            flags[b0:b1] = fl
 
     def _search_exhaustive(self, tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
         """Shapes outside the selection kernels' limits - k above hwer_knn_max_k() or d above hwer_knn_max_dim(); the reference
         takes any k <= N_t and any width (hwer/recommendation_base.py:74,79): all float64 distances (hwer_knn_all_dist2_f64,
-        scikit-learn's summation order), a stable device sort keeps the k nearest in (distance, row) order, hwer_pair_score
-        re-scores them against the anchors, a stable sort by score gives the reference's final order.  Same values and order
-        as the regular path; works on a shard too (ids = id_base + local row)."""
+        scikit-learn's summation order), hwer_knn_topk_rows_f64 + hwer_knn_order_rows_f64 keep the k nearest in (distance, row) order,
+        hwer_pair_score re-scores them against the anchors, one more ordering by score gives the reference's final order.  Same values and
+        order as the regular path; works on a shard too (ids = id_base + local row).  The certified fallback of _search_candidates."""
         torch = _torch()
         B, n = Q64.shape[0], tt.n
         per = max(1, min(B, 65535, (1 << 30) // (8 * n)))   # <= 1 GiB of distances at a time
@@ -487,32 +527,9 @@ class DeviceIndex:
             D = torch.empty((nb, n), dtype=torch.float64, device=self.device)
             native.check(self.lib.hwer_knn_all_dist2_f64(native.ptr(tt.X), n, self.d, self.ldx, native.ptr(Q64[b0:b1]), nb,
                                                          native.ptr(D), stream), "knn_all_dist2")
-            d_sorted, order = torch.sort(D, dim=1, stable=True)          # ties keep the row (= id) order
-            d2 = d_sorted[:, :k].contiguous()
-            local = order[:, :k]
-            rows = tt.rows_dev[local]                                    # rows of the vector table (pair scoring)
-            ids = rows if use_rows else local + int(id_base)             # reported ids
-            if score_mode == 2:
-                sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
-            else:
-                a = anchors_dev[b0:b1].to(torch.int32)
-                src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
-                dst = rows.to(torch.int32).contiguous().view(-1)
-                if score_mode == 0:
-                    out = torch.empty(nb * k, dtype=torch.float64, device=self.device)
-                    fn = self.lib.hwer_pair_score_f64
-                else:
-                    out = torch.empty(nb * k, dtype=torch.float32, device=self.device)
-                    fn = self.lib.hwer_pair_score_f32
-                native.check(fn(native.ptr(self.V), self.N, self.d, self.ldv, native.ptr(src), native.ptr(dst), nb * k,
-                                native.ptr(out), stream), "pair_score")
-                sc = out.view(nb, k).to(torch.float64)
-            if sort_by_score:
-                sc, o2 = torch.sort(sc, dim=1, descending=True, stable=True)
-                ids, d2 = ids.gather(1, o2), d2.gather(1, o2)
-            idx[b0:b1], score[b0:b1] = ids, sc
-            if dist2 is not None:
-                dist2[b0:b1] = d2
+            d2, local = self._nearest_of_all(D, n, k)                     # ties keep the row (= id) order
+            del D
+            self._score_and_emit(b0, b1, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
         flags.fill_(2)
 
     #: more uncertified queries than this go through the exact-threshold retry first

@@ -75,6 +75,14 @@ PROTOTYPES = {
     "hwer_pca_padded_components": (c_int, [c_int]),
     "hwer_pca_project_unit_f64": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int64, _P, c_int, _P, c_int, c_int, _P, c_int64,
                                           _P, c_int64, _P]),
+    "hwer_knn_keys_f32": (c_int, [_P, _P, c_int64, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int64, _P]),
+    "hwer_knn_topk_rows_f32": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P]),
+    "hwer_knn_topk_rows_f64": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P]),
+    "hwer_knn_order_rows_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    # values, ld, gather, ld_gather, ids, ld_ids, B, n_in, n_out, descending, out_values, out_ids, id_add, id_map, pay_i, out_pay_i, pay_f, out_pay_f,
+    # bound, out_flags, every_row, workspace, workspace_bytes, stream
+    "hwer_knn_order_rows_f64": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int64, c_int64, c_int64, c_int, _P, _P, c_int64, _P, _P, _P, _P, _P,
+                                        _P, _P, c_int, _P, c_size_t, _P]),
     "hwer_merge_topk_strided": (c_int, [_P, _P, _P, c_int64, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "hwer_merge_topk_lists": (c_int, [_P, _P, _P, c_int64, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
 }

@@ -334,6 +334,42 @@ int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int
                         int64_t B, int64_t kc, const double* Q64, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * W1-W4  exact k-NN for the shapes the fused search does not take (round 4) - tables wider than hwer_knn_max_dim(), k above
+ *        hwer_knn_max_k(), genuine float64 rows.  The reference's KD-tree takes any width and any k <= N_t
+ *        (hwer/recommendation_base.py:74,79; hwer/content_recommender.py:67 emits n_dims-wide rows); its final order is a stable sort
+ *        by score (:172-173).  The host mirror (hwer/device_index.py: _search_candidates / _search_exhaustive) composes these into
+ *        "screen a superset, re-rank it exactly (hwer_knn_cand_dist2), certify"; rounds 1-3 used a library GEMM / top-k / sort here.
+ *
+ *   hwer_knn_keys_f32      keys[q * ld_keys + i] = Q32[q] . X[i] - hnorm[i] for q < B, i < n_items: float32 MFMA
+ *                          (v_mfma_f32_32x32x2_f32 = an fmaf chain), the columns consumed in 16-column slabs through LDS into the
+ *                          same accumulators.  X: (n_rows_padded, ldx) with ldx % 16 == 0 and zero padding (hwer_pack_rows_f32 with
+ *                          ldx = roundup16(d) for wide tables), Q32: (B, ldq >= ldx) zero-padded, ld_keys % 4 == 0, >= roundup4(n_items).
+ *                          |key - exact| <= (2 d + 32) 2^-24 (||q|| ||x|| + 0.5 ||x||^2) whatever the summation order.
+ *   hwer_knn_topk_rows_f32 per query the kc LARGEST of its n keys: out_idx[q][0..kc) = their positions ASCENDING (ties at the cut: the
+ *                          lowest positions), out_kth[q] (nullable) = the kc-th largest key.  Exact (byte radix select + ordered compaction).
+ *   hwer_knn_topk_rows_f64 the same for the k SMALLEST of n float64 values per row (squared distances of the all-rows fallback).
+ *   hwer_knn_order_rows_f64 per query: entries c < n_in with value values[q][c] (or values[q][gather[q][c]]) and id ids[q][c] (default: the
+ *                          position c; with gather: gather[q][c]) are put in (value ascending | descending, id ascending) order - what a
+ *                          STABLE sort of id-ordered input returns - and the first n_out go to out_values / out_ids (= id_map[id] when id_map
+ *                          is given, else id + id_add); payload arrays (B, n_in) are permuted alongside (position ids only);
+ *                          out_flags[q] (nullable) = 1 when every_row or bound == NULL or out_values[q][n_out - 1] < bound[q] (the
+ *                          certificate of the candidate scheme), else 0.  n_in <= 8 192: one bitonic network in LDS per query; longer rows
+ *                          need hwer_knn_order_rows_workspace_bytes(B, n_in) bytes of workspace (rank sort).  B <= 65 535.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_knn_keys_f32(const float* X, const float* hnorm, int64_t n_rows_padded, int64_t n_items, int64_t ldx, const float* Q32, int64_t ldq,
+                      int64_t B, float* keys, int64_t ld_keys, void* stream);
+int hwer_knn_topk_rows_f32(const float* keys, int64_t ld_keys, int64_t n, int64_t B, int64_t kc, int64_t* out_idx, int64_t ld_out,
+                           float* out_kth /*nullable*/, void* stream);
+int hwer_knn_topk_rows_f64(const double* dist2, int64_t ld, int64_t n, int64_t B, int64_t k, int64_t* out_idx, int64_t ld_out, void* stream);
+size_t hwer_knn_order_rows_workspace_bytes(int64_t B, int64_t n_in);
+int hwer_knn_order_rows_f64(const double* values, int64_t ld_values, const int64_t* gather /*nullable*/, int64_t ld_gather,
+                            const int64_t* ids /*nullable*/, int64_t ld_ids, int64_t B, int64_t n_in, int64_t n_out, int descending,
+                            double* out_values, int64_t* out_ids /*nullable*/, int64_t id_add, const int64_t* id_map /*nullable*/,
+                            const int64_t* payload_i64 /*nullable*/, int64_t* out_payload_i64, const double* payload_f64 /*nullable*/,
+                            double* out_payload_f64, const double* bound /*nullable*/, int32_t* out_flags /*nullable*/, int every_row,
+                            void* workspace /*nullable*/, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * K12    seen-item filter + cuts of the Recall@K evaluation — replaces the per-user list comprehensions of
  *        validation.extraction_efficiency (hwer/validation.py:133-141):
  *          unseen = [i for i in ranked[b] if i not in seen(b)][:cut_max]

@@ -155,3 +155,119 @@ def test_sharded_search_rccl_world1(hw, tmp_path):
     from test_gpu_round2 import _run_workers
     _run_workers("nccl", 1, tmp_path, (20011, 64, 97, 200))
     assert "nccl world=1" in (tmp_path / "ok0").read_text()
+
+
+# ------------------------------------------------------------------------------------------------- wide tables / large k: the round-4 kernels
+@pytest.mark.parametrize("B,N,d", [(130, 1000, 515), (7, 129, 16), (300, 4100, 100), (64, 64, 1024)])
+def test_knn_keys_kernel_vs_numpy(hw, B, N, d):
+    """hwer_knn_keys_f32 (float32 MFMA, 16-column slabs, 128 x 128 tiles; ragged tiles on both sides): every key within the stated bound
+    (2 d + 32) 2^-24 (||q|| ||x|| + 0.5 ||x||^2) of the float64 value; rows past n_items are not written."""
+    import torch
+    from hwer import native
+    lib, P = native.lib(), native.ptr
+    rng = np.random.default_rng(B + N + d)
+    ldx = (d + 15) // 16 * 16
+    n_pad = int(lib.hwer_knn_padded_rows(N))
+    X = np.zeros((n_pad, ldx), np.float32)
+    X[:N, :d] = rng.standard_normal((N, d)).astype(np.float32) * rng.uniform(0.1, 2.0, (N, 1)).astype(np.float32)
+    Q = np.zeros((B, ldx), np.float32)
+    Q[:, :d] = rng.standard_normal((B, d)).astype(np.float32)
+    hn = np.full(n_pad, np.inf, np.float32)
+    hn[:N] = (0.5 * (X[:N].astype(np.float64) ** 2).sum(1)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    Xd, Qd, hd = (torch.from_numpy(a).to(dev) for a in (X, Q, hn))
+    keys = torch.full((B, n_pad), 7.0, dtype=torch.float32, device=dev)
+    native.check(lib.hwer_knn_keys_f32(P(Xd), P(hd), n_pad, N, ldx, P(Qd), ldx, B, P(keys), n_pad, native.stream_ptr(dev)), "knn_keys")
+    got = keys.cpu().numpy()
+    ref = Q.astype(np.float64) @ X[:N].astype(np.float64).T - hn[:N].astype(np.float64)
+    qn, xn = np.linalg.norm(Q.astype(np.float64), axis=1), np.linalg.norm(X[:N].astype(np.float64), axis=1)
+    tol = (2 * d + 32) * 2.0 ** -24 * (qn[:, None] * xn[None, :] + 0.5 * xn[None, :] ** 2)
+    assert (np.abs(got[:, :N] - ref) <= tol).all()
+    assert (got[:, (N + 3) // 4 * 4:] == 7.0).all()
+
+
+@pytest.mark.parametrize("B,n,k", [(50, 5000, 232), (3, 70, 70), (9, 1000, 1), (20, 26744, 1032), (4, 300, 299)])
+def test_topk_rows_kernels_vs_numpy(hw, B, n, k):
+    """hwer_knn_topk_rows_f32 / _f64: exactly the k largest keys (smallest distances) of every row, positions ascending, ties at the cut
+    resolved towards the lowest positions; the k-th key returned.  Rows with many duplicates (quantised values) included."""
+    import torch
+    from hwer import native
+    lib, P = native.lib(), native.ptr
+    rng = np.random.default_rng(B * n + k)
+    dev = torch.device("cuda", 0)
+    keys = rng.standard_normal((B, n)).astype(np.float32)
+    keys[1::3] = np.round(keys[1::3] * 4) / 4          # heavy ties
+    keys[0, : n // 2] = keys[0, 0]
+    kd = torch.from_numpy(keys).to(dev)
+    out = torch.empty((B, k), dtype=torch.int64, device=dev)
+    kth = torch.empty(B, dtype=torch.float32, device=dev)
+    native.check(lib.hwer_knn_topk_rows_f32(P(kd), n, n, B, k, P(out), k, P(kth), native.stream_ptr(dev)), "topk32")
+    got, gk = out.cpu().numpy(), kth.cpu().numpy()
+    for b in range(B):
+        order = np.lexsort((np.arange(n), -keys[b].astype(np.float64)))[:k]       # (key desc, position asc)
+        assert np.array_equal(got[b], np.sort(order)) and gk[b] == keys[b][order[-1]]
+    D = (keys.astype(np.float64) ** 2)
+    Dd = torch.from_numpy(D).to(dev)
+    native.check(lib.hwer_knn_topk_rows_f64(P(Dd), n, n, B, k, P(out), k, native.stream_ptr(dev)), "topk64")
+    got = out.cpu().numpy()
+    for b in range(B):
+        order = np.lexsort((np.arange(n), D[b]))[:k]
+        assert np.array_equal(got[b], np.sort(order))
+
+
+@pytest.mark.parametrize("B,n_in,n_out,desc", [(40, 232, 200, False), (5, 1032, 1000, False), (3, 9000, 8500, True), (7, 200, 200, True), (2, 1, 1, False),
+                                                (3, 8192, 100, False)])
+def test_order_rows_kernel_vs_numpy(hw, B, n_in, n_out, desc):
+    """hwer_knn_order_rows_f64: (value, id) order with ties by id = a stable sort of id-ordered input (LDS network up to 8 192 entries, rank
+    sort beyond), the cut to n_out, the certificate flag, payload permutation (the score ordering of find_closest_neighbours,
+    hwer/recommendation_base.py:172-173)."""
+    import torch
+    from hwer import native
+    lib, P = native.lib(), native.ptr
+    rng = np.random.default_rng(n_in * 7 + n_out)
+    dev = torch.device("cuda", 0)
+    vals = np.round(rng.standard_normal((B, n_in)) * 8) / 8      # many exact ties
+    ids = np.stack([rng.permutation(10 * n_in)[:n_in] for _ in range(B)]).astype(np.int64)
+    bound = np.sort(vals, axis=1)[:, n_out - 1] + rng.choice([0.0, 0.125], B)      # at the k-th value (not certified) or above it
+    S = native.stream_ptr(dev)
+    wsb = lib.hwer_knn_order_rows_workspace_bytes(B, n_in)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    vd, idd, bd = torch.from_numpy(vals).to(dev), torch.from_numpy(ids).to(dev), torch.from_numpy(bound).to(dev)
+    o_v = torch.empty((B, n_out), dtype=torch.float64, device=dev)
+    o_i = torch.empty((B, n_out), dtype=torch.int64, device=dev)
+    fl = torch.empty(B, dtype=torch.int32, device=dev)
+    if not desc:      # candidate ordering: ids given, certificate
+        native.check(lib.hwer_knn_order_rows_f64(P(vd), n_in, None, 0, P(idd), n_in, B, n_in, n_out, 0, P(o_v), P(o_i), 5, None, None, None, None, None,
+                                                 P(bd), P(fl), 0, P(ws) if wsb else None, wsb, S), "order")
+        gv, gi, gf = o_v.cpu().numpy(), o_i.cpu().numpy(), fl.cpu().numpy()
+        for b in range(B):
+            order = np.lexsort((ids[b], vals[b]))[:n_out]
+            assert np.array_equal(gv[b], vals[b][order]) and np.array_equal(gi[b], ids[b][order] + 5)
+            assert gf[b] == int(vals[b][order[-1]] < bound[b])
+    else:             # score ordering: descending, stable in the position, payloads follow
+        pay_i = rng.integers(0, 1 << 40, (B, n_in)).astype(np.int64)
+        pay_f = rng.standard_normal((B, n_in))
+        pid, pfd = torch.from_numpy(pay_i).to(dev), torch.from_numpy(pay_f).to(dev)
+        o_pi = torch.empty((B, n_out), dtype=torch.int64, device=dev)
+        o_pf = torch.empty((B, n_out), dtype=torch.float64, device=dev)
+        native.check(lib.hwer_knn_order_rows_f64(P(vd), n_in, None, 0, None, 0, B, n_in, n_out, 1, P(o_v), P(o_i), 0, None, P(pid), P(o_pi), P(pfd), P(o_pf),
+                                                 None, None, 0, P(ws) if wsb else None, wsb, S), "order")
+        for b in range(B):
+            order = np.argsort(-vals[b], kind="stable")[:n_out]
+            assert np.array_equal(o_v[b].cpu().numpy(), vals[b][order]) and np.array_equal(o_i[b].cpu().numpy(), order)
+            assert np.array_equal(o_pi[b].cpu().numpy(), pay_i[b][order]) and np.array_equal(o_pf[b].cpu().numpy(), pay_f[b][order])
+
+
+def test_large_k_beyond_the_lds_network(hw):
+    """k = 9 000 of 9 500 rows (k + 32 candidates > 8 192 entries: the rank-sort path of hwer_knn_order_rows_f64), duplicates included:
+    ids, scores and distances == the oracle."""
+    from hwer.device_index import DeviceIndex
+    U, N, d, k = 3, 9500, 24, 9000
+    V32 = np.concatenate([unit_rows_f32(51, U, d), unit_rows_f32(52, N, d)])
+    V32[U + 100] = V32[U + 7]
+    V = V32.astype(np.float64)
+    ix = DeviceIndex(V, {"user": np.arange(U), "item": np.arange(U, U + N)}, arith=0)
+    idx, score, dist, flags = ix.search("item", np.arange(U), k=k)
+    Qh = np.stack([orc.query_vector(V, u) for u in range(U)])
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(V32[U:], Qh, V[:U], k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(idx, o_idx + U) and np.array_equal(score, o_sc) and np.array_equal(dist, np.sqrt(o_d2)) and (flags > 0).all()

@@ -244,3 +244,11 @@ def test_lazy_rows_mapping_api():
     with pytest.raises(KeyError):
         del m["z"]
     assert list(m) == ["a", "b", "c"]
+
+
+def test_no_library_gemm_topk_sort_in_the_host_mirror():
+    """the host mirror composes libhwer_hip.so kernels only: no library GEMM / top-k / sort on the retrieval path (round-3 verdict item 5)"""
+    import glob
+    import re
+    for f in glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hybrid-weighted-embedding-recommender_amd", "hwer", "*.py")):
+        assert not re.search(r"torch\.(matmul|topk|sort|argsort|mm|bmm|einsum)\b", open(f).read()), f
