@@ -693,11 +693,30 @@ def api_latency(torch, Vh, U, I, d, arrays_only=False):
             r[u]
     out["model_get_topk_all_lists_materialised"] = med(materialise, 3)
     n_loop = min(U, 64)
+    m.find_closest_neighbours("item", users[0], k=K)      # (first call: builds the cached hipGraph of this (node type, k))
     t1 = time.perf_counter()
     for u in users[:n_loop]:
         m.find_closest_neighbours("item", u, k=K)
     out["find_closest_neighbours_per_anchor"] = (time.perf_counter() - t1) / n_loop * 1e3
-    out["find_closest_neighbours_per_anchor_note"] = "the reference-shaped loop (one call per anchor) through the drop-in class, ms per anchor"
+    out["find_closest_neighbours_per_anchor_note"] = "the reference-shaped loop (one call per anchor) through the drop-in class, ms per anchor (each call = one cached hipGraph replay)"
+    m.find_closest_neighbours("item", users[0], k=K)
+    ts = []
+    for u in users[:min(U, 256)]:
+        t = time.perf_counter()
+        m.find_closest_neighbours("item", u, k=K)
+        ts.append(time.perf_counter() - t)
+    out["find_closest_neighbours"] = float(np.median(ts)) * 1e3
+    out["find_closest_neighbours_note"] = "median wall time of ONE find_closest_neighbours call (hwer/recommendation_base.py:157-174): list of 200 (Node, score) on the host"
+    import gc
+    gc.collect()
+    gc.disable()      # (timeit's convention: the loop keeps 943 x 200 tuples alive, and full collections over a process that has torch imported
+    try:              #  cost tens of milliseconds each - measured 305 ms with, 70 ms without)
+        t1 = time.perf_counter()
+        validation.model_get_topk_knn_per_anchor(m, users, "item")
+        out["model_get_topk_knn_per_anchor"] = (time.perf_counter() - t1) * 1e3
+    finally:
+        gc.enable()
+    out["model_get_topk_knn_per_anchor_note"] = "the reference's retrieval loop as it stands (hwer/validation.py:30-35: one call per anchor, all %d anchors, every list materialised), beside the batched model_get_topk above" % U
     # extraction_efficiency end to end on synthetic edges: per user 20 train items + 1 validation item
     rng = np.random.default_rng(4001)
     train, valid = [], []
@@ -839,6 +858,9 @@ def compact_line(full, detail_path):
         out["speedup_vs_reference_shaped_loop"] = _r(full.get("speedup_vs_reference_shaped_loop"), 4)
     if "recall_latency_ms" in full:
         out["recall_latency_ms"] = _r(full["recall_latency_ms"], 4)
+    al = full.get("api_latency_ms") or {}
+    if "find_closest_neighbours" in al:      # one call of the reference's per-anchor API, and its loop over every anchor, beside the batched sweep
+        out["api_latency_ms"] = {"find_closest_neighbours": _r(al["find_closest_neighbours"], 4), "per_anchor_loop_all": _r(al.get("model_get_topk_knn_per_anchor"), 4)}
     tr = full.get("timed_region")
     if tr:      # always in the line: which region is reported, and whether a second one was taken
         out["timed_region"] = {"attempts": tr["attempts"], "reported": tr.get("reported"), "remeasured_ms_per_step": tr.get("remeasured_ms_per_step")}

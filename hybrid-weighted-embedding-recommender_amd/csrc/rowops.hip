@@ -1065,6 +1065,11 @@ extern "C" {
 
 int hwer_abi_version(void) { return HWER_ABI_VERSION; }
 const char* hwer_last_error(void) { return g_err; }
+int hwer_stream_synchronize(void* stream) {
+    hipError_t e = hipStreamSynchronize(as_stream(stream));
+    if (e != hipSuccess) return fail(HWER_ELAUNCH, "stream_synchronize: %s", hipGetErrorString(e));
+    return HWER_OK;
+}
 
 int hwer_pair_score_f32(const float* V, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst,
                         int64_t P, float* out, void* stream) {

@@ -71,6 +71,90 @@ class _TypeTable:
         self.x16_exp = 0
 
 
+class _OneAnchorSearch:
+    """The reference calls find_closest_neighbours once per anchor (hwer/validation.py:30-35; hwer/recommendation_base.py:157-174): one
+    anchor -> query -> k nearest of one node type -> scores.  Per (node type, k, score mode) this object keeps every buffer of that call
+    resident and the whole device chain - anchor id H2D, hwer_query_mix, hwer_knn_search_opts_f32, hwer_knn_exact_device, results D2H -
+    captured ONCE as a hipGraph: a call writes the anchor id into pinned host memory, replays the graph, waits for the stream and reads
+    k ids + k scores + the flag from pinned host memory.  No allocation, no per-call stream / pointer plumbing in Python."""
+
+    def __init__(self, ix, node_type, k, mode, sort_by_score=True):
+        torch = _torch()
+        lib, dev = ix.lib, ix.device
+        tt = ix.tables[node_type]
+        self.k, self.mode = int(k), int(mode)
+        self.h_anchor = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.h_anchor_np = self.h_anchor.numpy()
+        self.d_anchor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.Q64 = torch.empty((1, ix.d), dtype=torch.float64, device=dev)
+        self.Q32 = torch.empty((1, ix.ldx), dtype=torch.float32, device=dev)
+        # one result buffer, one D2H copy: [k ids | k score bit patterns | flag]
+        self.buf = torch.zeros(2 * k + 1, dtype=torch.int64, device=dev)
+        self.h_buf = torch.zeros(2 * k + 1, dtype=torch.int64).pin_memory()
+        self.h_np = self.h_buf.numpy()
+        idx = self.buf[:k].view(1, k)
+        score = self.buf[k:2 * k].view(torch.float64).view(1, k)
+        flags = self.buf[2 * k:].view(torch.int32)[:1]
+        d2 = torch.empty((1, k), dtype=torch.float64, device=dev) if mode == 2 else None   # (the GcnNCF score is a function of the distance)
+        path_opt = ix._path_options()
+        x16, x16_exp = ix._x16(tt, 1)
+        opt = (ix.KNN_F16_SCREEN if (ix.f16_screen and x16 is not None) else 0) | path_opt
+        wsb = lib.hwer_knn_workspace_bytes_opts(1, tt.n, ix.d, k, path_opt)
+        if wsb == 0:
+            raise native.HwerNativeError("knn: unsupported shape (n=%d, d=%d, k=%d)" % (tt.n, ix.d, k))
+        self.ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+        self.wse = torch.empty(int(lib.hwer_knn_exact_device_workspace_bytes(tt.n, k)), dtype=torch.uint8, device=dev)
+        P = native.ptr
+        A32 = P(ix.V) if mode != 2 else None
+        use_rows = True
+
+        def launch():      # on the CURRENT torch stream of the index's device
+            st = native.stream_ptr(dev)
+            self.d_anchor.copy_(self.h_anchor, non_blocking=True)
+            native.check(lib.hwer_query_mix(P(ix.V), ix.N, ix.d, ix.ldv, P(self.d_anchor), None, None, None, None, 1, ix.arith, P(self.Q64), P(self.Q32),
+                                            ix.ldx, st), "query_mix")
+            native.check(lib.hwer_knn_search_opts_f32(
+                P(tt.X), P(tt.hnorm), tt.n, ix.d, ix.ldx, P(self.Q32), P(self.Q64), A32, ix.ldv, P(self.d_anchor), 1, k, mode, 1 if sort_by_score else 0,
+                P(tt.rows_dev) if use_rows else None, 0, tt.hnorm_max, P(idx), P(score), P(d2), P(flags), P(self.ws), self.ws.numel(), opt, P(x16), x16_exp, st),
+                "knn_search")
+            native.check(lib.hwer_knn_exact_device(
+                P(tt.X), tt.n, ix.d, ix.ldx, P(self.Q64), A32, ix.ldv, P(self.d_anchor), k, mode, 1 if sort_by_score else 0, P(tt.rows_dev), 0, P(idx), P(score),
+                P(d2), P(flags), P(self.ws), None, P(self.wse), self.wse.numel(), st), "knn_exact_device")
+            self.h_buf.copy_(self.buf, non_blocking=True)
+        with native.device_guard(dev):
+            native.check(lib.hwer_knn_workspace_init(P(self.ws), self.ws.numel(), native.stream_ptr(dev)), "knn_workspace_init")
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    launch()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch()
+            self.graph = g
+        self.dev = dev
+        self.dev_index = dev.index
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._sync = lib.hwer_stream_synchronize
+
+    def run(self, anchor: int):
+        """-> (ids (k,) int64, scores (k,) float64, flag) as fresh numpy arrays"""
+        self.h_anchor_np[0] = anchor
+        self.graph.replay()          # on the current stream of the index's device
+        raw = self._raw_stream
+        if raw is not None:          # the raw hipStream_t of that stream (one C call) -> hwer_stream_synchronize
+            rc = self._sync(raw(self.dev_index))
+            if rc:
+                native.check(rc, "stream_synchronize")
+        else:
+            _torch().cuda.current_stream(self.dev).synchronize()
+        k = self.k
+        h = self.h_np
+        return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k] & 0xFFFFFFFF)
+
+
 class DeviceIndex:
     #: queries per launch of the k-NN kernels = 512 workgroup slots (256 CUs x 2) x 256 queries: one full round of
     #: workgroups without item splits; also bounds the candidate workspace (8 KiB per query and list)
@@ -228,6 +312,20 @@ class DeviceIndex:
                                              native.ptr(pi), native.ptr(np_), native.ptr(ni), B, self.arith,
                                              native.ptr(Q64), native.ptr(Q32), self.ldx, native.stream_ptr(self.device)), "query_mix")
         return Q64, Q32, a
+
+    #: single-anchor searches without positive / negative lists replay a cached hipGraph (see _OneAnchorSearch); False: the general path
+    one_anchor_graphs = True
+
+    @staticmethod
+    def _has_lists(lists):
+        return lists is not None and any(l is not None and len(l) > 0 for l in lists)
+
+    @property
+    def _max_k(self):
+        mk = self.__dict__.get("_max_k_cached")
+        if mk is None:
+            mk = self.__dict__["_max_k_cached"] = int(self.lib.hwer_knn_max_k())
+        return mk
 
     #: catalogues above this many rows keep a float16 copy of their table for small query batches
     F16_MIN_ROWS = 8193
@@ -584,8 +682,23 @@ class DeviceIndex:
                scoring: str = "base", sort_by_score: bool = True, want_dist: bool = True):
         """Batched find_closest_neighbours on resolved indices.
         -> numpy (idx (B,k) int64, score (B,k) in the reference's dtype, dist (B,k) float64 or None, flags (B))."""
-        Q64, Q32, a = self.build_queries(anchors, positive, negative)
         mode = 2 if scoring == "gcn" else self.arith
+        if (self.one_anchor_graphs and np.size(anchors) == 1 and sort_by_score and not want_dist and self.V64 is None and not self.wide
+                and k <= self._max_k and k <= self.tables[node_type].n and not self._has_lists(positive) and not self._has_lists(negative)):
+            # the reference-shaped per-anchor call (hwer/validation.py:30-35): one hipGraph replay per call (_OneAnchorSearch)
+            a0 = int(np.asarray(anchors).reshape(-1)[0])
+            if 0 <= a0 < self.N:
+                cache = self.__dict__.setdefault("_one_anchor", {})
+                one = cache.get((node_type, k, mode))
+                if one is None:
+                    one = cache[(node_type, k, mode)] = _OneAnchorSearch(self, node_type, k, mode)
+                ids, sc, flag = one.run(a0)
+                if flag > 0:
+                    if mode == 1:
+                        sc = sc.astype(np.float32)
+                    return ids.reshape(1, k), sc.reshape(1, k), None, np.asarray([flag], dtype=np.int32)
+                # (uncertified beyond the on-device exhaustive pass: the general path below runs the host-driven tiers)
+        Q64, Q32, a = self.build_queries(anchors, positive, negative)
         fh = []
         idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist, _flags_host_out=fh)
         sc = score.cpu().numpy()

@@ -17,6 +17,7 @@ _P = c_void_p
 PROTOTYPES = {
     "hwer_abi_version": (c_int, []),
     "hwer_last_error": (c_char_p, []),
+    "hwer_stream_synchronize": (c_int, [_P]),
     "hwer_profile_enable": (c_int, [c_int]),
     "hwer_profile_read": (c_int, [c_int, _P, _P]),
     "hwer_pair_score_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),

@@ -74,6 +74,15 @@ class LazyRows(MutableMapping):
         return key in self._pos
 
 
+def model_get_topk_knn_per_anchor(model, anchors: List[Node], node_type: NodeType) -> Dict[Node, List[Tuple[Node, float]]]:
+    """The reference's loop as it stands (hwer/validation.py:30-35): one `find_closest_neighbours` call per anchor, every list
+    materialised.  Each call is one hipGraph replay (DeviceIndex: _OneAnchorSearch); `model_get_topk_knn` below is the batched form."""
+    results = defaultdict(list)
+    for u in anchors:
+        results[u] = model.find_closest_neighbours(node_type, u)
+    return results
+
+
 def model_get_topk_knn(model, anchors: List[Node], node_type: NodeType) -> Dict[Node, List[Tuple[Node, float]]]:
     """{anchor: [(Node, score)] * 200} ordered by score desc (reference: hwer/validation.py:30-35).  ONE batched search;
     the per-anchor lists of (Node, score) tuples are materialised lazily (LazyRows)."""

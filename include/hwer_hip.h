@@ -34,6 +34,10 @@ extern "C" {
 /* library identity / diagnostics */
 int hwer_abi_version(void);
 const char* hwer_last_error(void);
+/* Blocks the calling host thread until `stream` has drained (hipStreamSynchronize).  The ONLY entry point that synchronises: the host
+ * mirror's per-anchor call (one cached hipGraph replay per find_closest_neighbours, hwer/recommendation_base.py:157-174) waits for its
+ * results with it instead of going through a framework stream object. */
+int hwer_stream_synchronize(void* stream);
 /* Optional kernel timing: hwer_profile_enable(n), n >= 1, makes every n-th hwer_knn_search_f32 call bracket its screen
  * kernel (which = 0) and its select / re-rank kernels (which = 1) with HIP events recorded on the launch stream
  * (n = 0: off).  hwer_profile_read sums the bracketed durations, reports how many there were, and clears. */

@@ -271,3 +271,31 @@ def test_large_k_beyond_the_lds_network(hw):
     Qh = np.stack([orc.query_vector(V, u) for u in range(U)])
     o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(V32[U:], Qh, V[:U], k, threads=c_oracle.effective_cpus())
     assert np.array_equal(idx, o_idx + U) and np.array_equal(score, o_sc) and np.array_equal(dist, np.sqrt(o_d2)) and (flags > 0).all()
+
+
+# ------------------------------------------------------------------------------------------------- per-anchor calls: cached hipGraph
+@pytest.mark.parametrize("U,N,d,k,flav", [(50, 1682, 64, 200, "f64"), (20, 3706, 128, 10, "f32"), (12, 20000, 100, 200, "f64"), (9, 500, 32, 300, "gcn")])
+def test_one_anchor_graph_equals_the_general_path(hw, U, N, d, k, flav):
+    """find_closest_neighbours called once per anchor (the reference's loop, hwer/validation.py:30-35) replays ONE cached hipGraph per
+    (node type, k, score mode) - anchor id in pinned memory, query, search, on-device exhaustive pass, results back - and must return
+    exactly what the general path returns and what the oracle says: every anchor in turn (the graph is reused), dense and streaming
+    catalogues, both score flavours and the GcnNCF one, duplicates (ties at the cut -> flag 2 inside the graph), k = every row."""
+    from hwer import Node, VectorIndex, validation
+    V32 = np.concatenate([unit_rows_f32(61, U, d), unit_rows_f32(62, N, d)])
+    V32[U + 5] = V32[U + 3]
+    V32[U + N - 1] = V32[U + 3]
+    V = V32 if flav in ("f32", "gcn") else V32.astype(np.float64)
+    users, items = [Node("user", i) for i in range(U)], [Node("item", i) for i in range(N)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=d)
+    if flav == "gcn":
+        m.scoring = "gcn"
+    m.fit(users + items, V)
+    ix = m.knn.index
+    per_anchor = validation.model_get_topk_knn_per_anchor(m, users, "item") if k == 200 else {u: m.find_closest_neighbours("item", u, k=k) for u in users}
+    assert ("item", k, ix.arith if flav != "gcn" else 2) in ix.__dict__.get("_one_anchor", {})       # the graph path was taken
+    ix.one_anchor_graphs = False
+    for j, u in enumerate(users):
+        general = m.find_closest_neighbours("item", u, k=k)
+        assert per_anchor[u] == general, j
+        o_idx, o_sc, _ = orc.find_closest(V, np.arange(U, U + N), j, k=k, scoring="gcn" if flav == "gcn" else "base")
+        assert [m.nodes_to_idx[n] for n, _ in general] == o_idx.tolist() and [s for _, s in general] == o_sc.tolist()
