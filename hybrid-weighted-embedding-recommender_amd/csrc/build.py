@@ -13,7 +13,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
-LIB = os.path.join(LIBDIR, "libhwer_hip.so")
+# HWER_LIB_NAME=libhwer_hip_diag.so HIPCC_EXTRA=-DHWER_DIAG_STAMPS python build.py: a diagnostic library beside the production one (own objects)
+LIB = os.path.join(LIBDIR, os.environ.get("HWER_LIB_NAME", "libhwer_hip.so"))
+OBJ_TAG = "" if os.path.basename(LIB) == "libhwer_hip.so" else "." + os.path.basename(LIB).replace(".so", "")
 SOURCES = ["rowops.hip", "knn_screen.hip", "knn_small.hip", "knn_select.hip", "fit_pca.hip", "rows_f64.hip", "knn_wide.hip"]
 HEADERS = ["hwer_common.h", "knn_internal.h", os.path.join(ROOT, "include", "hwer_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
@@ -41,7 +43,7 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        obj = os.path.join(LIBDIR, src.replace(".hip", OBJ_TAG + ".o"))
         objs.append(obj)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
         if verbose:

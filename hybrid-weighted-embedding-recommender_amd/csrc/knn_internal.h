@@ -39,6 +39,7 @@ struct ScreenPlan {
     int64_t split_items;  // items per split (multiple of SCREEN_IB)
     int n_lists;   // n_splits * wi
     int64_t bq;    // B rounded up to qb (stream addressing)
+    int pp;        // float16 streaming screen as 512-thread ping-pong workgroups (round 4): n_qblocks is even, a workgroup takes two blocks
     int kprime;
     int scaled_first;  // use the sample-scaled first threshold (verified; UNDERFULL lists are flagged)
     int dense;         // small catalogue: write every key to a (B, ld_dense) float matrix, select from it

@@ -726,6 +726,334 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
     }
 }
 
+// =====================================================================================================
+// Round 4: the float16 streaming screen as a PING-PONG of SIMD partners (screen16_pp_kernel).
+// =====================================================================================================
+// screen_kernel above runs two independent 256-thread workgroups per CU: the two waves that share a SIMD belong to DIFFERENT workgroups,
+// nothing couples their phases, and their MFMA phases overlap most of the time - matrix beside matrix on one pipe, filter beside filter
+// on one issue port (round-3 stamps: an MFMA phase of 512 pipe-cycles takes 1 280 - 1 330 cycles, the pipe is busy 0.33 - 0.42 of the
+// launch; a start-phase stagger changed nothing because nothing holds a phase).  Here ONE 512-thread workgroup owns the CU: waves w and
+// w + 4 sit on the same SIMD (cdna guide, "Two waves per SIMD") and take turns on the matrix pipe through a TOKEN in LDS (one word per
+// SIMD, strict alternation): a wave runs the 8 NG / 16 TQ MFMAs of a 32-row subtile only while it holds the token and hands it over
+// right behind its last MFMA, so a wave's MFMA burst always runs beside its partner's filter / LDS-DMA / bookkeeping code - matrix beside
+// VALU and memory on every SIMD, by construction - and the burst takes ~880 instead of ~1 300 cycles (in-kernel stamps).
+//   * 8 waves x 32 TQ queries per workgroup (512 at TQ = 2); every wave streams every item tile of the workgroup's split;
+//   * item tiles of 64 rows in a 3-slot LDS ring, ONE workgroup barrier per tile (ring safety only), STAGGERED: waves 0-3 take it behind the
+//     tile's last filter segment, waves 4-7 between the tile's last burst and that filter segment, so SIMD partners leave every barrier half
+//     a step apart; every wave requests its 1/8 of tile t + 2 behind the MFMA burst of (t, subtile 0) - the slot held tile t - 1, which
+//     nobody reads after the barrier that closed tile t - 1 - and waits for those pieces one tile later at the same place;
+//   * everything a wave does to its keys - thresholds in the query's scaled units, pass masks / max-tree filter, appends, capacity check,
+//     compaction, hand-over - is screen_kernel's float16 streaming code, unchanged: the candidate lists are identical in content.
+// First version (measured, not kept): rigid lockstep - two workgroup barriers per subtile, waves 4-7 one barrier behind - ran 10 %
+// SLOWER than screen_kernel: every half step then costs the slowest of eight waves plus the barrier (stamps: segments of 877 / 776
+// cycles, 970 cycles per subtile spent waiting at the two barriers).
+#ifndef HWER_PP_WIDE_PARK
+#define HWER_PP_WIDE_PARK 0   // 1: d = 256 under the ping-pong kernel filters by the expected-hits rule (its LDS has room for the key park)
+#endif
+#ifndef HWER_PP_TOKEN
+#define HWER_PP_TOKEN 0      // 0: no token - SIMD partners are only staggered at the tile barrier (A/B switch)
+#endif
+#ifndef HWER_PP_PREFETCH
+#define HWER_PP_PREFETCH 2   // A fragments requested this many k-steps ahead of their MFMAs (the MFMA segment has the pipe to itself)
+#endif
+template <int NG, int TQ>
+__global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a) {
+    constexpr int IB = 64, NSUB = 2, NSLOT = 3;
+    constexpr int CH = NG;                          // 16-byte chunks per float16 row
+    constexpr int TILE_CHUNKS = IB * CH;
+    constexpr int DMA_PER_WAVE = TILE_CHUNKS / 512 > 0 ? TILE_CHUNKS / 512 : 1;   // 1-KiB pieces per wave and tile
+    static_assert(TILE_CHUNKS % 512 == 0, "every wave issues the same number of pieces");
+    constexpr int NQF = NG / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* xs = reinterpret_cast<float*>(smem_raw);                         // [NSLOT][IB][CH * 4]
+    float* hn = xs + NSLOT * IB * CH * 4;                                   // [NSLOT][IB]
+    float* keypark_all = hn + NSLOT * IB;                                   // [8][64][16 * TQ]
+    int* tok = reinterpret_cast<int*>(keypark_all + 8 * 64 * 16 * TQ);      // [4]: whose turn it is on the matrix pipe of SIMD (wave & 3)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int role = wave >> 2;       // 0: waves 0-3, 1: their SIMD partners 4-7 (one barrier behind)
+    const int r = lane & 31, h = lane >> 5;
+    if (blockIdx.x == 0) hdr_reset(a.hdr, tid, 512);
+    if (tid < 4) tok[tid] = 0;        // waves 0-3 first
+    const unsigned n_wg = gridDim.x;
+    const unsigned wg = (n_wg & 7u) == 0u ? (blockIdx.x & 7u) * (n_wg >> 3) + (blockIdx.x >> 3) : blockIdx.x;   // XCD-aware order (screen_kernel)
+    const int n_qb2 = a.n_qblocks >> 1;                                      // workgroups along the queries: two 4-wave query blocks each
+    const int qblock = int(wg % unsigned(n_qb2)), split = int(wg / unsigned(n_qb2));
+    const int list = split;
+    const int64_t qw0 = int64_t(qblock) * (8 * 32 * TQ) + int64_t(wave) * 32 * TQ;
+    float* keypark = keypark_all + wave * (64 * 16 * TQ);
+
+    half8_t qf[TQ][NQF];
+    int e_tot[TQ];
+    float2_t nscale[TQ];
+    float tau[TQ];
+    int cnt[TQ];
+    bool first[TQ], scaled[TQ], seeded[TQ];
+    uint32_t soff[TQ];
+    uint64_t* const wg_cand = a.cand + ((int64_t(list) * a.bq + qw0) * 2) * CAPH;
+#pragma unroll
+    for (int b = 0; b < TQ; ++b) {
+        const int64_t q = qw0 + 32 * b + r;
+        const bool live = q < a.B;
+        e_tot[b] = a.x_exp + a.qexp[q];
+        nscale[b] = float2_t{-ldexpf(1.0f, e_tot[b]), -ldexpf(1.0f, e_tot[b])};
+        const float t0 = (a.tau0 && live) ? a.tau0[q] : a.debug_tau0;
+        seeded[b] = a.tau0 != nullptr && live && t0 > -INFINITY;
+        tau[b] = live ? ldexpf(t0, e_tot[b]) : INFINITY;
+        cnt[b] = 0;
+        first[b] = true;
+        scaled[b] = false;
+        soff[b] = (uint32_t(32 * b + r) * 2u + uint32_t(h)) * CAPH;
+    }
+    const int64_t i_begin = int64_t(split) * a.split_items;
+    const int64_t i_end = std::min<int64_t>(i_begin + a.split_items, a.n_items);
+    const int n_tiles = int((i_end - i_begin + IB - 1) / IB);
+    const int tile_mul = a.scaled_first ? coprime_step(n_tiles) : 1;
+    auto perm_next = [&](int p) { p += tile_mul; return p >= n_tiles ? p - n_tiles : p; };
+    constexpr int PIECE_ROWS = 64 / CH > 0 ? 64 / CH : 1;
+    const uint32_t row_bytes = uint32_t(a.ldx) * 2u;
+    const uint32_t lane_row = uint32_t(lane / CH), lane_chunk = uint32_t(lane % CH);
+    const uint32_t xs_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(xs)) + uint32_t(wave) * 1024u;
+    const uint32_t hn_addr0 = __builtin_amdgcn_readfirstlane(lds_addr(hn));
+    const char* const x_split = reinterpret_cast<const char*>(a.X16) + i_begin * a.ldx * 2;
+    const float* const hn_split = a.hnorm + i_begin;
+    const uint32_t tile_bytes = uint32_t(IB) * row_bytes;
+    auto tile_dma = [&](int slot, int ptile) {     // this wave's pieces of catalogue tile `ptile` -> ring slot `slot`
+        const uint32_t xb_addr = xs_addr0 + uint32_t(slot) * uint32_t(IB * CH * 16);
+        const char* tile_ptr = x_split + uint64_t(uint32_t(ptile)) * tile_bytes;
+#pragma unroll
+        for (int i = 0; i < DMA_PER_WAVE; ++i) {   // piece = wave + 8 i covers rows piece * PIECE_ROWS + lane / CH
+            const uint32_t row = uint32_t(wave * PIECE_ROWS) + uint32_t(8 * i * PIECE_ROWS) + lane_row;
+            const uint32_t off = __umul24(row, row_bytes) + ((lane_chunk ^ uint32_t(swz<CH>(int(row)))) << 4);
+            lds_dma16(tile_ptr, off, xb_addr + uint32_t(i) * 8192u);
+        }
+        if (wave == 0) lds_dma4(hn_split + int64_t(ptile) * IB, uint32_t(lane) * 4u, hn_addr0 + uint32_t(slot) * uint32_t(IB * 4));
+    };
+    auto append = [&](int b, uint64_t key) {
+        wg_cand[soff[b] + uint32_t(cnt[b])] = key;
+        ++cnt[b];
+    };
+    __builtin_amdgcn_s_setprio(HWER_F16_REST_PRIO);
+    // prologue: tiles 0 and 1 requested, then the query fragments
+    int p_cur = 0;        // perm(t)
+    int p_dma = 0;        // perm(next tile to request)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        if (s < n_tiles) tile_dma(s, p_dma);
+        p_dma = perm_next(p_dma);
+    }
+#pragma unroll
+    for (int b = 0; b < TQ; ++b)
+#pragma unroll
+        for (int g = 0; g < NQF; ++g)
+            qf[b][g] = reinterpret_cast<const half8_t*>(a.Qf16)[((qw0 / 32 + b) * NQF + g) * 64 + lane];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the fragments are made opaque HERE: the compiler then waits for their loads in front of this statement, not - per register, ending
+    // in vmcnt(0), a drain of the pieces and appends in flight - inside the first MFMA segment of every tile
+#pragma unroll
+    for (int b = 0; b < TQ; ++b)
+#pragma unroll
+        for (int g = 0; g < NQF; ++g) make_opaque(qf[b][g]);
+    __syncthreads();      // tiles 0 and 1 have landed for every wave, the tokens are set (the only fenced barrier of the kernel)
+    int* const my_tok = tok + (wave & 3);
+    auto tok_acquire = [&]() {
+        if constexpr (HWER_PP_TOKEN) {
+            while (__hip_atomic_load(my_tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != role) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto tok_release = [&]() {
+        if constexpr (HWER_PP_TOKEN) {
+            __builtin_amdgcn_sched_barrier(0);        // behind the last MFMA of the burst (issue order), not before
+            __hip_atomic_store(my_tok, 1 - role, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0, pa_w1 = 0, pa_mfma = 0, pa_w2 = 0, pa_filt = 0, pclk0 = 0, prt0 = 0;
+    if (DIAG_STAMPS) { pclk0 = __builtin_amdgcn_s_memtime(); prt0 = __builtin_amdgcn_s_memrealtime(); }
+    for (int t = 0; t < n_tiles; ++t) {
+        const int slot = t % NSLOT;
+        const float* xb_tile = xs + slot * IB * CH * 4;
+        const float* hb_tile = hn + slot * IB;
+        const int64_t i0_tile = i_begin + int64_t(p_cur) * IB;
+        p_cur = perm_next(p_cur);
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+            const float* xb = xb_tile + sub * 32 * CH * 4;
+            const float* hb = hb_tile + sub * 32;
+            const int64_t i0 = i0_tile + 32 * sub;
+            // ---- accumulator set-up and the first fragments: before the token ----------------------------------------------
+            f32x16 acc[TQ];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
+#pragma unroll
+                for (int b = 0; b < TQ; ++b) {
+                    const float2_t lo2 = float2_t{hv.x, hv.y} * nscale[b], hi2 = float2_t{hv.z, hv.w} * nscale[b];
+                    acc[b][4 * rg + 0] = lo2.x;
+                    acc[b][4 * rg + 1] = lo2.y;
+                    acc[b][4 * rg + 2] = hi2.x;
+                    acc[b][4 * rg + 3] = hi2.y;
+                }
+            }
+            {
+                int sw = swz<CH>(r);
+                asm volatile("" : "+v"(sw));
+                const unsigned char* abase = reinterpret_cast<const unsigned char*>(xb) + r * (NG * 16);
+                auto a_ptr = [&](int g) { return abase + 16 * ((2 * g + h) ^ sw); };
+                constexpr int PF = HWER_PP_PREFETCH < NQF ? HWER_PP_PREFETCH : NQF;
+                half8_t avq[PF];
+#pragma unroll
+                for (int g = 0; g < PF; ++g) avq[g] = *reinterpret_cast<const half8_t*>(a_ptr(g));
+                // ---- MFMA burst: only while this wave holds its SIMD's token (the partner filters meanwhile) ---------------
+                STAMP(pt0);
+                tok_acquire();
+                STAMP(pt1);
+                __builtin_amdgcn_s_setprio(HWER_F16_MFMA_PRIO);
+#pragma unroll
+                for (int g = 0; g < NQF; ++g) {
+                    const half8_t av = avq[g % PF];
+                    if (g + PF < NQF) avq[g % PF] = *reinterpret_cast<const half8_t*>(a_ptr(g + PF));
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, qf[b][g], acc[b], 0, 0, 0);
+                }
+                tok_release();
+                __builtin_amdgcn_s_setprio(HWER_F16_REST_PRIO);
+            }
+            if (DIAG_STAMPS) { asm volatile("" :: "v"(acc[0][0]), "v"(acc[TQ - 1][15])); pt2 = stamp(); pt3 = pt2; }
+            // ---- the tile barrier (ring safety: every wave is done READING tile t and has waited for its pieces of tile t + 1), STAGGERED:
+            // waves 4-7 take it here, between the last MFMA burst of the tile and its filter segment, waves 0-3 behind that filter segment
+            // (below).  After the barrier waves 0-3 go straight into the next tile's first burst while their partners still filter - the
+            // two waves of a SIMD leave every barrier half a step apart, and from there bursts and filter segments interleave by themselves.
+            if (sub == NSUB - 1 && role == 1) {
+                __builtin_amdgcn_s_barrier();
+                if (DIAG_STAMPS) { pt3 = stamp(); pa_w2 += pt3 - pt2; }
+            }
+            // ---- filter segment (the partner runs its MFMAs) --------------------------------------------------------------
+            if (sub == 0) {
+                // ONE drain per tile, in front of this segment's appends: outstanding are this wave's pieces of tile t + 1 (requested a
+                // tile ago) and the appends of the last tile's filter segments (a whole MFMA burst old or more) - the wait is free.
+                // Then the pieces of tile t + 2 into the slot tile t - 1 held: nobody reads that one after this tile's barrier.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t + 2 < n_tiles) tile_dma((t + 2) % NSLOT, p_dma);
+                p_dma = perm_next(p_dma);
+            }
+            if (a.sparse_hits) {   // (wave-uniform) max-tree variant: see screen_kernel
+                const uint32_t item0 = uint32_t(i0) + 4 * h;
+#pragma unroll
+                for (int b = 0; b < TQ; ++b) {
+                    const float m0 = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]), m1 = fmaxf(fmaxf(acc[b][3], acc[b][4]), acc[b][5]);
+                    const float m2 = fmaxf(fmaxf(acc[b][6], acc[b][7]), acc[b][8]), m3 = fmaxf(fmaxf(acc[b][9], acc[b][10]), acc[b][11]);
+                    const float m4 = fmaxf(fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
+                    const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[b][15]));
+                    if (__any(mx > tau[b])) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            if (acc[b][q] > tau[b]) append(b, pack_key(ldexpf(acc[b][q], -e_tot[b]), item0 + (q & 3) + 8 * (q >> 2)));
+                        }
+                    }
+                }
+            } else {
+                uint32_t mask = 0;
+#pragma unroll
+                for (int b = TQ - 1; b >= 0; --b) {
+                    const float2_t tau2 = {tau[b], tau[b]};
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        const float2_t df = tau2 - float2_t{acc[b][q], acc[b][q + 1]};
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.x), 31);
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.y), 31);
+                    }
+                }
+                if (__any(mask != 0u)) {
+                    const uint32_t item0 = uint32_t(i0) + 4 * h;
+                    float* park = keypark + lane;
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b)
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) park[(16 * b + q) * 64] = acc[b][q];
+                    while (__any(mask != 0u)) {
+                        if (mask != 0u) {
+                            const int bit = __builtin_ctz(mask);
+                            mask &= mask - 1u;
+                            const int q = 15 - (bit & 15);
+                            float kval = park[((bit & 16) + q) * 64];
+                            kval = ldexpf(kval, -((TQ == 2 && (bit & 16)) ? e_tot[TQ - 1] : e_tot[0]));
+                            const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
+                            if constexpr (TQ == 1) {
+                                append(0, key);
+                            } else {
+                                if ((bit & 16) != 0) append(1, key);
+                                else append(0, key);
+                            }
+                        }
+                    }
+                }
+            }
+            if (sub == NSUB - 1) {
+                // ---- stream capacity (every 64 rows) ----------------------------------------------------------------------
+#pragma unroll
+                for (int b = 0; b < TQ; ++b) {
+                    uint64_t need = __ballot(cnt[b] > CAPH - 32);
+                    while (need != 0ull) {
+                        const int jj = (__builtin_ctzll(need)) & 31;
+                        const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
+                        const int was_first = __shfl(int(first[b]), jj, kWave);
+                        uint64_t* s0 = wg_cand + (uint32_t(32 * b + jj) * 2u) * CAPH;
+                        int rank = a.kprime;
+                        if (was_first && a.scaled_first) {
+                            const float mu = float(a.kprime) * float(c0 + c1) / float(i_end - i_begin);
+                            const int mrank = int(mu + 4.0f * sqrtf(mu) + 5.0f);
+                            if (2 * mrank < a.kprime) rank = mrank;
+                        }
+                        float T;
+                        int n0, n1;
+                        compact_query(s0, s0 + CAPH, c0, c1, rank, rank == a.kprime ? COMPACT_SLACK : min(COMPACT_SLACK, rank / 4 + 1), T, n0, n1);
+                        if (r == jj) {
+                            tau[b] = ldexpf(T, e_tot[b]);
+                            cnt[b] = h == 0 ? n0 : n1;
+                            scaled[b] = scaled[b] || (rank != a.kprime);
+                            first[b] = false;
+                        }
+                        need &= ~((1ull << jj) | (1ull << (jj + 32)));
+                    }
+                }
+            }
+            if (DIAG_STAMPS) { pt4 = stamp(); pa_w1 += pt1 - pt0; pa_mfma += pt2 - pt1; pa_filt += pt4 - pt3; }
+            if (sub == NSUB - 1 && role == 0) {
+                __builtin_amdgcn_s_barrier();
+                if (DIAG_STAMPS) pa_w2 += stamp() - pt4;
+            }
+        }
+    }
+    if (DIAG_STAMPS && lane == 0) {   // same 8-word record per wave as screen_kernel: [1] MFMA segments, [2] filter segments, [3] token waits, [4] tile barriers
+        unsigned long long* o = a.debug_stamps + (size_t(blockIdx.x) * 8 + wave) * 8;
+        o[0] = 0; o[1] = pa_mfma; o[2] = pa_filt; o[3] = pa_w1; o[4] = pa_w2; o[5] = 2ull * n_tiles;
+        o[6] = __builtin_amdgcn_s_memtime() - pclk0; o[7] = __builtin_amdgcn_s_memrealtime() - prt0;
+    }
+    // ---- hand-over: screen_kernel's ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int b = 0; b < TQ; ++b) {
+        const int partner = __shfl_xor(cnt[b], 32, kWave);
+        const int total = cnt[b] + partner;
+        const bool underfull = scaled[b] && total < a.kprime;
+        const bool seeded_short = seeded[b] && first[b] && total < a.kprime;
+        uint64_t need = __ballot(total > a.kprime) & 0xFFFFFFFFull;
+        while (need != 0ull) {
+            const int jj = __builtin_ctzll(need);
+            const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
+            uint64_t* s0 = wg_cand + (uint32_t(32 * b + jj) * 2u) * CAPH;
+            float T;
+            int n0, n1;
+            compact_query(s0, s0 + CAPH, c0, c1, a.kprime, 0, T, n0, n1);
+            if (r == jj) cnt[b] = h == 0 ? n0 : n1;
+            need &= ~(1ull << jj);
+        }
+        const int64_t q = qw0 + 32 * b + r;
+        a.cand_cnt[(int64_t(list) * a.bq + q) * 2 + h] = cnt[b] | (underfull ? CNT_UNDERFULL : 0) | (seeded_short ? CNT_SEEDED_SHORT : 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void repack_queries_kernel(const float* __restrict__ Q, int64_t B, int ldx, int ng, float4* __restrict__ Qf, int64_t n_out) {
     const int64_t o = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (o >= n_out) return;
@@ -776,6 +1104,11 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     p.wq = B > 2 * qpw ? 4 : (B > qpw ? 2 : 1);
     p.qb = p.wq * qpw;
     p.n_qblocks = int(cdiv64(B, p.qb));
+    // Round 4: the float16 streaming screen runs as 512-thread ping-pong workgroups (screen16_pp_kernel) that cover TWO query blocks
+    // each: whole pairs of blocks (the padding queries are dead lanes, as in any last block)
+    p.pp = ((options & HWER_KNN_F16_SCREEN) && !(options & HWER_KNN_NO_PINGPONG) && p.ng >= 8 && p.wq == 4 &&
+            !(n_items <= DENSE_MAX_ITEMS && !(options & HWER_KNN_NO_DENSE))) ? 1 : 0;
+    if (p.pp) p.n_qblocks = (p.n_qblocks + 1) & ~1;
     p.bq = int64_t(p.n_qblocks) * p.qb;
     const int wi = 4 / p.wq;
     // item splits: every split re-pays the selection warm-up (~4 K' appends + a compaction per query), so split
@@ -944,6 +1277,22 @@ static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStr
     return check_launch("knn_screen16");
 }
 
+template <int NG, int TQ>
+static int launch_screen16_pp_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
+    // ring 3 x 64 rows x (NG * 16 B) | half norms 3 x 64 | key park 8 x 64 x 16 TQ | 4 tokens
+    const size_t lds = size_t(3) * 64 * NG * 16 + size_t(3) * 64 * 4 + size_t(8) * 64 * 16 * TQ * 4 + 16;
+    static uint64_t attr_done = 0;   // per device
+    int dev;
+    if (attr_pending(attr_done, &dev)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen16_pp_kernel<NG, TQ>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done |= 1ull << dev;
+    }
+    const int grid = (plan.n_qblocks / 2) * plan.n_splits;
+    hipLaunchKernelGGL((screen16_pp_kernel<NG, TQ>), dim3(grid), dim3(512), lds, stream, a);
+    return check_launch("knn_screen16_pp");
+}
+
 int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnorm, int64_t n_items, int64_t ldx, const float* Qf, int64_t B,
                        float* seed_keys, WsHeader* hdr, hipStream_t stream, const ScreenF16* f16) {
     (void)n_items;
@@ -1013,8 +1362,18 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
                  f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0,
                  // expected passing keys per 32-row tile and wave (32 tq queries) under the seeded thresholds
                  (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < 0.6 && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ||
-                 (f16 && WIDE64 && plan.ng > 16 && !plan.dense) ? 1 : 0, 0};
+                 (f16 && WIDE64 && plan.ng > 16 && !plan.dense && !(plan.pp && HWER_PP_WIDE_PARK)) ? 1 : 0, 0};
     const int key = plan.ng * 10 + plan.tq;
+    if (f16 && plan.pp && !plan.dense && (plan.n_qblocks & 1) == 0) {
+        switch (key) {
+            case 81: return launch_screen16_pp_t<8, 1>(plan, a, stream);
+            case 82: return launch_screen16_pp_t<8, 2>(plan, a, stream);
+            case 161: return launch_screen16_pp_t<16, 1>(plan, a, stream);
+            case 162: return launch_screen16_pp_t<16, 2>(plan, a, stream);
+            case 321: return launch_screen16_pp_t<32, 1>(plan, a, stream);
+            default: return fail(HWER_EINVAL, "knn_screen16_pp: unsupported padded dim %d / tq %d", plan.ng * 8, plan.tq);
+        }
+    }
     if (f16) {
         switch (key) {
             case 81: return launch_screen16_t<8, 1>(plan, a, stream);

@@ -99,7 +99,7 @@ class _OneAnchorSearch:
         path_opt = ix._path_options()
         x16, x16_exp = ix._x16(tt, 1)
         opt = (ix.KNN_F16_SCREEN if (ix.f16_screen and x16 is not None) else 0) | path_opt
-        wsb = lib.hwer_knn_workspace_bytes_opts(1, tt.n, ix.d, k, path_opt)
+        wsb = lib.hwer_knn_workspace_bytes_opts(1, tt.n, ix.d, k, opt)
         if wsb == 0:
             raise native.HwerNativeError("knn: unsupported shape (n=%d, d=%d, k=%d)" % (tt.n, ix.d, k))
         self.ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
@@ -369,9 +369,10 @@ class DeviceIndex:
 
     @staticmethod
     def _path_options():
-        """Path-forcing switches for tests (results are identical on every path): HWER_NO_DENSE / HWER_NO_SMALL in the
-        environment of the HOST mirror map to the library's HWER_KNN_NO_DENSE / HWER_KNN_NO_SMALL options."""
-        return (4 if os.environ.get("HWER_NO_DENSE") else 0) | (8 if os.environ.get("HWER_NO_SMALL") else 0)
+        """Path-forcing switches for tests (results are identical on every path): HWER_NO_DENSE / HWER_NO_SMALL / HWER_NO_PINGPONG in the
+        environment of the HOST mirror map to the library's HWER_KNN_NO_DENSE / HWER_KNN_NO_SMALL / HWER_KNN_NO_PINGPONG options."""
+        return ((4 if os.environ.get("HWER_NO_DENSE") else 0) | (8 if os.environ.get("HWER_NO_SMALL") else 0) |
+                (64 if os.environ.get("HWER_NO_PINGPONG") else 0))     # HWER_KNN_NO_PINGPONG: rounds 1-3's float16 streaming kernel
 
     @_on_device
     def search_queries(self, node_type: str, Q64, Q32, k: int, anchors_dev=None, score_mode: Optional[int] = None,
@@ -420,18 +421,18 @@ class DeviceIndex:
         for b0 in range(0, B, self.QUERY_CHUNK):
             b1 = min(B, b0 + self.QUERY_CHUNK)
             nb = b1 - b0
-            key = (nb, tt.n, k, path_opt)
+            # the small-batch screen always reads the float16 copy; the streaming screen only with f16_screen
+            x16, x16_exp = self._x16(tt, nb) if (nb <= 1024 or self.f16_screen) else (None, 0)
+            opt = (self.KNN_F16_SCREEN if (self.f16_screen and x16 is not None) else 0) | path_opt
+            key = (nb, tt.n, k, opt)      # (the plan - and with it the workspace layout - is a function of the options of the call)
             if key not in sizes:
-                sizes[key] = (self.lib.hwer_knn_workspace_bytes_opts(nb, tt.n, self.d, k, path_opt), self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
+                sizes[key] = (self.lib.hwer_knn_workspace_bytes_opts(nb, tt.n, self.d, k, opt), self.lib.hwer_knn_exact_device_workspace_bytes(tt.n, k))
             wsb, wseb = sizes[key]
             if wsb == 0:
                 raise native.HwerNativeError("knn: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" %
                                              (nb, tt.n, self.d, k, self.lib.hwer_knn_max_k()))
             ws = self._workspace(wsb)
             a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
-            # the small-batch screen always reads the float16 copy; the streaming screen only with f16_screen
-            x16, x16_exp = self._x16(tt, nb) if (nb <= 1024 or self.f16_screen) else (None, 0)
-            opt = (self.KNN_F16_SCREEN if (self.f16_screen and x16 is not None) else 0) | path_opt
             native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,

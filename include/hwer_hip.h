@@ -249,6 +249,10 @@ int hwer_knn_search_f32(const float* X, const float* hnorm, int64_t n_items, int
  * hwer_knn_query_padding(...) rows); honoured by the dense / streaming screens (float32 and float16), ignored (the search repacks)
  * on the small-batch path. */
 #define HWER_KNN_QUERIES_READY 32u
+/* HWER_KNN_NO_PINGPONG: the float16 streaming screen as two independent 256-thread workgroups per CU (rounds 1-3) instead of one
+ * 512-thread workgroup whose SIMD partners alternate MFMA and filter segments (round 4).  Same candidate lists, same results; kept for
+ * same-box A/B measurements and path coverage in the tests. */
+#define HWER_KNN_NO_PINGPONG 64u
 size_t hwer_knn_workspace_bytes_opts(int64_t B, int64_t n_items, int d, int k, uint32_t options);
 int64_t hwer_knn_query_padding(int64_t B, int64_t n_items, int d, int k, uint32_t options); /* rows of query fragments the search reads (>= B) */
 int hwer_knn_search_opts_f32(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32,

@@ -299,3 +299,37 @@ def test_one_anchor_graph_equals_the_general_path(hw, U, N, d, k, flav):
         assert per_anchor[u] == general, j
         o_idx, o_sc, _ = orc.find_closest(V, np.arange(U, U + N), j, k=k, scoring="gcn" if flav == "gcn" else "base")
         assert [m.nodes_to_idx[n] for n, _ in general] == o_idx.tolist() and [s for _, s in general] == o_sc.tolist()
+
+
+# ------------------------------------------------------------------------------------------------- ping-pong float16 streaming screen
+@pytest.mark.parametrize("d,N,B,k,note", [(128, 30000, 2100, 200, "TQ = 1, item splits, odd number of 128-query blocks"), (64, 20000, 3000, 50, "d = 64"),
+                                           (256, 16000, 1500, 100, "d = 256: 4 pieces per wave"), (100, 12000, 1100, 10, "padded width"),
+                                           (128, 70000, 2500, 200, "TQ = 2: 64 queries per wave, 512 per workgroup"),
+                                           (128, 9000, 70000, 200, "one list per query, TQ = 2"), (128, 66000, 2048, 392, "k = 392"),
+                                           (32, 9000, 1300, 20, "d = 32: no float16 tiles - the float32 kernel under a ping-pong plan")])
+def test_pingpong_screen_equals_the_two_workgroup_screen(hw, monkeypatch, d, N, B, k, note):
+    """screen16_pp_kernel (round 4: one 512-thread workgroup per CU, SIMD partners alternating MFMA and filter segments, 3-slot tile
+    ring) against screen_kernel<.., F16> (rounds 1-3; HWER_KNN_NO_PINGPONG): ids, scores, distances and flags identical for every
+    query, and == the oracle on a sample; duplicates planted at a few queries' cut; a ragged last query block and a ragged last tile."""
+    from hwer.device_index import DeviceIndex
+    X = unit_rows_f32(235 + d, N, d)
+    users = unit_rows_f32(236 + d, B, d)
+    X[N // 3] = X[7]
+    X[N - 1] = X[7]
+    V = np.concatenate([users, X]).astype(np.float64)
+    type_rows = {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}
+    res = []
+    for no_pp in ("", "1"):
+        if no_pp:
+            monkeypatch.setenv("HWER_NO_PINGPONG", "1")
+        else:
+            monkeypatch.delenv("HWER_NO_PINGPONG", raising=False)
+        ix = DeviceIndex(V, type_rows, arith=0)
+        res.append(ix.search("item", np.arange(B), k=k))
+    for a, b_ in zip(res[0], res[1]):
+        assert np.array_equal(a, b_), note
+    assert (res[0][3] > 0).all()
+    sel = np.unique(np.linspace(0, B - 1, 96).astype(np.int64))
+    Qs = np.stack([orc.query_vector(V, int(u)) for u in sel])
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(X, Qs, V[sel], k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(res[0][0][sel], o_idx + B) and np.array_equal(res[0][1][sel], o_sc) and np.array_equal(res[0][2][sel], np.sqrt(o_d2)), note
