@@ -66,27 +66,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict__ V, int d, int d4, int64_t ldv,
                                                          const int32_t* __restrict__ src,
                                                          const int32_t* __restrict__ dst, int64_t P,
-                                                         T* __restrict__ out, int stride) {
+                                                         T* __restrict__ out, int stride, int pb_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    T* slab = reinterpret_cast<T*>(smem_raw) + size_t(wave) * 8 * stride;
+    // pb_n = pairs per wave and trip: 8, or 4 / 2 for wide rows - the product slab of a trip then stays below ~9 KB per wave, and the CU
+    // keeps 16 waves instead of 8 (d = 256, float64: round 4).  The kernel waits for gathered rows; waves in flight hide that, the chain
+    // phase's idle lanes (8 lanes per pair, pb_n pairs) cost issue slots it does not need.
+    T* slab = reinterpret_cast<T*>(smem_raw) + size_t(wave) * pb_n * stride;
 
     const int L = min(64, pow2ceil(d4));  // lanes per row in the load phase
     const int rows_per_instr = 64 / L;
     const int sub = lane / L;             // which of the rows_per_instr rows this lane loads
     const int c0 = lane % L;
 
-    const int64_t n_batches = cdiv64(P, 8);
+    const int64_t n_batches = cdiv64(P, pb_n);
     const int nw = int(blockDim.x) >> 6;   // 4 waves, fewer when a wave's slab is large (wide float64 rows)
     const int64_t wave_global = int64_t(blockIdx.x) * nw + wave;
     const int64_t wave_stride = int64_t(gridDim.x) * nw;
 
     for (int64_t b = wave_global; b < n_batches; b += wave_stride) {
-        const int64_t p0 = b * 8;
+        const int64_t p0 = b * pb_n;
         // (round 3: issuing all 16 row loads of a step before the first product - 64 more VGPRs - measured SLOWER: 0.72 -> 0.50 of the
         // HBM roofline on the 1.25 M-row table, 0.40 -> 0.38 at d = 256; the loop below already keeps several waves' loads in flight)
-        for (int pb = 0; pb < 8; pb += rows_per_instr) {
+        for (int pb = 0; pb < pb_n; pb += rows_per_instr) {
             const int64_t p = p0 + pb + sub;
             if (p < P) {
                 const int32_t s = src[p], t = dst[p];
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256) void pair_score_kernel(const float* __restrict
         }
         wave_lds_sync();
         const int p8 = lane >> 3, k = lane & 7;
-        const T r = np_pairwise<T, kPairwiseDepth>(slab + p8 * stride, d, k);
-        if (k == 0 && p0 + p8 < P) out[p0 + p8] = (r + T(1)) / T(2);
+        const T r = np_pairwise<T, kPairwiseDepth>(slab + min(p8, pb_n - 1) * stride, d, k);
+        if (k == 0 && p8 < pb_n && p0 + p8 < P) out[p0 + p8] = (r + T(1)) / T(2);
         wave_lds_sync();
     }
 }
@@ -123,7 +126,13 @@ static int launch_pair_score(const float* V, int64_t N, int d, int64_t ldv, cons
     while (stride % 32 != 8) ++stride;  // chain reads of 4 pairs x 8 chains hit 32 distinct banks
     // one slab of 8 product rows per wave; 4 waves per workgroup while they fit the CU's 160 KB of LDS (d = 1024 in
     // float64: 66 KB per wave -> 2 waves)
-    const size_t slab = size_t(8) * stride * sizeof(T);
+    // pairs per wave and trip: 8 while a trip's slab stays below ~4.7 KB (d = 128 in float32, d = 64 in float64), else 4 or 2 - measured on tables
+    // beyond the Infinity Cache (tools/pair_probe.py, fraction of 8 TB/s at 8 / 4 / 2 pairs): d = 256 float64 0.38 / 0.57 / 0.58, d = 256 float32 0.64 /
+    // 0.73 / 0.65, d = 128 float64 0.61 / 0.67 / 0.58, d = 128 float32 0.77 / 0.72 / 0.66 (HWER_PAIR_PB overrides in diagnostic builds)
+    int pb_n = 8;
+    while (pb_n > 2 && size_t(pb_n) * stride * sizeof(T) > size_t(4800)) pb_n >>= 1;
+    if (const char* e = diag_env("HWER_PAIR_PB")) pb_n = std::max(1, std::min(8, atoi(e)));
+    const size_t slab = size_t(pb_n) * stride * sizeof(T);
     int nw = 4;
     while (nw > 1 && size_t(nw) * slab > size_t(160) * 1024) nw >>= 1;
     const size_t lds = size_t(nw) * slab;
@@ -132,10 +141,10 @@ static int launch_pair_score(const float* V, int64_t N, int d, int64_t ldv, cons
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pair_score_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "pair_score: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(e));
     }
-    const int64_t n_batches = cdiv64(P, 8);
+    const int64_t n_batches = cdiv64(P, pb_n);
     const int grid = int(std::min<int64_t>(cdiv64(n_batches, nw), kMaxStreamBlocks * 2));
     hipLaunchKernelGGL(pair_score_kernel<T>, dim3(grid), dim3(64 * nw), lds, as_stream(stream), V, d, d4, ldv, src, dst,
-                       P, out, stride);
+                       P, out, stride, pb_n);
     return check_launch("pair_score");
 }
 
