@@ -747,6 +747,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 // First version (measured, not kept): rigid lockstep - two workgroup barriers per subtile, waves 4-7 one barrier behind - ran 10 %
 // SLOWER than screen_kernel: every half step then costs the slowest of eight waves plus the barrier (stamps: segments of 877 / 776
 // cycles, 970 cycles per subtile spent waiting at the two barriers).
+#ifndef HWER_PP_SPARSE_MAX
+#define HWER_PP_SPARSE_MAX 0.6   // expected passing keys per 32-row subtile and wave below which the ping-pong kernel takes the max-tree filter (4.0 measured: c4 +-0)
+#endif
 #ifndef HWER_PP_WIDE_PARK
 #define HWER_PP_WIDE_PARK 0   // 1: d = 256 under the ping-pong kernel filters by the expected-hits rule (its LDS has room for the key park)
 #endif
@@ -1361,7 +1364,9 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
                  diag_env("HWER_SCREEN_TAU0") ? float(atof(diag_env("HWER_SCREEN_TAU0"))) : -INFINITY, diag_env("HWER_SCREEN_STAMPS") ? dbg : nullptr, hdr,
                  f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr, f16 ? f16->x_exp : 0, tau0, 1, 0,
                  // expected passing keys per 32-row tile and wave (32 tq queries) under the seeded thresholds
-                 (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < 0.6 && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ||
+                 // (ping-pong kernel: the park-free variant up to ~4 expected hits was 2 % faster in the diagnostic build at c4 - 1.7 hits per subtile and
+                 //  wave - and +-0 in the production build: the 0.6 rule stays for both kernels)
+                 (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < ((f16 && plan.pp) ? HWER_PP_SPARSE_MAX : 0.6) && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ||
                  (f16 && WIDE64 && plan.ng > 16 && !plan.dense && !(plan.pp && HWER_PP_WIDE_PARK)) ? 1 : 0, 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16 && plan.pp && !plan.dense && (plan.n_qblocks & 1) == 0) {
