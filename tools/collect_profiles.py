@@ -63,10 +63,14 @@ for c in cfgs:
             if pred(kern) and (best is None or e["bytes_per_launch"] > ent["kernels"][best]["bytes_per_launch"]):
                 best = kern
         return best
-    main = pick(lambda k: "screen_kernel<" in k and ", false, " in k) or pick(lambda k: "screen_kernel<" in k)
+    # (round 4: the float16 streaming screen is screen16_pp_kernel<NG, TQ>; its seed pre-pass is still screen_kernel<NG, TQ, true, true>)
+    main = (pick(lambda k: "screen16_pp_kernel<" in k) or pick(lambda k: "screen_kernel<" in k and ", false, " in k) or pick(lambda k: "screen_kernel<" in k))
     parts = [main]
-    if main and ", false, " in main:
-        seed = main.replace(", false, ", ", true, ")
+    if main and ("screen16_pp_kernel<" in main or ", false, " in main):
+        if "screen16_pp_kernel<" in main:
+            seed = pick(lambda k: "screen_kernel<" in k and ", true, true" in k)
+        else:
+            seed = main.replace(", false, ", ", true, ")
         if seed in ent["kernels"]:
             parts.append(seed)
         thr = pick(lambda k: "small_threshold" in k or "seed_pick" in k)
