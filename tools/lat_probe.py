@@ -27,7 +27,7 @@ def main():
     o = w.sets[0]
     ob = dict(idx=o["idx"][:B], score=o["score"][:B], dist2=None, flags=o["flags"][:B])
     opts = (w.opts if B > 1024 else 0) | int(os.environ.get("HWER_BENCH_OPTS", "0"))
-    need = lib.hwer_knn_workspace_bytes_opts(B, w.I, w.d, bench.K, opts & ~2)
+    need = lib.hwer_knn_workspace_bytes_opts(B, w.I, w.d, bench.K, opts)      # (the plan - hence the layout - is a function of the options)
     if need > w.ws.numel():
         w.ws = torch.empty(need, dtype=torch.uint8, device=dev)
     ms = bench.cuda_time(torch, lambda: w.stage_search(ob, B=B, opts=opts), reps, warm=3)
