@@ -60,6 +60,7 @@ struct ScreenArgs {
     int tile_stride;     // 1; the seed pre-pass visits every tile_stride-th tile of the catalogue (its items are sample-local)
     int dense_f16;       // DENSE mode: `dense` holds float16 keys (the seed pre-pass: its keys only place a threshold - half the bytes)
     int sparse_hits;     // streaming float16 mode: fewer than ~0.6 passing keys expected per tile and wave -> the max-tree filter (FILTER_V2)
+    int many_hits;       // ping-pong kernel: >= ~8 passing keys expected per 32-row subtile and wave -> up to four pops per round of the pop loop
     int seed_m;          // DENSE mode, seed pre-pass (round 3): 0 = store every key; M in {1, 2, 4} = every lane keeps the M largest keys it
                          // sees for its query and stores only those: dense[q * ld_dense + bin * M + j], bin = (split * wi + wave_i) * 2 + lane half
 };
@@ -872,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
         }
     };
 
-    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0, pa_w1 = 0, pa_mfma = 0, pa_w2 = 0, pa_filt = 0, pclk0 = 0, prt0 = 0;
+    unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0, pt4 = 0, pa_w1 = 0, pa_mfma = 0, pa_w2 = 0, pa_filt = 0, pa_drain = 0, pclk0 = 0, prt0 = 0;
     if (DIAG_STAMPS) { pclk0 = __builtin_amdgcn_s_memtime(); prt0 = __builtin_amdgcn_s_memrealtime(); }
     for (int t = 0; t < n_tiles; ++t) {
         const int slot = t % NSLOT;
@@ -937,7 +938,10 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                 // ONE drain per tile, in front of this segment's appends: outstanding are this wave's pieces of tile t + 1 (requested a
                 // tile ago) and the appends of the last tile's filter segments (a whole MFMA burst old or more) - the wait is free.
                 // Then the pieces of tile t + 2 into the slot tile t - 1 held: nobody reads that one after this tile's barrier.
+                unsigned long long pd0 = 0;
+                STAMP(pd0);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (DIAG_STAMPS) pa_drain += stamp() - pd0;
                 if (t + 2 < n_tiles) tile_dma((t + 2) % NSLOT, p_dma);
                 p_dma = perm_next(p_dma);
             }
@@ -968,6 +972,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                         mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.y), 31);
                     }
                 }
+                if (ABLATE(2)) mask = 0u;      // (diagnostic: masks computed, nothing popped)
                 if (__any(mask != 0u)) {
                     const uint32_t item0 = uint32_t(i0) + 4 * h;
                     float* park = keypark + lane;
@@ -975,6 +980,38 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                     for (int b = 0; b < TQ; ++b)
 #pragma unroll
                         for (int q = 0; q < 16; ++q) park[(16 * b + q) * 64] = acc[b][q];
+                    if (ABLATE(8)) mask = 0u;  // (diagnostic: masks + park, no pops)
+                    if (a.many_hits) {
+                        // (wave-uniform) many passing keys per subtile (single-list plans: c3 lets 2.25 K' keys of a 26 744-row catalogue through -
+                        // 0.7 per lane and subtile): the pop loop below is a chain of one LDS round trip per pop and runs max-over-lanes times
+                        // (3 - 4).  Here a round takes up to FOUR set bits per lane, issues their LDS reads together and appends branch-free (the
+                        // stream of a key is selected arithmetically, not by a divergent branch): one LDS latency per round instead of four.
+                        while (__any(mask != 0u)) {
+                            int bits[4];
+                            float kv4[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                bits[j] = mask != 0u ? __builtin_ctz(mask) : -1;
+                                mask &= mask - 1u;      // (0 stays 0)
+                                const int bb = bits[j] < 0 ? 0 : bits[j];
+                                kv4[j] = park[((bb & 16) + 15 - (bb & 15)) * 64];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (bits[j] >= 0) {
+                                    const int q = 15 - (bits[j] & 15);
+                                    const bool second = TQ == 2 && (bits[j] & 16) != 0;
+                                    const float kval = ldexpf(kv4[j], -(second ? e_tot[TQ - 1] : e_tot[0]));
+                                    const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
+                                    const uint32_t pos = second ? soff[TQ - 1] + uint32_t(cnt[TQ - 1]) : soff[0] + uint32_t(cnt[0]);
+                                    if (!ABLATE(1)) wg_cand[pos] = key;
+                                    else asm volatile("" :: "v"(key), "v"(pos));
+                                    if constexpr (TQ == 2) { cnt[0] += second ? 0 : 1; cnt[1] += second ? 1 : 0; }
+                                    else cnt[0] += 1;
+                                }
+                            }
+                        }
+                    } else
                     while (__any(mask != 0u)) {
                         if (mask != 0u) {
                             const int bit = __builtin_ctz(mask);
@@ -1031,7 +1068,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
     }
     if (DIAG_STAMPS && lane == 0) {   // same 8-word record per wave as screen_kernel: [1] MFMA segments, [2] filter segments, [3] token waits, [4] tile barriers
         unsigned long long* o = a.debug_stamps + (size_t(blockIdx.x) * 8 + wave) * 8;
-        o[0] = 0; o[1] = pa_mfma; o[2] = pa_filt; o[3] = pa_w1; o[4] = pa_w2; o[5] = 2ull * n_tiles;
+        o[0] = 0; o[1] = pa_mfma; o[2] = pa_filt; o[3] = pa_drain /* (diagnosis: the once-per-tile vmcnt drain, part of the filter segments) */; o[4] = pa_w2; o[5] = 2ull * n_tiles;
         o[6] = __builtin_amdgcn_s_memtime() - pclk0; o[7] = __builtin_amdgcn_s_memrealtime() - prt0;
     }
     // ---- hand-over: screen_kernel's ---------------------------------------------------------------------------------------------
@@ -1311,7 +1348,7 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
     // seed_top_m: the lanes keep their M best keys and store only those, (bq, seed_cand_ld) float32; else every key as float16
     ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_top_m ? plan.seed_cand_ld : plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
                  plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
-                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, plan.seed_top_m ? 0 : 1, 0, plan.seed_top_m};
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, plan.seed_top_m ? 0 : 1, 0, 0, plan.seed_top_m};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {
@@ -1367,7 +1404,9 @@ int launch_screen(const ScreenPlan& plan, const float* X, const float* hnorm, in
                  // (ping-pong kernel: the park-free variant up to ~4 expected hits was 2 % faster in the diagnostic build at c4 - 1.7 hits per subtile and
                  //  wave - and +-0 in the production build: the 0.6 rule stays for both kernels)
                  (tau0 && plan.seed && plan.seed_frac * 32.0 * 32.0 * plan.tq < ((f16 && plan.pp) ? HWER_PP_SPARSE_MAX : 0.6) && !diag_env("HWER_SCREEN_DENSE_HITS")) || diag_env("HWER_SCREEN_SPARSE_HITS") ||
-                 (f16 && WIDE64 && plan.ng > 16 && !plan.dense && !(plan.pp && HWER_PP_WIDE_PARK)) ? 1 : 0, 0};
+                 (f16 && WIDE64 && plan.ng > 16 && !plan.dense && !(plan.pp && HWER_PP_WIDE_PARK)) ? 1 : 0,
+                 // many_hits: >= 8 expected passing keys per subtile and wave (single-list plans; unseeded launches): four pops per round
+                 diag_env("HWER_SCREEN_MANY_HITS") ? atoi(diag_env("HWER_SCREEN_MANY_HITS")) : ((!tau0 || !plan.seed || plan.seed_frac * 32.0 * 32.0 * plan.tq >= 8.0) ? 1 : 0), 0};
     const int key = plan.ng * 10 + plan.tq;
     if (f16 && plan.pp && !plan.dense && (plan.n_qblocks & 1) == 0) {
         switch (key) {
