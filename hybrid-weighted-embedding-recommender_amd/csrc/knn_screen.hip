@@ -748,6 +748,9 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 // First version (measured, not kept): rigid lockstep - two workgroup barriers per subtile, waves 4-7 one barrier behind - ran 10 %
 // SLOWER than screen_kernel: every half step then costs the slowest of eight waves plus the barrier (stamps: segments of 877 / 776
 // cycles, 970 cycles per subtile spent waiting at the two barriers).
+#ifndef HWER_PP_PK_MASKS
+#define HWER_PP_PK_MASKS 1    // pass masks of the ping-pong kernel from v_pk_add_f32 differences (0: one v_sub_f32 per key)
+#endif
 #ifndef HWER_PP_SPARSE_MAX
 #define HWER_PP_SPARSE_MAX 0.6   // expected passing keys per 32-row subtile and wave below which the ping-pong kernel takes the max-tree filter (4.0 measured: c4 +-0)
 #endif
@@ -964,12 +967,21 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                 uint32_t mask = 0;
 #pragma unroll
                 for (int b = TQ - 1; b >= 0; --b) {
-                    const float2_t tau2 = {tau[b], tau[b]};
+                    if constexpr (HWER_PP_PK_MASKS) {
+                        const float2_t tau2 = {tau[b], tau[b]};
 #pragma unroll
-                    for (int q = 0; q < 16; q += 2) {
-                        const float2_t df = tau2 - float2_t{acc[b][q], acc[b][q + 1]};
-                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.x), 31);
-                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.y), 31);
+                        for (int q = 0; q < 16; q += 2) {
+                            const float2_t df = tau2 - float2_t{acc[b][q], acc[b][q + 1]};
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.x), 31);
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.y), 31);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            float df = tau[b] - acc[b][q];
+                            asm volatile("" : "+v"(df));      // (keeps the compiler from re-packing the subtractions into v_pk_add_f32)
+                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df), 31);
+                        }
                     }
                 }
                 if (ABLATE(2)) mask = 0u;      // (diagnostic: masks computed, nothing popped)
