@@ -1,4 +1,4 @@
-"""Multi-process (world_size 2, gloo, CPU) coverage of the N > 1 path: shard bounds, the single all-gather of packed
+"""Multi-process (world_size 2 and 4, gloo, CPU) coverage of the N > 1 path: shard bounds, the single all-gather of packed
 local results, global-id bookkeeping and the merge order.  The per-shard search and the merge are HIP kernels in the
 product; here they are replaced by oracle-based stand-ins (tests may use the oracle) so that the collective plumbing
 of hwer.distributed.ShardedSearch runs without a GPU."""
@@ -104,6 +104,39 @@ def test_sharded_search_short_lists_world2_gloo(tmp_path, n_items, k, list_len):
     assert rep[0] == rep[1]
     if list_len * 2 == k:
         assert rep[0] > 0   # 2 x 10 = 20: a list is exhausted unless the two shards hold exactly 10 each
+
+
+@pytest.mark.parametrize("n_items,k,list_len", [(101, 20, None), (101, 20, 8), (9, 8, 3)])
+def test_sharded_search_world4_gloo(tmp_path, n_items, k, list_len):
+    """Four ranks (round 4): ragged shards (101 = 26 + 26 + 26 + 23; 9 rows over 4 ranks leave the last shard short of the list length), both
+    exchanges, full and shortened lists - every rank holds the single-process result (asserted inside the worker)."""
+    port = 33500 + (os.getpid() + n_items + (list_len or 0)) % 2000
+    mp.spawn(_worker, args=(4, port, n_items, k, str(tmp_path), list_len), nprocs=4, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(4))
+    if list_len is not None:
+        rep = [int((tmp_path / ("rep%d" % r)).read_text()) for r in range(4)]
+        assert len(set(rep)) == 1
+
+
+def test_local_search_without_rows_keeps_full_lists():
+    """A local_search written against the rounds-1/2 contract (three arguments, no `rows=`) must never meet the data-dependent repeat of the
+    shortened lists: ShardedSearch then keeps full lists whatever list_len says (advisor finding, round 3)."""
+    from hwer.distributed import ShardedSearch
+
+    class FakeDist:
+        pass
+    sh = ShardedSearch.__new__(ShardedSearch)
+    sh.exchange, sh.world, sh.list_len = "all_gather", 8, 72
+    from hwer.distributed import merge_on_device
+    sh.merge = merge_on_device
+    sh.local_search = lambda Q64, Q32, k: None
+    assert sh._list_len(200) == 200
+    sh.local_search = lambda Q64, Q32, k, rows=None: None
+    assert sh._list_len(200) == 72
+    sh.list_len = None
+    assert sh._list_len(200) == 72       # the device merge's default: local_list_len(200, 8)
+    sh.local_search = lambda Q64, Q32, k, **kw: None
+    assert sh._list_len(200) == 72
 
 
 def test_local_list_len_rule():
