@@ -134,6 +134,7 @@ class _OneAnchorSearch:
             with torch.cuda.graph(g):
                 launch()
             self.graph = g
+        self._keep = (tt, x16, ix.V)      # the captured launches hold raw pointers: keep their tensors alive as long as the graph
         self.dev = dev
         self.dev_index = dev.index
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -242,6 +243,11 @@ class DeviceIndex:
                      "pack_rows")
         tt.hnorm_max = float(tt.hnorm[:tt.n].max().item()) if tt.n else 0.0
         self.tables[node_type] = tt
+        # cached one-anchor graphs of this type hold raw pointers into the table they were captured on: drop them
+        cache = self.__dict__.get("_one_anchor")
+        if cache:
+            for key in [k_ for k_ in cache if k_[0] == node_type]:
+                del cache[key]
         return tt
 
     # ------------------------------------------------------------------------------------------------
