@@ -1070,6 +1070,88 @@ using namespace hwer;
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
+// =====================================================================================================
+// K12b  Recall@K / binary NDCG@K of the retrieval evaluation as floats, on the device (round 4) - the per-user values of
+//       utils.recall (hwer/utils.py:118-121) and utils.binary_ndcg (:101-111) from the hit masks of hwer_rank_filter_seen, and their means
+//       over the validation users (hwer/validation.py:167-172), in numpy's arithmetic: a per-user DCG is np.sum over a row of <= 128 terms
+//       (8 strided chains, pairwise combine, sequential tail), a mean is np.add.reduce over the users (8192-element pieces in order, each by the pairwise recursion with leaves of <= 128) / V.
+// =====================================================================================================
+__device__ __forceinline__ double np_sum_leaf_seq(const double* p, int64_t n) {   // numpy's <= 128-element leaf, by one thread
+    if (n < 8) {
+        double r = 0.0;
+        for (int64_t i = 0; i < n; ++i) r = __dadd_rn(r, p[i]);
+        return r;
+    }
+    double r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3], r4 = p[4], r5 = p[5], r6 = p[6], r7 = p[7];
+    const int64_t lim = n - (n & 7);
+    for (int64_t i = 8; i < lim; i += 8) {
+        r0 = __dadd_rn(r0, p[i]); r1 = __dadd_rn(r1, p[i + 1]); r2 = __dadd_rn(r2, p[i + 2]); r3 = __dadd_rn(r3, p[i + 3]);
+        r4 = __dadd_rn(r4, p[i + 4]); r5 = __dadd_rn(r5, p[i + 5]); r6 = __dadd_rn(r6, p[i + 6]); r7 = __dadd_rn(r7, p[i + 7]);
+    }
+    double res = __dadd_rn(__dadd_rn(__dadd_rn(r0, r1), __dadd_rn(r2, r3)), __dadd_rn(__dadd_rn(r4, r5), __dadd_rn(r6, r7)));
+    for (int64_t i = lim; i < n; ++i) res = __dadd_rn(res, p[i]);
+    return res;
+}
+__device__ double np_pairwise_sum_seq(const double* p, int64_t n) {   // numpy's recursion (loops_utils.h.src DOUBLE_pairwise_sum)
+    if (n <= 128) return np_sum_leaf_seq(p, n);
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    const double a = np_pairwise_sum_seq(p, n2);
+    const double b = np_pairwise_sum_seq(p + n2, n - n2);
+    return __dadd_rn(a, b);
+}
+
+struct RankMetricsArgs {
+    const uint64_t* hits;     // (B, hit_words)
+    int hit_words;
+    const int32_t* n_pred;    // (B) survivors of every anchor (hwer_rank_filter_seen: out_len)
+    const int64_t* vrow;      // (V) row of validation user v in the two arrays above
+    const int64_t* n_true;    // (V) validation items of user v that are not training items
+    int64_t V;
+    int n_cuts;
+    int cuts[8];
+    const double* log2_tab;   // (cut_max + 1, ld_log2): row L = np.log2(np.arange(L) + 2) - numpy's values for a list of L predictions
+    int ld_log2;
+    const double* idcg_tab;   // (cut_max + 1) ideal DCG of m hits
+    double* vals;             // (2 n_cuts, V): recall then ndcg of every cut
+    double* out;              // (2 n_cuts) means
+};
+
+// one thread per (validation user, cut)
+__global__ __launch_bounds__(256) void rank_metrics_rows_kernel(const RankMetricsArgs a) {
+    const int64_t v = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int ci = blockIdx.y;
+    if (v >= a.V) return;
+    const int c = a.cuts[ci];
+    const int64_t row = a.vrow[v];
+    const int lp = min(a.n_pred[row], c);
+    const int64_t nt = a.n_true[v];
+    const uint64_t* hw = a.hits + row * a.hit_words;
+    int h = 0;
+    double terms[128];      // (gain / discount of position p: 1 / log2(p + 2) for a hit, 0.0 / log2(p + 2) = 0.0 otherwise)
+    for (int pp = 0; pp < lp; ++pp) {
+        const bool hit = (hw[pp >> 6] >> (pp & 63)) & 1ull;
+        h += hit ? 1 : 0;
+        terms[pp] = hit ? __ddiv_rn(1.0, a.log2_tab[int64_t(lp) * a.ld_log2 + pp]) : 0.0;
+    }
+    const double denom = fmax(double(min(int64_t(lp), nt)), 1.0);
+    a.vals[int64_t(ci) * a.V + v] = __ddiv_rn(double(h), denom);
+    const double dcg = lp ? np_sum_leaf_seq(terms, lp) : 0.0;
+    const int64_t ideal = min(nt, int64_t(lp));
+    a.vals[int64_t(a.n_cuts + ci) * a.V + v] = __ddiv_rn(dcg, __dadd_rn(a.idcg_tab[ideal], 1e-8));
+}
+// one thread per metric: np.mean over the validation users
+__global__ void rank_metrics_mean_kernel(const RankMetricsArgs a) {
+    const int m = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    // np.add.reduce over a 1-D array runs its inner loop on the ufunc buffer's 8192-element pieces (numpy 2.2: the pairwise recursion is per
+    // piece, the pieces are added to the running sum in order) - measured against np.sum / np.mean for V up to 100003 (tests/test_host_api.py)
+    const double* p = a.vals + int64_t(m) * a.V;
+    double r = 0.0;
+    for (int64_t i = 0; i < a.V; i += 8192) r = __dadd_rn(r, np_pairwise_sum_seq(p + i, min(int64_t(8192), a.V - i)));
+    a.out[m] = __ddiv_rn(r, double(a.V));
+}
+
 extern "C" {
 
 int hwer_abi_version(void) { return HWER_ABI_VERSION; }
@@ -1196,6 +1278,25 @@ static int blend_impl(const float* const* tables, int64_t ld_tables, const int32
                        ld_tables, row_idx, alpha, alpha_per_row, T, R, d4, out, ldo, out_norm, audit_eps,
                        reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev);
     return check_launch("blend_normalize");
+}
+
+int hwer_rank_metrics(const uint64_t* hits, int hit_words, const int32_t* n_pred, const int64_t* vrow, const int64_t* n_true, int64_t V,
+                      const int32_t* cuts_host, int n_cuts, const double* log2_table, int ld_log2, const double* idcg_table, double* vals_ws,
+                      double* out_means, void* stream) {
+    if (!hits || !n_pred || !vrow || !n_true || !cuts_host || !log2_table || !idcg_table || !vals_ws || !out_means)
+        return fail(HWER_EINVAL, "rank_metrics: null pointer");
+    if (V < 1 || n_cuts < 1 || n_cuts > 8 || hit_words < 1) return fail(HWER_EINVAL, "rank_metrics: need V >= 1, 1 <= n_cuts <= 8");
+    RankMetricsArgs a{hits, hit_words, n_pred, vrow, n_true, V, n_cuts, {0, 0, 0, 0, 0, 0, 0, 0}, log2_table, ld_log2, idcg_table, vals_ws, out_means};
+    for (int i = 0; i < n_cuts; ++i) {
+        if (cuts_host[i] < 1 || cuts_host[i] > 128 || cuts_host[i] > hit_words * 64 || cuts_host[i] > ld_log2)
+            return fail(HWER_EINVAL, "rank_metrics: cuts must lie in 1 .. min(128, 64 hit_words, ld_log2)");
+        a.cuts[i] = cuts_host[i];
+    }
+    hipLaunchKernelGGL(rank_metrics_rows_kernel, dim3(unsigned(cdiv64(V, 256)), unsigned(n_cuts)), dim3(256), 0, as_stream(stream), a);
+    int rc;
+    if ((rc = check_launch("rank_metrics(rows)"))) return rc;
+    hipLaunchKernelGGL(rank_metrics_mean_kernel, dim3(unsigned(2 * n_cuts)), dim3(64), 0, as_stream(stream), a);
+    return check_launch("rank_metrics(mean)");
 }
 
 int hwer_rank_filter_seen(const int64_t* ranked, int64_t B, int k, const int64_t* seen_ptr, const int64_t* seen_idx,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "hwer_knn_exact_device": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, c_int, c_int, c_int,
                                       _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "hwer_rank_filter_seen": (c_int, [_P, c_int64, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, _P]),
+    "hwer_rank_metrics": (c_int, [_P, c_int, _P, _P, _P, c_int64, _P, c_int, _P, c_int, _P, _P, _P, _P]),
     "hwer_merge_topk": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "hwer_knn_all_dist2_f64": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, _P]),
     "hwer_pack_exchange": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),

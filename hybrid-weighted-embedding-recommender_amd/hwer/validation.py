@@ -6,6 +6,7 @@ host.  The HPO / plotting / results-table drivers of th
 """
 from __future__ import annotations
 
+import ctypes
 import operator
 import random
 import time
@@ -264,11 +265,34 @@ def _extraction_efficiency_device(model, train_edges, validation_edges, node_typ
     n_true = np.asarray([len(val_scores.get(u, ())) for u in validation_users], dtype=np.int64)
     n_pred = ulen_h[vrow]
 
+    # Round 4: the float metrics themselves come from the device too (hwer_rank_metrics: per-user recall / binary NDCG from the hit masks in
+    # np.sum's order, the means over the validation users by np.add.reduce's pairwise recursion - bit-identical to the numpy expressions of
+    # recall_rows / binary_ndcg_rows above, which stay as the host statement of the same arithmetic and as the tests' cross-check).
+    dev_cuts = (100, 10, 20)
+    if len(validation_users):
+        log2_tab = np.zeros((cmax + 1, cmax), dtype=np.float64)      # row L: numpy's np.log2 over an array of L positions (see include/hwer_hip.h)
+        for L in range(1, cmax + 1):
+            log2_tab[L, :L] = np.log2(np.arange(L) + 2)
+        idcg_tab = np.asarray([np.sum((np.power(2, [1] * m) - 1) / np.log2(np.arange(m) + 2)) for m in range(cmax + 1)], dtype=np.float64)
+        d_vrow, d_ntrue, d_l2, d_id = T(vrow), T(n_true), T(log2_tab), T(idcg_tab)
+        vals_ws = torch.empty(2 * len(dev_cuts) * len(vrow), dtype=torch.float64, device=dev)
+        means_dev = torch.empty(2 * len(dev_cuts), dtype=torch.float64, device=dev)
+        cuts_h = np.asarray(dev_cuts, dtype=np.int32)
+        with native.device_guard(dev):
+            native.check(lib.hwer_rank_metrics(native.ptr(hits), hits.shape[1], native.ptr(ulen), native.ptr(d_vrow), native.ptr(d_ntrue), len(vrow),
+                                               cuts_h.ctypes.data_as(ctypes.c_void_p), len(dev_cuts), native.ptr(d_l2), cmax, native.ptr(d_id), native.ptr(vals_ws),
+                                               native.ptr(means_dev), native.stream_ptr(dev)), "rank_metrics")
+        means = means_dev.cpu().numpy()
+        dev_recall = {c: means[j] for j, c in enumerate(dev_cuts)}
+        dev_ndcg = {c: means[len(dev_cuts) + j] for j, c in enumerate(dev_cuts)}
+    else:
+        dev_recall = dev_ndcg = {}
+
     def recall_at(c):
-        return recall_rows(hitbits, n_pred, n_true, c)
+        return dev_recall[c] if c in dev_recall else recall_rows(hitbits, n_pred, n_true, c)
 
     def binary_ndcg_at(c):
-        return binary_ndcg_rows(hitbits, n_pred, n_true, c)
+        return dev_ndcg[c] if c in dev_ndcg else binary_ndcg_rows(hitbits, n_pred, n_true, c)
 
     table = model.knn.idx_to_node()
     cuts100 = LazyRows(all_users, lambda j: [table[i] for i in unseen_h[j, :ulen_h[j]].tolist()])

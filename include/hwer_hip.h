@@ -387,12 +387,26 @@ int hwer_knn_order_rows_f64(const double* values, int64_t ld_values, const int64
  *   outputs  : out_unseen (B, cut_max) ids padded with -1, out_len (B), out_hits (B, ceil(cut_max/64)) bit p = the p-th
  *              survivor is a truth item; cover_bits (nullable, caller-zeroed, ceil(cover_n/32) words): bit (id - cover_base)
  *              set for every survivor ("diversity", hwer/validation.py:177).
- *   The float metrics (utils.recall / ndcg, hwer/utils.py:101-121) are computed from these integers by the caller.
+ *   The float metrics (utils.recall / ndcg, hwer/utils.py:101-121) follow from these integers: hwer_rank_metrics below, or the caller.
  * ------------------------------------------------------------------------------------------------- */
 int hwer_rank_filter_seen(const int64_t* ranked, int64_t B, int k, const int64_t* seen_ptr, const int64_t* seen_idx,
                           const int64_t* truth_ptr, const int64_t* truth_idx, int cut_max, int64_t* out_unseen,
                           int32_t* out_len, uint64_t* out_hits, uint32_t* cover_bits, int64_t cover_base, int64_t cover_n,
                           void* stream);
+
+/* K12b   the float metrics of the same evaluation, on the device (round 4) - per validation user v (row vrow[v] of the arrays above) and cut c:
+ *          recall = hits / max(min(min(n_pred, c), n_true), 1)                                  utils.recall,      hwer/utils.py:118-121
+ *          ndcg_b = sum_p hit_p / log2(p + 2)  /  (idcg_table[min(n_true, min(n_pred, c))] + 1e-8)   utils.binary_ndcg, hwer/utils.py:101-111
+ *        and out_means[ci] = mean_v recall, out_means[n_cuts + ci] = mean_v ndcg_b (hwer/validation.py:167-172) in numpy's arithmetic: the
+ *        per-user sums in np.sum's order over <= 128 terms, the means as np.add.reduce's pairwise recursion / V - bit-identical to the
+ *        reference's numpy expressions.  The discounts come from the host as numpy computes them: log2_table[L * ld_log2 + p] = np.log2(np.arange(L) + 2)[p]
+ *        for every list length L <= cut_max (numpy's vectorised log2 and its scalar remainder loop may differ in the last place, so the value of
+ *        position p depends on the length of the array it was computed in - the reference evaluates np.log2 on an array of the user's own list
+ *        length); idcg_table[m] = np.sum(1 / np.log2(np.arange(m) + 2)).  cuts_host: HOST array of n_cuts <= 8 cuts <= min(128, 64 hit_words, ld_log2);
+ *        vals_ws: 2 * n_cuts * V doubles (the per-user values stay there: recall rows first, then ndcg rows). */
+int hwer_rank_metrics(const uint64_t* hits, int hit_words, const int32_t* n_pred, const int64_t* vrow, const int64_t* n_true, int64_t V,
+                      const int32_t* cuts_host /*host*/, int n_cuts, const double* log2_table, int ld_log2, const double* idcg_table, double* vals_ws,
+                      double* out_means, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * X1     multi-GPU merge (no reference counterpart): n_lists per-shard results, each

@@ -333,3 +333,48 @@ def test_pingpong_screen_equals_the_two_workgroup_screen(hw, monkeypatch, d, N, 
     Qs = np.stack([orc.query_vector(V, int(u)) for u in sel])
     o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(X, Qs, V[sel], k, threads=c_oracle.effective_cpus())
     assert np.array_equal(res[0][0][sel], o_idx + B) and np.array_equal(res[0][1][sel], o_sc) and np.array_equal(res[0][2][sel], np.sqrt(o_d2)), note
+
+
+# ------------------------------------------------------------------------------------------------- float metrics on the device
+@pytest.mark.parametrize("B,V,seed", [(300, 211, 1), (30000, 20011, 2), (5, 1, 3), (900, 129, 4)])
+def test_rank_metrics_kernel_equals_the_numpy_expressions(hw, B, V, seed):
+    """hwer_rank_metrics (round 4): mean recall@c and mean binary NDCG@c over the validation users from the hit masks of
+    hwer_rank_filter_seen, against the host statement of the reference's numpy expressions (hwer/utils.py:101-121, hwer/validation.py:167-172:
+    validation.recall_rows / binary_ndcg_rows, themselves held to the reference's per-user loops by tests/test_host_api.py) - BIT-identical:
+    ragged prediction lengths (0 ... 100), users without truth, more than 128 users (the pairwise recursion of np.mean), cuts 100 / 10 / 20."""
+    import ctypes
+    import torch
+    from hwer import native, validation
+    lib, P = native.lib(), native.ptr
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    cmax, cuts = 100, (100, 10, 20)
+    hit_words = (cmax + 63) // 64
+    hits = (rng.integers(0, 1 << 62, (B, hit_words)).astype(np.uint64) & rng.integers(0, 1 << 62, (B, hit_words)).astype(np.uint64)
+            & rng.integers(0, 1 << 62, (B, hit_words)).astype(np.uint64))                        # ~1/8 of the positions are hits
+    n_pred_all = rng.integers(0, cmax + 1, B).astype(np.int32)
+    n_pred_all[::7] = cmax
+    vrow = np.sort(rng.choice(B, V, replace=False)).astype(np.int64)
+    n_true = rng.integers(0, 40, V).astype(np.int64)
+    hitbits = validation._unpack_hit_bits(hits[vrow], cmax)
+    n_pred = n_pred_all[vrow].astype(np.int64)
+    # (a hit beyond a user's prediction length cannot occur in the kernel's input: mask them as hwer_rank_filter_seen would)
+    keep = (np.arange(cmax)[None, :] < n_pred_all[:, None])
+    bits_all = validation._unpack_hit_bits(hits, cmax) * keep
+    hits = np.packbits(np.pad(bits_all, ((0, 0), (0, hit_words * 64 - cmax))).astype(np.uint8), axis=1, bitorder="little").view(np.uint64).reshape(B, hit_words)
+    hitbits = validation._unpack_hit_bits(hits[vrow], cmax)
+    log2_tab = np.zeros((cmax + 1, cmax))
+    for L in range(1, cmax + 1):
+        log2_tab[L, :L] = np.log2(np.arange(L) + 2)      # numpy's values for a list of L predictions (vector body vs scalar remainder may differ in the last place)
+    idcg_tab = np.asarray([np.sum((np.power(2, [1] * m) - 1) / np.log2(np.arange(m) + 2)) for m in range(cmax + 1)], dtype=np.float64)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)       # noqa: E731
+    d_hits, d_np, d_vr, d_nt, d_l2, d_id = T(hits.view(np.int64)), T(n_pred_all), T(vrow), T(n_true), T(log2_tab), T(idcg_tab)
+    vals = torch.empty(2 * len(cuts) * V, dtype=torch.float64, device=dev)
+    means = torch.empty(2 * len(cuts), dtype=torch.float64, device=dev)
+    cuts_h = np.asarray(cuts, dtype=np.int32)
+    native.check(lib.hwer_rank_metrics(P(d_hits), hit_words, P(d_np), P(d_vr), P(d_nt), V, cuts_h.ctypes.data_as(ctypes.c_void_p), len(cuts), P(d_l2), cmax, P(d_id),
+                                       P(vals), P(means), native.stream_ptr(dev)), "rank_metrics")
+    got = means.cpu().numpy()
+    for j, c in enumerate(cuts):
+        assert got[j] == validation.recall_rows(hitbits, n_pred, n_true, c), ("recall", c)
+        assert got[len(cuts) + j] == validation.binary_ndcg_rows(hitbits, n_pred, n_true, c), ("ndcg", c)

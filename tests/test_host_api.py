@@ -252,3 +252,43 @@ def test_no_library_gemm_topk_sort_in_the_host_mirror():
     import re
     for f in glob.glob(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hybrid-weighted-embedding-recommender_amd", "hwer", "*.py")):
         assert not re.search(r"torch\.(matmul|topk|sort|argsort|mm|bmm|einsum)\b", open(f).read()), f
+
+
+def test_np_mean_order_restated_for_the_device_metrics():
+    """The summation order hwer_rank_metrics follows for a mean over the validation users (csrc/rowops.hip: rank_metrics_mean_kernel),
+    restated in Python and held to numpy itself: np.add.reduce over a contiguous 1-D float64 array adds 8192-element pieces to the running
+    sum in order, each piece by the pairwise recursion (halves rounded down to a multiple of 8, leaves of <= 128 elements with 8 strided
+    partial sums).  If a numpy release changes this, this test says so before the GPU parity test does."""
+    def leaf(p):
+        n = len(p)
+        if n < 8:
+            r = 0.0
+            for x in p:
+                r += x
+            return r
+        r = [float(x) for x in p[:8]]
+        lim = n - (n & 7)
+        for i in range(8, lim, 8):
+            for j in range(8):
+                r[j] += p[i + j]
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+        for i in range(lim, n):
+            res += p[i]
+        return res
+
+    def pairwise(p):
+        n = len(p)
+        if n <= 128:
+            return leaf(p)
+        n2 = n // 2
+        n2 -= n2 % 8
+        return pairwise(p[:n2]) + pairwise(p[n2:])
+
+    rng = np.random.default_rng(11)
+    for n in (1, 7, 129, 8192, 8193, 20011, 100003):
+        a = rng.random(n) * np.where(rng.random(n) < 0.03, 1e8, 1.0)      # mixed magnitudes: the order shows in the last place
+        r = 0.0
+        for i in range(0, n, 8192):
+            r = r + pairwise(a[i:i + 8192])
+        assert r == np.sum(a), n
+        assert r / n == np.mean(a), n
