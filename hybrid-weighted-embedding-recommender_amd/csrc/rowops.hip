@@ -1053,10 +1053,18 @@ __global__ __launch_bounds__(256) void blend_prepare_search_kernel(const BlendAr
         ba.audit_counts[0] = ba.audit_counts[1] = ba.audit_counts[2] = ~0ull;
         ba.audit_counts[3] = ~0ull;
     }
+#if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
+    const int ablate = wpb >> 8;   // diagnostic builds: HWER_PROLOGUE_ABLATE (1 no QUERY blocks, 2 no PACK, 4 no OTHER, 8 no audit atomics)
+    wpb &= 0xff;
+    if (blk >= n_pack_blocks + n_other_blocks ? (ablate & 1) : (blk < n_pack_blocks ? (ablate & 2) : (ablate & 4))) return;
+#endif
     if (blk < n_pack_blocks + n_other_blocks) {
         AuditAcc au;
         if (blk < n_pack_blocks) blend_rows_body<true, U>(ba, pack, pk, blk, n_pack_blocks, au);
         else blend_rows_body<false, U>(ba, other, pk, blk - n_pack_blocks, n_other_blocks, au);
+#if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
+        if (ablate & 8) return;
+#endif
         audit_finish(ba, au);
     } else {
         blend_query_body<T>(ba, qa, smem_raw, int64_t(blk) - n_pack_blocks - n_other_blocks, int64_t(gridDim.x) - n_pack_blocks - n_other_blocks, wpb, gq);
@@ -1571,8 +1579,13 @@ int hwer_blend_prepare_search_f32(const float* const* tables, int64_t ld_tables,
     const dim3 grid(n_pack + n_oth + n_mix);
     // four rows in flight per row group whatever T is (measured at T = 4, d = 256: 1.63 ms, against 2.38 with one row in flight and
     // 1.84 for the three separate launches - the stand-alone blend kernel prefers one row there, this one does not)
-    if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb, gq);
-    else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb, gq);
+    int wpb_arg = wpb;
+    if (const char* e = diag_env("HWER_PROLOGUE_ABLATE")) {   // diagnostic builds only; the first launches run whole so that every buffer holds valid rows
+        static int calls = 0;
+        if (++calls > 3) wpb_arg |= atoi(e) << 8;
+    }
+    if (arith == 0) hipLaunchKernelGGL((blend_prepare_search_kernel<double, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb_arg, gq);
+    else hipLaunchKernelGGL((blend_prepare_search_kernel<float, 4>), grid, dim3(256), per_wave * wpb, as_stream(stream), ba, pack, other, pk, qa, n_pack, n_oth, wpb_arg, gq);
     return check_launch("blend_prepare_search");
 }
 
