@@ -142,6 +142,19 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes (lane i <- v[0] + ... + v[i]) in six DPP steps, no LDS traffic: Hillis-Steele inside the 16-lane
+// rows (row_shr never crosses a row: a lane whose source lies outside keeps `old` = 0), then lane 15 of rows 0 / 2 onto rows 1 / 3
+// (row_bcast:15) and lane 31 onto rows 2 and 3 (row_bcast:31).  tools/ubench/scan_test.hip checks it against a host prefix sum.
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 // ---- wave-level selection on register-resident floats ------------------------------------------------------------
 // v[0..NV) per lane (entries that do not exist hold -inf).  wave_find_rank returns `lo` with
 //   rank <= count(v >= lo) <= rank + slack

@@ -174,7 +174,13 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
 
 #pragma unroll 1
     for (int g0 = 64 * coop_wave; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += COOP ? 256 : 64) {   // wave-uniform rounds of 64 candidates
+#ifdef HWER_DIAG_STAMPS   // ablation of the round's ingredients (HWER_SELECT_SKIP bits 8 no distances, 16 no score arithmetic, 32 no row gathers, 64 no LDS staging)
+        const bool need_d2 = (!lazy || g0 < n_b) && !(a.debug_skip & 8);
+        const bool abl_score = a.debug_skip & 16, abl_gather = a.debug_skip & 32, abl_stage = a.debug_skip & 64;
+#else
         const bool need_d2 = !lazy || g0 < n_b;   // wave-uniform
+        constexpr bool abl_score = false, abl_gather = false, abl_stage = false;
+#endif
         const int ci = g0 + lane;
         const bool live = ci < n_r;
         const uint32_t it = min(cand[live ? ci : g0], a.item_max);
@@ -197,25 +203,27 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
+            if (!abl_stage) {
             *reinterpret_cast<float4*>(dst) = pre0;
             *reinterpret_cast<float4*>(dst + 16 * RR_RS) = pre1;
             *reinterpret_cast<float4*>(dst + 32 * RR_RS) = pre2;
             *reinterpret_cast<float4*>(dst + 48 * RR_RS) = pre3;
-            if (c + 1 < n_chunks) {
+            }
+            if (c + 1 < n_chunks && !abl_gather) {
                 const int o = RR_CW * (c + 1);
                 pre0 = *reinterpret_cast<const float4*>(src0 + o);
                 pre1 = *reinterpret_cast<const float4*>(src1 + o);
                 pre2 = *reinterpret_cast<const float4*>(src2 + o);
                 pre3 = *reinterpret_cast<const float4*>(src3 + o);
             }
-            wave_lds_sync();
+            if (!abl_stage) wave_lds_sync();
             float xv[RR_CW];
 #pragma unroll
             for (int t = 0; t < RR_CW / 4; ++t) {
-                const float4 v = *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
+                const float4 v = abl_stage ? pre0 : *reinterpret_cast<const float4*>(stage + lane * RR_RS + 4 * t);
                 xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
             }
-            wave_lds_sync();
+            if (!abl_stage) wave_lds_sync();
             const int j0 = RR_CW * c;
             if (!need_d2) {
             } else if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
@@ -237,7 +245,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
 #pragma unroll
                 for (int gg = 0; gg < RR_CW / 8; ++gg) {
                     const int g8 = (RR_CW / 8) * c + gg;
-                    if (g8 < n_groups8) {   // uniform
+                    if (g8 < n_groups8 && !abl_score) {   // uniform
                         const bool first = g8 == 0 || g8 == gA;
                         const int jj = 8 * g8;
                         if constexpr (mode == 0) {
@@ -294,7 +302,9 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     bool presorted = false;
     const uint64_t* s_sorted = nullptr;
     if constexpr (COOP) {   // all four waves' rounds are in the shared tables
+        SEL_STAMP(12);
         __syncthreads();
+        SEL_STAMP(13);
         if (lazy && n_b <= 64 && n_r <= 256 && !(a.debug_skip & 6)) {   // block-uniform
             uint64_t* skeys = reinterpret_cast<uint64_t*>(cand + kp);     // the four staging areas (20 KB) are free now
             uint64_t* sfinal = skeys + 256;
@@ -312,6 +322,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 }
                 member = rank < a.k - (n_r - n_b);
             }
+            SEL_STAMP(14);
             // unique keys: members by (approximate score, slot), everything else behind them by slot
             const uint64_t mykey = (uint64_t(member ? ~f32_orderable(float(t_sc[min(i, kp - 1)])) : 0xFFFFFFFFu) << 32) | uint64_t(uint32_t(i));
             skeys[i] = mykey;
@@ -325,6 +336,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             }
             sfinal[pos] = mykey;
             __syncthreads();
+            SEL_STAMP(15);
             presorted = true;
             s_sorted = sfinal;
         }
@@ -659,11 +671,18 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
         vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
     }
+    // 2 x 64 counters of the histogram rank search below, in the (not yet used) distance table of the re-rank; zeroed ahead of the barrier
+    int* const hist = reinterpret_cast<int*>(lds_emit);
     if constexpr (COOP) {   // extrema of the whole row: the four waves' values through LDS
+        if (wave < 2) hist[threadIdx.x] = 0;
         if (lane == 0) { s_mm[wave] = vmax; s_mm[4 + wave] = vmin; }
         __syncthreads();
         vmax = fmaxf(fmaxf(s_mm[0], s_mm[1]), fmaxf(s_mm[2], s_mm[3]));
         vmin = fminf(fminf(s_mm[4], s_mm[5]), fminf(s_mm[6], s_mm[7]));
+    } else {
+        hist[lane] = 0;
+        hist[64 + lane] = 0;
+        wave_lds_sync();
     }
     SEL_STAMP(1);
     auto count_ge = [&](float t) {
@@ -689,7 +708,96 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     //  three thresholds per workgroup exchange - 9.5 -> 4.3 barrier rounds, the same ~9.7 K cycles of rank search; the whole search by ONE
     //  wave on the whole row in its registers, ballot counts 13.0 K cycles, per-lane VALU counts + one wave reduction per probe ~ the same
     //  step time; a probe's cost follows the compares a SIMD has to issue for its four resident workgroups, not the barrier)
-    const float t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo, &t_hi, lazy_ok);   // <= k-th largest key, at most c_lo - k extra keys above it
+    // Round 4: the bracket comes from TWO histogram rounds instead of ~10 counting probes.  Every key gets a 12-bit bin number
+    // bin(key) = int((key - vmin) * 4096 / (vmax - vmin)) - monotone in the key, so "bin(key) >= B" is "key >= the smallest key with bin >= B" and
+    // the counts above a bin edge are exact.  Round 1 counts the keys by the upper 6 bits (64 LDS counters, one ds_add per key; linear bins
+    // over the row's own range keep the lanes of an instruction on different counters, unlike a radix over raw float bits), a DPP suffix scan
+    // finds the coarse bin that holds the k-th largest key; round 2 does the same with the lower 6 bits of the keys of that bin.  The fine bin
+    // B* found holds pop >= 1 keys (about N / 4096 x the local density: one or two); t_k = the smallest key with bin >= B*, t_hi = the smallest
+    // key above the bin: k <= count(>= t_k) = k - 1 + ... <= k + pop - 1 and k - pop <= count(>= t_hi) < k.  With pop <= 12 that is the
+    // bracket the probes would have delivered (ties, clusters: the probes take over on the narrowed interval).  ~165 instead of ~450
+    // instructions on the one-query-per-workgroup path, 3 workgroup barriers instead of ~10, and the SAME cost for every query: the probe
+    // count (6 ... 13) was what spread the workgroups' end times (c1: rank search 6.8 K ... 19 K cycles, select launch 26.5 us).
+    // (the wave-per-query form with 64 or 128 keys per lane keeps the probes: three more passes over that many registers spill)
+    float t_k = 0.f;
+    bool bracketed = false;
+    if constexpr (COOP || MAXV <= 8) {
+        const float range = vmax - vmin;
+        const float scale = 4096.0f / range;
+        if (range > 0.f && scale < 1e30f && vmin > -INFINITY && !(a.emit.debug_skip & 128)) {   // (workgroup-uniform)
+            // (recomputed in each of the three passes - 3 VALU - rather than kept: the wave-per-query form holds up to 128 keys per lane)
+            // -inf pads: (-inf) * scale = -inf -> INT_MIN (v_cvt_i32_f32 saturates): negative = "no key"
+            const float vmin0 = vmin;
+            auto bin_of = [&](float key) { return min(int((key - vmin0) * scale), 4095); };
+#pragma unroll
+            for (int m = 0; m < MV; ++m) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int bb = bin_of(kv[m][c]);
+                    if (bb >= 0) atomicAdd(&hist[63 - (bb >> 6)], 1);   // lane l of the scan <-> coarse bin 63 - l
+                }
+            }
+            if constexpr (COOP) __syncthreads();
+            else wave_lds_sync();
+            int s1 = wave_incl_scan_i32(hist[lane]);   // keys in coarse bins >= 63 - lane
+            const uint64_t m1 = __ballot(s1 >= k);
+            if (m1 != 0ull) {   // (else: fewer than k keys - the probes' own handling below)
+                const int l1 = __builtin_ctzll(m1);
+                const int c_above = l1 ? __shfl(s1, l1 - 1, kWave) : 0;   // keys in coarser bins above the one that holds the k-th
+                const int coarse = 63 - l1;
+#pragma unroll
+                for (int m = 0; m < MV; ++m) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int bb = bin_of(kv[m][c]);
+                        if ((bb >> 6) == coarse) atomicAdd(&hist[64 + 63 - (bb & 63)], 1);
+                    }
+                }
+                if constexpr (COOP) __syncthreads();
+                else wave_lds_sync();
+                int s2 = c_above + wave_incl_scan_i32(hist[64 + lane]);
+                const uint64_t m2 = __ballot(s2 >= k);   // never empty: the coarse bin holds the k-th key
+                const int l2 = __builtin_ctzll(m2);
+                const int n_lo = __shfl(s2, l2, kWave);                       // count(bin >= B*)
+                const int n_hi = l2 ? __shfl(s2, l2 - 1, kWave) : c_above;   // count(bin > B*) < k
+                const int bstar = coarse * 64 + 63 - l2;
+                float lo = INFINITY, hi = INFINITY;
+#pragma unroll
+                for (int m = 0; m < MV; ++m) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int bb = bin_of(kv[m][c]);
+                        lo = fminf(lo, bb >= bstar ? kv[m][c] : INFINITY);
+                        hi = fminf(hi, bb > bstar ? kv[m][c] : INFINITY);
+                    }
+                }
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    lo = fminf(lo, __shfl_xor(lo, off, kWave));
+                    hi = fminf(hi, __shfl_xor(hi, off, kWave));
+                }
+                if constexpr (COOP) {
+                    if (lane == 0) { s_mm[wave] = lo; s_mm[4 + wave] = hi; }
+                    __syncthreads();
+                    lo = fminf(fminf(s_mm[0], s_mm[1]), fminf(s_mm[2], s_mm[3]));
+                    hi = fminf(fminf(s_mm[4], s_mm[5]), fminf(s_mm[6], s_mm[7]));
+                }
+                if (n_lo - n_hi <= 12 || !lazy_ok) {
+                    if (n_lo <= k + 12) {
+                        t_k = lo;
+                        t_hi = hi;   // +inf when no key lies above the bin (k-th key in the top bin): no provable members, all boundary
+                        c_lo = n_lo;
+                        bracketed = true;
+                    }
+                }
+                if (!bracketed) {   // more than 12 keys in one 1 / 4096 of the range: the probes finish on the narrowed interval
+                    vmin = lo;
+                    if (hi < INFINITY) vmax = hi;
+                }
+            }
+        }
+    }
+    if (!bracketed) t_k = wave_find_rank_fn(count_ge, vmin, vmax, k, 12, c_lo, &t_hi, lazy_ok);   // <= k-th largest key, at most c_lo - k extra keys above it
     SEL_STAMP(2);
     double Q2 = 0.0;
     {
@@ -1589,6 +1697,18 @@ static unsigned long long* sel_stamps_buffer(int64_t B) {
                 line += b;
             }
             fprintf(stderr, "%s\n", line.c_str());
+        }
+        {   // one-query-per-workgroup launches: inside "rerank-rounds" (wave 0's clock)
+            double r[5] = {0, 0, 0, 0, 0};
+            int64_t nr = 0;
+            for (int64_t q = 0; q < buf_B; ++q) {
+                const unsigned long long* t = &h[size_t(q) * 16];
+                if (!(t[12] && t[13] && t[14] && t[15]) || t[6] <= t[0]) continue;
+                r[0] += double(t[12] - t[3]); r[1] += double(t[13] - t[12]); r[2] += double(t[14] - t[13]); r[3] += double(t[15] - t[14]); r[4] += double(t[4] - t[15]);
+                ++nr;
+            }
+            if (nr) fprintf(stderr, "[select stamps]   inside rerank-rounds (%lld queries): wave 0's rounds=%.0f wait for the other waves=%.0f boundary rank=%.0f counting order=%.0f rest=%.0f\n",
+                            (long long)nr, r[0] / nr, r[1] / nr, r[2] / nr, r[3] / nr, r[4] / nr);
         }
         if (nt) fprintf(stderr, "[select stamps]   tail of %lld lazy queries: boundary-rank=%.0f keys=%.0f sort=%.0f fixup=%.0f\n", (long long)nt, tail[0] / nt, tail[1] / nt, tail[2] / nt, tail[3] / nt);
         if (n) fprintf(stderr, "[select stamps] queries=%lld cycles/query: load+minmax=%.0f rank-search=%.0f collect=%.0f rerank-rounds=%.0f sorts=%.0f emit=%.0f total=%.0f\n",
