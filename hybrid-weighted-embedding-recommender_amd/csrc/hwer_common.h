@@ -257,6 +257,34 @@ __device__ __forceinline__ void wave_sort_u64(uint64_t (&key)[NE]) {
         }
     }
 }
+// ONE key per lane, ascending over the lanes (lane l ends up with the l-th smallest): the 21 compare-exchange stages of the 64-input bitonic
+// network on DPP / permlane-swap exchanges.  With a single key per lane a stage has nothing to pipeline through the LDS crossbar, so the
+// VALU exchanges win here (the multi-key sort above keeps ds_bpermute).  Keys must be distinct or identical copies.
+template <int SIZE, int LM>
+__device__ __forceinline__ void wave_sort1_stage(uint64_t& key, int lane) {
+    const uint64_t o = lane_xor64<LM>(key);
+    const bool keep_min = ((lane & LM) == 0) == ((lane & SIZE) == 0);   // SIZE = 64: ascending everywhere
+    if ((o < key) == keep_min) key = o;
+}
+__device__ __forceinline__ void wave_sort1_u64(uint64_t& key) {
+    const int lane = threadIdx.x & (kWave - 1);
+    wave_sort1_stage<2, 1>(key, lane);
+    wave_sort1_stage<4, 2>(key, lane); wave_sort1_stage<4, 1>(key, lane);
+    wave_sort1_stage<8, 4>(key, lane); wave_sort1_stage<8, 2>(key, lane); wave_sort1_stage<8, 1>(key, lane);
+    wave_sort1_stage<16, 8>(key, lane); wave_sort1_stage<16, 4>(key, lane); wave_sort1_stage<16, 2>(key, lane); wave_sort1_stage<16, 1>(key, lane);
+    wave_sort1_stage<32, 16>(key, lane); wave_sort1_stage<32, 8>(key, lane); wave_sort1_stage<32, 4>(key, lane); wave_sort1_stage<32, 2>(key, lane);
+    wave_sort1_stage<32, 1>(key, lane);
+    wave_sort1_stage<64, 32>(key, lane); wave_sort1_stage<64, 16>(key, lane); wave_sort1_stage<64, 8>(key, lane); wave_sort1_stage<64, 4>(key, lane);
+    wave_sort1_stage<64, 2>(key, lane); wave_sort1_stage<64, 1>(key, lane);
+}
+// number of entries of an ascending run of 64 distinct keys (LDS) that are smaller than `key`: seven dependent probes
+__device__ __forceinline__ int run64_count_less(const uint64_t* run, uint64_t key) {
+    int idx = 0;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) idx += run[idx + s - 1] < key ? s : 0;
+    return idx + ((idx == 63 && run[63] < key) ? 1 : 0);
+}
+
 // The keys sorted above are (approximation << 32 | payload) with a MONOTONE approximation of the exact sort key, so
 // only runs of equal approximations can be out of order.  Detect such runs (rare) and finish them with odd-even
 // transposition passes under the exact comparator `ex_less(key_x, key_y)`.  Approximation 0xFFFFFFFF = padding.

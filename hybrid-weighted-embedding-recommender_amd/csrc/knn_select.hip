@@ -325,16 +325,18 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             SEL_STAMP(14);
             // unique keys: members by (approximate score, slot), everything else behind them by slot
             const uint64_t mykey = (uint64_t(member ? ~f32_orderable(float(t_sc[min(i, kp - 1)])) : 0xFFFFFFFFu) << 32) | uint64_t(uint32_t(i));
-            skeys[i] = mykey;
+            // Round 4: every wave sorts its 64 keys in registers (21 DPP / permlane-swap stages), the four ascending runs go to LDS and a key's
+            // position is its lane + its lower bounds in the three other runs (7 dependent probes each, the three searches interleaved): ~250
+            // instructions per wave where counting the smaller ones among all 256 keys took ~900 (128 broadcast reads, 256 64-bit compares) -
+            // stamps: 8.0 K -> ~2.5 K cycles of wave 0's chain per query.
+            uint64_t skey = mykey;
+            wave_sort1_u64(skey);
+            skeys[i] = skey;      // run w = skeys[64 w .. 64 w + 63]
             __syncthreads();
-            int pos = 0;
-#pragma unroll 8
-            for (int j = 0; j < 256; j += 2) {
-                const uint4 two = *reinterpret_cast<const uint4*>(skeys + j);   // broadcast read of two keys
-                const uint64_t k0 = (uint64_t(two.y) << 32) | two.x, k1 = (uint64_t(two.w) << 32) | two.z;
-                pos += (k0 < mykey ? 1 : 0) + (k1 < mykey ? 1 : 0);
-            }
-            sfinal[pos] = mykey;
+            int pos = lane;
+#pragma unroll
+            for (int w2 = 1; w2 < 4; ++w2) pos += run64_count_less(skeys + 64 * ((coop_wave + w2) & 3), skey);
+            sfinal[pos] = skey;
             __syncthreads();
             SEL_STAMP(15);
             presorted = true;
