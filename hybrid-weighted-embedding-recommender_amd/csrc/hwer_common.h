@@ -142,6 +142,37 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
+// wave-wide max / min / float64 sum (result in every lane) on the VALU lane exchanges above: six dependent steps of one or two moves
+// instead of six ds_bpermute round trips (~100 cycles each in a chain that has nothing else to issue); the butterfly order of __shfl_xor
+// reductions, so float64 sums are bit-identical to them
+__device__ __forceinline__ float wave_max_f32(float v) {
+    v = fmaxf(v, __uint_as_float(lane_xor32<1>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(lane_xor32<2>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(lane_xor32<4>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(lane_xor32<8>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(lane_xor32<16>(__float_as_uint(v))));
+    v = fmaxf(v, __uint_as_float(lane_xor32<32>(__float_as_uint(v))));
+    return v;
+}
+__device__ __forceinline__ float wave_min_f32(float v) {
+    v = fminf(v, __uint_as_float(lane_xor32<1>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(lane_xor32<2>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(lane_xor32<4>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(lane_xor32<8>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(lane_xor32<16>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(lane_xor32<32>(__float_as_uint(v))));
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += __longlong_as_double((long long)lane_xor64<1>((uint64_t)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<2>((uint64_t)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<4>((uint64_t)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<8>((uint64_t)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<16>((uint64_t)__double_as_longlong(v)));
+    v += __longlong_as_double((long long)lane_xor64<32>((uint64_t)__double_as_longlong(v)));
+    return v;
+}
+
 // inclusive prefix sum over the 64 lanes (lane i <- v[0] + ... + v[i]) in six DPP steps, no LDS traffic: Hillis-Steele inside the 16-lane
 // rows (row_shr never crosses a row: a lane whose source lies outside keeps `old` = 0), then lane 15 of rows 0 / 2 onto rows 1 / 3
 // (row_bcast:15) and lane 31 onto rows 2 and 3 (row_bcast:31).  tools/ubench/scan_test.hip checks it against a host prefix sum.

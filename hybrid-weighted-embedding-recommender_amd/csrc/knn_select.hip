@@ -201,6 +201,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         // (round 3: a second chunk of look-ahead - +16 VGPRs, 128 with a few spilled - measured slower: c2 search 0.155 -> 0.160 ms, c3 4.80 -> 4.99)
         float4 pre0 = *reinterpret_cast<const float4*>(src0), pre1 = *reinterpret_cast<const float4*>(src1);
         float4 pre2 = *reinterpret_cast<const float4*>(src2), pre3 = *reinterpret_cast<const float4*>(src3);
+        if (COOP && g0 == 0) SEL_STAMP(7);
 #pragma unroll 1
         for (int c = 0; c < n_chunks; ++c) {
             if (!abl_stage) {
@@ -217,6 +218,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 pre3 = *reinterpret_cast<const float4*>(src3 + o);
             }
             if (!abl_stage) wave_lds_sync();
+            if (COOP && g0 == 0 && c == 0) SEL_STAMP(8);
             float xv[RR_CW];
 #pragma unroll
             for (int t = 0; t < RR_CW / 4; ++t) {
@@ -275,6 +277,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 }
             }
         }
+        if (COOP && g0 == 0) SEL_STAMP(9);
         double sco;
         const float* xr = a.X + int64_t(it) * a.ldx;
         if constexpr (mode == 0) {
@@ -555,8 +558,7 @@ __global__ __launch_bounds__(256, 4) void select_rerank_kernel(const SelectArgs 
     {
         const double* q = a.emit.Q64 + b * d;
         for (int j = lane; j < d; j += 64) Q2 += q[j] * q[j];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
+        Q2 = wave_sum_f64(Q2);
     }
     const float e32 = e32_bound(d, Q2, a.hnorm_max) + a.key_rel_err * float(sqrt(Q2)) * sqrtf(2.0f * a.hnorm_max) * 1.0001f;
     const float thr = t_k - 2.0f * e32;
@@ -668,11 +670,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
             if (kv[m][c] > -INFINITY) vmin = fminf(vmin, kv[m][c]);
         }
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
-        vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
-    }
+    vmax = wave_max_f32(vmax);
+    vmin = wave_min_f32(vmin);
     // 2 x 64 counters of the histogram rank search below, in the (not yet used) distance table of the re-rank; zeroed ahead of the barrier
     int* const hist = reinterpret_cast<int*>(lds_emit);
     if constexpr (COOP) {   // extrema of the whole row: the four waves' values through LDS
@@ -745,7 +744,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
             const uint64_t m1 = __ballot(s1 >= k);
             if (m1 != 0ull) {   // (else: fewer than k keys - the probes' own handling below)
                 const int l1 = __builtin_ctzll(m1);
-                const int c_above = l1 ? __shfl(s1, l1 - 1, kWave) : 0;   // keys in coarser bins above the one that holds the k-th
+                const int c_above = l1 ? __builtin_amdgcn_readlane(s1, l1 - 1) : 0;   // keys in coarser bins above the one that holds the k-th
                 const int coarse = 63 - l1;
 #pragma unroll
                 for (int m = 0; m < MV; ++m) {
@@ -760,8 +759,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
                 int s2 = c_above + wave_incl_scan_i32(hist[64 + lane]);
                 const uint64_t m2 = __ballot(s2 >= k);   // never empty: the coarse bin holds the k-th key
                 const int l2 = __builtin_ctzll(m2);
-                const int n_lo = __shfl(s2, l2, kWave);                       // count(bin >= B*)
-                const int n_hi = l2 ? __shfl(s2, l2 - 1, kWave) : c_above;   // count(bin > B*) < k
+                const int n_lo = __builtin_amdgcn_readlane(s2, l2);                     // count(bin >= B*)
+                const int n_hi = l2 ? __builtin_amdgcn_readlane(s2, l2 - 1) : c_above;   // count(bin > B*) < k
                 const int bstar = coarse * 64 + 63 - l2;
                 float lo = INFINITY, hi = INFINITY;
 #pragma unroll
@@ -773,11 +772,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
                         hi = fminf(hi, bb > bstar ? kv[m][c] : INFINITY);
                     }
                 }
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    lo = fminf(lo, __shfl_xor(lo, off, kWave));
-                    hi = fminf(hi, __shfl_xor(hi, off, kWave));
-                }
+                lo = wave_min_f32(lo);
+                hi = wave_min_f32(hi);
                 if constexpr (COOP) {
                     if (lane == 0) { s_mm[wave] = lo; s_mm[4 + wave] = hi; }
                     __syncthreads();
@@ -805,8 +801,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     {
         const double* q = a.emit.Q64 + b * d;
         for (int j = lane; j < d; j += 64) Q2 += q[j] * q[j];
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) Q2 += __shfl_xor(Q2, off, kWave);
+        Q2 = wave_sum_f64(Q2);
     }
     const float e32 = e32_bound(d, Q2, a.hnorm_max) + a.key_rel_err * float(sqrt(Q2)) * sqrtf(2.0f * a.hnorm_max) * 1.0001f;
     const float thr = t_k - 2.0f * e32;
@@ -840,13 +835,8 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
         mine_b += __builtin_popcount(pass_b[w]);
         mine_s += __builtin_popcount(pass_s[w]);
     }
-    int incl = (mine_b << 16) | mine_s;   // inclusive scan over lanes of both counts at once (each < 2^15)
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl += t;
-    }
-    int tot = __shfl(incl, 63, kWave);
+    const int incl = wave_incl_scan_i32((mine_b << 16) | mine_s);   // inclusive scan over lanes of both counts at once (each < 2^15)
+    int tot = __builtin_amdgcn_readlane(incl, 63);
     int wave_off = 0;   // COOP: boundary / sure candidates of the waves before this one (packed like `incl`)
     if constexpr (COOP) {
         if (lane == 0) s_tot[wave] = tot;
@@ -1701,16 +1691,19 @@ static unsigned long long* sel_stamps_buffer(int64_t B) {
             fprintf(stderr, "%s\n", line.c_str());
         }
         {   // one-query-per-workgroup launches: inside "rerank-rounds" (wave 0's clock)
-            double r[5] = {0, 0, 0, 0, 0};
+            double r[5] = {0, 0, 0, 0, 0}, rr[4] = {0, 0, 0, 0};
             int64_t nr = 0;
             for (int64_t q = 0; q < buf_B; ++q) {
                 const unsigned long long* t = &h[size_t(q) * 16];
                 if (!(t[12] && t[13] && t[14] && t[15]) || t[6] <= t[0]) continue;
+                if (t[7] && t[8] && t[9]) { rr[0] += double(t[7] - t[3]); rr[1] += double(t[8] - t[7]); rr[2] += double(t[9] - t[8]); rr[3] += double(t[12] - t[9]); }
                 r[0] += double(t[12] - t[3]); r[1] += double(t[13] - t[12]); r[2] += double(t[14] - t[13]); r[3] += double(t[15] - t[14]); r[4] += double(t[4] - t[15]);
                 ++nr;
             }
             if (nr) fprintf(stderr, "[select stamps]   inside rerank-rounds (%lld queries): wave 0's rounds=%.0f wait for the other waves=%.0f boundary rank=%.0f counting order=%.0f rest=%.0f\n",
                             (long long)nr, r[0] / nr, r[1] / nr, r[2] / nr, r[3] / nr, r[4] / nr);
+            if (nr && rr[1] > 0) fprintf(stderr, "[select stamps]   inside wave 0's rounds: set-up + first gathers issued=%.0f until the first chunk is staged=%.0f rest of the chunk loop=%.0f score + table writes=%.0f\n",
+                                         rr[0] / nr, rr[1] / nr, rr[2] / nr, rr[3] / nr);
         }
         if (nt) fprintf(stderr, "[select stamps]   tail of %lld lazy queries: boundary-rank=%.0f keys=%.0f sort=%.0f fixup=%.0f\n", (long long)nt, tail[0] / nt, tail[1] / nt, tail[2] / nt, tail[3] / nt);
         if (n) fprintf(stderr, "[select stamps] queries=%lld cycles/query: load+minmax=%.0f rank-search=%.0f collect=%.0f rerank-rounds=%.0f sorts=%.0f emit=%.0f total=%.0f\n",
