@@ -244,11 +244,8 @@ __device__ __forceinline__ float wave_find_rank(const float (&v)[NV], int rank, 
         vmax = fmaxf(vmax, v[i]);
         if (v[i] > -INFINITY) vmin = fminf(vmin, v[i]);
     }
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        vmax = fmaxf(vmax, __shfl_xor(vmax, off, kWave));
-        vmin = fminf(vmin, __shfl_xor(vmin, off, kWave));
-    }
+    vmax = wave_max_f32(vmax);
+    vmin = wave_min_f32(vmin);
     return wave_find_rank_fn([&](float t) { return wave_count_ge<NV>(v, t); }, vmin, vmax, rank, slack, count_ge_lo, hi_out, tighten_hi);
 }
 

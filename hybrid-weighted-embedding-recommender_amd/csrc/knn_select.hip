@@ -974,14 +974,10 @@ __global__ __launch_bounds__(64 * REDW_WAVES, NVMAX <= 32 ? 3 : 1) void reduce_l
     const int n_streams = 2 * a.n_lists;   // <= 64: lane s owns stream s = (list s / 2, half s % 2)
     const int craw = lane < n_streams ? a.cnt_in[(int64_t(lane >> 1) * a.bq + b) * 2 + (lane & 1)] : 0;
     const int n = craw & ~CNT_FLAGS;
-    int flags = craw & CNT_FLAGS, incl = n;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        flags |= __shfl_xor(flags, off, kWave);
-        const int t = __shfl_up(incl, off, kWave);
-        if (lane >= off) incl += t;
-    }
-    const int M = __shfl(incl, 63, kWave);
+    int flags = craw & CNT_FLAGS;
+    flags = (__ballot((flags & CNT_UNDERFULL) != 0) ? CNT_UNDERFULL : 0) | (__ballot((flags & CNT_SEEDED_SHORT) != 0) ? CNT_SEEDED_SHORT : 0);   // OR over the lanes
+    const int incl = wave_incl_scan_i32(n);
+    const int M = __builtin_amdgcn_readlane(incl, 63);
     if (lane == 0) a.todo[b] = 0;   // (round 3: every query is finished here - the workgroup rounds are no longer launched behind this kernel)
     const int excl = incl - n;
     const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -1761,7 +1757,10 @@ static WsLayout ws_layout(const ScreenPlan& p, int64_t B) {
 
 // Up to this many queries a launch gives every query a whole workgroup (COOP): with fewer queries than ~2 waves per SIMD the
 // kernel's time is the serial chain of one wave, which the four waves of a workgroup split.
-constexpr int64_t COOP_MAX_QUERIES_DEFAULT = 2048;
+#ifndef HWER_COOP_MAX_QUERIES
+#define HWER_COOP_MAX_QUERIES 2048
+#endif
+constexpr int64_t COOP_MAX_QUERIES_DEFAULT = HWER_COOP_MAX_QUERIES;
 static int64_t coop_max_queries() {   // (diagnostic builds: HWER_COOP_MAX overrides)
     const char* e = diag_env("HWER_COOP_MAX");
     return e ? atoll(e) : COOP_MAX_QUERIES_DEFAULT;
