@@ -29,7 +29,9 @@ def _digest():
     for f in SOURCES + HEADERS + [os.path.abspath(__file__)]:
         with open(os.path.join(HERE, f) if not os.path.isabs(f) else f, "rb") as fh:
             h.update(fh.read())
-    h.update(" ".join(FLAGS).encode())
+    # (flags with the checkout's own location taken out: the digest of one source tree is the same wherever it is checked out - a GPU box runs
+    # the snapshot from a scratch path - so that the build stamp and the profiles' `library_digest` hold there as well)
+    h.update(" ".join(FLAGS).replace(ROOT, "<ROOT>").encode())
     return h.hexdigest()
 
 

@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 #ifndef HWER_PP_PREFETCH
 #define HWER_PP_PREFETCH 2   // A fragments requested this many k-steps ahead of their MFMAs (the MFMA segment has the pipe to itself)
 #endif
-template <int NG, int TQ>
+template <int NG, int TQ, bool FOLD>   // FOLD: the threshold folded into the accumulators (pass-mask launches); max-tree launches (a.sparse_hits) run <.., false>
 __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a) {
     constexpr int IB = 64, NSUB = 2, NSLOT = 3;
     constexpr int CH = NG;                          // 16-byte chunks per float16 row
@@ -803,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
         const int64_t q = qw0 + 32 * b + r;
         const bool live = q < a.B;
         e_tot[b] = a.x_exp + a.qexp[q];
-        nscale[b] = float2_t{-ldexpf(1.0f, e_tot[b]), -ldexpf(1.0f, e_tot[b])};
+        nscale[b] = float2_t{ldexpf(1.0f, e_tot[b]), ldexpf(1.0f, e_tot[b])};      // (+: the accumulators hold tau - key, see below)
         const float t0 = (a.tau0 && live) ? a.tau0[q] : a.debug_tau0;
         seeded[b] = a.tau0 != nullptr && live && t0 > -INFINITY;
         tau[b] = live ? ldexpf(t0, e_tot[b]) : INFINITY;
@@ -812,6 +812,31 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
         scaled[b] = false;
         soff[b] = (uint32_t(32 * b + r) * 2u + uint32_t(h)) * CAPH;
     }
+    // THE THRESHOLD LIVES IN THE ACCUMULATOR (round 4).  The query fragments are negated once, here, and a subtile's accumulators start at
+    // (half norm + tau) 2^e, so what the MFMAs leave is  tau' - key'  (scaled units): a key passes exactly when its accumulator is negative, the
+    // pass mask is the 32 sign bits (one v_alignbit each), and the 16 v_pk_add_f32 of "tau - key" per subtile are gone (packed float32 adds cost
+    // two issue slots each beside MFMAs; this loop's time is what its waves issue).  The key of a passing item is recovered as tau' - accumulator
+    // when it is appended (one subtraction per APPENDED key).  tau' is a key of the same query or absent: a lane whose threshold is still open
+    // (-inf: everything passes) folds 0 and forces its 16 mask bits (tau_or); a lane without a query (+inf: nothing passes) folds 3e38.
+    // Rounding: the partial sums are bounded by |tau'| + |key'| <= 2 (||q|| ||x||max + hnorm_max) instead of 1 x that, and the recovery rounds once
+    // more: (2 d + 7) u M to first order, inside the (2 d + 16) u M of the select stage's bound (knn_select.hip: e32_bound); keys that do NOT pass
+    // have tau' - acc <= tau' in this same arithmetic, which is all the certificate's "every item outside the list is below the list" needs.
+    // The max-tree filter of sparse launches (a.sparse_hits: one compare per 16 keys) has no subtraction to lose and keeps plain -key' accumulators:
+    // FOLD = false (the launcher picks the instantiation).
+    constexpr bool fold = FOLD;
+    float tau_f[TQ];
+    uint32_t tau_or = 0u;        // 16 forced mask bits per query subtile whose threshold is open
+    auto fold_tau = [&]() {
+        tau_or = 0u;
+#pragma unroll
+        for (int b = 0; b < TQ; ++b) {
+            const bool open_b = tau[b] == -INFINITY, dead_b = tau[b] == INFINITY;
+            // no query (+inf: nothing passes): a huge finite threshold - the lane's fragments are zero, its accumulators stay positive
+            tau_f[b] = open_b ? 0.f : (dead_b ? 3.0e38f : tau[b]);
+            if (open_b) tau_or |= 0xFFFFu << (16 * b);
+        }
+    };
+    fold_tau();
     const int64_t i_begin = int64_t(split) * a.split_items;
     const int64_t i_end = std::min<int64_t>(i_begin + a.split_items, a.n_items);
     const int n_tiles = int((i_end - i_begin + IB - 1) / IB);
@@ -855,6 +880,10 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
         for (int g = 0; g < NQF; ++g)
             qf[b][g] = reinterpret_cast<const half8_t*>(a.Qf16)[((qw0 / 32 + b) * NQF + g) * 64 + lane];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < TQ; ++b)
+#pragma unroll
+        for (int g = 0; g < NQF; ++g) qf[b][g] = -qf[b][g];      // accumulators = tau' - key' (above)
     // the fragments are made opaque HERE: the compiler then waits for their loads in front of this statement, not - per register, ending
     // in vmcnt(0), a drain of the pieces and appends in flight - inside the first MFMA segment of every tile
 #pragma unroll
@@ -896,11 +925,20 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                 const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
-                    const float2_t lo2 = float2_t{hv.x, hv.y} * nscale[b], hi2 = float2_t{hv.z, hv.w} * nscale[b];
-                    acc[b][4 * rg + 0] = lo2.x;
-                    acc[b][4 * rg + 1] = lo2.y;
-                    acc[b][4 * rg + 2] = hi2.x;
-                    acc[b][4 * rg + 3] = hi2.y;
+                    if constexpr (fold) {   // tau' - key': two v_pk_fma_f32 (four plain v_fma_f32 held apart by a compiler barrier measured 3 - 4 % slower)
+                        const float2_t tf2 = {tau_f[b], tau_f[b]};
+                        const float2_t lo2 = __builtin_elementwise_fma(float2_t{hv.x, hv.y}, nscale[b], tf2), hi2 = __builtin_elementwise_fma(float2_t{hv.z, hv.w}, nscale[b], tf2);
+                        acc[b][4 * rg + 0] = lo2.x;
+                        acc[b][4 * rg + 1] = lo2.y;
+                        acc[b][4 * rg + 2] = hi2.x;
+                        acc[b][4 * rg + 3] = hi2.y;
+                    } else {                // -key': exact scaling, two keys per v_pk_mul_f32
+                        const float2_t lo2 = float2_t{hv.x, hv.y} * nscale[b], hi2 = float2_t{hv.z, hv.w} * nscale[b];
+                        acc[b][4 * rg + 0] = lo2.x;
+                        acc[b][4 * rg + 1] = lo2.y;
+                        acc[b][4 * rg + 2] = hi2.x;
+                        acc[b][4 * rg + 3] = hi2.y;
+                    }
                 }
             }
             {
@@ -952,14 +990,18 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                 const uint32_t item0 = uint32_t(i0) + 4 * h;
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
-                    const float m0 = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]), m1 = fmaxf(fmaxf(acc[b][3], acc[b][4]), acc[b][5]);
-                    const float m2 = fmaxf(fmaxf(acc[b][6], acc[b][7]), acc[b][8]), m3 = fmaxf(fmaxf(acc[b][9], acc[b][10]), acc[b][11]);
-                    const float m4 = fmaxf(fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
-                    const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[b][15]));
-                    if (__any(mx > tau[b])) {
+                    const float m0 = fminf(fminf(acc[b][0], acc[b][1]), acc[b][2]), m1 = fminf(fminf(acc[b][3], acc[b][4]), acc[b][5]);
+                    const float m2 = fminf(fminf(acc[b][6], acc[b][7]), acc[b][8]), m3 = fminf(fminf(acc[b][9], acc[b][10]), acc[b][11]);
+                    const float m4 = fminf(fminf(acc[b][12], acc[b][13]), acc[b][14]);
+                    const float mn = fminf(fminf(fminf(m0, m1), m2), fminf(fminf(m3, m4), acc[b][15]));
+                    // (not folded: the accumulators hold -key', compared with -tau': +inf where the threshold is open, -inf where there is no query)
+                    // (folded accumulators - a diagnostic switch forcing the max tree onto a pass-mask launch - compare with 0; open thresholds
+                    // do not occur there: the switch needs seeded launches)
+                    const float ntau = fold ? 0.f : -tau[b];
+                    if (__any(mn < ntau)) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
-                            if (acc[b][q] > tau[b]) append(b, pack_key(ldexpf(acc[b][q], -e_tot[b]), item0 + (q & 3) + 8 * (q >> 2)));
+                            if (acc[b][q] < ntau) append(b, pack_key(ldexpf((fold ? tau_f[b] : 0.f) - acc[b][q], -e_tot[b]), item0 + (q & 3) + 8 * (q >> 2)));
                         }
                     }
                 }
@@ -967,23 +1009,20 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                 uint32_t mask = 0;
 #pragma unroll
                 for (int b = TQ - 1; b >= 0; --b) {
-                    if constexpr (HWER_PP_PK_MASKS) {
+                    if constexpr (fold) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[b][q]), 31);   // sign of tau' - key'
+                    } else {   // (only reached when a diagnostic switch forces the mask filter onto a max-tree launch)
                         const float2_t tau2 = {tau[b], tau[b]};
 #pragma unroll
                         for (int q = 0; q < 16; q += 2) {
-                            const float2_t df = tau2 - float2_t{acc[b][q], acc[b][q + 1]};
+                            const float2_t df = tau2 + float2_t{acc[b][q], acc[b][q + 1]};   // tau' - key' with -key' accumulators
                             mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.x), 31);
                             mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df.y), 31);
                         }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 16; ++q) {
-                            float df = tau[b] - acc[b][q];
-                            asm volatile("" : "+v"(df));      // (keeps the compiler from re-packing the subtractions into v_pk_add_f32)
-                            mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(df), 31);
-                        }
                     }
                 }
+                if constexpr (fold) mask |= tau_or;      // lanes with an open threshold
                 if (ABLATE(2)) mask = 0u;      // (diagnostic: masks computed, nothing popped)
                 if (__any(mask != 0u)) {
                     const uint32_t item0 = uint32_t(i0) + 4 * h;
@@ -1013,7 +1052,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                                 if (bits[j] >= 0) {
                                     const int q = 15 - (bits[j] & 15);
                                     const bool second = TQ == 2 && (bits[j] & 16) != 0;
-                                    const float kval = ldexpf(kv4[j], -(second ? e_tot[TQ - 1] : e_tot[0]));
+                                    const float kval = ldexpf((fold ? (second ? tau_f[TQ - 1] : tau_f[0]) : 0.f) - kv4[j], -(second ? e_tot[TQ - 1] : e_tot[0]));
                                     const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
                                     const uint32_t pos = second ? soff[TQ - 1] + uint32_t(cnt[TQ - 1]) : soff[0] + uint32_t(cnt[0]);
                                     if (!ABLATE(1)) wg_cand[pos] = key;
@@ -1030,7 +1069,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                             mask &= mask - 1u;
                             const int q = 15 - (bit & 15);
                             float kval = park[((bit & 16) + q) * 64];
-                            kval = ldexpf(kval, -((TQ == 2 && (bit & 16)) ? e_tot[TQ - 1] : e_tot[0]));
+                            kval = ldexpf((fold ? ((TQ == 2 && (bit & 16)) ? tau_f[TQ - 1] : tau_f[0]) : 0.f) - kval, -((TQ == 2 && (bit & 16)) ? e_tot[TQ - 1] : e_tot[0]));
                             const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
                             if constexpr (TQ == 1) {
                                 append(0, key);
@@ -1047,6 +1086,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
 #pragma unroll
                 for (int b = 0; b < TQ; ++b) {
                     uint64_t need = __ballot(cnt[b] > CAPH - 32);
+                    const bool refold = need != 0ull;      // (wave-uniform) a compaction sets a lane's threshold: fold it again
                     while (need != 0ull) {
                         const int jj = (__builtin_ctzll(need)) & 31;
                         const int c0 = __shfl(cnt[b], jj, kWave), c1 = __shfl(cnt[b], jj + 32, kWave);
@@ -1069,6 +1109,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                         }
                         need &= ~((1ull << jj) | (1ull << (jj + 32)));
                     }
+                    if (refold) fold_tau();
                 }
             }
             if (DIAG_STAMPS) { pt4 = stamp(); pa_w1 += pt1 - pt0; pa_mfma += pt2 - pt1; pa_filt += pt4 - pt3; }
@@ -1336,12 +1377,18 @@ static int launch_screen16_pp_t(const ScreenPlan& plan, const ScreenArgs& a, hip
     static uint64_t attr_done = 0;   // per device
     int dev;
     if (attr_pending(attr_done, &dev)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen16_pp_kernel<NG, TQ>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen16_pp_kernel<NG, TQ, true>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&screen16_pp_kernel<NG, TQ, false>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
         if (e != hipSuccess) return fail(HWER_ELAUNCH, "knn_screen16_pp: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done |= 1ull << dev;
     }
     const int grid = (plan.n_qblocks / 2) * plan.n_splits;
-    hipLaunchKernelGGL((screen16_pp_kernel<NG, TQ>), dim3(grid), dim3(512), lds, stream, a);
+    // pass-mask launches fold the threshold into the accumulators; max-tree launches (sparse_hits) have nothing to gain from it
+#ifndef HWER_PP_FOLD_TQ1
+#define HWER_PP_FOLD_TQ1 0      // one query subtile per wave (d = 256): 8 v_pk_add_f32 saved against 8 v_pk_mul_f32 -> v_pk_fma_f32: measured 3 - 6 % slower
+#endif
+    if (a.sparse_hits || (TQ == 1 && !HWER_PP_FOLD_TQ1)) hipLaunchKernelGGL((screen16_pp_kernel<NG, TQ, false>), dim3(grid), dim3(512), lds, stream, a);
+    else hipLaunchKernelGGL((screen16_pp_kernel<NG, TQ, true>), dim3(grid), dim3(512), lds, stream, a);
     return check_launch("knn_screen16_pp");
 }
 

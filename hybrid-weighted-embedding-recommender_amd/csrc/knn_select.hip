@@ -122,6 +122,10 @@ __host__ __device__ inline size_t coop_lds_bytes(int d, int kp) { return wave_ld
 __device__ __forceinline__ float e32_bound(int d, double Q2, float hnorm_max) {
     // |key32 - (q.x - 0.5||x||^2)| <= E32 for every item: fmaf chain of d+1 terms, float32 rounding of q and of the
     // half norm.  Generous constant factor; typical errors are ~100x smaller.
+    // With M = ||q|| ||x||max + hnorm_max the first-order error of the plain chain is (d + 3) u M (d + 1 additions on partial sums <= M, the
+    // roundings of q and of the half norm).  The ping-pong screen's folded form (knn_screen.hip: the accumulator runs tau' - key', the key is
+    // recovered as tau' - accumulator) has partial sums <= |tau'| + M <= 2 M (tau' is a key of the same query) over d + 2 additions and one more
+    // rounding in the recovery: (2 d + 7) u M - still inside the (2 d + 16) u M used here, whose second-order remainder (d u)^2 M is 1e-9 M.
     const double u = 5.9604644775390625e-08;  // 2^-24
     const double xn = sqrt(2.0 * double(hnorm_max)) * (1.0 + 1e-6);
     return float((2.0 * d + 16.0) * u * (sqrt(Q2) * xn + double(hnorm_max)) * (1.0 + 1e-6));
