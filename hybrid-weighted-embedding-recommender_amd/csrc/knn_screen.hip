@@ -1027,10 +1027,16 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                 if (__any(mask != 0u)) {
                     const uint32_t item0 = uint32_t(i0) + 4 * h;
                     float* park = keypark + lane;
+                    // (only the query subtiles that have a passing key are parked: on a 1.25 M-row shard a subtile of a wave has a hit 57 % of the time -
+                    // c4 screen -1.5 %.  Measured with it and left out: the second subtile's accumulator set-up inside the first subtile's burst (second
+                    // accumulator set) +-0; the fragments' swizzled offsets kept in registers: +-0, c4full +0.7 % - both sit in the MFMAs' shadow already)
 #pragma unroll
-                    for (int b = 0; b < TQ; ++b)
+                    for (int b = 0; b < TQ; ++b) {
+                        if (TQ == 1 || a.many_hits || __any(((mask >> (16 * b)) & 0xFFFFu) != 0u)) {
 #pragma unroll
-                        for (int q = 0; q < 16; ++q) park[(16 * b + q) * 64] = acc[b][q];
+                            for (int q = 0; q < 16; ++q) park[(16 * b + q) * 64] = acc[b][q];
+                        }
+                    }
                     if (ABLATE(8)) mask = 0u;  // (diagnostic: masks + park, no pops)
                     if (a.many_hits) {
                         // (wave-uniform) many passing keys per subtile (single-list plans: c3 lets 2.25 K' keys of a 26 744-row catalogue through -
