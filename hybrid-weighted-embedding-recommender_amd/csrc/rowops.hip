@@ -1042,8 +1042,11 @@ __device__ __forceinline__ void blend_query_body(const BlendArgs& a, const Query
     }
 }
 
+#ifndef HWER_PROLOGUE_MINWAVES
+#define HWER_PROLOGUE_MINWAVES 1
+#endif
 template <typename T, int U>
-__global__ __launch_bounds__(256) void blend_prepare_search_kernel(const BlendArgs ba, const RowRange pack, const RowRange other, const RowNormArgs pk,
+__global__ __launch_bounds__(256, HWER_PROLOGUE_MINWAVES) void blend_prepare_search_kernel(const BlendArgs ba, const RowRange pack, const RowRange other, const RowNormArgs pk,
                                                                    const QueryMixArgs qa, int n_pack_blocks, int n_other_blocks, int wpb, int gq) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int blk = int(blockIdx.x);
