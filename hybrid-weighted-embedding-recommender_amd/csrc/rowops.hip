@@ -1042,6 +1042,8 @@ __device__ __forceinline__ void blend_query_body(const BlendArgs& a, const Query
     }
 }
 
+// (experiment switch: waves per SIMD the compiler must make room for.  5 / 6 instead of the 4 the kernel's 121 VGPRs allow: the QUERY role's float64
+// arithmetic sets that number, and capping it spills in the row-streaming roles too - c4 0.47 -> 0.55 / 0.82 ms, profiles/r4_ab_pingpong.txt)
 #ifndef HWER_PROLOGUE_MINWAVES
 #define HWER_PROLOGUE_MINWAVES 1
 #endif
