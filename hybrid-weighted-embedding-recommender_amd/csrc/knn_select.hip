@@ -1813,7 +1813,94 @@ static int launch_select_rerank(const SelectArgs& sa, int d, int score_mode, hip
     return check_launch("knn_select");
 }
 
+// ---- self-test of the wave primitives (hwer_selftest_wave_ops) -------------------------------------------------------------------------
+namespace hwer {
+__global__ __launch_bounds__(64) void selftest_wave_ops_kernel(const int* in_i, const uint64_t* in_k, const float* in_f, const double* in_d, int* out_scan,
+                                                               uint64_t* out_sorted, int* out_lb, float* out_mm, double* out_sum) {
+    __shared__ uint64_t run[64];
+    const int w = blockIdx.x, lane = threadIdx.x, i = w * 64 + lane;
+    out_scan[i] = wave_incl_scan_i32(in_i[i]);
+    uint64_t key = in_k[i];
+    wave_sort1_u64(key);
+    out_sorted[i] = key;
+    run[lane] = key;
+    __syncthreads();
+    out_lb[i] = run64_count_less(run, in_k[(w ^ 1) * 64 + lane]);      // lower bounds of the NEIGHBOUR wave's keys in this wave's sorted run
+    out_mm[2 * i] = wave_max_f32(in_f[i]);
+    out_mm[2 * i + 1] = wave_min_f32(in_f[i]);
+    out_sum[i] = wave_sum_f64(in_d[i]);
+}
+}  // namespace hwer
+
 extern "C" {
+
+int hwer_selftest_wave_ops(int n_waves, unsigned seed) {
+    if (n_waves < 2 || (n_waves & 1) || n_waves > 4096) return fail(HWER_EINVAL, "selftest_wave_ops: n_waves must be even, 2 .. 4096");
+    const size_t n = size_t(n_waves) * 64;
+    std::vector<int> hi(n), sc(n), lb(n);
+    std::vector<uint64_t> hk(n), so(n);
+    std::vector<float> hf(n), mm(2 * n);
+    std::vector<double> hd(n), su(n);
+    uint64_t st = 0x9E3779B97F4A7C15ull ^ seed;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+    for (size_t i = 0; i < n; ++i) {
+        hi[i] = int(rnd() % 2001) - 1000;
+        hk[i] = rnd();
+        hf[i] = float(int(rnd() % 200001) - 100000) * 1e-3f;
+        hd[i] = double(int64_t(rnd() % 2000001) - 1000000) * 1e-7;
+    }
+    for (size_t i = 0; i < n; ++i) hk[i] = (hk[i] & ~uint64_t(127)) | uint64_t(i & 127);      // distinct keys inside every pair of waves (128 lanes)
+    void *d_i, *d_k, *d_f, *d_d, *o_sc, *o_so, *o_lb, *o_mm, *o_su;
+    bool ok = hipMalloc(&d_i, n * 4) == hipSuccess && hipMalloc(&d_k, n * 8) == hipSuccess && hipMalloc(&d_f, n * 4) == hipSuccess && hipMalloc(&d_d, n * 8) == hipSuccess &&
+              hipMalloc(&o_sc, n * 4) == hipSuccess && hipMalloc(&o_so, n * 8) == hipSuccess && hipMalloc(&o_lb, n * 4) == hipSuccess && hipMalloc(&o_mm, n * 8) == hipSuccess &&
+              hipMalloc(&o_su, n * 8) == hipSuccess;
+    if (!ok) return fail(HWER_ELAUNCH, "selftest_wave_ops: hipMalloc failed");
+    (void)hipMemcpy(d_i, hi.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_k, hk.data(), n * 8, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_f, hf.data(), n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_d, hd.data(), n * 8, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(selftest_wave_ops_kernel, dim3(unsigned(n_waves)), dim3(64), 0, nullptr, static_cast<const int*>(d_i), static_cast<const uint64_t*>(d_k),
+                       static_cast<const float*>(d_f), static_cast<const double*>(d_d), static_cast<int*>(o_sc), static_cast<uint64_t*>(o_so), static_cast<int*>(o_lb),
+                       static_cast<float*>(o_mm), static_cast<double*>(o_su));
+    int rc = check_launch("selftest_wave_ops");
+    if (rc == HWER_OK && hipDeviceSynchronize() != hipSuccess) rc = fail(HWER_ELAUNCH, "selftest_wave_ops: kernel failed");
+    if (rc == HWER_OK) {
+        (void)hipMemcpy(sc.data(), o_sc, n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(so.data(), o_so, n * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(lb.data(), o_lb, n * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(mm.data(), o_mm, n * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(su.data(), o_su, n * 8, hipMemcpyDeviceToHost);
+        for (int w = 0; w < n_waves && rc == HWER_OK; ++w) {
+            const size_t b = size_t(w) * 64;
+            std::vector<uint64_t> ref(hk.begin() + b, hk.begin() + b + 64);
+            std::sort(ref.begin(), ref.end());
+            int run_sum = 0;
+            float fmx = hf[b], fmn = hf[b];
+            for (int l = 0; l < 64; ++l) { fmx = std::max(fmx, hf[b + l]); fmn = std::min(fmn, hf[b + l]); }
+            // the butterfly order of the float64 sum: pairs at distance 1, 2, 4, ... (every lane ends with the same value)
+            double bf[64];
+            for (int l = 0; l < 64; ++l) bf[l] = hd[b + l];
+            for (int off = 1; off < 64; off <<= 1) {
+                double nx[64];
+                for (int l = 0; l < 64; ++l) nx[l] = bf[l] + bf[l ^ off];
+                for (int l = 0; l < 64; ++l) bf[l] = nx[l];
+            }
+            for (int l = 0; l < 64 && rc == HWER_OK; ++l) {
+                run_sum += hi[b + l];
+                const uint64_t other = hk[size_t(w ^ 1) * 64 + l];
+                const int want_lb = int(std::lower_bound(ref.begin(), ref.end(), other) - ref.begin());
+                if (sc[b + l] != run_sum) rc = fail(HWER_EINVAL, "selftest_wave_ops: scan wave %d lane %d: %d != %d", w, l, sc[b + l], run_sum);
+                else if (so[b + l] != ref[l]) rc = fail(HWER_EINVAL, "selftest_wave_ops: sort wave %d lane %d", w, l);
+                else if (lb[b + l] != want_lb) rc = fail(HWER_EINVAL, "selftest_wave_ops: lower bound wave %d lane %d: %d != %d", w, l, lb[b + l], want_lb);
+                else if (mm[2 * (b + l)] != fmx || mm[2 * (b + l) + 1] != fmn) rc = fail(HWER_EINVAL, "selftest_wave_ops: max / min wave %d lane %d", w, l);
+                else if (su[b + l] != bf[l]) rc = fail(HWER_EINVAL, "selftest_wave_ops: float64 sum wave %d lane %d: %.17g != %.17g", w, l, su[b + l], bf[l]);
+            }
+        }
+    }
+    for (void* p_ : {d_i, d_k, d_f, d_d, o_sc, o_so, o_lb, o_mm, o_su}) (void)hipFree(p_);
+    return rc;
+}
+
 
 int hwer_knn_max_k(void) { return K_MAX; }
 int hwer_knn_max_dim(void) { return 256; }

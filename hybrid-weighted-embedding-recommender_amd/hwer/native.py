@@ -18,6 +18,7 @@ PROTOTYPES = {
     "hwer_abi_version": (c_int, []),
     "hwer_last_error": (c_char_p, []),
     "hwer_stream_synchronize": (c_int, [_P]),
+    "hwer_selftest_wave_ops": (c_int, [c_int, ctypes.c_uint]),
     "hwer_profile_enable": (c_int, [c_int]),
     "hwer_profile_read": (c_int, [c_int, _P, _P]),
     "hwer_pair_score_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),

@@ -43,6 +43,11 @@ int hwer_stream_synchronize(void* stream);
  * (n = 0: off).  hwer_profile_read sums the bracketed durations, reports how many there were, and clears. */
 int hwer_profile_enable(int on);
 int hwer_profile_read(int which, double* total_ms, int64_t* launches);
+/* Self-test of the wave-level primitives the select kernels are built from since round 4 (csrc/hwer_common.h: the DPP prefix scan, the
+ * one-key-per-lane register sort, the lower bound in a sorted run, the DPP max / min / float64 sum): `n_waves` waves of seeded pseudo-random
+ * lane values on the device, every result checked on the host against a plain loop.  Returns HWER_OK, or HWER_EINVAL with the first
+ * mismatch in hwer_last_error().  Test infrastructure (the driver-run GPU suite calls it); synchronises the device. */
+int hwer_selftest_wave_ops(int n_waves, unsigned seed);
 
 /* ---------------------------------------------------------------------------------------------------
  * K1+K2  pair scoring — replaces RecommendationBase.predict, hwer/recommendation_base.py:135-144

@@ -378,3 +378,56 @@ def test_rank_metrics_kernel_equals_the_numpy_expressions(hw, B, V, seed):
     for j, c in enumerate(cuts):
         assert got[j] == validation.recall_rows(hitbits, n_pred, n_true, c), ("recall", c)
         assert got[len(cuts) + j] == validation.binary_ndcg_rows(hitbits, n_pred, n_true, c), ("ndcg", c)
+
+
+# ------------------------------------------------------------------------------------------------- round 4, second half: the select's new building blocks
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_wave_primitives_selftest(hw, seed):
+    """hwer_selftest_wave_ops: the DPP prefix scan, the one-key-per-lane register sort, the lower bound in a sorted run and the DPP max / min /
+    float64 sum (csrc/hwer_common.h) on 512 waves of seeded lane values, each checked on the host against a plain loop (the float64 sum against
+    the butterfly order the kernels' bit-exact results rely on)."""
+    from hwer import native
+    native.check(native.lib().hwer_selftest_wave_ops(512, seed), "selftest_wave_ops")
+
+
+def _tie_heavy_rows(rng, n, d, kind):
+    """item tables that stress the histogram rank search of the dense select (knn_select.hip): 'dups' = 20 prototypes repeated (exact ties fill
+    single bins: more than 12 keys per bin -> the counting probes take over, then the certificate fails -> exhaustive pass); 'clusters' = the same
+    prototypes + 1e-4 noise (hundreds of distinct keys inside one 1/4096 of the key range); 'outlier' = unit rows + ONE row of norm 40 (the key range
+    is set by it: every other key lands in a handful of bins)"""
+    if kind == "outlier":
+        x = rng.standard_normal((n, d))
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+        x[n // 3] *= 40.0
+        return x.astype(np.float32)
+    proto = rng.standard_normal((20, d))
+    proto /= np.linalg.norm(proto, axis=1, keepdims=True)
+    x = proto[rng.integers(0, 20, n)]
+    if kind == "clusters":
+        x = x + 1e-4 * rng.standard_normal((n, d))
+        x /= np.linalg.norm(x, axis=1, keepdims=True)
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize("B,N,d,k,kind", [(64, 2000, 64, 200, "dups"), (64, 2000, 64, 200, "clusters"), (300, 1682, 64, 200, "outlier"), (5, 8192, 128, 392, "clusters"),
+                                          (2500, 1500, 32, 50, "clusters"), (2500, 2048, 64, 200, "outlier"), (1, 700, 16, 1, "dups"), (40, 4000, 128, 100, "dups")])
+def test_dense_select_rank_search_under_ties_and_clusters(hw, B, N, d, k, kind):
+    """The dense select's two-round histogram bracket (round 4) where it cannot finish by itself: exact duplicates, tight clusters, a key range
+    blown up by one outlier - one query per workgroup (B <= 2 048) and the wave-per-query form (rows up to 2 048 keys), float64 flavour with
+    distances: ids, scores and distances == the C oracle for every query, flags in {1, 2}."""
+    from hwer.device_index import DeviceIndex
+    rng = np.random.default_rng(B * 7 + N + d + len(kind))
+    items = _tie_heavy_rows(rng, N, d, kind)
+    users = rng.standard_normal((B, d))
+    users /= np.linalg.norm(users, axis=1, keepdims=True)
+    users = users.astype(np.float32)
+    if kind != "outlier":
+        users[::3] = items[rng.integers(0, N, len(users[::3]))]      # queries that ARE catalogue rows: distance 0 to a whole cluster
+    V = np.concatenate([users, items]).astype(np.float64)
+    ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}, arith=0, audit=False)
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k, want_dist=True)
+    assert ((flags == 1) | (flags == 2)).all()
+    Q64, _, _ = ix.build_queries(np.arange(B))
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(items, Q64.cpu().numpy(), V[:B], k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(idx, o_idx + B)
+    assert np.array_equal(score, o_sc) and np.array_equal(dist, np.sqrt(o_d2))
