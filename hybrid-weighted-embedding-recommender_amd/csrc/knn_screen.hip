@@ -776,6 +776,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
     float* hn = xs + NSLOT * IB * CH * 4;                                   // [NSLOT][IB]
     float* keypark_all = hn + NSLOT * IB;                                   // [8][64][16 * TQ]
     int* tok = reinterpret_cast<int*>(keypark_all + 8 * 64 * 16 * TQ);      // [4]: whose turn it is on the matrix pipe of SIMD (wave & 3)
+    float* hpriv_all = reinterpret_cast<float*>(tok + 4);                   // [8][TQ][64]: UNI - the tile's half norms in the wave's key units, one copy per query subtile
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int role = wave >> 2;       // 0: waves 0-3, 1: their SIMD partners 4-7 (one barrier behind)
@@ -798,11 +799,52 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
     bool first[TQ], scaled[TQ], seeded[TQ];
     uint32_t soff[TQ];
     uint64_t* const wg_cand = a.cand + ((int64_t(list) * a.bq + qw0) * 2) * CAPH;
+    // UNI (launches that do not fold the threshold; round 4): ONE key exponent per wave.  The float16 fragments of a query are scaled by the
+    // query's own power of two (its largest element in [2^13, 2^14)); scaled down further to the smallest exponent of the wave's queries they keep
+    // every bit (float16 is floating point; the shift is at most 10 binades, so an element would have to be 2^-17 of its row's largest to leave the
+    // normal range) - and then the accumulators' initial value, half norm x 2^e, is the same for every lane: each wave scales a tile's 64 half norms
+    // ONCE (one multiply per lane and tile) into a private LDS row, and a subtile's set-up is eight ds_read_b128 straight into the accumulators
+    // instead of four reads + 16 v_pk_mul_f32.  A wave whose queries' exponents differ by more than 10 keeps the per-lane scaling.
+#ifndef HWER_PP_UNIFORM_EXP
+#define HWER_PP_UNIFORM_EXP 1
+#endif
+
+    // (one query subtile per wave only: with two, eight LDS reads - or four reads and sixteen register copies - in front of every burst measured
+    // 3 - 6 % SLOWER than four reads + 16 v_pk_mul_f32 on the 10 M-row launch; with one - d = 256 - the screen stage gains 4.6 %)
+    constexpr bool UNI = HWER_PP_UNIFORM_EXP && !FOLD && TQ == 1;
+    bool uni = false;      // (wave-uniform)
+    int delta[TQ];
+#pragma unroll
+    for (int b = 0; b < TQ; ++b) {
+        e_tot[b] = a.x_exp + a.qexp[qw0 + 32 * b + r];
+        delta[b] = 0;
+    }
+    if constexpr (UNI) {
+        int emin = 0x7FFFFFFF, emax = -0x7FFFFFFF;
+#pragma unroll
+        for (int b = 0; b < TQ; ++b) {
+            if (qw0 + 32 * b + r < a.B) { emin = min(emin, e_tot[b]); emax = max(emax, e_tot[b]); }
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            emin = min(emin, __shfl_xor(emin, off, kWave));
+            emax = max(emax, __shfl_xor(emax, off, kWave));
+        }
+        uni = emin != 0x7FFFFFFF && emax - emin <= 10;
+        if (uni) {
+#pragma unroll
+            for (int b = 0; b < TQ; ++b) {
+                delta[b] = (qw0 + 32 * b + r < a.B) ? e_tot[b] - emin : 0;
+                e_tot[b] = emin;
+            }
+        }
+    }
+    float* const hpriv = hpriv_all + wave * (TQ * 64);
+    const float hscale_w = ldexpf(1.0f, e_tot[0]);      // (UNI: the wave's key units)
 #pragma unroll
     for (int b = 0; b < TQ; ++b) {
         const int64_t q = qw0 + 32 * b + r;
         const bool live = q < a.B;
-        e_tot[b] = a.x_exp + a.qexp[q];
         nscale[b] = float2_t{ldexpf(1.0f, e_tot[b]), ldexpf(1.0f, e_tot[b])};      // (+: the accumulators hold tau - key, see below)
         const float t0 = (a.tau0 && live) ? a.tau0[q] : a.debug_tau0;
         seeded[b] = a.tau0 != nullptr && live && t0 > -INFINITY;
@@ -884,6 +926,14 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
     for (int b = 0; b < TQ; ++b)
 #pragma unroll
         for (int g = 0; g < NQF; ++g) qf[b][g] = -qf[b][g];      // accumulators = tau' - key' (above)
+    if (UNI && uni) {
+#pragma unroll
+        for (int b = 0; b < TQ; ++b) {
+            const _Float16 down = (_Float16)ldexpf(1.0f, -delta[b]);      // (2^0 ... 2^-10: exact)
+#pragma unroll
+            for (int g = 0; g < NQF; ++g) qf[b][g] = qf[b][g] * down;
+        }
+    }
     // the fragments are made opaque HERE: the compiler then waits for their loads in front of this statement, not - per register, ending
     // in vmcnt(0), a drain of the pieces and appends in flight - inside the first MFMA segment of every tile
 #pragma unroll
@@ -913,6 +963,12 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
         const float* hb_tile = hn + slot * IB;
         const int64_t i0_tile = i_begin + int64_t(p_cur) * IB;
         p_cur = perm_next(p_cur);
+        if (UNI && uni) {      // (tile t is complete in LDS: this wave has passed tile t - 1's barrier)
+            const float hs = hb_tile[lane] * hscale_w;
+#pragma unroll
+            for (int b = 0; b < TQ; ++b) hpriv[64 * b + lane] = hs;
+            wave_lds_sync();
+        }
 #pragma unroll
         for (int sub = 0; sub < NSUB; ++sub) {
             const float* xb = xb_tile + sub * 32 * CH * 4;
@@ -920,6 +976,18 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
             const int64_t i0 = i0_tile + 32 * sub;
             // ---- accumulator set-up and the first fragments: before the token ----------------------------------------------
             f32x16 acc[TQ];
+            if (UNI && uni) {      // (wave-uniform) the scaled half norms straight into the accumulators
+#pragma unroll
+                for (int b = 0; b < TQ; ++b)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const float4 hv = *reinterpret_cast<const float4*>(hpriv + 64 * b + 32 * sub + 8 * rg + 4 * h);
+                        acc[b][4 * rg + 0] = hv.x;
+                        acc[b][4 * rg + 1] = hv.y;
+                        acc[b][4 * rg + 2] = hv.z;
+                        acc[b][4 * rg + 3] = hv.w;
+                    }
+            } else
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const float4 hv = *reinterpret_cast<const float4*>(hb + 8 * rg + 4 * h);
@@ -1378,8 +1446,8 @@ static int launch_screen16_t(const ScreenPlan& plan, const ScreenArgs& a, hipStr
 
 template <int NG, int TQ>
 static int launch_screen16_pp_t(const ScreenPlan& plan, const ScreenArgs& a, hipStream_t stream) {
-    // ring 3 x 64 rows x (NG * 16 B) | half norms 3 x 64 | key park 8 x 64 x 16 TQ | 4 tokens
-    const size_t lds = size_t(3) * 64 * NG * 16 + size_t(3) * 64 * 4 + size_t(8) * 64 * 16 * TQ * 4 + 16;
+    // ring 3 x 64 rows x (NG * 16 B) | half norms 3 x 64 | key park 8 x 64 x 16 TQ | 4 tokens | the waves' scaled half norms
+    const size_t lds = size_t(3) * 64 * NG * 16 + size_t(3) * 64 * 4 + size_t(8) * 64 * 16 * TQ * 4 + 16 + size_t(8) * TQ * 64 * 4;   // ... | 8 x TQ x 64 scaled half norms
     static uint64_t attr_done = 0;   // per device
     int dev;
     if (attr_pending(attr_done, &dev)) {

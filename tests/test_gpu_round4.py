@@ -431,3 +431,33 @@ def test_dense_select_rank_search_under_ties_and_clusters(hw, B, N, d, k, kind):
     o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(items, Q64.cpu().numpy(), V[:B], k, threads=c_oracle.effective_cpus())
     assert np.array_equal(idx, o_idx + B)
     assert np.array_equal(score, o_sc) and np.array_equal(dist, np.sqrt(o_d2))
+
+
+@pytest.mark.parametrize("B,N,d,k", [(1100, 9000, 256, 100), (1500, 9000, 128, 200), (2100, 8200, 64, 50)])
+def test_streaming_screen_with_queries_of_mixed_magnitudes(hw, B, N, d, k):
+    """The float16 streaming screen's per-wave key exponent (round 4: one query subtile per wave rescales its fragments to the smallest exponent of
+    its 32 queries and sets the accumulators up from pre-scaled half norms; a wave whose exponents spread over more than 10 binades keeps the
+    per-lane scaling) and the folded threshold, under queries the unit-norm callers never produce: norms log-uniform over 1e-6 ... 1, shuffled so
+    that every 32-query block mixes them - DeviceIndex.search_queries on arbitrary query rows (the C ABI takes any Q), GcnNCF-style distance
+    scoring: ids, scores and distances == the C oracle for every query, flags in {1, 2}."""
+    import torch
+    from hwer.device_index import DeviceIndex
+    rng = np.random.default_rng(B + N + d)
+    items = unit_rows_f32(3, N, d)
+    Q = rng.standard_normal((B, d))
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    Q *= np.exp(rng.uniform(np.log(1e-6), 0.0, size=(B, 1)))
+    Q[::5] = items[rng.integers(0, N, len(Q[::5]))]          # some queries ARE catalogue rows (distance 0)
+    Q32 = Q.astype(np.float32)
+    Q64 = Q32.astype(np.float64)
+    V = np.concatenate([np.zeros((1, d), np.float32), items]).astype(np.float64)
+    V[0, 0] = 1.0
+    ix = DeviceIndex(V, {"user": np.arange(1, dtype=np.int64), "item": np.arange(1, 1 + N, dtype=np.int64)}, arith=0, audit=False)
+    dev = ix.device
+    idx, score, dist2, flags = ix.search_queries("item", torch.from_numpy(Q64).to(dev), torch.from_numpy(np.ascontiguousarray(Q32)).to(dev), k, score_mode=2)
+    flags = flags.cpu().numpy()
+    assert ((flags == 1) | (flags == 2)).all()
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(items, Q64, None, k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(idx.cpu().numpy(), o_idx + 1)
+    assert np.array_equal(dist2.cpu().numpy(), o_d2)
+    assert np.array_equal(score.cpu().numpy(), (2.0 - np.sqrt(o_d2)) / 2.0)
