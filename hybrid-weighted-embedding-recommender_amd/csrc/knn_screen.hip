@@ -479,13 +479,16 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                     for (int b = 0; b < TQ; ++b)
 #pragma unroll
                         for (int q = 0; q < 16; ++q) {
+                            // insertion into the sorted four as ONE max and THREE medians of the OLD values (t0 >= t1 >= t2 >= t3: the new t_j is the
+                            // median of t_(j-1), t_j and x) - four independent instructions per key where the max / min chain took seven; the wave-level
+                            // "any lane improves" test in front of it is gone: with 64 lanes it was true for nearly every key (round 4: the pre-pass
+                            // spent ~290 vector instructions per 32-row tile on this against the MFMAs' 16)
                             const float x = acc[b][q];
-                            if (__any(x > top[b][3])) {   // rare after the first tiles: a lane's 4th best rises quickly
-                                const float m0 = fmaxf(top[b][0], x), r0 = fminf(top[b][0], x);
-                                const float m1 = fmaxf(top[b][1], r0), r1 = fminf(top[b][1], r0);
-                                const float m2 = fmaxf(top[b][2], r1), r2 = fminf(top[b][2], r1);
-                                top[b][0] = m0; top[b][1] = m1; top[b][2] = m2; top[b][3] = fmaxf(top[b][3], r2);
-                            }
+                            const float n0 = fmaxf(top[b][0], x);
+                            const float n1 = __builtin_amdgcn_fmed3f(top[b][0], top[b][1], x);
+                            const float n2 = __builtin_amdgcn_fmed3f(top[b][1], top[b][2], x);
+                            const float n3 = __builtin_amdgcn_fmed3f(top[b][2], top[b][3], x);
+                            top[b][0] = n0; top[b][1] = n1; top[b][2] = n2; top[b][3] = n3;
                         }
                 } else {
                 // small catalogues: keep every key (lane (r, h): query r, items i0 + 8 rg + 4 h + 0..3 -> one 16-byte store)
