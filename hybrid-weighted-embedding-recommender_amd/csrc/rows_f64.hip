@@ -8,6 +8,8 @@
 //                                         scikit-learn's sequential order - the re-rank of the candidate sets that the float32 search
 //                                         (d <= 256, k <= 392) or a library GEMM screen (wider tables, larger k) hands over
 // None of them is on the throughput path of the float32 flavour; they are written for clarity, HBM-coalescing where it is free.
+#include <algorithm>
+
 #include "hwer_common.h"
 
 namespace hwer {
@@ -64,11 +66,232 @@ __global__ __launch_bounds__(256) void cand_dist2_kernel(const TV* __restrict__ 
 int launch_cand_dist2_f32x4(const float* table, int64_t ld, int d, const int64_t* cand, int64_t ld_cand, int64_t B, int64_t kc, const double* Q64,
                             double* out, hipStream_t st);
 
+
+// =====================================================================================================================
+// Round 5: the BLEND stage in float64 - the reference's own arithmetic.  hwer/content_recommender.py:83 (`E[adj].mean(0)`), :85
+// (`(E + A)/2.0`) and :96 + hwer/utils.py:43-44 (`a / expand_dims(norm(a, 1), 1)`) all run on float64 arrays; rounds 1-4 had float32
+// kernels only (within 1e-6 of the reference).  These produce the reference's bits from the same float64 table:
+//   neighbour mean : sequential row adds in adjacency order, then one IEEE division by the count           (ndarray.mean(0))
+//   blend          : (E + A) / 2.0 (content tail); sum_t alpha_t * T_t accumulated left to right, product and sum rounded separately (general)
+//   norm           : squares summed in numpy's pairwise order (np_pairwise over an LDS row), sqrt, one IEEE division per element
+// One wave works on `pb_n` rows per trip: L lanes per row load 16-byte chunks (coalesced), the blended row goes to an LDS slab, 8 lanes per
+// row replay numpy's summation order on its squares, then the L lanes divide and store.  HBM-bound: 8 d (nnz + 2) bytes per row for the tail,
+// 8 d (T + 1) for the blend.
+// =====================================================================================================================
+struct Rows64Args {
+    const double* const* tables;   // blend
+    const int32_t* const* row_idx;
+    const double* alpha;
+    int alpha_per_row, T;
+    const double* E;               // neighbour mean / content tail (also: the table stride for the blend)
+    int64_t lde;
+    const int64_t* indptr;
+    const int32_t* indices;
+    int64_t R;
+    int d, d2;
+    double* out;
+    int64_t ldo;
+    double* out_norm;
+    int stride, pb_n;
+};
+
+__device__ __forceinline__ int pow2ceil64(int x) {
+    int p = 1;
+    while (p < x) p <<= 1;
+    return p;
+}
+
+// numpy's pairwise order over the SQUARES of p[0..n) (8 lanes per row, k = lane & 7) - np_pairwise with x*x formed on the way in
+__device__ __forceinline__ double np_pairwise_sq_leaf(const double* p, int n, int k) {
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; ++i) r = r + p[i] * p[i];
+        return r;
+    }
+    const int lim = n - (n & 7);
+    double r = p[k] * p[k];
+    for (int i = 8; i < lim; i += 8) r = r + p[i + k] * p[i + k];
+    r = r + shfl_xor_t(r, 1);
+    r = r + shfl_xor_t(r, 2);
+    r = r + shfl_xor_t(r, 4);
+    for (int i = lim; i < n; ++i) r = r + p[i] * p[i];
+    return r;
+}
+template <int DEPTH>
+__device__ __forceinline__ double np_pairwise_sq(const double* p, int n, int k) {
+    if constexpr (DEPTH == 0) {
+        return np_pairwise_sq_leaf(p, n, k);
+    } else {
+        if (n <= 128) return np_pairwise_sq_leaf(p, n, k);
+        int n2 = n / 2;
+        n2 -= n2 & 7;
+        const double a = np_pairwise_sq<DEPTH - 1>(p, n2, k);
+        const double b = np_pairwise_sq<DEPTH - 1>(p + n2, n - n2, k);
+        return a + b;
+    }
+}
+
+// MODE 0: out = mean_adj(E)   1: out = unit((E + mean_adj(E)) / 2)   2: out = unit(sum_t alpha_t T_t[idx_t])
+template <int MODE>
+__global__ __launch_bounds__(256) void rows64_kernel(const Rows64Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nw = int(blockDim.x) >> 6;
+    double* slab = reinterpret_cast<double*>(smem_raw) + size_t(wave) * (size_t(a.pb_n) * a.stride + 8);
+    double* s_nrm = slab + size_t(a.pb_n) * a.stride;
+    const int L = min(64, pow2ceil64(a.d2));   // lanes per row
+    const int rpi = 64 / L;                    // rows per load instruction
+    const int sub = lane / L, c0 = lane % L;
+    const int64_t n_trips = cdiv64(a.R, a.pb_n);
+    for (int64_t b = int64_t(blockIdx.x) * nw + wave; b < n_trips; b += int64_t(gridDim.x) * nw) {
+        const int64_t p0 = b * a.pb_n;
+        for (int pb = 0; pb < a.pb_n; pb += rpi) {
+            const int slot = pb + sub;
+            const int64_t r = p0 + slot;
+            if (slot >= a.pb_n || r >= a.R) continue;
+            if constexpr (MODE == 2) {
+                for (int c = c0; c < a.d2; c += L) {
+                    double2 acc = make_double2(0.0, 0.0);
+                    for (int t = 0; t < a.T; ++t) {
+                        const int32_t* ri = a.row_idx ? a.row_idx[t] : nullptr;
+                        const int64_t row = ri ? int64_t(ri[r]) : r;
+                        const double al = a.alpha_per_row ? a.alpha[r * a.T + t] : a.alpha[t];
+                        const double2 v = *reinterpret_cast<const double2*>(a.tables[t] + row * a.lde + 2 * c);
+                        acc.x = acc.x + al * v.x;     // product and sum rounded separately (-ffp-contract=off): `acc = acc + alpha * rows`
+                        acc.y = acc.y + al * v.y;
+                    }
+                    *reinterpret_cast<double2*>(slab + slot * a.stride + 2 * c) = acc;
+                }
+            } else {
+                const int64_t e0 = a.indptr[r], e1 = a.indptr[r + 1];
+                const double deg = double(e1 - e0);
+                for (int c = c0; c < a.d2; c += L) {
+                    double2 acc = make_double2(0.0, 0.0);
+                    int64_t e = e0;
+                    for (; e + 4 <= e1; e += 4) {   // four neighbour rows in flight, added in adjacency order
+                        const double2 v0 = *reinterpret_cast<const double2*>(a.E + int64_t(a.indices[e]) * a.lde + 2 * c);
+                        const double2 v1 = *reinterpret_cast<const double2*>(a.E + int64_t(a.indices[e + 1]) * a.lde + 2 * c);
+                        const double2 v2 = *reinterpret_cast<const double2*>(a.E + int64_t(a.indices[e + 2]) * a.lde + 2 * c);
+                        const double2 v3 = *reinterpret_cast<const double2*>(a.E + int64_t(a.indices[e + 3]) * a.lde + 2 * c);
+                        acc.x = (((acc.x + v0.x) + v1.x) + v2.x) + v3.x;
+                        acc.y = (((acc.y + v0.y) + v1.y) + v2.y) + v3.y;
+                    }
+                    for (; e < e1; ++e) {
+                        const double2 v = *reinterpret_cast<const double2*>(a.E + int64_t(a.indices[e]) * a.lde + 2 * c);
+                        acc.x = acc.x + v.x;
+                        acc.y = acc.y + v.y;
+                    }
+                    acc.x = acc.x / deg;              // IEEE division: mean(0) = add.reduce / count
+                    acc.y = acc.y / deg;
+                    if constexpr (MODE == 0) {
+                        *reinterpret_cast<double2*>(a.out + r * a.ldo + 2 * c) = acc;
+                    } else {
+                        const double2 v = *reinterpret_cast<const double2*>(a.E + r * a.lde + 2 * c);
+                        acc.x = (v.x + acc.x) / 2.0;
+                        acc.y = (v.y + acc.y) / 2.0;
+                        *reinterpret_cast<double2*>(slab + slot * a.stride + 2 * c) = acc;
+                    }
+                }
+            }
+        }
+        if constexpr (MODE != 0) {
+            wave_lds_sync();
+            {
+                const int p8 = lane >> 3, k = lane & 7;
+                const double ss = np_pairwise_sq<kPairwiseDepth>(slab + min(p8, a.pb_n - 1) * a.stride, a.d, k);
+                if (k == 0 && p8 < a.pb_n) s_nrm[p8] = sqrt(ss);   // no epsilon: a zero row divides by zero like hwer/utils.py:43-44
+            }
+            wave_lds_sync();
+            for (int pb = 0; pb < a.pb_n; pb += rpi) {
+                const int slot = pb + sub;
+                const int64_t r = p0 + slot;
+                if (slot >= a.pb_n || r >= a.R) continue;
+                const double nrm = s_nrm[slot];
+                for (int c = c0; c < a.d2; c += L) {
+                    double2 v = *reinterpret_cast<const double2*>(slab + slot * a.stride + 2 * c);
+                    v.x = v.x / nrm;
+                    v.y = v.y / nrm;
+                    *reinterpret_cast<double2*>(a.out + r * a.ldo + 2 * c) = v;
+                }
+                if (a.out_norm && c0 == 0) a.out_norm[r] = nrm;
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+template <int MODE>
+static int launch_rows64(const char* fn, Rows64Args a, void* stream) {
+    a.d2 = (a.d + 1) / 2;
+    int stride = 2 * a.d2;
+    while (stride % 32 != 8) stride += 2;   // 4 rows x 8 chains of a ds_read_b64 group on 64 distinct banks; even: 16-byte slab rows
+    int pb_n = 8;
+    while (pb_n > 2 && size_t(pb_n) * stride * 8 > size_t(4800)) pb_n >>= 1;   // (pair_score's rule: narrow slabs keep more waves resident)
+    a.stride = stride;
+    a.pb_n = pb_n;
+    const size_t per_wave = MODE == 0 ? 0 : (size_t(pb_n) * stride + 8) * 8;
+    const int nw = 4;
+    const size_t lds = per_wave * nw;
+    if (lds > size_t(64) * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rows64_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        if (e != hipSuccess) return fail(HWER_ELAUNCH, "%s: hipFuncSetAttribute(%zu): %s", fn, lds, hipGetErrorString(e));
+    }
+    const int64_t n_trips = cdiv64(a.R, pb_n);
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(n_trips, nw), kMaxStreamBlocks * 2)));
+    hipLaunchKernelGGL(rows64_kernel<MODE>, dim3(grid), dim3(64 * nw), lds, as_stream(stream), a);
+    return check_launch(fn);
+}
+
+static int check_table64(const char* fn, const void* p, int64_t ld, int d) {
+    if (!p) return fail(HWER_EINVAL, "%s: null table", fn);
+    if (d < 1 || d > 1024) return fail(HWER_EINVAL, "%s: need 1 <= d <= 1024 (d=%d)", fn, d);
+    if (ld % 2 != 0 || ld < 2 * ((d + 1) / 2)) return fail(HWER_EINVAL, "%s: the row stride must be even and >= roundup2(d) (ld=%lld, d=%d)", fn, (long long)ld, d);
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return fail(HWER_EINVAL, "%s: the table must be 16-byte aligned", fn);
+    return HWER_OK;
+}
+
 }  // namespace hwer
 
 using namespace hwer;
 
 extern "C" {
+
+int hwer_segment_mean_f64(const double* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N, int d, double* out, int64_t ldo,
+                          void* stream) {
+    if (N == 0) return HWER_OK;
+    int rc;
+    if ((rc = check_table64("segment_mean_f64(E)", E, lde, d))) return rc;
+    if ((rc = check_table64("segment_mean_f64(out)", out, ldo, d))) return rc;
+    if (!indptr || !indices) return fail(HWER_EINVAL, "segment_mean_f64: null CSR");
+    Rows64Args a{};
+    a.E = E; a.lde = lde; a.indptr = indptr; a.indices = indices; a.R = N; a.d = d; a.out = out; a.ldo = ldo;
+    return launch_rows64<0>("segment_mean_f64", a, stream);
+}
+
+int hwer_content_tail_f64(const double* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N, int d, double* out, int64_t ldo,
+                          void* stream) {
+    if (N == 0) return HWER_OK;
+    int rc;
+    if ((rc = check_table64("content_tail_f64(E)", E, lde, d))) return rc;
+    if ((rc = check_table64("content_tail_f64(out)", out, ldo, d))) return rc;
+    if (!indptr || !indices) return fail(HWER_EINVAL, "content_tail_f64: null CSR");
+    Rows64Args a{};
+    a.E = E; a.lde = lde; a.indptr = indptr; a.indices = indices; a.R = N; a.d = d; a.out = out; a.ldo = ldo;
+    return launch_rows64<1>("content_tail_f64", a, stream);
+}
+
+int hwer_blend_normalize_f64(const double* const* tables, int64_t ld_tables, const int32_t* const* row_idx, const double* alpha, int alpha_per_row,
+                             int T, int64_t R, int d, double* out, int64_t ldo, double* out_norm, void* stream) {
+    if (R == 0) return HWER_OK;
+    if (!tables || !alpha || T < 1) return fail(HWER_EINVAL, "blend_normalize_f64: null tables/alpha or T < 1");
+    int rc;
+    if ((rc = check_table64("blend_normalize_f64(out)", out, ldo, d))) return rc;
+    if (ld_tables % 2 != 0 || ld_tables < 2 * ((d + 1) / 2)) return fail(HWER_EINVAL, "blend_normalize_f64: ld_tables must be even and >= roundup2(d)");
+    Rows64Args a{};
+    a.tables = tables; a.row_idx = row_idx; a.alpha = alpha; a.alpha_per_row = alpha_per_row; a.T = T; a.lde = ld_tables; a.R = R; a.d = d;
+    a.out = out; a.ldo = ldo; a.out_norm = out_norm;
+    return launch_rows64<2>("blend_normalize_f64", a, stream);
+}
 
 int hwer_pair_score_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst, int64_t P, double* out,
                             void* stream) {

@@ -45,10 +45,31 @@ def _dev_table(t, device, ld):
     return out
 
 
+def _is_f64(t) -> bool:
+    """float64 input (numpy or torch): the blend stage then runs in the reference's own float64 arithmetic (hwer_*_f64)."""
+    if isinstance(t, np.ndarray):
+        return t.dtype == np.float64
+    return str(getattr(t, "dtype", "")) == "torch.float64"
+
+
+def _dev_table64(t, device, ld):
+    import torch
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(t, dtype=np.float64))
+    t = t.to(device=device, dtype=torch.float64)
+    if t.shape[1] == ld and t.is_contiguous():
+        return t
+    out = torch.zeros((t.shape[0], ld), dtype=torch.float64, device=device)
+    out[:, :t.shape[1]] = t
+    return out
+
+
 @native.on_device_kw
 def content_tail(E, src, dst, device=None, return_device=False, d=None):
     """unit_rows((E + mean_adj(E)) / 2) on the GPU.  E: (N, D) array; src/dst: edge endpoints as row ids.
-    d: logical width when E is a device table whose rows are already padded to a multiple of 4."""
+    d: logical width when E is a device table whose rows are already padded to a multiple of 4.
+    A float64 table runs hwer_content_tail_f64 - the reference's float64 arithmetic in its summation orders: the result equals
+    hwer/content_recommender.py:77-86 + :96 bit for bit (float64 out); a float32 table runs the float32 kernel (float32 out)."""
     import torch
     from .device_index import _require_gpu, roundup
     lib = native.lib()
@@ -58,13 +79,14 @@ def content_tail(E, src, dst, device=None, return_device=False, d=None):
         assert roundup(d, 4) == D, "a pre-padded table must have roundup4(d) columns"
         D = d
     ld = roundup(D, 4)
-    Ed = _dev_table(E, dev, ld)
+    f64 = _is_f64(E)
+    Ed = _dev_table64(E, dev, ld) if f64 else _dev_table(E, dev, ld)
     indptr, indices = adjacency_csr(N, src, dst)
     ip = torch.from_numpy(indptr).to(dev)
     ix = torch.from_numpy(indices).to(dev)
-    out = torch.zeros((N, ld), dtype=torch.float32, device=dev)
-    native.check(lib.hwer_content_tail_f32(native.ptr(Ed), ld, native.ptr(ip), native.ptr(ix), N, D, native.ptr(out), ld,
-                                           native.stream_ptr()), "content_tail")
+    out = torch.zeros((N, ld), dtype=torch.float64 if f64 else torch.float32, device=dev)
+    fn = lib.hwer_content_tail_f64 if f64 else lib.hwer_content_tail_f32
+    native.check(fn(native.ptr(Ed), ld, native.ptr(ip), native.ptr(ix), N, D, native.ptr(out), ld, native.stream_ptr()), "content_tail")
     return out if return_device else out[:, :D].cpu().numpy()
 
 
@@ -77,12 +99,13 @@ def segment_mean(E, indptr, indices, device=None):
     dev = _require_gpu(device)
     N, D = E.shape
     ld = roundup(D, 4)
-    Ed = _dev_table(E, dev, ld)
+    f64 = _is_f64(E)       # float64 table: the reference's float64 mean(0), bit for bit (hwer_segment_mean_f64)
+    Ed = _dev_table64(E, dev, ld) if f64 else _dev_table(E, dev, ld)
     ip = torch.from_numpy(np.ascontiguousarray(indptr, dtype=np.int64)).to(dev)
     ix = torch.from_numpy(np.ascontiguousarray(indices, dtype=np.int32)).to(dev)
-    out = torch.zeros((N, ld), dtype=torch.float32, device=dev)
-    native.check(lib.hwer_segment_mean_f32(native.ptr(Ed), ld, native.ptr(ip), native.ptr(ix), N, D, native.ptr(out), ld,
-                                           native.stream_ptr()), "segment_mean")
+    out = torch.zeros((N, ld), dtype=torch.float64 if f64 else torch.float32, device=dev)
+    fn = lib.hwer_segment_mean_f64 if f64 else lib.hwer_segment_mean_f32
+    native.check(fn(native.ptr(Ed), ld, native.ptr(ip), native.ptr(ix), N, D, native.ptr(out), ld, native.stream_ptr()), "segment_mean")
     return out[:, :D].cpu().numpy()
 
 
@@ -91,7 +114,9 @@ def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, de
                  return_norm=False):
     """out[r] = unit(sum_t alpha[r, t] * tables[t][row_idx[t][r]]) — the weighted blend of content and
     collaborative tables (north_star; reference special case hwer/content_recommender.py:85 with alpha=(.5,.5)).
-    alpha: (T,) shared weights or (R, T) per-row weights.  row_idx[t]: None (row r) or an int array (R,)."""
+    alpha: (T,) shared weights or (R, T) per-row weights.  row_idx[t]: None (row r) or an int array (R,).
+    float64 tables (all of them) run hwer_blend_normalize_f64: float64 weights, products and sums in the order of
+    `acc = acc + alpha_t * T_t`, numpy's norm - float64 rows out, identical to that numpy expression."""
     import torch
     from .device_index import _require_gpu, roundup
     lib = native.lib()
@@ -99,6 +124,9 @@ def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, de
     T = len(tables)
     D = tables[0].shape[1]
     ld = roundup(D, 4)
+    f64 = all(_is_f64(t) for t in tables)
+    if f64:
+        return _blend_tables_f64(tables, alpha, row_idx, dev, ld, return_device, return_norm)
     tabs = [_dev_table(t, dev, ld) for t in tables]
     alpha = np.asarray(alpha, dtype=np.float32)
     per_row = alpha.ndim == 2
@@ -114,6 +142,29 @@ def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, de
     native.check(lib.hwer_blend_normalize_f32(native.ptr(tab_ptrs), ld, native.ptr(idx_ptrs), native.ptr(al), 1 if per_row else 0,
                                               T, R, D, native.ptr(out), ld, native.ptr(norm), native.stream_ptr()),
                  "blend_normalize")
+    res = out if return_device else out[:, :D].cpu().numpy()
+    return (res, norm if return_device else norm.cpu().numpy()) if return_norm else res
+
+
+def _blend_tables_f64(tables, alpha, row_idx, dev, ld, return_device, return_norm):
+    import torch
+    lib = native.lib()
+    T, D = len(tables), tables[0].shape[1]
+    tabs = [_dev_table64(t, dev, ld) for t in tables]
+    alpha = np.asarray(alpha, dtype=np.float64)
+    per_row = alpha.ndim == 2
+    idx = [None] * T if row_idx is None else [None if r is None else
+                                               torch.from_numpy(np.ascontiguousarray(r, dtype=np.int32)).to(dev) for r in row_idx]
+    R = alpha.shape[0] if per_row else next((len(r) for r in (row_idx or []) if r is not None), tabs[0].shape[0])
+    tab_ptrs = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=dev)
+    has_idx = any(i is not None for i in idx)
+    idx_ptrs = torch.tensor([0 if i is None else i.data_ptr() for i in idx], dtype=torch.int64, device=dev) if has_idx else None
+    al = torch.from_numpy(np.ascontiguousarray(alpha)).to(dev)
+    out = torch.zeros((R, ld), dtype=torch.float64, device=dev)
+    norm = torch.empty(R, dtype=torch.float64, device=dev) if return_norm else None
+    native.check(lib.hwer_blend_normalize_f64(native.ptr(tab_ptrs), ld, native.ptr(idx_ptrs), native.ptr(al), 1 if per_row else 0,
+                                              T, R, D, native.ptr(out), ld, native.ptr(norm), native.stream_ptr()),
+                 "blend_normalize_f64")
     res = out if return_device else out[:, :D].cpu().numpy()
     return (res, norm if return_device else norm.cpu().numpy()) if return_norm else res
 
@@ -157,16 +208,25 @@ class ContentRecommendation(RecommendationBase):
         type_id = np.fromiter((cat_id[n.node_type] for n in nodes), dtype=np.int64, count=len(nodes))
         return blocks, type_id, visit
 
+    #: arithmetic of the blend stage behind fit(): "float64" = the reference's own (its table is float64 from the PCA on:
+    #: hwer/content_recommender.py:68-96), rows come back as genuine float64 values and the index answers from them; "float32" = rounds
+    #: 1-4's flavour (float32 rows widened: within 1e-6 of the reference, half the bytes, the fused float32 search)
+    blend_dtype = "float64"
+
     def __build_feature_table__(self, nodes: List[Node], node_data, n_dims):
         """Reference hwer/content_recommender.py:50-76 on the GPU (hwer/fit_pca.py): the block-diagonal table is never
         built; IncrementalPCA's data passes, the row normalisation and the one-hot columns are HIP kernels.
-        -> (float32 device table (N, ld), its logical width)."""
+        -> (device table (N, ld) in `blend_dtype`, its logical width)."""
         from .fit_pca import device_feature_table
         blocks, type_id, visit = self.__build_feature_blocks__(nodes, node_data)
+        if self.blend_dtype == "float64":
+            _, E64, D = device_feature_table(blocks, type_id, n_dims, block_order=visit, device=self.device, want_f64=True)
+            return E64, D
         return device_feature_table(blocks, type_id, n_dims, block_order=visit, device=self.device)
 
     def __build_content_embeddings__(self, nodes, edges, node_data, n_dims):
-        """-> unit-norm (N, D) float32 rows: embedders on the host, PCA + neighbour blend + normalise on the GPU."""
+        """-> unit-norm (N, D) rows: embedders on the host, PCA + neighbour blend + normalise on the GPU (float64 by default,
+        like the reference)."""
         E, D = self.__build_feature_table__(nodes, node_data, n_dims)
         get = self.nodes_to_idx.__getitem__
         src = np.fromiter((get(e.src) for e in edges), dtype=np.int64, count=len(edges))
@@ -176,7 +236,8 @@ class ContentRecommendation(RecommendationBase):
     def fit(self, nodes: List[Node], edges: List[Edge], node_data: Dict[Node, Dict[FeatureName, object]], **kwargs):
         super().fit(nodes, edges, node_data)
         embeddings = self.__build_content_embeddings__(nodes, edges, node_data, self.n_dims)
-        # the reference returns float64 rows; these are the device's float32 rows widened
+        # the reference returns float64 rows: blend_dtype "float64" computed them in float64 (nothing to widen); "float32": the
+        # device's float32 rows widened
         embeddings = embeddings.astype(np.float64)
         self.__build_knn__(embeddings)
         self.fit_done = True
@@ -187,7 +248,7 @@ class ContentRecommendation(RecommendationBase):
         assert not self.fit_done
         self.add_nodes(nodes)
         # like fit(): the model's `vectors` are float64 (the reference's ContentRecommendation flavour: float64 score arithmetic) -
-        # the device's float32 rows widened
+        # float64 tables are blended in float64 (hwer_blend_normalize_f64), float32 tables in float32 and widened
         vec = blend_tables(tables, alpha, row_idx, device=self.device).astype(np.float64)
         self.__build_knn__(vec)
         self.fit_done = True

@@ -79,26 +79,33 @@ class _OneAnchorSearch:
     k ids + k scores + the flag from pinned host memory.  No allocation, no per-call stream / pointer plumbing in Python."""
 
     def __init__(self, ix, node_type, k, mode, sort_by_score=True):
+        import threading
         torch = _torch()
         lib, dev = ix.lib, ix.device
         tt = ix.tables[node_type]
         self.k, self.mode = int(k), int(mode)
+        # ONE pinned anchor word, ONE pinned result buffer and ONE workspace per cached graph: a call owns them from the anchor
+        # write to the copy-out of its results (run() holds this lock; a second thread calling search() with one anchor waits)
+        self.lock = threading.Lock()
         self.h_anchor = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.h_anchor_np = self.h_anchor.numpy()
         self.d_anchor = torch.zeros(1, dtype=torch.int32, device=dev)
         self.Q64 = torch.empty((1, ix.d), dtype=torch.float64, device=dev)
         self.Q32 = torch.empty((1, ix.ldx), dtype=torch.float32, device=dev)
-        # one result buffer, one D2H copy: [k ids | k score bit patterns | flag]
-        self.buf = torch.zeros(2 * k + 1, dtype=torch.int64, device=dev)
-        self.h_buf = torch.zeros(2 * k + 1, dtype=torch.int64).pin_memory()
+        # one result buffer, one D2H copy: [k ids | k score bit patterns | flag | GcnNCF flavour: k squared-distance bit patterns]
+        # (the GcnNCF score is a function of the distance and the general path returns the distances with it: so does this one)
+        nw = 2 * k + 1 + (k if mode == 2 else 0)
+        self.buf = torch.zeros(nw, dtype=torch.int64, device=dev)
+        self.h_buf = torch.zeros(nw, dtype=torch.int64).pin_memory()
         self.h_np = self.h_buf.numpy()
         idx = self.buf[:k].view(1, k)
         score = self.buf[k:2 * k].view(torch.float64).view(1, k)
-        flags = self.buf[2 * k:].view(torch.int32)[:1]
-        d2 = torch.empty((1, k), dtype=torch.float64, device=dev) if mode == 2 else None   # (the GcnNCF score is a function of the distance)
+        flags = self.buf[2 * k:2 * k + 1].view(torch.int32)[:1]
+        d2 = self.buf[2 * k + 1:].view(torch.float64).view(1, k) if mode == 2 else None
         path_opt = ix._path_options()
         x16, x16_exp = ix._x16(tt, 1)
         opt = (ix.KNN_F16_SCREEN if (ix.f16_screen and x16 is not None) else 0) | path_opt
+        self.opt = opt
         wsb = lib.hwer_knn_workspace_bytes_opts(1, tt.n, ix.d, k, opt)
         if wsb == 0:
             raise native.HwerNativeError("knn: unsupported shape (n=%d, d=%d, k=%d)" % (tt.n, ix.d, k))
@@ -141,19 +148,22 @@ class _OneAnchorSearch:
         self._sync = lib.hwer_stream_synchronize
 
     def run(self, anchor: int):
-        """-> (ids (k,) int64, scores (k,) float64, flag) as fresh numpy arrays"""
-        self.h_anchor_np[0] = anchor
-        self.graph.replay()          # on the current stream of the index's device
-        raw = self._raw_stream
-        if raw is not None:          # the raw hipStream_t of that stream (one C call) -> hwer_stream_synchronize
-            rc = self._sync(raw(self.dev_index))
-            if rc:
-                native.check(rc, "stream_synchronize")
-        else:
-            _torch().cuda.current_stream(self.dev).synchronize()
-        k = self.k
-        h = self.h_np
-        return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k] & 0xFFFFFFFF)
+        """-> (ids (k,) int64, scores (k,) float64, flag, squared distances (k,) float64 or None) as fresh numpy arrays.  Thread-safe: the pinned anchor word, the replay and
+        the pinned result buffer belong to one caller at a time."""
+        with self.lock:
+            self.h_anchor_np[0] = anchor
+            self.graph.replay()          # on the current stream of the index's device
+            raw = self._raw_stream
+            if raw is not None:          # the raw hipStream_t of that stream (one C call) -> hwer_stream_synchronize
+                rc = self._sync(raw(self.dev_index))
+                if rc:
+                    native.check(rc, "stream_synchronize")
+            else:
+                _torch().cuda.current_stream(self.dev).synchronize()
+            k = self.k
+            h = self.h_np
+            d2 = h[2 * k + 1:].view(np.float64).copy() if self.mode == 2 else None
+            return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k] & 0xFFFFFFFF), d2
 
 
 class DeviceIndex:
@@ -684,6 +694,30 @@ class DeviceIndex:
             native.ptr(idx), native.ptr(score), native.ptr(dist2) if dist2 is not None else None, native.ptr(flags), native.ptr(ws), ws.numel(),
             native.stream_ptr(self.device)), "knn_exact")
 
+    #: cached one-anchor graphs kept per index (each pins a search workspace, an exhaustive-pass workspace and a hipGraph): least recently
+    #: used entries beyond this many are dropped
+    ONE_ANCHOR_CACHE = 8
+
+    def _one_anchor_search(self, node_type, k, mode):
+        """The cached graph of (node type, k, score mode) UNDER THE CURRENT path switches: everything a captured graph bakes in is part of
+        the key - the float16 switches, the HWER_NO_* path options of the environment and the identity of the float16 copy it reads."""
+        import threading
+        lock = self.__dict__.get("_one_anchor_lock")
+        if lock is None:
+            lock = self.__dict__.setdefault("_one_anchor_lock", threading.Lock())
+        tt = self.tables[node_type]
+        key = (node_type, int(k), int(mode), bool(self.f16_screen), bool(self.use_f16_storage), self._path_options(), id(tt.X16))
+        with lock:      # (construction captures a hipGraph: one thread at a time)
+            cache = self.__dict__.setdefault("_one_anchor", {})
+            one = cache.pop(key, None)
+            if one is None:
+                one = _OneAnchorSearch(self, node_type, k, mode)
+                key = key[:-1] + (id(tt.X16),)       # (the constructor may have built the float16 copy)
+            cache[key] = one                         # most recently used last
+            while len(cache) > self.ONE_ANCHOR_CACHE:
+                cache.pop(next(iter(cache)))
+        return one
+
     @_on_device
     def search(self, node_type: str, anchors: np.ndarray, k: int = 200, positive=None, negative=None,
                scoring: str = "base", sort_by_score: bool = True, want_dist: bool = True):
@@ -695,15 +729,14 @@ class DeviceIndex:
             # the reference-shaped per-anchor call (hwer/validation.py:30-35): one hipGraph replay per call (_OneAnchorSearch)
             a0 = int(np.asarray(anchors).reshape(-1)[0])
             if 0 <= a0 < self.N:
-                cache = self.__dict__.setdefault("_one_anchor", {})
-                one = cache.get((node_type, k, mode))
-                if one is None:
-                    one = cache[(node_type, k, mode)] = _OneAnchorSearch(self, node_type, k, mode)
-                ids, sc, flag = one.run(a0)
+                one = self._one_anchor_search(node_type, k, mode)
+                ids, sc, flag, d2 = one.run(a0)
                 if flag > 0:
                     if mode == 1:
                         sc = sc.astype(np.float32)
-                    return ids.reshape(1, k), sc.reshape(1, k), None, np.asarray([flag], dtype=np.int32)
+                    # (GcnNCF scoring: the distances come back with the scores, as on the general path - the shape of the result does
+                    # not depend on the number of anchors)
+                    return ids.reshape(1, k), sc.reshape(1, k), (np.sqrt(d2).reshape(1, k) if d2 is not None else None), np.asarray([flag], dtype=np.int32)
                 # (uncertified beyond the on-device exhaustive pass: the general path below runs the host-driven tiers)
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
         fh = []

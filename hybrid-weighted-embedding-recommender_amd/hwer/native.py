@@ -27,6 +27,9 @@ PROTOTYPES = {
     "hwer_blend_normalize_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int64, c_int, _P, c_int64, _P, _P]),
     "hwer_blend_normalize_audit_f32": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int64, c_int, _P, c_int64, c_float, _P, _P, _P]),
     "hwer_content_tail_f32": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P]),
+    "hwer_segment_mean_f64": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P]),
+    "hwer_content_tail_f64": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, _P, c_int64, _P]),
+    "hwer_blend_normalize_f64": (c_int, [_P, c_int64, _P, _P, c_int, c_int, c_int64, c_int, _P, c_int64, _P, _P]),
     "hwer_unit_audit_ws_floats": (c_int64, [c_int64]),
     "hwer_knn_count_uncertified": (c_int, [_P, c_int64, _P, _P]),
     "hwer_unit_audit_f32": (c_int, [_P, c_int64, c_int, c_int64, c_float, _P, _P, _P, _P]),

@@ -165,6 +165,10 @@ def _unpack_hit_bits(words: np.ndarray, n_bits: int) -> np.ndarray:
     return bits[:, :n_bits].astype(np.int64)
 
 
+#: None until the first device evaluation of this process has compared hwer_rank_metrics' means with numpy's (see below)
+_DEVICE_MEANS_MATCH_NUMPY = None
+
+
 def recall_rows(hitbits, n_pred, n_true, c):
     """mean over users of utils.recall(truth, pred[:c]) from hit marks (reference: hwer/utils.py:118-121)."""
     if len(n_pred) == 0:
@@ -285,6 +289,20 @@ def _extraction_efficiency_device(model, train_edges, validation_edges, node_typ
         means = means_dev.cpu().numpy()
         dev_recall = {c: means[j] for j, c in enumerate(dev_cuts)}
         dev_ndcg = {c: means[len(dev_cuts) + j] for j, c in enumerate(dev_cuts)}
+        # The kernel restates numpy's reduce schedule (8 192-element pieces, 128-element pairwise leaves) as numpy 2.2 runs it.  On the
+        # FIRST evaluation of a process the device means are held to this numpy's own expressions on the same integers (already on the
+        # host): equal -> later calls trust the device; different (a numpy build that reduces in another order) -> the host values are
+        # reported from then on, so "bit-identical to the reference's numpy" never silently stops holding.
+        global _DEVICE_MEANS_MATCH_NUMPY
+        if _DEVICE_MEANS_MATCH_NUMPY is None:
+            host = [recall_rows(hitbits, n_pred, n_true, c) for c in dev_cuts] + [binary_ndcg_rows(hitbits, n_pred, n_true, c) for c in dev_cuts]
+            _DEVICE_MEANS_MATCH_NUMPY = bool(np.array_equal(np.asarray(host, dtype=np.float64), means, equal_nan=True))
+            if not _DEVICE_MEANS_MATCH_NUMPY:
+                import warnings
+                warnings.warn("hwer_rank_metrics: this numpy (%s) sums in another order than the kernel restates; extraction_efficiency reports the "
+                              "host expressions instead of the device means" % np.__version__, RuntimeWarning, stacklevel=2)
+        if not _DEVICE_MEANS_MATCH_NUMPY:
+            dev_recall = dev_ndcg = {}
     else:
         dev_recall = dev_ndcg = {}
 

@@ -92,6 +92,24 @@ int hwer_blend_normalize_audit_f32(const float* const* tables, int64_t ld_tables
 int hwer_content_tail_f32(const float* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N,
                           int d, float* out, int64_t ldo, void* stream);
 
+/* The same three stages in FLOAT64 - the arithmetic the reference itself runs them in (round 5).  ContentRecommendation keeps its table
+ * in float64 from the PCA on: `all_embeddings[adj].mean(0)` (hwer/content_recommender.py:83), `(all_embeddings + adjacent_vectors)/2.0`
+ * (:85) and `unit_length(embeddings, axis=1)` (:96 -> hwer/utils.py:43-44) are float64 numpy expressions.  On the same float64 table
+ * these entry points return the reference's BITS (tests/golden g6 / g15: `final` array_equal), where the _f32 flavours are within 1e-6:
+ *   neighbour mean : rows added sequentially in CSR (= adjacency append) order, one IEEE division by the count   (numpy mean(0))
+ *   blend          : content tail (E + A) / 2.0;  general form acc = 0, acc = acc + alpha_t * T_t[row] for t = 0 .. T-1, product and sum
+ *                    rounded separately (numpy evaluates `acc + a * rows` as two ufunc passes)
+ *   unit rows      : x / sqrt(add.reduce(x * x)) with numpy's pairwise summation order, one IEEE division per element, no epsilon
+ * Tables: row-major float64, row stride EVEN (ld >= roundup2(d)), 16-byte aligned, pad column (odd d) readable.  1 <= d <= 1024.
+ * alpha is float64 here: (T) or (R, T).  out_norm (nullable): the pre-normalisation norms.  HBM-bound: 8 d (deg + 2) bytes per row
+ * (tail), 8 d (T + 1) (blend). */
+int hwer_segment_mean_f64(const double* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N, int d, double* out,
+                          int64_t ldo, void* stream);
+int hwer_content_tail_f64(const double* E, int64_t lde, const int64_t* indptr, const int32_t* indices, int64_t N, int d, double* out,
+                          int64_t ldo, void* stream);
+int hwer_blend_normalize_f64(const double* const* tables, int64_t ld_tables, const int32_t* const* row_idx, const double* alpha,
+                             int alpha_per_row, int T, int64_t R, int d, double* out, int64_t ldo, double* out_norm, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * F1+F2  fit-side table construction — the data passes of
  *          IncrementalPCA(n_components, batch_size=2**16).fit_transform(table)   hwer/content_recommender.py:68-69

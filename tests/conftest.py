@@ -59,3 +59,26 @@ def g12_scenario(g, tag):
     order = [srt.index(str(t)) for t in g[tag + "_type_order"]]
     return dict(types=srt, type_id=remap[tid], feats=feats_sorted, with_data=data_sorted, src=src, dst=dst, order=order,
                 n_dims=n_dims, N=N)
+
+
+def g15_scenario(g):
+    """Inputs of G15 (tools/capture_goldens.py g15) regenerated from its recipe: 6 000 nodes in 3 types, per-type feature blocks, edges
+    (24 000 random + the first 200 repeated), and the float64 table E the reference's blend stage saw (captured PCA-unit block + one-hot of
+    the SORTED type names padded to 4 columns)."""
+    N, seed, n_edges, n_dup, n_dims, k = (int(x) for x in g["recipe"][:6])
+    dims = [int(x) for x in g["recipe"][6:9]]
+    types = [str(t) for t in g["types"]]
+    tid = np.asarray([0 if i % 6 == 0 else (2 if i % 6 == 1 else 1) for i in range(N)], dtype=np.int32)
+    rng = np.random.default_rng(seed)
+    feats = [rng.standard_normal((int((tid == ti).sum()), dims[ti])) for ti in range(3)]
+    src = rng.integers(0, N, n_edges)
+    dst = rng.integers(0, N, n_edges)
+    src = np.concatenate([src, src[:n_dup]])
+    dst = np.concatenate([dst, dst[:n_dup]])
+    srt = sorted(types)
+    cat = np.asarray([srt.index(types[t]) for t in tid])
+    ohe = np.zeros((N, 4))
+    ohe[np.arange(N), cat] = 1.0
+    E = np.concatenate([g["pca_unit"], ohe], axis=1)
+    return dict(N=N, n_dims=n_dims, k=k, dims=dims, types=types, tid=tid, feats=feats, src=src, dst=dst, E=E,
+                users=np.flatnonzero(tid == 0), items=np.flatnonzero(tid == 1))

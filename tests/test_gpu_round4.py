@@ -292,7 +292,11 @@ def test_one_anchor_graph_equals_the_general_path(hw, U, N, d, k, flav):
     m.fit(users + items, V)
     ix = m.knn.index
     per_anchor = validation.model_get_topk_knn_per_anchor(m, users, "item") if k == 200 else {u: m.find_closest_neighbours("item", u, k=k) for u in users}
-    assert ("item", k, ix.arith if flav != "gcn" else 2) in ix.__dict__.get("_one_anchor", {})       # the graph path was taken
+    assert any(key[:3] == ("item", k, ix.arith if flav != "gcn" else 2) for key in ix.__dict__.get("_one_anchor", {}))       # the graph path was taken
+    if flav == "gcn":     # GcnNCF scoring: one anchor or many, search() returns the distances with the scores
+        one = ix.search("item", np.asarray([3]), k=k, scoring="gcn", want_dist=False)
+        many = ix.search("item", np.asarray([3, 4]), k=k, scoring="gcn", want_dist=False)
+        assert one[2] is not None and np.array_equal(one[2][0], many[2][0]) and np.array_equal(one[0][0], many[0][0])
     ix.one_anchor_graphs = False
     for j, u in enumerate(users):
         general = m.find_closest_neighbours("item", u, k=k)

@@ -1,0 +1,177 @@
+"""GPU parity tests added in round 5: the BLEND stage in the reference's own float64 arithmetic (hwer_segment_mean_f64,
+hwer_content_tail_f64, hwer_blend_normalize_f64) - `final` of ContentRecommendation.fit identical to the reference bit for bit on the
+captured table (G6, G15), the reference's neighbours from fit() end to end at 6 000 nodes (G15), the general T-table blend against the
+numpy oracle.  Bit-exact unless an assert states a tolerance."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import g15_scenario, unit_rows_f32
+from oracle import hwer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hw():
+    import hwer
+    from hwer import native
+    native.lib()
+    return hwer
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ------------------------------------------------------------------------------------------------- float64 blend stage
+def test_content_tail_f64_golden_g6(golden, hw):
+    """hwer/content_recommender.py:77-86 + :96 on the table the reference's fit() saw (captured E, float64): neighbour mean, (E + A)/2,
+    unit rows - every bit of `adjacent` and `final` as the reference computed them."""
+    from hwer.content_recommender import adjacency_csr, blend_tables, content_tail, segment_mean
+    g = golden("g6_content_tail")
+    E = g["E"]
+    assert E.dtype == np.float64
+    got = content_tail(E, g["src"], g["dst"])
+    assert got.dtype == np.float64 and np.array_equal(got, g["final"])
+    indptr, indices = adjacency_csr(300, g["src"], g["dst"])
+    A = segment_mean(E, indptr, indices)
+    assert A.dtype == np.float64 and np.array_equal(A, g["adjacent"])
+    # the general blend with T = (E, A), alpha = (.5, .5) is the same numbers ((E + A)/2 == .5 E + .5 A exactly)
+    b, nrm = blend_tables([E, g["adjacent"]], np.array([0.5, 0.5]), return_norm=True)
+    assert b.dtype == np.float64 and np.array_equal(b, g["final"])
+    assert np.array_equal(nrm, np.linalg.norm(g["blend"], axis=1))
+    # the float32 flavour is still there for float32 tables (and is NOT the reference's bits)
+    got32 = content_tail(E.astype(np.float32), g["src"], g["dst"])
+    assert got32.dtype == np.float32 and np.abs(got32 - g["final"]).max() <= 1e-6
+
+
+def test_content_tail_f64_golden_g15(golden, hw):
+    """G15, 6 000 x 12: sha256 of all of `final` equals the reference's."""
+    from hwer.content_recommender import content_tail
+    g = golden("g15_content_fit_6k")
+    sc = g15_scenario(g)
+    final = content_tail(sc["E"], sc["src"], sc["dst"])
+    assert _sha(final) == str(g["final_sha"])
+    assert np.array_equal(final[g["final_rows"]], g["final_sample"])
+
+
+@pytest.mark.parametrize("d,T", [(128, 2), (256, 4), (66, 3), (8, 1), (7, 2), (1, 2), (129, 2), (515, 3), (1024, 2)])
+def test_blend_normalize_f64_vs_numpy(hw, d, T):
+    """out[r] = unit(sum_t alpha[r, t] T_t[idx_t[r]]) on float64 tables: bit-identical to the numpy expression `acc = acc + a * rows`
+    followed by hwer/utils.py:43-44 (oracle.blend_normalize); per-row weights with cold-start zeros, row gathers, shared weights; widths
+    on both sides of numpy's 8 / 128-element pairwise-summation breaks."""
+    from hwer.content_recommender import blend_tables
+    rng = np.random.default_rng(1000 * d + T)
+    R = 1237
+    tables = [rng.standard_normal((900 + 50 * t, d)) * (0.3 + t) for t in range(T)]
+    tables[0] = rng.standard_normal((R, d))
+    idx = [None if t == 0 else rng.integers(0, tables[t].shape[0], R).astype(np.int32) for t in range(T)]
+    alpha = rng.dirichlet(np.ones(T), R)
+    if T > 1:
+        alpha[::5, -1] = 0.0
+    out, norm = blend_tables(tables, alpha, idx, return_norm=True)
+    ref = orc.blend_normalize(tables, idx, alpha)
+    assert out.dtype == np.float64 and np.array_equal(out, ref)
+    pre = np.zeros((R, d))
+    for t in range(T):
+        pre = pre + alpha[:, t][:, None] * (tables[t] if idx[t] is None else tables[t][idx[t]])
+    assert np.array_equal(norm, np.linalg.norm(pre, axis=1))
+    shared = rng.dirichlet(np.ones(T))
+    out2 = blend_tables([t[:900] for t in tables], shared)
+    assert np.array_equal(out2, orc.blend_normalize([t[:900] for t in tables], [None] * T, shared))
+
+
+def test_segment_mean_f64_ragged(hw):
+    """neighbour lists of length 1 ... 300 (the 4-deep load pipeline and its tail), d on both sides of one 16-byte chunk per lane"""
+    from hwer.content_recommender import segment_mean
+    rng = np.random.default_rng(55)
+    for d in (3, 12, 64, 130, 300):
+        N = 500
+        E = rng.standard_normal((N, d))
+        deg = rng.integers(1, 12, N)
+        deg[::50] = rng.integers(100, 300, len(deg[::50]))
+        indptr = np.zeros(N + 1, dtype=np.int64)
+        np.cumsum(deg, out=indptr[1:])
+        indices = rng.integers(0, N, int(indptr[-1])).astype(np.int32)
+        got = segment_mean(E, indptr, indices)
+        assert np.array_equal(got, orc.segment_mean(E, indptr, indices)), d
+
+
+def test_zero_row_becomes_nan_like_the_reference(hw):
+    """hwer/utils.py:43-44 has no epsilon: a zero blend row is 0 / 0 = NaN in the reference, and here"""
+    from hwer.content_recommender import blend_tables
+    E = np.random.default_rng(3).standard_normal((64, 10))
+    E[5] = 0.0
+    with np.errstate(invalid="ignore"):
+        ref = orc.blend_normalize([E], [None], np.array([1.0]))
+    got = blend_tables([E], np.array([1.0]))
+    assert np.array_equal(got, ref, equal_nan=True) and np.isnan(got[5]).all()
+
+
+# ------------------------------------------------------------------------------------------------- fit() end to end
+def test_fit_6k_neighbours_equal_the_reference_g15(golden, hw):
+    """ContentRecommendation.fit on the G15 scenario, everything after the (out-of-scope) embedders on the device in float64: the
+    device PCA differs from scikit-learn's SVD by rounding noise (~1e-13 on E), the blend stage adds none - `final` within 1e-9 of the
+    reference's rows - and for EVERY one of the 1 000 users the 200 nearest items are the reference's, in the reference's order, with
+    scores within 1e-9.  Then the same model built on the reference's own `final` (content_tail_f64 of the captured table): ids AND
+    scores identical to the reference for all 1 000 users (sha256 of the scores)."""
+    from hwer import ContentRecommendation, Edge, IdentityEmbedding, Node, VectorIndex
+    from hwer.content_recommender import content_tail
+    g = golden("g15_content_fit_6k")
+    sc = g15_scenario(g)
+    types, tid, N, k = sc["types"], sc["tid"], sc["N"], sc["k"]
+    nodes = [Node(types[tid[i]], i) for i in range(N)]
+    cursor, node_data = [0, 0, 0], {}
+    for i, n in enumerate(nodes):
+        node_data[n] = {"f": sc["feats"][tid[i]][cursor[tid[i]]]}
+        cursor[tid[i]] += 1
+    edges = [Edge(nodes[s], nodes[t], 1.0) for s, t in zip(sc["src"], sc["dst"])]
+    model = ContentRecommendation({t: {"f": IdentityEmbedding(n_dims=sc["dims"][ti])} for ti, t in enumerate(types)}, set(types),
+                                  n_dims=sc["n_dims"])
+    final = model.fit(nodes, edges, node_data)
+    assert final.dtype == np.float64 and final.shape == (N, 12)
+    assert np.abs(final[g["final_rows"]] - g["final_sample"]).max() <= 1e-9
+    users = [nodes[i] for i in sc["users"]]
+    ref_idx = g["knn_idx"].astype(np.int64)
+    idx, score = model.find_closest_neighbours_batch("item", users, k=k)
+    assert np.array_equal(idx, ref_idx)
+    assert np.abs(score[::125] - g["score_sample"]).max() <= 1e-9
+    # the per-anchor API, a few users
+    for i in (0, 499, 999):
+        res = model.find_closest_neighbours("item", users[i], k=k)
+        assert [model.nodes_to_idx[n] for n, _ in res] == ref_idx[i].tolist()
+    # the reference's own rows (blend stage on the captured table): everything identical
+    exact = content_tail(sc["E"], sc["src"], sc["dst"])
+    assert _sha(exact) == str(g["final_sha"])
+    m2 = VectorIndex(node_types=set(types), n_dims=12)
+    m2.fit(nodes, exact)
+    idx2, score2 = m2.find_closest_neighbours_batch("item", users, k=k)
+    assert np.array_equal(idx2, ref_idx)
+    assert _sha(np.ascontiguousarray(score2, dtype=np.float64)) == str(g["score_sha"])
+
+
+def test_fit_float32_flavour_still_available(golden, hw):
+    """blend_dtype = "float32" keeps rounds 1-4's flavour: float32 rows widened, within 1e-6 of the reference"""
+    from hwer import ContentRecommendation, Edge, IdentityEmbedding, Node
+    g6 = golden("g6_content_tail")
+    rng = np.random.default_rng(7)
+    types = ["user", "item", "tag"]
+    nodes = [Node(types[i % 3], i) for i in range(300)]
+    feats = rng.standard_normal((300, 5))
+    node_data = {n: {"f": feats[i]} for i, n in enumerate(nodes)}
+    edges = [Edge(nodes[s], nodes[t], 1.0) for s, t in zip(g6["src"], g6["dst"])]
+    model = ContentRecommendation({t: {"f": IdentityEmbedding(n_dims=5)} for t in types}, set(types), n_dims=8)
+    model.blend_dtype = "float32"
+    final = model.fit(nodes, edges, node_data)
+    assert np.array_equal(final, final.astype(np.float32).astype(np.float64))
+    assert np.abs(final - g6["final"]).max() <= 1e-6
+    model64 = ContentRecommendation({t: {"f": IdentityEmbedding(n_dims=5)} for t in types}, set(types), n_dims=8)
+    final64 = model64.fit(nodes, edges, node_data)
+    assert np.abs(final64 - g6["final"]).max() <= 1e-11      # float64 blend: only the PCA's rounding noise is left
+    res = model64.find_closest_neighbours("item", nodes[0], k=7)
+    assert [model64.nodes_to_idx[n] for n, _ in res] == g6["knn_idx"].tolist()
+    assert np.abs(np.array([s for _, s in res]) - g6["knn_score"]).max() <= 1e-11

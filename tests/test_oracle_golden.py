@@ -129,6 +129,27 @@ def test_g7_content_fit_tail_consistency(golden):
     assert np.array_equal(idx, g["knn_idx"]) and np.array_equal(score, g["knn_score"])
 
 
+def test_g15_content_fit_6k(golden):
+    """G15: the reference's ContentRecommendation.fit on 6 000 nodes.  The float64 restatement of hwer/content_recommender.py:77-96 on
+    the captured table reproduces `final` bit for bit (sha256 of all 6 000 x 12 values), and the oracle's k-NN on those rows returns the
+    reference's 200 neighbours and scores for every one of the 1 000 users."""
+    import hashlib
+    from conftest import g15_scenario
+    g = golden("g15_content_fit_6k")
+    sc = g15_scenario(g)
+    _, final = orc.content_tail(sc["E"], sc["src"], sc["dst"])
+    assert hashlib.sha256(np.ascontiguousarray(final).tobytes()).hexdigest() == str(g["final_sha"])
+    assert np.array_equal(final[g["final_rows"]], g["final_sample"])
+    k = sc["k"]
+    scores = np.empty((len(sc["users"]), k))
+    for i, u in enumerate(sc["users"]):
+        idx, s_, _ = orc.find_closest(final, sc["items"], int(u), k=k)
+        assert np.array_equal(idx, g["knn_idx"][i].astype(np.int64)), i
+        scores[i] = s_
+    assert hashlib.sha256(scores.tobytes()).hexdigest() == str(g["score_sha"])
+    assert np.array_equal(scores[::125], g["score_sample"])
+
+
 def test_g8_unit_audit(golden):
     g = golden("g8_unit_audit")
     for name in ("rows", "rows_zero", "rows_nan"):

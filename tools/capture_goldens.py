@@ -574,6 +574,66 @@ def g14(pkg):
                         pn_neg=flat(neg), pn_idx=idx_pn, pn_score=sc_pn.astype(np.float64))
 
 
+def g15(pkg):
+    """ContentRecommendation.fit end to end at a size where "identical neighbours" means something (round 5): 6 000 nodes in 3 types
+    (1 000 users, 1 000 tags, 4 000 items), IdentityEmbedding features, 24 000 random edges + 200 duplicates, n_dims = 8 -> the reference's
+    float64 `final` rows and, for EVERY user, find_closest_neighbours("item", user, k=200).  Captured: the PCA-unit block (so that the test
+    can rebuild the float64 table E the blend stage saw), sha256 + a row sample of `final`, all 1 000 x 200 neighbour ids, the scores'
+    sha256 + the scores of 8 users.  Inputs are regenerated by the test from the recipe (seed)."""
+    cr = pkg.content_recommender
+    rb = pkg.recommendation_base
+    emb = pkg.embed_base
+    Node, Edge = rb.Node, rb.Edge
+    types = ["user", "item", "tag"]
+    dims = [6, 7, 4]
+    N, seed, n_edges, n_dup, n_dims, k = 6000, 15, 24000, 200, 8, 200
+
+    def type_of(i):
+        return 0 if i % 6 == 0 else (2 if i % 6 == 1 else 1)
+    rng = np.random.default_rng(seed)
+    tid = np.asarray([type_of(i) for i in range(N)], dtype=np.int32)
+    nodes = [Node(types[tid[i]], i) for i in range(N)]
+    feats = [rng.standard_normal((int((tid == ti).sum()), dims[ti])) for ti in range(3)]
+    cursor = [0, 0, 0]
+    node_data = {}
+    for i, n in enumerate(nodes):
+        node_data[n] = {"f": feats[tid[i]][cursor[tid[i]]]}
+        cursor[tid[i]] += 1
+    src = rng.integers(0, N, n_edges)
+    dst = rng.integers(0, N, n_edges)
+    src = np.concatenate([src, src[:n_dup]])
+    dst = np.concatenate([dst, dst[:n_dup]])
+    edges = [Edge(nodes[s], nodes[t], 1.0) for s, t in zip(src, dst)]
+    mapper = {t: {"f": emb.IdentityEmbedding(n_dims=dims[ti])} for ti, t in enumerate(types)}
+    rec_unit = []
+    orig_unit = cr.unit_length
+
+    def rec_unit_length(a, axis=0):
+        r = orig_unit(a, axis=axis)
+        rec_unit.append((np.array(a, copy=True), np.array(r, copy=True)))
+        return r
+    cr.unit_length = rec_unit_length
+    try:
+        model = cr.ContentRecommendation(embedding_mapper=mapper, node_types=set(types), n_dims=n_dims)
+        type_order = list(model.node_types)
+        final = model.fit(nodes, edges, node_data)
+    finally:
+        cr.unit_length = orig_unit
+    pca_unit = rec_unit[-2][1]
+    assert np.array_equal(rec_unit[-1][1], final) and pca_unit.shape == (N, n_dims)
+    users = [n for n in nodes if n.node_type == "user"]
+    idx = np.empty((len(users), k), dtype=np.int16)
+    scores = np.empty((len(users), k), dtype=np.float64)
+    for u_i, u in enumerate(users):
+        res = model.find_closest_neighbours("item", u, k=k)
+        idx[u_i] = [model.nodes_to_idx[n] for n, _ in res]
+        scores[u_i] = [s_ for _, s_ in res]
+    sample = np.arange(0, N, 97)
+    np.savez_compressed(os.path.join(OUT, "g15_content_fit_6k.npz"), recipe=np.asarray([N, seed, n_edges, n_dup, n_dims, k] + dims, dtype=np.int64),
+                        types=np.asarray(types), type_order=np.asarray(type_order), pca_unit=pca_unit, final_sha=np.asarray(sha(final)),
+                        final_rows=sample, final_sample=final[sample], knn_idx=idx, score_sha=np.asarray(sha(scores)), score_sample=scores[::125])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     pkg = ref_shims.install()
@@ -593,6 +653,7 @@ def main():
     g12(pkg)
     g13(pkg)
     g14(pkg)
+    g15(pkg)
     for f in sorted(os.listdir(OUT)):
         print("%-32s %8d B" % (f, os.path.getsize(os.path.join(OUT, f))))
 
