@@ -127,25 +127,65 @@ def host_description():
 # ====================================================================================================================
 # self-launch (N > 1 without a launcher): start the ranks as child processes BEFORE anything touches a GPU
 # ====================================================================================================================
-def self_launch(args, argv):
+def self_launch(args, argv, poll_s=0.2, grace_s=10.0, script=None):
+    """Start the N ranks as child processes (fresh interpreters: nothing here has touched a GPU) and WATCH ALL OF THEM: the first rank
+    that exits non-zero (a crash in RCCL initialisation, an out-of-memory kill, an assertion) ends the job - the other ranks are
+    terminated (they would otherwise sit in a collective until somebody's timeout), the failing rank's stderr tail is printed and the
+    launcher exits with that rank's code.  Rank 0's stdout (the ONE JSON line) is passed through."""
     import socket
+    import tempfile
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+        err = tempfile.TemporaryFile()
+        errs.append(err)
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=env, stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err))
+
+    def tail(f, n=2000):
+        f.seek(0, 2)
+        size = f.tell()
+        f.seek(max(0, size - n))
+        return f.read().decode("utf-8", "replace")
+
+    failed = None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(poll_s)
+    if failed is not None:
+        r, c = failed
+        for p in procs:                      # exactly the processes started above, by handle
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + grace_s
+        for p in procs:
+            while p.poll() is None and time.time() < t_end:
+                time.sleep(0.05)
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+        sys.stderr.write("[bench] rank %d of %d exited with code %s; the other ranks were terminated.  Its stderr tail:\n%s\n" % (r, args.gpus, c, tail(errs[r])))
+        sys.stderr.flush()
+        return c if isinstance(c, int) and c > 0 else 1
+    for r, err in enumerate(errs):           # a clean run: pass the ranks' stderr through (rank 0 first), then rank 0's line
+        t = tail(err, 20000)
+        if t.strip():
+            sys.stderr.write(t if r == 0 else "".join("[rank %d] %s\n" % (r, ln) for ln in t.splitlines()))
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
-    return rc
+    return 0
 
 
 # ====================================================================================================================
@@ -1031,17 +1071,26 @@ def run_sharded(args, rank, local_rank, world):
     import torch
     import torch.distributed as dist
     from hwer import native
-    from hwer.distributed import all_gather_results, exchange_by_query, local_list_len, merge_on_device, shard_bounds
+    import datetime
+    from hwer.distributed import ShardedStepPipeline, local_list_len, shard_bounds
     backend = os.environ.get("HWER_BENCH_BACKEND", "nccl")     # "gloo" only to exercise the N > 1 code path on a 1-GPU box
     if backend != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # a rank that never arrives (crashed before the rendezvous, wrong port) must not hold the others for torch's default 10-30 minutes:
+    # the rendezvous and every collective give up after HWER_BENCH_DIST_TIMEOUT_S (default 300 s) and the rank exits non-zero
+    # (self_launch / torchrun then end the job)
+    tmo = datetime.timedelta(seconds=float(os.environ.get("HWER_BENCH_DIST_TIMEOUT_S", "300")))
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+    if os.environ.get("HWER_BENCH_FAIL_RANK") == str(rank):     # rehearsal of a dead rank (tests/test_bench_launcher.py): die after the rendezvous
+        sys.stderr.write("[bench] rank %d: HWER_BENCH_FAIL_RANK set - exiting with code 3\n" % rank)
+        sys.stderr.flush()
+        os._exit(3)
     lib = native.lib()
     name = args.config or "c4full"
     cfg = dict(CONFIGS[name])
@@ -1058,43 +1107,16 @@ def run_sharded(args, rank, local_rank, world):
     if os.environ.get("HWER_BENCH_LIST_LEN"):     # rehearsals: force a list length (a 2-rank job keeps full lists by itself)
         k_in = max(min(int(os.environ["HWER_BENCH_LIST_LEN"]), K), -(-K // world))
     w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2, k=k_in)
-    ex_accum = torch.zeros((U,), dtype=torch.int32, device=dev)   # queries whose merge saw a list run out, over every step of the job
-    comm = torch.cuda.Stream(device=dev)
-    ev_searched = [torch.cuda.Event() for _ in range(2)]
-    ev_merged = [torch.cuda.Event() for _ in range(2)]
-    merged = [None, None]
-    step_no = [0]
+    # The step itself is the LIBRARY's: hwer.distributed.ShardedStepPipeline = the resident BlendSearchStep over this rank's shard, ONE
+    # exchange per search (all-gather or the user-partitioned all-to-all) + hwer_merge_topk_lists on a side stream, the exchange of step i
+    # under the search of step i + 1, the "a list ran out" mask OR-ed on the device over every step of the job (no host sync in a step).
+    pipes = {}
     ev_log = []      # (start, collective done, merge done) events of every step, read after the closing barrier
 
     def make_step(exchange):
-        def step():
-            # ONE exchange step per search.  The exchange + merge run on a side stream: while RCCL moves the lists of step i over
-            # xGMI, the compute stream is already searching step i + 1 into the other result set.  Every step's merge still
-            # completes inside the timed region (the closing barrier synchronises all streams).
-            s = step_no[0] & 1
-            step_no[0] += 1
-            o = w.sets[s]
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev_merged[s])          # the exchange that read this result set two steps ago is done
-            w.step(o)
-            ev_searched[s].record(cur)
-            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-            with torch.cuda.stream(comm):
-                comm.wait_event(ev_searched[s])
-                e0.record(comm)
-                g = exchange_by_query(o["idx"], o["score"], o["dist2"]) if exchange == "by_query" else all_gather_results(o["idx"], o["score"], o["dist2"])
-                e1.record(comm)
-                if k_in < K:
-                    *m3, ex = merge_on_device(*g, True, k=K, want_exhausted=True)
-                    merged[s] = tuple(m3)
-                    ex_accum[:ex.numel()] |= ex
-                else:
-                    merged[s] = merge_on_device(*g, True)
-                e2.record(comm)
-                ev_merged[s].record(comm)
-            ev_log.append((e0, e1, e2))
-            return merged[s]
-        return step
+        pipe = pipes[exchange] = ShardedStepPipeline(w, K, exchange=exchange, sort_by_score=True, time_events=True)
+        pipe.event_log = ev_log
+        return pipe.run
 
     def barrier():
         torch.cuda.synchronize()
@@ -1123,13 +1145,13 @@ def run_sharded(args, rank, local_rank, world):
     main_exchange = os.environ.get("HWER_BENCH_EXCHANGE", "all_gather")
     elapsed, res, xs = timed(make_step(main_exchange), args.steps, args.warmup, profile=True)
     screen_ms, select_ms, _ = read_profile(lib)
-    last = w.sets[(step_no[0] - 1) & 1]
+    last = pipes[main_exchange].last_local_set()
     n_exhaustive = w.checks(last)
     other = "by_query" if main_exchange == "all_gather" else "all_gather"
     el2, _, xs2 = timed(make_step(other), args.steps, min(args.warmup, 2))
     # any list that ran out, on any rank, in any step of either variant: the shortened lists are not valid for this catalogue -
     # the whole measurement is repeated with full lists (every rank takes the same branch: the count is all-reduced)
-    n_ran_out = torch.tensor([int(ex_accum.sum().item())], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    n_ran_out = torch.tensor([sum(p_.exhausted_queries() for p_ in pipes.values())], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(n_ran_out, op=dist.ReduceOp.MAX)
     lists_ran_out = int(n_ran_out.item())
     if lists_ran_out and k_in < K:
@@ -1139,10 +1161,9 @@ def run_sharded(args, rank, local_rank, world):
         torch.cuda.empty_cache()
         k_in = K
         w = Workload(torch, lib, cfg, dev, lo=lo, hi=hi, f32_screen=args.f32_screen, want_dist=True, local_order=True, n_sets=2, k=k_in)
-        step_no[0] = 0
         elapsed, res, xs = timed(make_step(main_exchange), args.steps, args.warmup, profile=True)
         screen_ms, select_ms, _ = read_profile(lib)
-        last = w.sets[(step_no[0] - 1) & 1]
+        last = pipes[main_exchange].last_local_set()
         n_exhaustive = w.checks(last)
         el2, _, xs2 = timed(make_step(other), args.steps, min(args.warmup, 2))
     idx_h, score_h = res[0].cpu().numpy(), res[1].cpu().numpy()
@@ -1152,7 +1173,7 @@ def run_sharded(args, rank, local_rank, world):
     per = (I_total + world - 1) // world
     shard = torch.zeros((per, d), dtype=torch.float32, device=dev)
     shard[:hi - lo] = w.V[U:, :d]
-    parity_n, result_sha = 0, None
+    parity_n, result_sha, cpu_base = 0, None, None
     if backend == "nccl":
         allv = torch.empty((world * per, d), dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(allv, shard)
@@ -1176,6 +1197,18 @@ def run_sharded(args, rank, local_rank, world):
         assert np.array_equal(score_h[sel], osc), "merged scores differ from the oracle (N = %d)" % world
         parity_n = len(sel)
         result_sha = hashlib.sha256(np.ascontiguousarray(idx_h[:64]).tobytes()).hexdigest()[:16]
+        # CPU baseline of the SAME workload (the whole catalogue), the oracle's C restatement on rank 0's host cores, bounded sample -
+        # measured after the timed region, beside the N-GPU value it is compared with (the N = 1 line carries the same leg)
+        if not args.no_cpu_baseline:
+            n_s = int(min(U, max(16, 0.7e9 * 4.0 * cores / (float(I_total) * d * 8))))
+            cs = np.linspace(0, U - 1, n_s).astype(np.int64)
+            Qc = V64[cs] / np.linalg.norm(V64[cs], axis=1, keepdims=True)
+            t1 = time.perf_counter()
+            c_oracle.find_closest_f64(items_h, Qc, V64[cs], K, threads=cores)
+            t_cpu = time.perf_counter() - t1
+            cpu_base = {"value": n_s * float(I_total) / t_cpu, "unit": "pairs/s", "cores": cores, "kind": "port",
+                        "sample": "%d of %d queries x %d items, one pass (%.1f s): exact float64 brute force + re-score + sort (oracle/hwer_oracle.c, OpenMP), rank 0's host"
+                                  % (n_s, U, I_total, t_cpu)}
         del items_h
 
     # ---- the same workload on ONE GPU, measured in this job by rank 0 (the denominator of the strong-scaling speedup) --------
@@ -1213,9 +1246,11 @@ def run_sharded(args, rank, local_rank, world):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16" if f16 else "f32", "data": "synthetic",
         "config": {"workload": cfg["name"] + ", strong scaling: the SAME catalogue for every N", "users": U, "items_per_gpu": hi - lo, "items_total": I_total,
                    "d": d, "k": K, "tables": cfg["T"], "alpha": "per-row" if cfg["per_row"] else "scalar", "f16_screen": f16,
-                   "sharding": "items row-sharded x%d, queries replicated, ONE %s of the local top-%d per step + hwer_merge_topk_strided; the exchange of step i "
-                               "overlaps the search of step i+1" % (world, "RCCL all-gather" if main_exchange == "all_gather" else "user-partitioned all-to-all", K),
-                   "backend": backend, "rccl_ranks": dist.get_world_size()},
+                   "sharding": "items row-sharded x%d, queries replicated, ONE %s (backend %s%s) of the local top-%d per step + hwer_merge_topk_lists "
+                               "(hwer.distributed.ShardedStepPipeline); the exchange of step i overlaps the search of step i+1"
+                               % (world, "all-gather" if main_exchange == "all_gather" else "user-partitioned all-to-all", backend,
+                                  " = RCCL over xGMI" if backend == "nccl" else ": a rehearsal, payload staged through host memory", k_in),
+                   "backend": backend, "ranks": dist.get_world_size()},
         "roofline": {"kernel": "knn_screen on this rank's shard", "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "vs_fp32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": screen_ms},
         "kernels_ms": {"knn_screen": screen_ms, "knn_select_rerank": select_ms},
@@ -1227,6 +1262,7 @@ def run_sharded(args, rank, local_rank, world):
                              "collective_ms": float(xb[:, 0].mean()) if len(xb) else None, "merge_ms": float(xb[:, 1].mean()) if len(xb) else None}},
         "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive, "parity_checked_queries": parity_n,
         "result_sha16_first64_queries": result_sha,
+        "cpu_baseline": cpu_base, "speedup_vs_cpu": (value / cpu_base["value"]) if cpu_base else None,
         "one_gpu_same_workload": n1, "speedup_vs_one_gpu": (value / n1["value"]) if n1 else None,
         "scaling_note": "N = 1 point of this curve: `configs.c4full` of the `--gpus 1` line, or one_gpu_same_workload here",
     }

@@ -214,10 +214,17 @@ class ShardedSearch:
             return max(min(int(self.list_len), k), -(-k // self.world))
         return local_list_len(k, self.world) if self.merge is merge_on_device else k
 
-    def search(self, Q64, Q32, k: int, sort_by_score: bool = True, _full: bool = False, _rows=None):
+    def search(self, Q64, Q32, k: int, sort_by_score: bool = True, _full: bool = False, _rows=None, deferred: bool = False):
+        """-> merged (idx, score, dist2).  Shortened local lists (k_in < k): the merge kernel leaves, per query, whether a list ran out
+        (`exhausted`, a device tensor); such queries are repeated with full lists - by `settle()`, which this call runs before it
+        returns unless `deferred=True`.  A deferred search returns at once (no host synchronisation at all: the count of exhausted
+        queries travels to pinned host memory behind an event) and its results are final after the caller's `settle()` - or after
+        the NEXT `search()`, which settles its predecessor first, one step late, when that count has long arrived."""
         import torch
         if k > self.n_rows:
             raise ValueError("k must be less than or equal to the number of training points")
+        if not _full:
+            self.settle()                     # (a deferred predecessor: its count was copied out a whole search ago)
         n_local = self.hi - self.lo
         k_in = k if _full else self._list_len(k)
         k_local = min(k_in, n_local)
@@ -241,13 +248,117 @@ class ShardedSearch:
             return self.merge(*g, sort_by_score)
         m_idx, m_score, m_dist2, exhausted = self.merge(*g, sort_by_score, k=k, want_exhausted=True)
         # Every rank merged the same gathered lists with the same kernel: `exhausted` is identical on all ranks, so they all take (or
-        # skip) the repeat - a second, full-list exchange for those queries only - together.
-        again = torch.nonzero(exhausted, as_tuple=False).flatten()
-        self.repeated_queries = int(again.numel())
+        # skip) the repeat - a second, full-list exchange for those queries only - together.  The mask stays on the device; only its
+        # SUM goes to the host, asynchronously (device tensors: pinned memory + an event; the CPU tensors of the gloo tests: at once).
+        count = exhausted.sum(dtype=torch.int64)
+        if count.is_cuda:
+            host = torch.zeros(1, dtype=torch.int64).pin_memory()
+            host.copy_(count.view(1), non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(count.device))
+        else:
+            host, ev = count.view(1).clone(), None
+        self._pending = (ev, host, exhausted, Q64, Q32, k, sort_by_score, (m_idx, m_score, m_dist2))
+        if not deferred:
+            self.settle()
+        return m_idx, m_score, m_dist2
+
+    _pending = None
+
+    def settle(self) -> int:
+        """Finish the last shortened-list search: wait for its exhausted-query count (8 bytes, copied out behind an event when the
+        search was issued), and if it is non-zero repeat exactly those queries with full lists and patch the result tensors the
+        search returned, in place.  -> the number of repeated queries (also `repeated_queries`).  Every rank sees the same count."""
+        import torch
+        p, self._pending = self._pending, None
+        if p is None:
+            return 0
+        ev, host, exhausted, Q64, Q32, k, sort_by_score, (m_idx, m_score, m_dist2) = p
+        if ev is not None:
+            ev.synchronize()
+        self.repeated_queries = int(host[0])
         if self.repeated_queries:
+            again = torch.nonzero(exhausted, as_tuple=False).flatten()
             r_idx, r_score, r_dist2 = self.search(Q64[again], Q32[again] if Q32 is not None else None, k, sort_by_score, _full=True, _rows=again)
             m_idx[again], m_score[again], m_dist2[again] = r_idx, r_score, r_dist2
-        return m_idx, m_score, m_dist2
+        return self.repeated_queries
+
+
+class ShardedStepPipeline:
+    """The N-GPU step of the hot path as ONE library object (round 5; `bench.py --gpus N` times exactly this): a resident
+    `BlendSearchStep` over this rank's shard (local (distance, id) order, shortened local lists of `k_in` entries, two result sets)
+    followed by ONE exchange - `all_gather` (every rank ends with every query's result) or `by_query` (the user-partitioned
+    all-to-all: a rank ends with its slice of the queries) - and the merge kernel, the exchange + merge of step i on a side stream
+    under the search of step i + 1.  Nothing in `run()` synchronises with the host: queries whose merge saw a shortened list run
+    out are OR-ed into a device mask over all steps (`exhausted_queries()` reads it - after the job, or whenever the caller can
+    afford a synchronisation); such a job is repeated with full lists (`k_in = k`), as `ShardedSearch.settle()` does per search.
+
+        step = BlendSearchStep(tables, alpha, ..., k=k_in, want_dist=True, sort_by_score=False, n_sets=2)
+        pipe = ShardedStepPipeline(step, k=200, exchange="all_gather")
+        for _ in range(n): merged = pipe.run()          # (idx, score, dist2) of the step just issued; final after pipe.wait()
+        pipe.wait(); assert pipe.exhausted_queries() == 0
+    """
+
+    def __init__(self, step, k: int, exchange: str = "all_gather", group=None, sort_by_score: bool = True, time_events: bool = False):
+        import torch
+        assert exchange in ("all_gather", "by_query")
+        assert len(step.sets) >= 2 and step.sets[0]["dist2"] is not None and not step.sort_by_score, \
+            "the local step keeps two result sets in ascending (distance, id) order with distances (n_sets=2, want_dist=True, sort_by_score=False)"
+        self.step, self.k, self.k_in, self.exchange, self.group = step, int(k), int(step.k), exchange, group
+        self.sort_by_score = bool(sort_by_score)
+        dev = self.dev = step.dev
+        self.comm = torch.cuda.Stream(device=dev)
+        self.ev_searched = [torch.cuda.Event() for _ in range(2)]
+        self.ev_merged = [torch.cuda.Event() for _ in range(2)]
+        self.merged = [None, None]
+        self.n_steps = 0
+        self.ex_accum = torch.zeros((step.B,), dtype=torch.int32, device=dev)
+        self.time_events = bool(time_events)
+        self.event_log = []        # time_events: (exchange start, collective done, merge done) events of every step
+
+    def run(self):
+        """issue one step on the current stream (search) and the side stream (exchange + merge); -> this step's merged tensors"""
+        torch = self.step.torch
+        s = self.n_steps & 1
+        self.n_steps += 1
+        o = self.step.sets[s]
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.ev_merged[s])          # the exchange that read this result set two steps ago is done
+        self.step.step(o)
+        self.ev_searched[s].record(cur)
+        te = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.time_events else None
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self.ev_searched[s])
+            if te:
+                te[0].record(self.comm)
+            g = (exchange_by_query if self.exchange == "by_query" else all_gather_results)(o["idx"], o["score"], o["dist2"], self.group)
+            if te:
+                te[1].record(self.comm)
+            if self.k_in < self.k:
+                *m3, ex = merge_on_device(*g, self.sort_by_score, k=self.k, want_exhausted=True)
+                self.merged[s] = tuple(m3)
+                self.ex_accum[:ex.numel()] |= ex
+            else:
+                self.merged[s] = merge_on_device(*g, self.sort_by_score)
+            if te:
+                te[2].record(self.comm)
+                self.event_log.append(tuple(te))
+            self.ev_merged[s].record(self.comm)
+        return self.merged[s]
+
+    def wait(self):
+        """the current stream waits for every exchange + merge issued so far (no host synchronisation)"""
+        torch = self.step.torch
+        cur = torch.cuda.current_stream(self.dev)
+        for e in self.ev_merged:
+            cur.wait_event(e)
+
+    def last_local_set(self):
+        return self.step.sets[(self.n_steps - 1) & 1]
+
+    def exhausted_queries(self) -> int:
+        """queries for which some step's merge saw a shortened list run out (synchronises); non-zero: repeat the job with k_in = k"""
+        return int(self.ex_accum.sum().item())
 
 
 def sharded_index_search(index, node_type: str, shard: ShardedSearch, Q64, Q32, k, anchors_dev=None, score_mode=None,

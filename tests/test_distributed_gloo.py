@@ -73,6 +73,16 @@ def _worker(rank, world, port, n_items, k, out_dir, list_len=None):
         assert np.array_equal(np.sqrt(dist2[b].numpy()), o_dist)
     with pytest.raises(ValueError):
         sh.search(torch.from_numpy(Q), torch.from_numpy(Q.astype(np.float32)), n_items + 1)
+    if list_len is not None:
+        # deferred searches (round 5): no host synchronisation inside search(); the repeat of the queries whose list ran out happens in
+        # settle() - called explicitly, or by the NEXT search one step late - and patches the tensors the search returned, in place
+        first = sh.search(torch.from_numpy(Q), torch.from_numpy(Q.astype(np.float32)), k, deferred=True)
+        second = sh.search(torch.from_numpy(Q), torch.from_numpy(Q.astype(np.float32)), k, deferred=True)   # settles `first`
+        rep_first = sh.repeated_queries
+        assert torch.equal(first[0], idx) and torch.equal(first[1], score) and torch.equal(first[2], dist2)
+        assert sh.settle() == rep_first == int(open(os.path.join(out_dir, "rep%d" % rank)).read())   # the same batch again: the same repeats
+        assert sh.settle() == 0                                                                       # nothing pending any more
+        assert torch.equal(second[0], idx) and torch.equal(second[1], score) and torch.equal(second[2], dist2)
     # user-partitioned exchange: this rank ends with the merged rows of its own query slice only
     from hwer.distributed import query_slice
     B = 6

@@ -175,3 +175,34 @@ def test_fit_float32_flavour_still_available(golden, hw):
     res = model64.find_closest_neighbours("item", nodes[0], k=7)
     assert [model64.nodes_to_idx[n] for n, _ in res] == g6["knn_idx"].tolist()
     assert np.abs(np.array([s for _, s in res]) - g6["knn_score"]).max() <= 1e-11
+
+
+# ------------------------------------------------------------------------------------------------- the N > 1 job, rehearsed on one GPU
+def _bench_n(n, extra_env, timeout):
+    import subprocess
+    import sys
+    import time
+    env = dict(os.environ, HWER_BENCH_BACKEND="gloo", HWER_BENCH_ITEMS="400000", HWER_BENCH_NO_ANCHOR="1", HWER_BENCH_DIST_TIMEOUT_S="120", **extra_env)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True,
+                       timeout=timeout)
+    return r, time.time() - t0
+
+
+def test_bench_n4_runs_the_library_pipeline_and_survives_a_dead_rank(hw):
+    """`python bench.py --gpus 4` with its own launcher, four ranks over gloo on this one GPU (the payload staged through host memory; kernels,
+    layouts, shortened lists and the merge are the job's): the step is hwer.distributed.ShardedStepPipeline, the line names the backend that
+    really ran, carries `cpu_baseline`, and the merged result passed the oracle check inside the job.  Then the same job with rank 2 killed
+    right after the rendezvous: the launcher ends the job with a non-zero exit code and that rank's stderr in well under a minute."""
+    import json
+    r, dt = _bench_n(4, {}, 400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["parity_checked_queries"] >= 8
+    assert "backend gloo" in line["config"]["sharding"] and "ShardedStepPipeline" in line["config"]["sharding"] and "RCCL" not in line["config"]["sharding"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["roofline"]["frac"] > 0
+    assert line["exchange"]["lists_ran_out_first_pass"] == 0 and line["variants"]["by_query"]["ms_per_step"] > 0
+    r, dt = _bench_n(4, {"HWER_BENCH_FAIL_RANK": "2"}, 200)
+    assert r.returncode != 0 and dt < 60.0, (r.returncode, dt)
+    assert "rank 2 of 4 exited with code 3" in r.stderr and "HWER_BENCH_FAIL_RANK" in r.stderr
+    assert r.stdout.strip() == ""
