@@ -243,6 +243,7 @@ def make_workload_class():
                              n_sets=n_sets, extra_options=int(env("HWER_BENCH_OPTS", "0")),     # A/B runs: e.g. 16 = HWER_KNN_NO_SEED
                              fused_blend=True if env("HWER_BENCH_FORCE_FUSED_BLEND") else (False if env("HWER_BENCH_NO_FUSED_BLEND") else None),
                              fused_prologue=False if env("HWER_BENCH_NO_FUSED_PROLOGUE") else None, tail_stream=bool(env("HWER_BENCH_TAIL_STREAM")),
+                             tail_under_select=bool(env("HWER_BENCH_TAIL_UNDER_SELECT")),
                              pipeline=bool(env("HWER_BENCH_PIPELINE")))
 
         def _alpha_rows(self, seed, lo, hi):

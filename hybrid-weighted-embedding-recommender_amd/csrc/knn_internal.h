@@ -56,6 +56,19 @@ struct ScreenPlan {
     int seed_rank;         // ... and tau0 = the seed_rank-th largest candidate (= sample rank seed_frac * sample size)
     int64_t seed_cand_ld;  // ... row stride of the candidate matrix (bins * M rounded up to 64; the tail is never read)
     int seed_cand_n;       // ... candidates per query = bins * M
+    // Round 5, plans whose pre-pass cannot hand over lane candidates (one workgroup per query block: c3's 131 072 queries over 26 744 rows
+    // gave every query a 2 464-key float16 sample row, 646 MB written and read back, and a 1 700-instruction rank search per query): the
+    // pre-pass keeps, per (sample tile, lane half), only the MAXIMUM of the lane's 16 keys - seed_groups = 2 seed_tiles values per query,
+    // stored transposed ((seed_groups, bq) float32: a wave's 32 queries are one 128-byte segment) - and tau0 = the seed_rank-th largest
+    // GROUP MAXIMUM.  A group clears a threshold that a fraction f of the keys clear with probability g(f) = 1 - (1 - f)^16, so the rank
+    // r' = g(seed_frac) seed_groups aims at the same threshold as the sample rank seed_frac S did; with 16 f well below 1 nearly every
+    // clearing group holds ONE clearing key and the estimate loses little (c3: relative spread 14.8 % against 13.7 % from the whole sample).
+    // Correlated neighbours (a catalogue sorted by cluster) put several good keys into one group: the threshold then comes out LOWER - more
+    // keys pass, never fewer.  The safety statement is the same as for the sample rank: the catalogue holds fewer than K' keys above tau0
+    // with probability P(Binomial(seed_groups, g(K' / n_items)) >= r') - r' is raised until that is below 1e-7 - and such a query is
+    // flagged and recomputed exhaustively, never wrong.
+    int seed_gmax;         // 1: group maxima instead of sample keys / lane candidates
+    int seed_groups;       // ... values per query
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options = 0);

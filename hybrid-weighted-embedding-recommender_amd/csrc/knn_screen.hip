@@ -474,7 +474,20 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // (second subtile of a 64-row tile: no wait - it would only stall on the appends the first one has just issued)
             if constexpr (!DENSE) { if (sub == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             if constexpr (DENSE) {
-                if (a.seed_m) {   // (wave-uniform) seed pre-pass: the lane's running top-4 per query subtile, sorted descending
+                if (a.seed_m < 0) {   // (wave-uniform) seed pre-pass, group maxima: ONE value per (sample tile, lane half, query) - the maximum of the
+                    // lane's 16 keys (a v_max3 tree: 8 instructions per subtile where the top-4 insertion took 64 and the float16 key rows 8
+                    // conversions + 4 stores), stored transposed: dense[(2 tile + h) * ld_dense + query], ld_dense = bq - the 32 queries of a
+                    // lane half are one 128-byte segment.  Exactly TQ stores per tile: the counted wait at the tile boundary relies on it.
+                    const int64_t slot = (i0 >> 5) * 2 + h;
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b) {
+                        const float m0 = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]), m1 = fmaxf(fmaxf(acc[b][3], acc[b][4]), acc[b][5]);
+                        const float m2 = fmaxf(fmaxf(acc[b][6], acc[b][7]), acc[b][8]), m3 = fmaxf(fmaxf(acc[b][9], acc[b][10]), acc[b][11]);
+                        const float m4 = fmaxf(fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
+                        const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[b][15]));
+                        a.dense[slot * a.ld_dense + (qw0 + 32 * b + r)] = F16 ? ldexpf(mx, -e_tot[b]) : mx;
+                    }
+                } else if (a.seed_m) {   // (wave-uniform) seed pre-pass: the lane's running top-4 per query subtile, sorted descending
 #pragma unroll
                     for (int b = 0; b < TQ; ++b)
 #pragma unroll
@@ -612,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
             // wait for everything but them, so the DMA has landed while the stores stay in flight
             // (the seed pre-pass with seed_m stores nothing in the loop: plain wait)
             if ((t & wi_mask) == wii && !a.seed_m) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TQ) : "memory");
+            else if ((t & wi_mask) == wii && a.seed_m < 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(TQ) : "memory");   // group maxima: TQ stores per tile
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             // waves that computed this tile waited for the DMA of tile t+1 before their appends; the others do it here
@@ -692,7 +706,7 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
         o[6] = __builtin_amdgcn_s_memtime() - clk0; o[7] = __builtin_amdgcn_s_memrealtime() - rt0;   // in-kernel clock = o[6] / o[7] x 100 MHz
     }
     if constexpr (DENSE) {
-        if (a.seed_m) {   // hand over the lane's top-M (real units; -inf where the lane saw fewer keys)
+        if (a.seed_m > 0) {   // hand over the lane's top-M (real units; -inf where the lane saw fewer keys)
             const int bin = ((split * wi_n + wii) * 2 + h) * a.seed_m;
 #pragma unroll
             for (int b = 0; b < TQ; ++b) {
@@ -1385,6 +1399,27 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
                     p.seed_cand_n = bins * m;
                 }
             }
+            // group maxima (knn_internal.h): streaming plans that would otherwise store every sample key; 16 f <= 0.8 keeps the statistic
+            // far from saturation (g <= 0.55), <= 4 096 groups keep the pick a one-wave job
+            if (!p.seed_top_m && !small && 16.0 * frac <= 0.8 && ns * 2 <= 4096 && ns * 2 >= 32 && !diag_env("HWER_SEED_NO_GMAX")) {
+                const int n_g = int(ns) * 2;
+                auto g_of = [](double f) { return 1.0 - pow(1.0 - f, 16.0); };
+                int rank = std::max(8, int(g_of(frac) * n_g + 0.5));
+                // raise the rank until P(Binomial(n_g, g(K' / n)) >= rank) <= 1e-7 (log-space terms, summed from the tail end)
+                const double g0 = g_of(std::min(1.0, double(p.kprime) / double(n_items)));
+                auto tail = [&](int r) {
+                    double sum = 0.0;
+                    for (int j = n_g; j >= r; --j)
+                        sum += exp(lgamma(n_g + 1.0) - lgamma(j + 1.0) - lgamma(n_g - j + 1.0) + j * log(g0) + (n_g - j) * log1p(-g0));
+                    return sum;
+                };
+                while (rank < n_g && tail(rank) > 1e-7) ++rank;
+                if (rank <= n_g / 2) {   // (a sample too small for that: keep the sample-key path)
+                    p.seed_gmax = 1;
+                    p.seed_groups = n_g;
+                    p.seed_rank = rank;
+                }
+            }
         }
     }
     return p;
@@ -1482,9 +1517,10 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
     sp.n_splits = int(cdiv64(plan.seed_ld, per));
     sp.n_lists = 0;
     // seed_top_m: the lanes keep their M best keys and store only those, (bq, seed_cand_ld) float32; else every key as float16
-    ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_top_m ? plan.seed_cand_ld : plan.seed_ld, nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
+    // ... or (round 5) the group maxima: (seed_groups, bq) float32, seed_m = -1
+    ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_gmax ? plan.bq : (plan.seed_top_m ? plan.seed_cand_ld : plan.seed_ld), nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
                  plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
-                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, plan.seed_top_m ? 0 : 1, 0, 0, plan.seed_top_m};
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, (plan.seed_top_m || plan.seed_gmax) ? 0 : 1, 0, 0, plan.seed_gmax ? -1 : plan.seed_top_m};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

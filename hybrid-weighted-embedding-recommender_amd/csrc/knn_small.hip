@@ -961,9 +961,11 @@ int launch_seed_threshold(const float* keys, int64_t ld, int64_t n, int64_t B, d
 
 // tau0 of one query = the `rank`-th largest of its n <= 64 * PER candidates (the lanes' top-M of the seed pre-pass), one wave per
 // query, four queries per block; fewer finite candidates than `rank` (tiny samples): the smallest of them
+// (round 5: the same pick over the GROUP MAXIMA of a query, stored transposed - candidate i of query b at cand[i * ld_i + b * ld]; the lane
+// candidates above: ld_i = 1)
 template <int PER>
 __global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict__ cand, int64_t ld, int n, int64_t B, int rank,
-                                                        float* __restrict__ tau0, int32_t* __restrict__ count) {
+                                                        float* __restrict__ tau0, int32_t* __restrict__ count, int64_t ld_i) {
     const int lane = threadIdx.x & 63;
     const int64_t b = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -973,7 +975,7 @@ __global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict_
 #pragma unroll
     for (int m = 0; m < PER; ++m) {
         const int i = lane + 64 * m;
-        v[m] = i < n ? row[i] : -INFINITY;
+        v[m] = i < n ? row[int64_t(i) * ld_i] : -INFINITY;
         fin += __builtin_popcountll(__ballot(v[m] > -INFINITY));
     }
     float t = -INFINITY;   // no finite candidate: open threshold
@@ -988,6 +990,44 @@ __global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict_
     }
 }
 
+// Group maxima (round 5): tau0 of 64 consecutive queries per workgroup.  The (n, bq) matrix is read in whole 256-byte rows (64 queries x 4 bytes,
+// the layout the pre-pass wrote) into an LDS tile [n][65] - the odd row stride spreads a column over all banks - and every wave then picks the
+// rank-th largest of a query's column, 16 queries per wave, with the same interpolated rank search as seed_pick_kernel.  (The column-strided
+// variant of that kernel read 64 different cache lines per wave-instruction: 95 us for 131 072 queries x 154 groups, against 86 us for the
+// pre-pass that produced them.)
+template <int PER>
+__global__ __launch_bounds__(256) void seed_pick_gmax_kernel(const float* __restrict__ gm, int64_t bq, int n, int64_t B, int rank,
+                                                             float* __restrict__ tau0, int32_t* __restrict__ count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* tile = reinterpret_cast<float*>(smem_raw);   // [n][65]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t q0 = int64_t(blockIdx.x) * 64;
+    for (int i = wave; i < n; i += 4) tile[i * 65 + lane] = gm[int64_t(i) * bq + q0 + lane];   // bq is a multiple of 64: whole rows, in bounds
+    __syncthreads();
+    for (int qq = wave * 16; qq < wave * 16 + 16; ++qq) {   // wave-uniform
+        const int64_t b = q0 + qq;
+        if (b >= B) break;
+        float v[PER];
+        int fin = 0;
+#pragma unroll
+        for (int m = 0; m < PER; ++m) {
+            const int i = lane + 64 * m;
+            v[m] = i < n ? tile[i * 65 + qq] : -INFINITY;
+            fin += __builtin_popcountll(__ballot(v[m] > -INFINITY));
+        }
+        float t = -INFINITY;
+        if (fin > 0) {
+            const int rk = min(rank, fin);
+            int c_lo;
+            t = wave_find_rank<PER>(v, rk, rk / HWER_SEED_SLACK_DIV, c_lo);
+        }
+        if (lane == 0) {
+            tau0[b] = t;
+            count[b * COUNT_STRIDE] = 0;
+        }
+    }
+}
+
 void small_outputs(const SmallPlan& p, const ScreenPlan* seed, unsigned char* ws, uint64_t** list_out, int32_t** cnt_out) {
     const SmallLayout w = small_layout(p, seed);
     *list_out = reinterpret_cast<uint64_t*>(ws + w.list);
@@ -995,16 +1035,33 @@ void small_outputs(const SmallPlan& p, const ScreenPlan* seed, unsigned char* ws
 }
 
 size_t seed_keys_bytes(const ScreenPlan& plan) {
+    if (plan.seed_gmax) return size_t(plan.seed_groups) * size_t(plan.bq) * 4;   // group maxima, (seed_groups, bq) float32
     return plan.seed_top_m ? size_t(plan.bq) * size_t(plan.seed_cand_ld) * 4 : size_t(plan.bq) * size_t(plan.seed_ld) * 2;   // float32 candidates | float16 sample keys
 }
 
 int launch_seed_tau0(const ScreenPlan& plan, const float* seed_keys, int64_t B, float* tau0, int32_t* count_scratch, hipStream_t stream) {
-    if (!plan.seed_top_m) return launch_seed_threshold(seed_keys, plan.seed_ld, plan.seed_ld, B, plan.seed_frac, tau0, count_scratch, stream);
-    const int n = plan.seed_cand_n;
+    if (!plan.seed_top_m && !plan.seed_gmax) return launch_seed_threshold(seed_keys, plan.seed_ld, plan.seed_ld, B, plan.seed_frac, tau0, count_scratch, stream);
+    // lane candidates: row b = candidates of query b; group maxima: column b of a (seed_groups, bq) matrix
+    const int n = plan.seed_gmax ? plan.seed_groups : plan.seed_cand_n;
+    const int64_t ld_b = plan.seed_gmax ? 1 : plan.seed_cand_ld, ld_i = plan.seed_gmax ? plan.bq : 1;
+    if (plan.seed_gmax && n <= 512 && plan.bq % 64 == 0) {   // whole-row reads through an LDS tile (n x 65 floats <= 133 KB)
+        const size_t lds = size_t(n) * 65 * 4;
+        const dim3 g64(unsigned(cdiv64(B, 64)));
+        if (n <= 256) {
+            if (lds > size_t(64) * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&seed_pick_gmax_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
+                return fail(HWER_ELAUNCH, "knn_seed(pick): hipFuncSetAttribute(%zu)", lds);
+            hipLaunchKernelGGL(seed_pick_gmax_kernel<4>, g64, dim3(256), lds, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
+        } else {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&seed_pick_gmax_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
+                return fail(HWER_ELAUNCH, "knn_seed(pick): hipFuncSetAttribute(%zu)", lds);
+            hipLaunchKernelGGL(seed_pick_gmax_kernel<8>, g64, dim3(256), lds, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
+        }
+        return check_launch("knn_seed(pick gmax)");
+    }
     const dim3 grid(unsigned(cdiv64(B, 4)));
-    if (n <= 256) hipLaunchKernelGGL(seed_pick_kernel<4>, grid, dim3(256), 0, stream, seed_keys, plan.seed_cand_ld, n, B, plan.seed_rank, tau0, count_scratch);
-    else if (n <= 1024) hipLaunchKernelGGL(seed_pick_kernel<16>, grid, dim3(256), 0, stream, seed_keys, plan.seed_cand_ld, n, B, plan.seed_rank, tau0, count_scratch);
-    else hipLaunchKernelGGL(seed_pick_kernel<64>, grid, dim3(256), 0, stream, seed_keys, plan.seed_cand_ld, n, B, plan.seed_rank, tau0, count_scratch);
+    if (n <= 256) hipLaunchKernelGGL(seed_pick_kernel<4>, grid, dim3(256), 0, stream, seed_keys, ld_b, n, B, plan.seed_rank, tau0, count_scratch, ld_i);
+    else if (n <= 1024) hipLaunchKernelGGL(seed_pick_kernel<16>, grid, dim3(256), 0, stream, seed_keys, ld_b, n, B, plan.seed_rank, tau0, count_scratch, ld_i);
+    else hipLaunchKernelGGL(seed_pick_kernel<64>, grid, dim3(256), 0, stream, seed_keys, ld_b, n, B, plan.seed_rank, tau0, count_scratch, ld_i);
     return check_launch("knn_seed(pick)");
 }
 
@@ -1040,8 +1097,8 @@ int launch_small(const SmallPlan& p, const float* X, const float* hnorm, int64_t
         // tau0 = the rank-th largest candidate, rank = the sample rank of the plan (the threshold kernel of the full sample took 10.7 us for
         // 9 766 keys; this pick 6)
         const int rank = std::max(16, int(seed->seed_frac * double(seed->seed_ld) + 0.5));
-        if (n_cand <= 256) hipLaunchKernelGGL(seed_pick_kernel<4>, dim3(1), dim3(256), 0, stream, seed_keys, int64_t(n_cand), n_cand, int64_t(1), rank, thr, count);
-        else hipLaunchKernelGGL(seed_pick_kernel<16>, dim3(1), dim3(256), 0, stream, seed_keys, int64_t(n_cand), n_cand, int64_t(1), rank, thr, count);
+        if (n_cand <= 256) hipLaunchKernelGGL(seed_pick_kernel<4>, dim3(1), dim3(256), 0, stream, seed_keys, int64_t(n_cand), n_cand, int64_t(1), rank, thr, count, int64_t(1));
+        else hipLaunchKernelGGL(seed_pick_kernel<16>, dim3(1), dim3(256), 0, stream, seed_keys, int64_t(n_cand), n_cand, int64_t(1), rank, thr, count, int64_t(1));
         if ((rc = check_launch("knn_small(seed pick)"))) return rc;
         sink.tau0 = thr;
     } else if (f16) {

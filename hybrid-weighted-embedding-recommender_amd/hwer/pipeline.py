@@ -45,7 +45,7 @@ class BlendSearchStep:
                  id_base: Optional[int] = None, arith: int = 0, want_dist: bool = False, sort_by_score: bool = True,
                  f16_screen: Optional[bool] = None, f16_dense: bool = False, n_sets: int = 1, extra_options: int = 0,
                  fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = False, eps: float = 1e-4,
-                 search_ids=None, other_ids=None, pipeline: Optional[bool] = None):
+                 search_ids=None, other_ids=None, pipeline: Optional[bool] = None, tail_under_select: Optional[bool] = None):
         import torch
         lib = self.lib = native.lib()
         self.torch, self.native = torch, native
@@ -126,9 +126,24 @@ class BlendSearchStep:
             # sitting on a SIMD keeps the second one out - a workgroup that starts late still needs its full 2.1 ms, so the step was
             # bimodal (rocprofv3: the main screen 2.19 ... 3.97 ms; steps of 4.96 or 6.2 ms, with or without stream priorities).
             # One search after the other: 5.05 ms, every step.
-            self.tail = B % self.CH if (B > self.CH and tail_stream) else 0
+            # Round 5 experiment, OFF by default: tail_under_select=True makes the side stream wait for the main chunk's screen launch
+            # (hwer_knn_screen_f32 / hwer_knn_select_f32: the search as two stream-ordered calls) and runs the short last search beside
+            # the main SELECT, whose workgroups are small (256 threads, 128 VGPRs).  Measured at c3 (profiles/r5_ab_c3.txt, rocprofv3
+            # timeline): the tail's 512-thread / 169-VGPR screen workgroups are not dispatched while the select's 34 000 workgroups keep
+            # every SIMD's register file full - the 158 us launch stretches to the select's whole 1.96 ms whatever the stream priorities -
+            # and its list merge and select still run behind the main select: 4.81 -> 4.76 ms, inside the noise.
+            self.tail_under_select = bool(tail_under_select) and B > self.CH and B % self.CH != 0 and not tail_stream and not pipeline
+            self.tail = B % self.CH if (B > self.CH and (tail_stream or self.tail_under_select)) else 0
             self.overlap_tail = True
-            if self.tail:
+            if self.tail_under_select:
+                # (high stream priority: the tail's few workgroups are dispatched as soon as slots free up instead of queueing behind the
+                # main select's 34 000 - measured below)
+                self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("HWER_TAIL_PRIO", "-1")))
+                self.ev_main_screen = torch.cuda.Event()
+                self.ws_tail = torch.empty(lib.hwer_knn_workspace_bytes_opts(self.tail, I, d, K, self.opts), dtype=torch.uint8, device=dev)
+                native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws_tail), self.ws_tail.numel(), self.S()), "knn_workspace_init")
+                self.ws_exact_tail = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
+            elif self.tail:
                 # the tail search runs BESIDE the main one, at a lower stream priority: without it the two searches' kernels compete for
                 # the CUs in whatever order the queues drain, and a c3 step was bimodal (4.96 or 6.2 ms: the main screen's 241-VGPR waves
                 # waiting for register space behind the tail's list-merge waves)
@@ -220,7 +235,31 @@ class BlendSearchStep:
                 P(ws), P(self.missed), P(ws_exact), ws_exact.numel(), self.S()), "knn_exact_device")
         if self.pipeline and U == self.B and self.overlap_tail:
             return self._search_pipelined(o, opts)
-        side_tail = self.tail and U == self.B and self.overlap_tail
+        if self.tail_under_select and U == self.B and self.overlap_tail:
+            torch = self.torch
+            cur = torch.cuda.current_stream(self.dev)
+            x16 = P(self.X16) if self.f16_screen else None
+            n_main = U - self.tail
+            for b0 in range(0, n_main, self.CH):
+                b1 = min(n_main, b0 + self.CH)
+                native.check(lib.hwer_knn_screen_f32(P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), b1 - b0, K, P(self.ws), self.ws.numel(),
+                                                     opts & ~KNN_QUERIES_READY, x16, self.x16_exp, self.S()), "knn_screen")
+                if b1 == n_main:      # the last full chunk's screen is on its way: the tail search goes beside its select
+                    self.ev_main_screen.record(cur)
+                    self.side.wait_event(self.ev_main_screen)
+                    with torch.cuda.stream(self.side):
+                        search(n_main, U, self.ws_tail, self.ws_exact_tail)
+                native.check(lib.hwer_knn_select_f32(
+                    P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), b1 - b0, K, self.arith,
+                    self.sort_by_score, P(self.search_ids), self.id_base, self.hnorm_max, P(oi[b0:b1]), P(osc[b0:b1]),
+                    P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(), opts & ~KNN_QUERIES_READY, x16, self.S()), "knn_select")
+                native.check(lib.hwer_knn_exact_device(
+                    P(self.X), self.I, self.d, self.ldx, P(self.Q64[b0:b1]), P(self.V), self.ldv, P(self.anchors[b0:b1]), K, self.arith,
+                    self.sort_by_score, P(self.search_ids), self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]),
+                    P(self.ws), P(self.missed), P(self.ws_exact), self.ws_exact.numel(), self.S()), "knn_exact_device")
+            cur.wait_stream(self.side)
+            return
+        side_tail = self.tail and not self.tail_under_select and U == self.B and self.overlap_tail
         if side_tail:   # the short last search, on the second stream
             torch = self.torch
             cur = torch.cuda.current_stream(self.dev)
