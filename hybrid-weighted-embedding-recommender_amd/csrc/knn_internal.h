@@ -69,6 +69,7 @@ struct ScreenPlan {
     // flagged and recomputed exhaustively, never wrong.
     int seed_gmax;         // 1: group maxima instead of sample keys / lane candidates
     int seed_groups;       // ... values per query
+    int seed_group;        // seed_top_m plans: the lanes' top-M candidates are group maxima too (seed_rank is then a rank in groups)
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options = 0);

@@ -62,7 +62,10 @@ struct ScreenArgs {
     int sparse_hits;     // streaming float16 mode: fewer than ~0.6 passing keys expected per tile and wave -> the max-tree filter (FILTER_V2)
     int many_hits;       // ping-pong kernel: >= ~8 passing keys expected per 32-row subtile and wave -> up to four pops per round of the pop loop
     int seed_m;          // DENSE mode, seed pre-pass (round 3): 0 = store every key; M in {1, 2, 4} = every lane keeps the M largest keys it
-                         // sees for its query and stores only those: dense[q * ld_dense + bin * M + j], bin = (split * wi + wave_i) * 2 + lane half
+                         // sees for its query and stores only those: dense[q * ld_dense + bin * M + j], bin = (split * wi + wave_i) * 2 + lane half;
+                         // -1 (round 5): the maximum of the lane's 16 keys per sample tile, transposed (see knn_internal.h: seed_gmax)
+    int seed_group;      // seed_m > 0 (round 5): the lane's top-M of its GROUP MAXIMA (one candidate per 16 keys: a v_max3 tree + ONE insertion
+                         // per subtile instead of 16 insertions) - the pick then takes a rank in groups
 };
 
 // sc1 load: served by L2, never by a stale L1 line
@@ -486,6 +489,19 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
                         const float m4 = fmaxf(fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
                         const float mx = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[b][15]));
                         a.dense[slot * a.ld_dense + (qw0 + 32 * b + r)] = F16 ? ldexpf(mx, -e_tot[b]) : mx;
+                    }
+                } else if (a.seed_m && a.seed_group) {   // (wave-uniform) top-4 of the lane's group maxima: 8 + 4 instructions per 16 keys
+#pragma unroll
+                    for (int b = 0; b < TQ; ++b) {
+                        const float m0 = fmaxf(fmaxf(acc[b][0], acc[b][1]), acc[b][2]), m1 = fmaxf(fmaxf(acc[b][3], acc[b][4]), acc[b][5]);
+                        const float m2 = fmaxf(fmaxf(acc[b][6], acc[b][7]), acc[b][8]), m3 = fmaxf(fmaxf(acc[b][9], acc[b][10]), acc[b][11]);
+                        const float m4 = fmaxf(fmaxf(acc[b][12], acc[b][13]), acc[b][14]);
+                        const float x = fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[b][15]));
+                        const float n0 = fmaxf(top[b][0], x);
+                        const float n1 = __builtin_amdgcn_fmed3f(top[b][0], top[b][1], x);
+                        const float n2 = __builtin_amdgcn_fmed3f(top[b][1], top[b][2], x);
+                        const float n3 = __builtin_amdgcn_fmed3f(top[b][2], top[b][3], x);
+                        top[b][0] = n0; top[b][1] = n1; top[b][2] = n2; top[b][3] = n3;
                     }
                 } else if (a.seed_m) {   // (wave-uniform) seed pre-pass: the lane's running top-4 per query subtile, sorted descending
 #pragma unroll
@@ -1397,6 +1413,27 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
                     p.seed_rank = rank;
                     p.seed_cand_ld = ((int64_t(bins) * m + 63) / 64) * 64;
                     p.seed_cand_n = bins * m;
+                    // Round 5: the lanes' candidates are GROUP MAXIMA (the largest of a lane's 16 keys per sample tile) - one insertion per 16
+                    // keys.  With 16 f << 1 a group above the threshold holds one key above it, so the r-th largest group maximum is the r-th
+                    // largest key but for the rare groups with two: rank in groups r' = g(f) S / 16 <= r, g(f) = 1 - (1 - f)^16, raised until
+                    // P(Binomial(S / 16, g(K' / n)) >= r') <= 1e-7 (the statement that the catalogue holds K' keys above tau0).
+                    if (16.0 * frac <= 0.25 && !diag_env("HWER_SEED_NO_GROUPS")) {
+                        const int64_t n_g = int64_t(S) / 16;
+                        auto g_of = [](double f) { return 1.0 - pow(1.0 - f, 16.0); };
+                        int r2 = std::max(8, int(g_of(frac) * double(n_g) + 0.5));
+                        const double g0 = g_of(std::min(1.0, double(p.kprime) / double(n_items)));
+                        const double mu = double(n_g) * g0;          // Poisson tail (n_g is large, g0 tiny): P(X >= r2), summed upwards from r2
+                        auto tail = [&](int r) {
+                            double term = exp(-mu + r * log(mu) - lgamma(r + 1.0)), sum = 0.0;
+                            for (int j = r; j < r + 200 && term > 1e-30; ++j) { sum += term; term *= mu / double(j + 1); }
+                            return sum;
+                        };
+                        while (r2 < 4096 && tail(r2) > 1e-7) ++r2;
+                        if (int64_t(bins) * m >= int64_t(4) * r2) {
+                            p.seed_group = 1;
+                            p.seed_rank = r2;
+                        }
+                    }
                 }
             }
             // group maxima (knn_internal.h): streaming plans that would otherwise store every sample key; 16 f <= 0.8 keeps the statistic
@@ -1520,7 +1557,8 @@ int launch_seed_screen(const ScreenPlan& plan, const float* X, const float* hnor
     // ... or (round 5) the group maxima: (seed_groups, bq) float32, seed_m = -1
     ScreenArgs a{X, hnorm, plan.seed_ld, ldx, Qf, B, seed_keys, plan.seed_gmax ? plan.bq : (plan.seed_top_m ? plan.seed_cand_ld : plan.seed_ld), nullptr, nullptr, plan.n_qblocks, plan.wq, per, plan.bq,
                  plan.kprime, 0, 0, -INFINITY, nullptr, hdr, f16 ? f16->X16 : nullptr, f16 ? f16->Qf16 : nullptr, f16 ? f16->qexp : nullptr,
-                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, (plan.seed_top_m || plan.seed_gmax) ? 0 : 1, 0, 0, plan.seed_gmax ? -1 : plan.seed_top_m};
+                 f16 ? f16->x_exp : 0, nullptr, plan.seed_stride, (plan.seed_top_m || plan.seed_gmax) ? 0 : 1, 0, 0, plan.seed_gmax ? -1 : plan.seed_top_m,
+                 plan.seed_gmax ? 0 : plan.seed_group};
     const int key = plan.ng * 10 + plan.tq;
     if (f16) {
         switch (key) {

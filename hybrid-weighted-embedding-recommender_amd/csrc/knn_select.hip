@@ -258,6 +258,12 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                             // a and x are float32 values, so a * x is EXACT in float64 (48 significant bits): fma(a, x, r) rounds
                             // r + a x once, exactly like numpy's add of the (unrounded-because-exact) product - one instruction less
                             // per element than mul + add, bit-identical results.
+                            // (round 5, measured and NOT kept: the anchor row widened to float64 once per search and read as scalar float64 operands -
+                            // 2 instead of 3 vector instructions per element, but twice the scalar-load bytes and 32 SGPRs per 8-group in a kernel at
+                            // 106 SGPRs: c3 select 2.19 -> 2.42 ms, c4 / c5 +3 - 4 %, profiles/r5_ab_a64_anchors.txt)
+                            // (also measured and not kept: the chunk's 16 anchor floats requested at the top of the step, in front of the wait for the
+                            // gathered rows, so that their scalar-cache latency hides under it - 105 more spilled SGPRs and a full lgkmcnt drain in front
+                            // of the next gathers: c2 select 121 -> 125 us, c3 2.12 -> 2.16 ms, profiles/r5_ab_select_scalar_hoist.txt)
                             const double a0 = double(a32[jj + 0]), a1 = double(a32[jj + 1]), a2 = double(a32[jj + 2]), a3 = double(a32[jj + 3]);
                             const double a4 = double(a32[jj + 4]), a5 = double(a32[jj + 5]), a6 = double(a32[jj + 6]), a7 = double(a32[jj + 7]);
                             const double x0 = double(xv[8 * gg + 0]), x1 = double(xv[8 * gg + 1]), x2 = double(xv[8 * gg + 2]), x3 = double(xv[8 * gg + 3]);
@@ -400,13 +406,66 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             const uint64_t dm = mine ? f64_orderable(t_d2[lane]) : ~0ull;
             const uint32_t im = mine ? cand[lane] : 0xFFFFFFFFu;
             int rank = 0;
-            for (int j = 0; j < n_b; ++j) {   // wave-uniform; LDS broadcast reads
-                const uint64_t dj = f64_orderable(t_d2[j]);
-                const uint32_t ij = cand[j];
+            // (round 5) candidate j's (distance, id) comes out of lane j's registers through v_readlane - three scalar reads and four compares
+            // per boundary candidate, nothing waits: the LDS broadcast reads this loop made before were a dependent ~300-cycle round trip per
+            // candidate (c2 stamps: 8.9 K cycles for ~30 candidates)
+            for (int j = 0; j < n_b; ++j) {   // wave-uniform
+                const uint32_t dlo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(dm)), j)), dhi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(dm >> 32)), j));
+                const uint64_t dj = (uint64_t(dhi) << 32) | dlo;
+                const uint32_t ij = uint32_t(__builtin_amdgcn_readlane(int(im), j));
                 rank += (dj < dm || (dj == dm && ij < im)) ? 1 : 0;
             }
             const bool member_b = mine && rank < n_keep;
             SEL_STAMP(7);
+            bool ordered = false;
+            if constexpr (NE == 4) {
+            if (!(a.debug_skip & 256)) {
+                ordered = true;
+                // (round 5) score order from four register-sorted runs and their merge ranks - the one-workgroup-per-query select's method
+                // (round 4) inside one wave: every register is sorted across the lanes (21 DPP / permlane exchange stages), the four ascending
+                // runs go to the (now idle) staging area, a key's position is its lane + its lower bounds in the three other runs (7 probes
+                // each, twelve independent searches per lane), and the keys come back in the blocked layout the tie fix-up and the emission
+                // expect.  Non-members carry (0xFFFFFFFF, slot): distinct keys, behind every member.  ~600 instructions where the 36-stage
+                // bitonic network over 256 keys took ~1 300 and 300 ds_bpermute round trips.
+                uint64_t* skeys = reinterpret_cast<uint64_t*>(stage);      // 4 runs x 64 keys, then sfinal: 256 keys (4 KB of the 5 KB staging area)
+                uint64_t* sfinal = skeys + 256;
+                static_assert(size_t(64) * RR_RS * 4 >= size_t(256) * 8, "the staging area holds the 256 keys");
+                uint64_t sk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int i = 64 * j + lane;
+                    const bool member = i < n_r && (i >= n_b || (j == 0 && member_b));
+                    sk[j] = (uint64_t(member ? ~f32_orderable(float(t_sc[min(i, kp - 1)])) : 0xFFFFFFFFu) << 32) | uint64_t(uint32_t(i));
+                    wave_sort1_u64(sk[j]);
+                }
+                SEL_STAMP(8);
+                // the staging area holds 64 x RR_RS floats = 5 120 bytes: the four runs (2 KB) first, the merged order after a second pass
+                uint64_t* runs = skeys;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) runs[64 * j + lane] = sk[j];
+                wave_lds_sync();
+                int pos[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    pos[j] = lane;
+#pragma unroll
+                    for (int w2 = 1; w2 < 4; ++w2) pos[j] += run64_count_less(runs + 64 * ((j + w2) & 3), sk[j]);
+                }
+                wave_lds_sync();
+                uint64_t* merged = skeys;        // every lane has read what it needs of the runs: the merged order overwrites them
+#pragma unroll
+                for (int j = 0; j < 4; ++j) merged[pos[j]] = sk[j];
+                wave_lds_sync();
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const uint64_t kk = merged[(NE * lane + j) & 255];
+                    key[j] = (kk >> 32) == 0xFFFFFFFFull ? ~0ull : kk;
+                }
+                (void)sfinal;
+                SEL_STAMP(9);
+            }
+            }
+            if (!ordered) {
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int i = 64 * j + lane;
@@ -416,6 +475,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             SEL_STAMP(8);
             wave_sort_u64<NE>(key);
             SEL_STAMP(9);
+            }
             wave_sort_fixup<NE>(key, [&](uint64_t x, uint64_t y) {
                 const uint32_t sx = uint32_t(x) & 0xFFFFu, sy = uint32_t(y) & 0xFFFFu;
                 const uint64_t ax = ~f64_orderable(t_sc[sx]), ay = ~f64_orderable(t_sc[sy]);
