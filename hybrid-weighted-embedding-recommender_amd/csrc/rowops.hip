@@ -735,6 +735,95 @@ __device__ __forceinline__ void query_mix_body(const QueryMixArgs& a, unsigned c
         wave_lds_sync();
     }
 }
+// Anchor-only queries in bulk (round 5): q_b = unit(V[anchor_b]) with numpy's norm, for callers whose anchors outnumber what the 8-lanes-per-query
+// kernel above does well (it reads a row as 32-byte pieces and spends its time in LDS bank conflicts: 145 us for the 138 493 queries of the
+// ML-20M shape, 1.9 TB/s).  Same arithmetic, element for element - widen (clip an unknown anchor's row 0), squares summed in numpy's pairwise
+// order, one IEEE division per element - on the layout of the float64 blend kernels (rows_f64.hip): L lanes load a row as 16-byte chunks
+// (coalesced), the widened row waits in an LDS slab, 8 lanes replay the summation order, the L lanes divide and store Q64 / Q32.
+template <typename T>
+__device__ __forceinline__ T np_pairwise_sq_leaf_t(const T* p, int n, int k) {
+    if (n < 8) {
+        T r = T(0);
+        for (int i = 0; i < n; ++i) r = r + p[i] * p[i];
+        return r;
+    }
+    const int lim = n - (n & 7);
+    T r = p[k] * p[k];
+    for (int i = 8; i < lim; i += 8) r = r + p[i + k] * p[i + k];
+    r = r + shfl_xor_t(r, 1);
+    r = r + shfl_xor_t(r, 2);
+    r = r + shfl_xor_t(r, 4);
+    for (int i = lim; i < n; ++i) r = r + p[i] * p[i];
+    return r;
+}
+template <typename T, int DEPTH>
+__device__ __forceinline__ T np_pairwise_sq_t(const T* p, int n, int k) {
+    if constexpr (DEPTH == 0) {
+        return np_pairwise_sq_leaf_t(p, n, k);
+    } else {
+        if (n <= 128) return np_pairwise_sq_leaf_t(p, n, k);
+        int n2 = n / 2;
+        n2 -= n2 & 7;
+        const T a = np_pairwise_sq_t<T, DEPTH - 1>(p, n2, k);
+        const T b = np_pairwise_sq_t<T, DEPTH - 1>(p + n2, n - n2, k);
+        return a + b;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void anchor_query_kernel(const float* __restrict__ V, int64_t ldv, int d, int d4, const int32_t* __restrict__ anchor, int64_t B,
+                                                           double* __restrict__ Q64, float* __restrict__ Q32, int64_t ldq32, int stride, int pb_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T* slab = reinterpret_cast<T*>(smem_raw) + size_t(wave) * (size_t(pb_n) * stride + 8);
+    T* s_nrm = slab + size_t(pb_n) * stride;
+    const int q4 = int(ldq32 / 4);                 // float4 chunks of a Q32 row (>= d4: the padding columns are zero)
+    const int L = min(64, pow2ceil(q4));
+    const int rpi = 64 / L, sub = lane / L, c0 = lane % L;
+    const int64_t n_trips = cdiv64(B, pb_n);
+    for (int64_t t = int64_t(blockIdx.x) * 4 + wave; t < n_trips; t += int64_t(gridDim.x) * 4) {
+        const int64_t p0 = t * pb_n;
+        for (int pb = 0; pb < pb_n; pb += rpi) {
+            const int slot = pb + sub;
+            const int64_t b = p0 + slot;
+            if (slot >= pb_n || b >= B) continue;
+            const int32_t an = anchor[b];
+            const bool unknown = an < 0;
+            for (int c = c0; c < d4; c += L) {
+                const float4 v = load_row4(V, ldv, an, c);
+                T* w = slab + slot * stride + 4 * c;
+                w[0] = widen<T>(v.x, unknown); w[1] = widen<T>(v.y, unknown); w[2] = widen<T>(v.z, unknown); w[3] = widen<T>(v.w, unknown);
+            }
+        }
+        wave_lds_sync();
+        {
+            const int p8 = lane >> 3, k = lane & 7;
+            const T ss = np_pairwise_sq_t<T, kPairwiseDepth>(slab + min(p8, pb_n - 1) * stride, d, k);
+            if (k == 0 && p8 < pb_n) s_nrm[p8] = sqrt(ss);
+        }
+        wave_lds_sync();
+        for (int pb = 0; pb < pb_n; pb += rpi) {
+            const int slot = pb + sub;
+            const int64_t b = p0 + slot;
+            if (slot >= pb_n || b >= B) continue;
+            const T nrm = s_nrm[slot];
+            for (int c = c0; c < q4; c += L) {
+                float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int j = 4 * c + i;
+                    if (j < d) {
+                        const T v = (slab[slot * stride + j] / nrm) / T(1.0);   // (unit row) / (number of terms of the query mean = 1)
+                        Q64[b * d + j] = double(v);
+                        o[i] = float(v);
+                    }
+                }
+                *reinterpret_cast<float4*>(Q32 + b * ldq32 + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void query_mix_kernel(const QueryMixArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1442,6 +1531,23 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
     if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix: bad shape");
     if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix: ptr without idx");
     if (arith != 0 && arith != 1) return fail(HWER_EINVAL, "query_mix: arith must be 0 (float64) or 1 (float32)");
+    // anchor-only queries in bulk: the row-streaming kernel (same values; from 4 096 queries on it is the faster one)
+    if (!pos_ptr && !neg_ptr && B >= 4096 && ldv % 4 == 0 && ldq32 % 4 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(Q32) & 15) == 0 && !diag_env("HWER_NO_ANCHOR_QUERY_KERNEL")) {
+        const size_t ts = arith == 0 ? sizeof(double) : sizeof(float);
+        const int d4 = (d + 3) / 4;
+        int stride = 4 * d4;
+        if (arith == 0) { while (stride % 32 != 8) stride += 2; } else { while (stride % 32 != 8) ++stride; }   // the 8-lane chains of 4 rows on distinct banks
+        int pb_n = 8;
+        while (pb_n > 2 && size_t(pb_n) * stride * ts > size_t(4800)) pb_n >>= 1;
+        const size_t lds = size_t(4) * (size_t(pb_n) * stride + 8) * ts;
+        if (lds <= size_t(64) * 1024) {
+            const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(cdiv64(B, pb_n), 4), kMaxStreamBlocks * 2)));
+            if (arith == 0) hipLaunchKernelGGL(anchor_query_kernel<double>, dim3(grid), dim3(256), lds, as_stream(stream), V, ldv, d, d4, anchor, B, Q64, Q32, ldq32, stride, pb_n);
+            else hipLaunchKernelGGL(anchor_query_kernel<float>, dim3(grid), dim3(256), lds, as_stream(stream), V, ldv, d, d4, anchor, B, Q64, Q32, ldq32, stride, pb_n);
+            return check_launch("query_mix(anchors)");
+        }
+    }
     int gq = 8;
     while (gq > 1 && size_t(gq) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float)) > size_t(128) * 1024) gq >>= 1;
     const size_t per_wave = size_t(gq) * 3 * d * (arith == 0 ? sizeof(double) : sizeof(float));

@@ -206,3 +206,43 @@ def test_bench_n4_runs_the_library_pipeline_and_survives_a_dead_rank(hw):
     assert r.returncode != 0 and dt < 60.0, (r.returncode, dt)
     assert "rank 2 of 4 exited with code 3" in r.stderr and "HWER_BENCH_FAIL_RANK" in r.stderr
     assert r.stdout.strip() == ""
+
+
+# ------------------------------------------------------------------------------------------------- bulk anchor-only queries
+@pytest.mark.parametrize("d,arith", [(128, 0), (128, 1), (64, 0), (100, 0), (66, 1), (256, 0), (515, 0), (7, 1), (1, 0)])
+def test_anchor_query_kernel_equals_query_mix(hw, d, arith):
+    """hwer_query_mix with at least 4 096 anchor-only queries runs the row-streaming kernel (round 5); the same call with EMPTY positive
+    lists runs the general 8-lanes-per-query kernel: Q64 and Q32 (padding columns included) must be identical bit for bit - unknown anchors
+    (-1: row 0 clipped), repeated anchors, a ragged last trip - and equal the oracle's query_vector on a sample."""
+    import torch
+    from hwer import native
+    lib = native.lib()
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(900 + d)
+    N, B = 3000, 4099
+    ldv = (d + 3) // 4 * 4
+    ldq = max(32, (d + 15) // 16 * 16)
+    Vh = np.zeros((N, ldv), np.float32)
+    Vh[:, :d] = rng.standard_normal((N, d)).astype(np.float32) * rng.uniform(0.1, 3.0, (N, 1)).astype(np.float32)
+    V = torch.from_numpy(Vh).to(dev)
+    an = rng.integers(0, N, B).astype(np.int32)
+    an[::97] = -1
+    anchors = torch.from_numpy(an).to(dev)
+    empty_ptr = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+    dummy_idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    P, S = native.ptr, native.stream_ptr()
+
+    def run(with_lists):
+        Q64 = torch.full((B, d), 7.0, dtype=torch.float64, device=dev)
+        Q32 = torch.full((B, ldq), 7.0, dtype=torch.float32, device=dev)
+        native.check(lib.hwer_query_mix(P(V), N, d, ldv, P(anchors), P(empty_ptr) if with_lists else None, P(dummy_idx) if with_lists else None,
+                                        None, None, B, arith, P(Q64), P(Q32), ldq, S), "query_mix")
+        return Q64.cpu().numpy(), Q32.cpu().numpy()
+    a64, a32 = run(False)
+    b64, b32 = run(True)
+    assert np.array_equal(a64, b64) and np.array_equal(a32, b32)
+    assert np.all(a32[:, d:] == 0.0)
+    Vd = Vh[:, :d].astype(np.float64) if arith == 0 else Vh[:, :d]
+    for b in (0, 1, 97, 2048, B - 1):
+        ref = orc.query_vector(Vd, int(an[b]))
+        assert np.array_equal(a64[b], np.asarray(ref, dtype=np.float64)), b
