@@ -338,7 +338,7 @@ def load_traffic(config):
     that file carries the digest of the library that is running (`library_digest`; tools/pmc_summary.py writes it) - counters of
     another build of the kernels are not this run's traffic: then `traffic` is null and `traffic_source` says why."""
     dig = library_digest()
-    for fn in ("r4_pmc_traffic.json",):
+    for fn in ("r5_pmc_traffic.json", "r4_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 doc = json.load(fh)

@@ -990,41 +990,51 @@ __global__ __launch_bounds__(256) void seed_pick_kernel(const float* __restrict_
     }
 }
 
-// Group maxima (round 5): tau0 of 64 consecutive queries per workgroup.  The (n, bq) matrix is read in whole 256-byte rows (64 queries x 4 bytes,
-// the layout the pre-pass wrote) into an LDS tile [n][65] - the odd row stride spreads a column over all banks - and every wave then picks the
-// rank-th largest of a query's column, 16 queries per wave, with the same interpolated rank search as seed_pick_kernel.  (The column-strided
-// variant of that kernel read 64 different cache lines per wave-instruction: 95 us for 131 072 queries x 154 groups, against 86 us for the
-// pre-pass that produced them.)
-template <int PER>
-__global__ __launch_bounds__(256) void seed_pick_gmax_kernel(const float* __restrict__ gm, int64_t bq, int n, int64_t B, int rank,
-                                                             float* __restrict__ tau0, int32_t* __restrict__ count) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* tile = reinterpret_cast<float*>(smem_raw);   // [n][65]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t q0 = int64_t(blockIdx.x) * 64;
-    for (int i = wave; i < n; i += 4) tile[i * 65 + lane] = gm[int64_t(i) * bq + q0 + lane];   // bq is a multiple of 64: whole rows, in bounds
-    __syncthreads();
-    for (int qq = wave * 16; qq < wave * 16 + 16; ++qq) {   // wave-uniform
-        const int64_t b = q0 + qq;
-        if (b >= B) break;
-        float v[PER];
-        int fin = 0;
+// Group maxima (round 5): tau0 with ONE LANE PER QUERY.  The (n, bq) matrix is stored transposed, so lane q of a wave reads row i of its
+// query with the 63 neighbouring queries in one 256-byte segment; the n <= NV values stay in registers and the lane bisects on the VALUE for a
+// threshold with rank .. rank + slack values at or above it (what wave_find_rank returns for a wave-per-query pick): n compares + adds per
+// probe, ~10 probes, no cross-lane traffic, no LDS - the wave-per-query forms of this pick (column-strided reads: 95 us; through an LDS tile:
+// 101 us for 131 072 queries x 154 groups) spent their time in the dependent probes of one query after the other.
+template <int NV>
+__global__ __launch_bounds__(256) void seed_pick_gmax_lane_kernel(const float* __restrict__ gm, int64_t bq, int n, int64_t B, int rank,
+                                                                  float* __restrict__ tau0, int32_t* __restrict__ count) {
+    const int64_t q = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t qc = q < bq ? q : bq - 1;      // (whole rows of bq queries are in bounds; lanes past B compute and do not store)
+    float v[NV];
+    float vmax = -INFINITY, vmin = INFINITY;
+    int fin = 0;
 #pragma unroll
-        for (int m = 0; m < PER; ++m) {
-            const int i = lane + 64 * m;
-            v[m] = i < n ? tile[i * 65 + qq] : -INFINITY;
-            fin += __builtin_popcountll(__ballot(v[m] > -INFINITY));
+    for (int i = 0; i < NV; ++i) {
+        v[i] = i < n ? gm[int64_t(i) * bq + qc] : -INFINITY;
+        vmax = fmaxf(vmax, v[i]);
+        if (v[i] > -INFINITY) { vmin = fminf(vmin, v[i]); ++fin; }
+    }
+    float t = -INFINITY;   // no finite value: open threshold
+    if (fin > 0) {
+        const int rk = min(rank, fin), slack = rk / HWER_SEED_SLACK_DIV;
+        auto count_ge = [&](float x) {
+            int c = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) c += v[i] >= x ? 1 : 0;
+            return c;
+        };
+        float lo = vmin, hi = vmax;        // count(>= lo) >= rk always; count(>= hi) < rk after the first test
+        int c_lo = fin;
+        if (count_ge(hi) >= rk) {
+            lo = hi;                        // the rk-th largest IS the maximum (ties at the top)
+        } else {
+            for (int it = 0; it < 40 && c_lo > rk + slack; ++it) {
+                float mid = 0.5f * lo + 0.5f * hi;
+                if (!(mid > lo) || !(mid < hi)) break;   // adjacent floats: the interval is exhausted by ties
+                const int c = count_ge(mid);
+                if (c >= rk) { lo = mid; c_lo = c; } else { hi = mid; }
+            }
         }
-        float t = -INFINITY;
-        if (fin > 0) {
-            const int rk = min(rank, fin);
-            int c_lo;
-            t = wave_find_rank<PER>(v, rk, rk / HWER_SEED_SLACK_DIV, c_lo);
-        }
-        if (lane == 0) {
-            tau0[b] = t;
-            count[b * COUNT_STRIDE] = 0;
-        }
+        t = lo;
+    }
+    if (q < B) {
+        tau0[q] = t;
+        count[q * COUNT_STRIDE] = 0;
     }
 }
 
@@ -1044,18 +1054,11 @@ int launch_seed_tau0(const ScreenPlan& plan, const float* seed_keys, int64_t B, 
     // lane candidates: row b = candidates of query b; group maxima: column b of a (seed_groups, bq) matrix
     const int n = plan.seed_gmax ? plan.seed_groups : plan.seed_cand_n;
     const int64_t ld_b = plan.seed_gmax ? 1 : plan.seed_cand_ld, ld_i = plan.seed_gmax ? plan.bq : 1;
-    if (plan.seed_gmax && n <= 512 && plan.bq % 64 == 0) {   // whole-row reads through an LDS tile (n x 65 floats <= 133 KB)
-        const size_t lds = size_t(n) * 65 * 4;
-        const dim3 g64(unsigned(cdiv64(B, 64)));
-        if (n <= 256) {
-            if (lds > size_t(64) * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&seed_pick_gmax_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-                return fail(HWER_ELAUNCH, "knn_seed(pick): hipFuncSetAttribute(%zu)", lds);
-            hipLaunchKernelGGL(seed_pick_gmax_kernel<4>, g64, dim3(256), lds, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
-        } else {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&seed_pick_gmax_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds)) != hipSuccess)
-                return fail(HWER_ELAUNCH, "knn_seed(pick): hipFuncSetAttribute(%zu)", lds);
-            hipLaunchKernelGGL(seed_pick_gmax_kernel<8>, g64, dim3(256), lds, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
-        }
+    if (plan.seed_gmax && n <= 224) {   // one lane per query, the values in registers
+        const dim3 g(unsigned(cdiv64(B, 256)));
+        if (n <= 64) hipLaunchKernelGGL(seed_pick_gmax_lane_kernel<64>, g, dim3(256), 0, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
+        else if (n <= 160) hipLaunchKernelGGL(seed_pick_gmax_lane_kernel<160>, g, dim3(256), 0, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
+        else hipLaunchKernelGGL(seed_pick_gmax_lane_kernel<224>, g, dim3(256), 0, stream, seed_keys, plan.bq, n, B, plan.seed_rank, tau0, count_scratch);
         return check_launch("knn_seed(pick gmax)");
     }
     const dim3 grid(unsigned(cdiv64(B, 4)));

@@ -246,3 +246,36 @@ def test_anchor_query_kernel_equals_query_mix(hw, d, arith):
     for b in (0, 1, 97, 2048, B - 1):
         ref = orc.query_vector(Vd, int(an[b]))
         assert np.array_equal(a64[b], np.asarray(ref, dtype=np.float64)), b
+
+
+# ------------------------------------------------------------------------------------------------- group-maxima seed pre-pass
+@pytest.mark.parametrize("B,N,d,k,layout", [(70000, 30000, 128, 200, "clustered"), (70000, 30000, 128, 200, "random"), (9000, 26744, 128, 200, "clustered"),
+                                            (66000, 12000, 64, 50, "clustered")])
+def test_group_maxima_prepass_on_clustered_catalogues(hw, B, N, d, k, layout):
+    """The seed pre-pass of plans without lane candidates keeps ONE value per (sample tile, lane half, query) - the maximum of 16 keys - and takes
+    tau0 from the group maxima (round 5).  A catalogue SORTED BY CLUSTER puts a query's good rows next to each other: several of them share a
+    group, the threshold comes out lower, more keys pass (stream compactions inside the screen) - and the result must still be the oracle's,
+    every query certified or recomputed.  One list per query (70 000 / 66 000 queries) and eight lists (9 000 queries: the ML-20M tail's plan)."""
+    from hwer.device_index import DeviceIndex
+    from oracle import c_oracle
+    rng = np.random.default_rng(B + N)
+    if layout == "clustered":
+        n_c = 60
+        centres = unit_rows_f32(71, n_c, d).astype(np.float64)
+        lab = np.sort(rng.integers(0, n_c, N))                      # rows grouped by cluster
+        X = centres[lab] + 0.35 * rng.standard_normal((N, d)) / np.sqrt(d)
+        X = (X / np.linalg.norm(X, axis=1, keepdims=True)).astype(np.float32)
+        ul = rng.integers(0, n_c, B)
+        Q = centres[ul] + 0.35 * rng.standard_normal((B, d)) / np.sqrt(d)
+        Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    else:
+        X, Q = unit_rows_f32(72, N, d), unit_rows_f32(73, B, d)
+    V = np.concatenate([Q, X]).astype(np.float64)
+    ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all()
+    sel = np.unique(np.linspace(0, B - 1, 96).astype(np.int64))
+    Qh = np.stack([orc.query_vector(V, int(u)) for u in sel])
+    o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(X, Qh, V[sel], k, threads=c_oracle.effective_cpus())
+    assert np.array_equal(idx[sel], o_idx + B) and np.array_equal(score[sel], o_sc) and np.array_equal(dist[sel], np.sqrt(o_d2))
+    assert (flags == 2).mean() < 0.01          # the thresholds held: (almost) no query needed the exhaustive pass
