@@ -758,6 +758,27 @@ def api_latency(torch, Vh, U, I, d, arrays_only=False):
     finally:
         gc.enable()
     out["model_get_topk_knn_per_anchor_note"] = "the reference's retrieval loop as it stands (hwer/validation.py:30-35: one call per anchor, all %d anchors, every list materialised), beside the batched model_get_topk above" % U
+    # the ContentRecommendation flavour since round 5: GENUINE float64 rows (the float64 blend stage returns them) - the index screens on their
+    # float32 rounding and answers from the float64 table (DeviceIndex._search_candidates); no per-anchor hipGraph on this path
+    try:
+        rng64 = np.random.default_rng(64)
+        V64 = Vh.astype(np.float64) + 1e-9 * rng64.standard_normal(Vh.shape)
+        V64 /= np.linalg.norm(V64, axis=1, keepdims=True)
+        m64 = VectorIndex(node_types={"user", "item"}, n_dims=d)
+        m64.fit(users + items, V64)
+        assert m64.knn.index.V64 is not None
+        m64.find_closest_neighbours("item", users[0], k=K)
+        ts = []
+        for u in users[:min(U, 64)]:
+            t = time.perf_counter()
+            m64.find_closest_neighbours("item", u, k=K)
+            ts.append(time.perf_counter() - t)
+        out["find_closest_neighbours_f64rows"] = float(np.median(ts)) * 1e3
+        out["find_closest_neighbours_batch_f64rows"] = med(lambda: m64.find_closest_neighbours_batch("item", users, k=K), 3)
+        out["f64rows_note"] = "genuine float64 `vectors` (what ContentRecommendation.fit returns since the float64 blend stage): one call / all %d anchors in one call" % U
+        del m64
+    except Exception as e:      # (a probe: never fails the bench line)
+        out["find_closest_neighbours_f64rows_error"] = repr(e)[:200]
     # extraction_efficiency end to end on synthetic edges: per user 20 train items + 1 validation item
     rng = np.random.default_rng(4001)
     train, valid = [], []

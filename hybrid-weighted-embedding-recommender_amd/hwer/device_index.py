@@ -166,6 +166,78 @@ class _OneAnchorSearch:
             return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k] & 0xFFFFFFFF), d2
 
 
+class _OneAnchorSearchF64:
+    """The per-anchor call on GENUINE float64 rows (what ContentRecommendation.fit returns since round 5's float64 blend stage): anchor id H2D ->
+    hwer_query_mix_f64rows -> the candidate scheme of DeviceIndex._search_candidates without its host decisions (float32 MFMA search for k + 32
+    candidates, their exact float64 distances, (distance, id) order + certificate, float64 scores, order by score) -> ids / scores / flag D2H,
+    captured ONCE as a hipGraph per (node type, k).  A replay whose certificate failed (flag 0: near-ties across the bound) is answered by the
+    general, synchronising path instead.  0.37 -> ~0.1 ms per find_closest_neighbours call at the ML-100K shape."""
+
+    def __init__(self, ix, node_type, k):
+        import threading
+        torch = _torch()
+        dev = ix.device
+        self.k = int(k)
+        self.lock = threading.Lock()
+        tt = ix.tables[node_type]
+        self.h_anchor = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.h_anchor_np = self.h_anchor.numpy()
+        self.d_anchor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.Q64 = torch.empty((1, ix.d), dtype=torch.float64, device=dev)
+        self.Q32 = torch.empty((1, ix.ldx), dtype=torch.float32, device=dev)
+        self.idx = torch.empty((1, k), dtype=torch.int64, device=dev)
+        self.score = torch.empty((1, k), dtype=torch.float64, device=dev)
+        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.buf = torch.zeros(2 * k + 1, dtype=torch.int64, device=dev)
+        self.h_buf = torch.zeros(2 * k + 1, dtype=torch.int64).pin_memory()
+        self.h_np = self.h_buf.numpy()
+        self.workspaces = {}
+        P = native.ptr
+
+        def launch():
+            st = native.stream_ptr(dev)
+            self.d_anchor.copy_(self.h_anchor, non_blocking=True)
+            native.check(ix.lib.hwer_query_mix_f64rows(P(ix.V64), ix.N, ix.d, ix.d, P(self.d_anchor), None, None, None, None, 1, P(self.Q64), P(self.Q32),
+                                                        ix.ldx, st), "query_mix_f64rows")
+            ix._search_candidates(tt, self.Q64, self.Q32, k, self.d_anchor, 0, True, True, None, self.idx, self.score, None, self.flags, no_sync=True,
+                                  workspaces=self.workspaces)
+            self.buf[:k] = self.idx[0]
+            self.buf[k:2 * k] = self.score[0].view(torch.int64)
+            self.buf[2 * k:] = self.flags.to(torch.int64)
+            self.h_buf.copy_(self.buf, non_blocking=True)
+        with native.device_guard(dev):
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    launch()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                launch()
+            self.graph = g
+        self._keep = (tt, ix.V64, ix.V)
+        self.dev, self.dev_index = dev, dev.index
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+        self._sync = ix.lib.hwer_stream_synchronize
+
+    def run(self, anchor: int):
+        """-> (ids (k,) int64, scores (k,) float64, flag) as fresh numpy arrays; thread-safe like _OneAnchorSearch.run"""
+        with self.lock:
+            self.h_anchor_np[0] = anchor
+            self.graph.replay()
+            raw = self._raw_stream
+            if raw is not None:
+                rc = self._sync(raw(self.dev_index))
+                if rc:
+                    native.check(rc, "stream_synchronize")
+            else:
+                _torch().cuda.current_stream(self.dev).synchronize()
+            k, h = self.k, self.h_np
+            return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k])
+
+
 class DeviceIndex:
     #: queries per launch of the k-NN kernels = 512 workgroup slots (256 CUs x 2) x 256 queries: one full round of
     #: workgroups without item splits; also bounds the candidate workspace (8 KiB per query and list)
@@ -425,7 +497,7 @@ class DeviceIndex:
             _flags_host_out.append(fh)      # the host copy of `flags` the small-batch path already fetched (None otherwise)
         return idx, score, dist2, flags
 
-    def _search_f32(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags):
+    def _search_f32(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags, no_sync=False, workspaces=None):
         """the HIP search on the float32 table (d <= 256, k <= 392): MFMA screen -> float64 re-rank -> certificate, then the
         exhaustive tiers for uncertified queries; fills idx / score / dist2 / flags.  -> the host copy of the final flags when the
         small-batch branch fetched one and nothing changed them afterwards (else None)."""
@@ -447,7 +519,15 @@ class DeviceIndex:
             if wsb == 0:
                 raise native.HwerNativeError("knn: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" %
                                              (nb, tt.n, self.d, k, self.lib.hwer_knn_max_k()))
-            ws = self._workspace(wsb)
+            if workspaces is not None:
+                # a captured caller (_OneAnchorSearchF64) owns its workspaces: the shared ones may be re-allocated by a later, larger search
+                if "ws" not in workspaces:
+                    workspaces["ws"] = torch.empty(int(wsb), dtype=torch.uint8, device=self.device)
+                    native.check(self.lib.hwer_knn_workspace_init(native.ptr(workspaces["ws"]), int(wsb), st), "knn_workspace_init")
+                    workspaces["wse"] = torch.empty(max(int(wseb), 1), dtype=torch.uint8, device=self.device)
+                ws = workspaces["ws"]
+            else:
+                ws = self._workspace(wsb)
             a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
             native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
@@ -457,13 +537,15 @@ class DeviceIndex:
                 native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), opt, native.ptr(x16), x16_exp, st), "knn_search")
             # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
             # to 8 per call; anything beyond that is picked up by the host-driven pass below
-            wse = self._exact_workspace(wseb)
+            wse = workspaces["wse"] if workspaces is not None else self._exact_workspace(wseb)
             native.check(self.lib.hwer_knn_exact_device(
                 native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64[b0:b1]), native.ptr(self.V) if score_mode != 2 else None,
                 self.ldv, native.ptr(a_sub), k, score_mode, 1 if sort_by_score else 0,
                 native.ptr(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), native.ptr(idx[b0:b1]),
                 native.ptr(score[b0:b1]), native.ptr(dist2[b0:b1]) if want_dist else None, native.ptr(flags[b0:b1]), native.ptr(ws), None,
                 native.ptr(wse), wse.numel(), st), "knn_exact_device")
+        if no_sync:      # (hipGraph capture: the launches only - queries the on-device pass left uncertified keep flag 0 for the caller)
+            return None
         if B <= 4096:
             # small batches: the flags themselves come to the host (one copy; `search` reuses it) instead of a count kernel + its result
             flags_host = flags.cpu()
@@ -554,7 +636,7 @@ class DeviceIndex:
         if dist2 is not None:
             dist2[b0:b1] = d2
 
-    def _search_candidates(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
+    def _search_candidates(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags, no_sync=False, workspaces=None):
         """Exact k-NN as "screen a superset, re-rank it exactly, certify" for the shapes the fused HIP search does not take:
           * genuine float64 `vectors` (V64): the HIP search on the float32 rounding of the table returns the k + 32 nearest ROUNDED rows
             (exact for the rounded table); rounding moves a squared distance by at most eps(D) = 2 sqrt(D) delta + delta^2, delta =
@@ -590,7 +672,8 @@ class DeviceIndex:
                 c_sc = torch.empty((nb, kc), dtype=torch.float64, device=dev)
                 c_d2 = torch.empty((nb, kc), dtype=torch.float64, device=dev)
                 c_fl = torch.empty(nb, dtype=torch.int32, device=dev)
-                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, local, c_sc, c_d2, c_fl)   # ids = local rows
+                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, local, c_sc, c_d2, c_fl, no_sync=no_sync,
+                                 workspaces=workspaces)   # ids = local rows
                 T = c_d2[:, kc - 1]
                 delta = (2.0 ** -24) * xmax
                 bound = T - 2.0 * torch.sqrt(T) * delta - delta * delta - 1e-12 * torch.clamp(T, min=1.0)
@@ -613,7 +696,14 @@ class DeviceIndex:
                                                  native.ptr(D), stream), "knn_cand_dist2")
             d2, local, _, _, cert = self._order_rows(D, kc, k, ids=local, bound=bound.contiguous(), every_row=(kc >= n), want_flags=True)
             fl = torch.where(cert == 1, 1, 2).to(torch.int32)
-            bad = torch.nonzero(cert == 0).flatten()
+            if no_sync:
+                # hipGraph capture (one-anchor calls): no host decision here - a query whose certificate failed, or whose candidate search
+                # stayed uncertified, is reported with flag 0 and the caller takes the synchronising path
+                ok = (cert == 1) & (c_fl > 0) if use_hip else (cert == 1)
+                fl = torch.where(ok, 1, 0).to(torch.int32)
+                bad = cert[:0]
+            else:
+                bad = torch.nonzero(cert == 0).flatten()
             if bad.numel():     # near-ties across the bound: all rows of the type, a few queries at a time
                 step = max(1, (1 << 26) // n)
                 for c0 in range(0, int(bad.numel()), step):
@@ -706,12 +796,12 @@ class DeviceIndex:
         if lock is None:
             lock = self.__dict__.setdefault("_one_anchor_lock", threading.Lock())
         tt = self.tables[node_type]
-        key = (node_type, int(k), int(mode), bool(self.f16_screen), bool(self.use_f16_storage), self._path_options(), id(tt.X16))
+        key = (node_type, int(k), mode if isinstance(mode, str) else int(mode), bool(self.f16_screen), bool(self.use_f16_storage), self._path_options(), id(tt.X16))
         with lock:      # (construction captures a hipGraph: one thread at a time)
             cache = self.__dict__.setdefault("_one_anchor", {})
             one = cache.pop(key, None)
             if one is None:
-                one = _OneAnchorSearch(self, node_type, k, mode)
+                one = _OneAnchorSearchF64(self, node_type, k) if mode == "f64rows" else _OneAnchorSearch(self, node_type, k, mode)
                 key = key[:-1] + (id(tt.X16),)       # (the constructor may have built the float16 copy)
             cache[key] = one                         # most recently used last
             while len(cache) > self.ONE_ANCHOR_CACHE:
@@ -738,6 +828,16 @@ class DeviceIndex:
                     # not depend on the number of anchors)
                     return ids.reshape(1, k), sc.reshape(1, k), (np.sqrt(d2).reshape(1, k) if d2 is not None else None), np.asarray([flag], dtype=np.int32)
                 # (uncertified beyond the on-device exhaustive pass: the general path below runs the host-driven tiers)
+        if (self.one_anchor_graphs and np.size(anchors) == 1 and sort_by_score and not want_dist and mode == 0 and self.arith == 0 and self.V64 is not None and not self.wide
+                and k + self.CAND_MARGIN <= self._max_k and k + self.CAND_MARGIN <= self.tables[node_type].n and not self._has_lists(positive)
+                and not self._has_lists(negative) and not os.environ.get("HWER_FORCE_EXHAUSTIVE")):
+            # the same call on genuine float64 rows (ContentRecommendation.fit since round 5): a cached hipGraph of the candidate scheme
+            a0 = int(np.asarray(anchors).reshape(-1)[0])
+            if 0 <= a0 < self.N:
+                one = self._one_anchor_search(node_type, k, "f64rows")
+                ids, sc, flag = one.run(a0)
+                if flag > 0:
+                    return ids.reshape(1, k), sc.reshape(1, k), None, np.asarray([flag], dtype=np.int32)
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
         fh = []
         idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist, _flags_host_out=fh)

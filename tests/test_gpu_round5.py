@@ -279,3 +279,34 @@ def test_group_maxima_prepass_on_clustered_catalogues(hw, B, N, d, k, layout):
     o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(X, Qh, V[sel], k, threads=c_oracle.effective_cpus())
     assert np.array_equal(idx[sel], o_idx + B) and np.array_equal(score[sel], o_sc) and np.array_equal(dist[sel], np.sqrt(o_d2))
     assert (flags == 2).mean() < 0.01          # the thresholds held: (almost) no query needed the exhaustive pass
+
+
+# ------------------------------------------------------------------------------------------------- per-anchor calls on genuine float64 rows
+@pytest.mark.parametrize("U,N,d,k", [(40, 1682, 64, 200), (10, 20000, 96, 50), (6, 300, 24, 268)])
+def test_one_anchor_graph_on_float64_rows_equals_the_general_path(hw, U, N, d, k):
+    """Rows that are NOT float32-representable (what ContentRecommendation.fit returns since the float64 blend stage): one
+    find_closest_neighbours call replays the cached hipGraph of the candidate scheme (_OneAnchorSearchF64) and must return exactly the
+    general path's and the oracle's (id, score) lists; exact duplicates and float32-colliding rows sit at a few anchors' cut, so some
+    replays come back uncertified (flag 0) and are answered by the general path; k + 32 == every row in the last case."""
+    from hwer import Node, VectorIndex
+    rng = np.random.default_rng(700 + d)
+    V = rng.standard_normal((U + N, d))
+    V /= np.linalg.norm(V, axis=1, keepdims=True)
+    V[U + 5] = V[U + 3]
+    V[U + N - 1] = V[U + 3] * (1.0 + 2.0 ** -40)          # equal after rounding to float32, different in float64
+    users, items = [Node("user", i) for i in range(U)], [Node("item", i) for i in range(N)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=d)
+    m.fit(users + items, V)
+    ix = m.knn.index
+    assert ix.V64 is not None
+    Vd = ix.V64.cpu().numpy()
+    per_anchor = {u: m.find_closest_neighbours("item", u, k=k) for u in users}
+    assert any(key[:3] == ("item", k, "f64rows") for key in ix.__dict__.get("_one_anchor", {}))       # the graph path was taken
+    again = m.find_closest_neighbours("item", users[1], k=k)                                           # the graph is reused
+    assert again == per_anchor[users[1]]
+    ix.one_anchor_graphs = False
+    for j, u in enumerate(users):
+        general = m.find_closest_neighbours("item", u, k=k)
+        assert per_anchor[u] == general, j
+        o_idx, o_sc, _ = orc.find_closest(Vd, np.arange(U, U + N), j, k=k)
+        assert [m.nodes_to_idx[n] for n, _ in general] == o_idx.tolist() and [s for _, s in general] == o_sc.tolist()
