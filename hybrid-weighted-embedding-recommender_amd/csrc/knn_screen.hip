@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                     if constexpr (fold) {
 #pragma unroll
                         for (int q = 0; q < 16; ++q) mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(acc[b][q]), 31);   // sign of tau' - key'
-                    } else {   // (only reached when a diagnostic switch forces the mask filter onto a max-tree launch)
+                    } else {   // not folded: every pass-mask launch with one query subtile per wave (d = 256; launch_screen16_pp_t picks FOLD = false for TQ == 1)
                         const float2_t tau2 = {tau[b], tau[b]};
 #pragma unroll
                         for (int q = 0; q < 16; q += 2) {
@@ -1308,6 +1308,9 @@ ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t
     // each: whole pairs of blocks (the padding queries are dead lanes, as in any last block)
     p.pp = ((options & HWER_KNN_F16_SCREEN) && !(options & HWER_KNN_NO_PINGPONG) && p.ng >= 8 && p.wq == 4 &&
             !(n_items <= DENSE_MAX_ITEMS && !(options & HWER_KNN_NO_DENSE))) ? 1 : 0;
+    // (the ping-pong kernel streams 64-row tiles whatever the A/B switches say: a build with 32-row tiles - HWER_SCREEN16_IB=32, or HWER_WIDE64=0 at
+    // d = 256 - aligns the item splits to 32 rows and keeps the two-workgroup kernel, or a split's last tile would run into the next split's rows)
+    if (p.pp && !(SCREEN16_IB == 64 && (p.ng <= 16 || WIDE64))) p.pp = 0;
     if (p.pp) p.n_qblocks = (p.n_qblocks + 1) & ~1;
     p.bq = int64_t(p.n_qblocks) * p.qb;
     const int wi = 4 / p.wq;
