@@ -382,40 +382,48 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
             torch.cuda.synchronize()
             sys.stderr.write("[bench] hipGraph capture failed (%s): timing the eager step\n" % (str(e).splitlines()[0] if str(e) else type(e).__name__))
     run_step = graph.replay if graph is not None else w.step
-    for _ in range(warmup):
-        run_step()
-    torch.cuda.synchronize()
-    if graph is None and not w.tail and not w.pipeline:
-        lib.hwer_profile_enable(PROFILE_EVERY)   # HIP events around every PROFILE_EVERY-th search (a pair costs ~10 us of stream time)
+    profile_in_region = graph is None and not w.tail and not w.pipeline      # HIP events around every PROFILE_EVERY-th search (a pair costs ~10 us of stream time)
     # The timed region: EXACTLY `steps` steps between two synchronisations, wall clock (the contract's ms_per_step / value).  Eager
     # steps (>= ~0.2 ms each) also get one HIP event per step boundary inside the region - the per-step distribution
     # (median / min / max) costs nothing there; graph-replayed steps (c1 / c2: ~0.05-0.2 ms) get theirs from a second pass.
     in_loop = graph is None
     import gc
 
-    def timed_region():
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    def timed_region(n_steps=steps, n_warm=warmup, events=True):
+        # Round 5: the W warm-up steps run HERE, directly in front of the region - everything the host has to do for the region (event objects, a
+        # full garbage collection: 10 - 30 ms with torch imported) comes first.  With those between the warm-up and the region the device sat
+        # idle for milliseconds, its clocks came down, and a region of 20 x 0.042 ms ran 7 - 9 % slower than steady state (tools/
+        # probe_region_overhead.py, profiles/r5_probe_region_overhead.txt: K = 20 behind 5 warm replays 0.0438 ms/step without a gap, 0.0446 / 0.0459
+        # behind 10 / 100 ms of idling; steady state 0.0422).  warm-up, synchronize, t0 - as the contract words it.
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_steps + 1)] if events else None
         gc.collect()
         gc.disable()        # (as `timeit` does: a collection inside K x 0.05 ms would be most of the region)
         try:
-            t0 = time.perf_counter()
-            if in_loop:
-                evs[0].record()
-            for i in range(steps):
+            for _ in range(n_warm):
                 run_step()
-                if in_loop:
+            if profile_in_region:
+                lib.hwer_profile_enable(PROFILE_EVERY)      # (a flag of the library: the timed steps' searches, not the warm-up's)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if in_loop and events:
+                evs[0].record()
+            for i in range(n_steps):
+                run_step()
+                if in_loop and events:
                     evs[i + 1].record()
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
         finally:
             gc.enable()
+        if not events:
+            return el, None
         if not in_loop:
             evs[0].record()
-            for i in range(steps):
+            for i in range(n_steps):
                 run_step()
                 evs[i + 1].record()
             torch.cuda.synchronize()
-        return el, np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+        return el, np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(n_steps)])
 
     # THE timed region is the FIRST one, whatever it shows: `value` and `ms_per_step` always come from it (round 4: rounds 2-3 measured a
     # region again when its wall-clock mean was far above its own per-step median and reported the repeat - a best-of-3 with a rejection
@@ -428,6 +436,12 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         el2, series2 = timed_region()
         remeasured = {"ms_per_step": el2 / steps * 1e3, "ms_median": float(np.median(series2))}
     lib.hwer_profile_enable(0)
+    # graph-replayed configurations (c1, c2): the same step over a region long enough for the device's clocks to settle - a SECONDARY figure
+    # (`timed_region.steady_ms_per_step`); with the driver's --steps 20 the contract's region is 1 - 3 ms long and still on the ramp
+    steady = None
+    if graph is not None and steps < 500:
+        el_s, _ = timed_region(n_steps=500, n_warm=max(warmup, 100), events=False)
+        steady = el_s / 500 * 1e3
     in_step = None
     if graph is None and not w.tail and not w.pipeline:
         # Eager steps: the two parts of a step measured IN the step (an event between the prologue and the search of real steps, right behind
@@ -521,7 +535,8 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
         "value": value, "unit": "pairs/s", "ms_per_step": ms_per_step,
         "ms_median": float(np.median(series)), "ms_min": float(series.min()), "ms_max": float(series.max()), "ms_mean_events": float(series.mean()),
         "timed_region": {"attempts": 1 if remeasured is None else 2, "reported": "first", "remeasured_ms_per_step": None if remeasured is None else round(remeasured["ms_per_step"], 5),
-                         "rule": "value / ms_per_step = the FIRST region of exactly K steps, always; a region whose wall-clock mean exceeds 1.3x (graph replays) / 1.15x (eager) the median of "
+                         "steady_ms_per_step": None if steady is None else round(steady, 5),
+                         "rule": "value / ms_per_step = the FIRST region of exactly K steps (W warm-up steps, synchronize, clock), always; a region whose wall-clock mean exceeds 1.3x (graph replays) / 1.15x (eager) the median of "
                                  "its per-step event intervals is measured once more and that number is reported here only"},
         "ms_series": [round(float(x), 4) for x in series[:256]], "ms_series_note": "HIP-event interval of every step" + ("" if in_loop else " (second pass: the timed steps are graph replays)"),
         "user_rows": w.U,
@@ -926,6 +941,8 @@ def compact_line(full, detail_path):
     tr = full.get("timed_region")
     if tr:      # always in the line: which region is reported, and whether a second one was taken
         out["timed_region"] = {"attempts": tr["attempts"], "reported": tr.get("reported"), "remeasured_ms_per_step": tr.get("remeasured_ms_per_step")}
+        if tr.get("steady_ms_per_step") is not None:     # graph-replayed steps timed with fewer than 500 steps: the same step over 500 (clocks settled)
+            out["timed_region"]["steady_ms_per_step"] = tr["steady_ms_per_step"]
     if full.get("query_latency_ms"):
         out["query_latency_ms"] = {str(e["batch"]): _r(e["ms"], 4) for e in full["query_latency_ms"]}
     cfgs = {}
