@@ -1345,7 +1345,12 @@ def main():
     # the oracle's checker library is built / loaded BEFORE anything touches a GPU (its `make` is a fork + exec)
     from oracle import c_oracle
     c_oracle.lib()
-    if world > 1:
+    if world > 1 or os.environ.get("HWER_BENCH_SHARDED_WORLD1"):
+        # (HWER_BENCH_SHARDED_WORLD1=1: the N > 1 job's code - rendezvous, ShardedStepPipeline, both exchanges, parity gather - over the REAL
+        # backend (nccl = RCCL) at world size 1: what a one-GPU box can execute of it; tests/test_gpu_round5.py)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
         run_sharded(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world)
         return
     full = run_emulated_shards(args) if args.emulate_shards else run_single(args)

@@ -208,6 +208,22 @@ def test_bench_n4_runs_the_library_pipeline_and_survives_a_dead_rank(hw):
     assert r.stdout.strip() == ""
 
 
+def test_bench_sharded_job_over_rccl_at_world_size_one(hw):
+    """The N > 1 job's own code - rendezvous with a device id, ShardedStepPipeline, all-gather AND all-to-all exchanges, the merge, the parity
+    gather, the all-reduced timings - over backend nccl (= RCCL), at the world size a one-GPU box has: 1.  gloo rehearsals cover N = 2 / 4 with
+    the payload staged through the host; this is the branch the 8-GPU run takes, collectives on device buffers included."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HWER_BENCH_SHARDED_WORLD1="1", HWER_BENCH_ITEMS="600000", HWER_BENCH_DIST_TIMEOUT_S="120", MASTER_PORT="29591")
+    env.pop("HWER_BENCH_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and "backend nccl" in line["config"]["sharding"] and line["parity_checked_queries"] >= 8
+    assert line["exchange"]["lists_ran_out_first_pass"] == 0 and line["variants"]["by_query"]["ms_per_step"] > 0 and line["cpu_baseline"]["value"] > 0
+
+
 # ------------------------------------------------------------------------------------------------- bulk anchor-only queries
 @pytest.mark.parametrize("d,arith", [(128, 0), (128, 1), (64, 0), (100, 0), (66, 1), (256, 0), (515, 0), (7, 1), (1, 0)])
 def test_anchor_query_kernel_equals_query_mix(hw, d, arith):
