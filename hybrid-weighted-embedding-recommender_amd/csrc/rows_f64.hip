@@ -145,23 +145,54 @@ __global__ __launch_bounds__(256) void rows64_kernel(const Rows64Args a) {
     const int64_t n_trips = cdiv64(a.R, a.pb_n);
     for (int64_t b = int64_t(blockIdx.x) * nw + wave; b < n_trips; b += int64_t(gridDim.x) * nw) {
         const int64_t p0 = b * a.pb_n;
-        for (int pb = 0; pb < a.pb_n; pb += rpi) {
+        if constexpr (MODE == 2) {
+            // TWO rows x up to FOUR tables requested before the first is consumed: with one 16-byte load per lane in flight the kernel was a chain of
+            // HBM latencies (20 resident waves x 1 KB per CU: 3.9 TB/s by Little's law, measured 3.9 - 4.0).  The accumulation order is unchanged:
+            // tables left to right, product and sum rounded separately (-ffp-contract=off): `acc = acc + alpha * rows`.
+            for (int pb = 0; pb < a.pb_n; pb += 2 * rpi) {
+                const int slot_a = pb + sub, slot_b = pb + rpi + sub;
+                const int64_t r_a = p0 + slot_a, r_b = p0 + slot_b;
+                const bool live_a = slot_a < a.pb_n && r_a < a.R, live_b = slot_b < a.pb_n && r_b < a.R;
+                if (!live_a) continue;      // (slot_b > slot_a: nothing to do for this lane group)
+                for (int c = c0; c < a.d2; c += L) {
+                    double2 acc_a = make_double2(0.0, 0.0), acc_b = make_double2(0.0, 0.0);
+                    for (int t0 = 0; t0 < a.T; t0 += 4) {
+                        double2 va[4], vb[4];
+                        double ala[4], alb[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            va[j] = vb[j] = make_double2(0.0, 0.0);
+                            ala[j] = alb[j] = 0.0;
+                            if (t0 + j >= a.T) continue;      // (uniform)
+                            const int t = t0 + j;
+                            const int32_t* ri = a.row_idx ? a.row_idx[t] : nullptr;
+                            const int64_t row_a = ri ? int64_t(ri[r_a]) : r_a;
+                            const int64_t row_b = live_b ? (ri ? int64_t(ri[r_b]) : r_b) : row_a;
+                            ala[j] = a.alpha_per_row ? a.alpha[r_a * a.T + t] : a.alpha[t];
+                            alb[j] = (a.alpha_per_row && live_b) ? a.alpha[r_b * a.T + t] : ala[j];
+                            va[j] = *reinterpret_cast<const double2*>(a.tables[t] + row_a * a.lde + 2 * c);
+                            vb[j] = *reinterpret_cast<const double2*>(a.tables[t] + row_b * a.lde + 2 * c);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (t0 + j < a.T) {      // uniform
+                                acc_a.x = acc_a.x + ala[j] * va[j].x;
+                                acc_a.y = acc_a.y + ala[j] * va[j].y;
+                                acc_b.x = acc_b.x + alb[j] * vb[j].x;
+                                acc_b.y = acc_b.y + alb[j] * vb[j].y;
+                            }
+                        }
+                    }
+                    *reinterpret_cast<double2*>(slab + slot_a * a.stride + 2 * c) = acc_a;
+                    if (live_b) *reinterpret_cast<double2*>(slab + slot_b * a.stride + 2 * c) = acc_b;
+                }
+            }
+        }
+        for (int pb = 0; MODE != 2 && pb < a.pb_n; pb += rpi) {
             const int slot = pb + sub;
             const int64_t r = p0 + slot;
             if (slot >= a.pb_n || r >= a.R) continue;
             if constexpr (MODE == 2) {
-                for (int c = c0; c < a.d2; c += L) {
-                    double2 acc = make_double2(0.0, 0.0);
-                    for (int t = 0; t < a.T; ++t) {
-                        const int32_t* ri = a.row_idx ? a.row_idx[t] : nullptr;
-                        const int64_t row = ri ? int64_t(ri[r]) : r;
-                        const double al = a.alpha_per_row ? a.alpha[r * a.T + t] : a.alpha[t];
-                        const double2 v = *reinterpret_cast<const double2*>(a.tables[t] + row * a.lde + 2 * c);
-                        acc.x = acc.x + al * v.x;     // product and sum rounded separately (-ffp-contract=off): `acc = acc + alpha * rows`
-                        acc.y = acc.y + al * v.y;
-                    }
-                    *reinterpret_cast<double2*>(slab + slot * a.stride + 2 * c) = acc;
-                }
             } else {
                 const int64_t e0 = a.indptr[r], e1 = a.indptr[r + 1];
                 const double deg = double(e1 - e0);

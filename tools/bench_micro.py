@@ -102,6 +102,35 @@ def main():
                           "roofline": {"bound": "hbm (gathered rows)", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": byts / ms / 1e6 / HBM_PEAK_GBS}}))
         del E, indices, indptr, out
+        # ---- round 5: the float64 flavour (the reference's own arithmetic) - same shapes, 8-byte elements --------------------------------
+        for name, N, d, T, per_row in (("c3", 165237, 128, 2, False), ("1.25 M rows", 1250000, 128, 2, False), ("c5 shape", 1254096, 256, 4, True)):
+            tabs = [unit_rows(torch, N, d, dev, 30 + t).to(torch.float64) for t in range(T)]
+            tp = torch.tensor([t.data_ptr() for t in tabs], dtype=torch.int64, device=dev)
+            if per_row:
+                alpha = torch.rand((N, T), device=dev, dtype=torch.float64)
+                alpha = (alpha / alpha.sum(1, keepdim=True)).contiguous()
+            else:
+                alpha = torch.full((T,), 1.0 / T, device=dev, dtype=torch.float64)
+            out = torch.empty((N, d), dtype=torch.float64, device=dev)
+            ms = timeit(torch, lambda: native.check(lib.hwer_blend_normalize_f64(P(tp), d, None, P(alpha), 1 if per_row else 0, T, N, d, P(out), d, None, S()), "blend64"))
+            byts = N * (8.0 * d * (T + 1) + (8 * T if per_row else 0))
+            print(json.dumps({"kernel": "blend_normalize_f64", "case": name, "rows": N, "ms": ms, "rows_per_s": N / ms * 1e3,
+                              "roofline": {"bound": "hbm", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": byts / ms / 1e6 / HBM_PEAK_GBS}}))
+            del tabs, out, alpha
+        N, d, deg = 1000000, 128, 16
+        E = unit_rows(torch, N, d, dev, 40).to(torch.float64)
+        g = torch.Generator(device=dev).manual_seed(41)
+        indices = torch.randint(0, N, (N * deg,), generator=g, device=dev, dtype=torch.int32)
+        indptr = (torch.arange(N + 1, device=dev, dtype=torch.int64) * deg).contiguous()
+        out = torch.empty((N, d), dtype=torch.float64, device=dev)
+        for kname, fn in (("segment_mean_f64", lib.hwer_segment_mean_f64), ("content_tail_f64", lib.hwer_content_tail_f64)):
+            ms = timeit(torch, lambda: native.check(fn(P(E), d, P(indptr), P(indices), N, d, P(out), d, S()), kname))
+            byts = 8.0 * d * (N * deg + N + (N if kname.startswith("content") else 0)) + 8 * N + 4 * N * deg
+            print(json.dumps({"kernel": kname, "rows": N, "nnz": N * deg, "ms": ms,
+                              "roofline": {"bound": "hbm (gathered rows)", "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": byts / ms / 1e6 / HBM_PEAK_GBS}}))
+        del E, indices, indptr, out
 
 
     if "fit" in what:
