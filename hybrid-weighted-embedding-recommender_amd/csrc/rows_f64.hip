@@ -62,6 +62,73 @@ __global__ __launch_bounds__(256) void cand_dist2_kernel(const TV* __restrict__ 
     }
 }
 
+// The same for a float64 table whose rows are 16-byte aligned (ld even), COALESCED: a wave takes 64 candidates of one query; per 8-column
+// chunk 4 lanes load the 64-byte segment of a row (16 rows per instruction, 4 instructions), the rows are transposed through wave-private LDS
+// (row stride 80 bytes: conflict-free ds_read_b128) and every lane walks ITS candidate's 8 values in order - the data path of the select
+// kernel's re-rank rounds, for 8-byte elements.  The chunk c + 1 is in flight while chunk c is reduced.  (One lane walking its own row with
+// 8-byte loads touched 64 different 64-byte segments per instruction: 4 096 x 232 candidates of 128 columns took 0.61 ms, 41 % of a batched
+// search on float64 rows.)
+constexpr int CD_CW = 8;              // columns per chunk (one 64-byte segment of a float64 row)
+constexpr int CD_RS = CD_CW + 2;      // LDS row stride in doubles
+__global__ __launch_bounds__(256) void cand_dist2_f64_staged_kernel(const double* __restrict__ table, int64_t ld, int d, const int64_t* __restrict__ cand, int64_t ldc,
+                                                                    int64_t kc, const double* __restrict__ Q64, double* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) double stage_all[4 * 64 * CD_RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b = blockIdx.y;
+    double* stage = stage_all + wave * (64 * CD_RS);
+    typedef const __attribute__((address_space(4))) double* cdouble_p;      // wave-uniform: scalar loads
+    const cdouble_p q = (cdouble_p)(Q64 + b * d);
+    const int n_chunks = (d + CD_CW - 1) / CD_CW;
+    const int srow = lane >> 2, scol = 2 * (lane & 3);
+    for (int64_t c0 = (int64_t(blockIdx.x) * 4 + wave) * 64; c0 < kc; c0 += int64_t(gridDim.x) * 256) {   // c0 wave-uniform
+        const int64_t mine = c0 + lane < kc ? cand[b * ldc + c0 + lane] : -1;
+        // rows staged by this lane: candidates c0 + srow + 16 i (dead / absent candidates read row 0: their result is +inf)
+        const double* src[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t ci = c0 + srow + 16 * i;
+            const int64_t row = ci < kc ? cand[b * ldc + ci] : -1;
+            src[i] = table + (row >= 0 ? row : 0) * ld + scol;
+        }
+        auto load2 = [&](const double* p_, int col) {      // columns col, col + 1 of a row (zero beyond d)
+            double2 v = make_double2(0.0, 0.0);
+            if (col + 1 < d) v = *reinterpret_cast<const double2*>(p_);
+            else if (col < d) v.x = p_[0];
+            return v;
+        };
+        double2 pre[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pre[i] = load2(src[i], scol);
+        double acc = 0.0;
+        for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(stage + (srow + 16 * i) * CD_RS + scol) = pre[i];
+            if (c + 1 < n_chunks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pre[i] = load2(src[i] + CD_CW * (c + 1), CD_CW * (c + 1) + scol);
+            }
+            wave_lds_sync();
+            double xv[CD_CW];
+#pragma unroll
+            for (int t = 0; t < CD_CW / 2; ++t) {
+                const double2 v = *reinterpret_cast<const double2*>(stage + lane * CD_RS + 2 * t);
+                xv[2 * t] = v.x;
+                xv[2 * t + 1] = v.y;
+            }
+            wave_lds_sync();
+            const int j0 = CD_CW * c;
+#pragma unroll
+            for (int t = 0; t < CD_CW; ++t) {
+                if (j0 + t < d) {   // uniform
+                    const double tmp = __dsub_rn(q[j0 + t], xv[t]);
+                    acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                }
+            }
+        }
+        if (c0 + lane < kc) out[b * kc + c0 + lane] = mine >= 0 ? acc : INFINITY;
+    }
+}
+
 // knn_wide.hip: the same arithmetic with 16-byte row loads (float32 tables whose rows are 16-byte aligned)
 int launch_cand_dist2_f32x4(const float* table, int64_t ld, int d, const int64_t* cand, int64_t ld_cand, int64_t B, int64_t kc, const double* Q64,
                             double* out, hipStream_t st);
@@ -350,7 +417,10 @@ int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int
     const dim3 grid(unsigned(std::min<int64_t>(cdiv64(kc, 256), 1024)), unsigned(B));
     if (!table_is_f64 && ld % 4 == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0)
         return launch_cand_dist2_f32x4(static_cast<const float*>(table), ld, d, cand, ld_cand, B, kc, Q64, out, as_stream(stream));
-    if (table_is_f64)
+    if (table_is_f64 && ld % 2 == 0 && (reinterpret_cast<uintptr_t>(table) & 15) == 0 && kc >= 32) {
+        const dim3 grid_s(unsigned(std::min<int64_t>(cdiv64(kc, 256), 1024)), unsigned(B));
+        hipLaunchKernelGGL(cand_dist2_f64_staged_kernel, grid_s, dim3(256), 0, as_stream(stream), static_cast<const double*>(table), ld, d, cand, ld_cand, kc, Q64, out);
+    } else if (table_is_f64)
         hipLaunchKernelGGL(cand_dist2_kernel<double>, grid, dim3(256), 0, as_stream(stream), static_cast<const double*>(table), ld, d, cand, ld_cand, kc, Q64, out);
     else
         hipLaunchKernelGGL(cand_dist2_kernel<float>, grid, dim3(256), 0, as_stream(stream), static_cast<const float*>(table), ld, d, cand, ld_cand, kc, Q64, out);
