@@ -604,20 +604,19 @@ class DeviceIndex:
         d2, local, _, _, _ = self._order_rows(D, k, k, gather=sel)
         return d2, local
 
-    def _score_and_emit(self, b0, b1, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2):
+    def _score_and_emit(self, pos, nb, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2):
         """scores of the k nearest (hwer_pair_score*: numpy's pairwise order; GcnNCF flavour: from the distance), then the reference's final
         order - a stable sort by score descending (hwer/recommendation_base.py:172-173) = hwer_knn_order_rows_f64 on (score desc, position asc)
-        with the ids and distances as payloads - into rows b0:b1 of the outputs."""
+        with the ids and distances as payloads - into the rows `pos` (a slice, or an index tensor of `nb` positions) of the outputs."""
         torch = _torch()
         lib, dev = self.lib, self.device
         stream = native.stream_ptr(dev)
-        nb = b1 - b0
         rows = tt.rows_dev[local]                                      # rows of the vector table (pair scoring)
         ids = rows if use_rows else local + int(id_base)             # reported ids
         if score_mode == 2:
             sc = (-1.0 * torch.sqrt(d2) + 2.0) / 2.0                 # hwer/gcn_ncf.py:379-383
         else:
-            a = anchors_dev[b0:b1].to(torch.int32)
+            a = anchors_dev[pos].to(torch.int32)
             src = a.view(nb, 1).expand(nb, k).contiguous().view(-1)
             dst = rows.to(torch.int32).contiguous().view(-1)
             if score_mode == 0 and self.V64 is not None:
@@ -632,9 +631,9 @@ class DeviceIndex:
             sc = out.view(nb, k).to(torch.float64)
         if sort_by_score:
             sc, _, ids, d2, _ = self._order_rows(sc.contiguous(), k, k, descending=True, payload_i64=ids.contiguous(), payload_f64=d2.contiguous())
-        idx[b0:b1], score[b0:b1] = ids, sc
+        idx[pos], score[pos] = ids, sc
         if dist2 is not None:
-            dist2[b0:b1] = d2
+            dist2[pos] = d2
 
     def _search_candidates(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags, no_sync=False, workspaces=None):
         """Exact k-NN as "screen a superset, re-rank it exactly, certify" for the shapes the fused HIP search does not take:
@@ -672,8 +671,11 @@ class DeviceIndex:
                 c_sc = torch.empty((nb, kc), dtype=torch.float64, device=dev)
                 c_d2 = torch.empty((nb, kc), dtype=torch.float64, device=dev)
                 c_fl = torch.empty(nb, dtype=torch.int32, device=dev)
-                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, local, c_sc, c_d2, c_fl, no_sync=no_sync,
+                # (launches only: a query the candidate search - on-device exhaustive pass included - leaves uncertified is treated like a failed
+                # certificate below; its entries are clamped to valid rows so that the kernels behind this one read inside the table)
+                self._search_f32(tt, q64, Q32[b0:b1], kc, None, 2, False, False, 0, True, local, c_sc, c_d2, c_fl, no_sync=True,
                                  workspaces=workspaces)   # ids = local rows
+                local.clamp_(0, n - 1)
                 T = c_d2[:, kc - 1]
                 delta = (2.0 ** -24) * xmax
                 bound = T - 2.0 * torch.sqrt(T) * delta - delta * delta - 1e-12 * torch.clamp(T, min=1.0)
@@ -695,26 +697,27 @@ class DeviceIndex:
             native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(rows), kc, nb, kc, native.ptr(q64),
                                                  native.ptr(D), stream), "knn_cand_dist2")
             d2, local, _, _, cert = self._order_rows(D, kc, k, ids=local, bound=bound.contiguous(), every_row=(kc >= n), want_flags=True)
-            fl = torch.where(cert == 1, 1, 2).to(torch.int32)
-            if no_sync:
-                # hipGraph capture (one-anchor calls): no host decision here - a query whose certificate failed, or whose candidate search
-                # stayed uncertified, is reported with flag 0 and the caller takes the synchronising path
-                ok = (cert == 1) & (c_fl > 0) if use_hip else (cert == 1)
-                fl = torch.where(ok, 1, 0).to(torch.int32)
-                bad = cert[:0]
-            else:
-                bad = torch.nonzero(cert == 0).flatten()
-            if bad.numel():     # near-ties across the bound: all rows of the type, a few queries at a time
-                step = max(1, (1 << 26) // n)
-                for c0 in range(0, int(bad.numel()), step):
-                    sel = bad[c0:c0 + step]
-                    allrows = tt.rows_dev.unsqueeze(0).expand(sel.numel(), n).contiguous()
-                    Da = torch.empty((sel.numel(), n), dtype=torch.float64, device=dev)
-                    native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(allrows), n, sel.numel(), n,
-                                                         native.ptr(q64.index_select(0, sel).contiguous()), native.ptr(Da), stream), "knn_cand_dist2(all)")
-                    d2[sel], local[sel] = self._nearest_of_all(Da, n, k)       # ties keep the row (= id) order
-            self._score_and_emit(b0, b1, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
-            flags[b0:b1] = fl
+            # Round 5: no host decision inside the loop.  Every query is scored and emitted from its candidates; one whose certificate failed (near-ties
+            # across the bound) or whose candidate search stayed uncertified carries flag 0 and is repaired below, behind ONE synchronisation at
+            # the end of the path (rounds 3-4: two synchronisations per chunk - the candidate search's flags and this certificate).
+            ok = ((cert == 1) & (c_fl > 0)) if use_hip else (cert == 1)
+            self._score_and_emit(slice(b0, b1), nb, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
+            flags[b0:b1] = torch.where(ok, 1, 0).to(torch.int32)
+        if no_sync:      # hipGraph capture (one-anchor calls): flag 0 goes back to the caller, which takes this path again outside the capture
+            return
+        bad = torch.nonzero(flags[:B] == 0).flatten()
+        if bad.numel():     # all rows of the type, a few queries at a time (ties keep the row (= id) order); flag 2 like every exhaustive result
+            step = max(1, (1 << 26) // n)
+            for c0 in range(0, int(bad.numel()), step):
+                sel = bad[c0:c0 + step]
+                ns = int(sel.numel())
+                allrows = tt.rows_dev.unsqueeze(0).expand(ns, n).contiguous()
+                Da = torch.empty((ns, n), dtype=torch.float64, device=dev)
+                native.check(lib.hwer_knn_cand_dist2(native.ptr(table), is64, self.N, self.d, ld, native.ptr(allrows), n, ns, n,
+                                                     native.ptr(Q64.index_select(0, sel).contiguous()), native.ptr(Da), stream), "knn_cand_dist2(all)")
+                d2s, locs = self._nearest_of_all(Da, n, k)
+                self._score_and_emit(sel, ns, d2s, locs, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
+                flags[sel] = 2
 
     def _search_exhaustive(self, tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags):
         """Shapes outside the selection kernels' limits - k above hwer_knn_max_k() or d above hwer_knn_max_dim(); the reference
@@ -734,7 +737,7 @@ class DeviceIndex:
                                                          native.ptr(D), stream), "knn_all_dist2")
             d2, local = self._nearest_of_all(D, n, k)                     # ties keep the row (= id) order
             del D
-            self._score_and_emit(b0, b1, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
+            self._score_and_emit(slice(b0, b1), b1 - b0, d2, local, tt, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2)
         flags.fill_(2)
 
     #: more uncertified queries than this go through the exact-threshold retry first
