@@ -16,8 +16,8 @@ LIBDIR = os.path.join(os.path.dirname(HERE), "lib")
 # HWER_LIB_NAME=libhwer_hip_diag.so HIPCC_EXTRA=-DHWER_DIAG_STAMPS python build.py: a diagnostic library beside the production one (own objects)
 LIB = os.path.join(LIBDIR, os.environ.get("HWER_LIB_NAME", "libhwer_hip.so"))
 OBJ_TAG = "" if os.path.basename(LIB) == "libhwer_hip.so" else "." + os.path.basename(LIB).replace(".so", "")
-SOURCES = ["rowops.hip", "knn_screen.hip", "knn_small.hip", "knn_select.hip", "fit_pca.hip", "rows_f64.hip", "knn_wide.hip"]
-HEADERS = ["hwer_common.h", "knn_internal.h", os.path.join(ROOT, "include", "hwer_hip.h")]
+SOURCES = ["rowops.hip", "knn_screen.hip", "knn_small.hip", "knn_select.hip", "knn_select_f64.hip", "fit_pca.hip", "rows_f64.hip", "knn_wide.hip"]
+HEADERS = ["hwer_common.h", "knn_internal.h", "knn_select_kernels.h", os.path.join(ROOT, "include", "hwer_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-I" + os.path.join(ROOT, "include"), "-I" + HERE, "-Wno-unused-result"] + os.environ.get("HIPCC_EXTRA", "").split()
 # HIPCC_EXTRA=-DHWER_DIAG_STAMPS builds the screen kernel with its s_memtime phase stamps (diagnosis only: the stamps carry

@@ -5,8 +5,9 @@
 //   hwer_query_mix_f64rows   (rowops.hip)  queries from float64 rows, numpy's orders
 //   hwer_pair_score_f64rows               predict on float64 rows, numpy's pairwise order
 //   hwer_knn_cand_dist2                   exact squared distances of listed candidate rows (float32 or float64 table) in
-//                                         scikit-learn's sequential order - the re-rank of the candidate sets that the float32 search
-//                                         (d <= 256, k <= 392) or a library GEMM screen (wider tables, larger k) hands over
+//                                         scikit-learn's sequential order - the re-rank of the candidate sets that hwer_knn_keys_f32 +
+//                                         hwer_knn_topk_rows_f32 (wider tables, larger k) hand over (d <= 256, k <= 392: the fused
+//                                         float64-row select of knn_select_f64.hip, round 6)
 // None of them is on the throughput path of the float32 flavour; they are written for clarity, HBM-coalescing where it is free.
 #include <algorithm>
 
@@ -318,6 +319,64 @@ __global__ __launch_bounds__(256) void rows64_kernel(const Rows64Args a) {
     }
 }
 
+// Round 6: the float32 ROUNDING of float64 rows as the screen's table - X (zero-padded to ldx columns, pad rows zero with a +inf half norm),
+// hnorm = 0.5 ||x32||^2 (summed in float64 from the rounded elements, rounded once), optional float16 copy scaled by 2^x_exp - and the unit-norm
+// audit of the float64 rows themselves (hwer/recommendation_base.py:106-107) in the same pass.  16 lanes per row, 16-byte loads.
+struct Pack64Args {
+    const double* V64;
+    int64_t ld64;
+    int d;
+    const int64_t* row_ids;
+    int64_t n_rows, n_out;
+    float* X;
+    int64_t ldx;
+    float* hnorm;
+    _Float16* X16;
+    int x_exp;
+    double eps;
+    unsigned long long* counts;
+    double* absdev;
+};
+__global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args a) {
+    const int sub = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int x2 = int(a.ldx / 2), d2 = (a.d + 1) / 2;
+    for (int64_t r = int64_t(blockIdx.x) * 16 + sub; r < a.n_out; r += int64_t(gridDim.x) * 16) {   // (uniform per 16-lane group)
+        const bool live = r < a.n_rows;
+        const double* src = a.V64 + (live ? (a.row_ids ? a.row_ids[r] : r) : 0) * a.ld64;
+        double ss32 = 0.0, ss64 = 0.0;
+        for (int c = l; c < x2; c += 16) {
+            double2 v = make_double2(0.0, 0.0);
+            if (live && c < d2) {
+                v = *reinterpret_cast<const double2*>(src + 2 * c);
+                if (2 * c + 1 >= a.d) v.y = 0.0;
+            }
+            const float2 w = make_float2(float(v.x), float(v.y));
+            ss64 += v.x * v.x + v.y * v.y;
+            ss32 += double(w.x) * double(w.x) + double(w.y) * double(w.y);
+            *reinterpret_cast<float2*>(a.X + r * a.ldx + 2 * c) = w;
+            if (a.X16) {
+                typedef _Float16 half2_rt __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<half2_rt*>(a.X16 + r * a.ldx + 2 * c) = half2_rt{(_Float16)ldexpf(w.x, a.x_exp), (_Float16)ldexpf(w.y, a.x_exp)};
+            }
+        }
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+            ss32 += shfl_xor_t(ss32, m);
+            ss64 += shfl_xor_t(ss64, m);
+        }
+        if (l == 0) {
+            a.hnorm[r] = live ? float(0.5 * ss32) : INFINITY;
+            if (live && a.counts) {
+                const double n = sqrt(ss64);
+                if (n > 1.0 + a.eps) atomicAdd(&a.counts[0], 1ull);
+                if (n < 1.0 - a.eps) atomicAdd(&a.counts[1], 1ull);
+                if (n != n) atomicAdd(&a.counts[2], 1ull);
+                if (a.absdev) atomicAdd(a.absdev, fabs(n - 1.0));
+            }
+        }
+    }
+}
+
 template <int MODE>
 static int launch_rows64(const char* fn, Rows64Args a, void* stream) {
     a.d2 = (a.d + 1) / 2;
@@ -389,6 +448,22 @@ int hwer_blend_normalize_f64(const double* const* tables, int64_t ld_tables, con
     a.tables = tables; a.row_idx = row_idx; a.alpha = alpha; a.alpha_per_row = alpha_per_row; a.T = T; a.lde = ld_tables; a.R = R; a.d = d;
     a.out = out; a.ldo = ldo; a.out_norm = out_norm;
     return launch_rows64<2>("blend_normalize_f64", a, stream);
+}
+
+int hwer_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, const int64_t* row_ids, int64_t n_rows, float* X, int64_t ldx,
+                           float* hnorm, void* X16, int x_exp, float eps, uint64_t* audit_counts, double* audit_absdev_sum, void* stream) {
+    int rc;
+    if ((rc = check_table64("pack_rows_f64rows(V64)", V64, ld64, d))) return rc;
+    if (!X || !hnorm) return fail(HWER_EINVAL, "pack_rows_f64rows: null X / hnorm");
+    if (ldx < d || ldx % 2 != 0 || (reinterpret_cast<uintptr_t>(X) & 7) || (X16 && (reinterpret_cast<uintptr_t>(X16) & 3)))
+        return fail(HWER_EINVAL, "pack_rows_f64rows: ldx must be even and >= d, X 8-byte aligned");
+    if (n_rows < 0 || (!row_ids && n_rows > N)) return fail(HWER_EINVAL, "pack_rows_f64rows: n_rows > N without row_ids");
+    Pack64Args a{V64, ld64, d, row_ids, n_rows, hwer_knn_padded_rows(n_rows), X, ldx, hnorm, static_cast<_Float16*>(X16), x_exp, double(eps),
+                 reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum};
+    if (a.n_out == 0) return HWER_OK;
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_out, 16), kMaxStreamBlocks * 4)));
+    hipLaunchKernelGGL(pack_rows_f64rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    return check_launch("pack_rows_f64rows");
 }
 
 int hwer_pair_score_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst, int64_t P, double* out,

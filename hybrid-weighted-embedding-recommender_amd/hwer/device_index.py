@@ -168,16 +168,16 @@ class _OneAnchorSearch:
 
 class _OneAnchorSearchF64:
     """The per-anchor call on GENUINE float64 rows (what ContentRecommendation.fit returns since round 5's float64 blend stage): anchor id H2D ->
-    hwer_query_mix_f64rows -> the candidate scheme of DeviceIndex._search_candidates without its host decisions (float32 MFMA search for k + 32
-    candidates, their exact float64 distances, (distance, id) order + certificate, float64 scores, order by score) -> ids / scores / flag D2H,
-    captured ONCE as a hipGraph per (node type, k).  A replay whose certificate failed (flag 0: near-ties across the bound) is answered by the
-    general, synchronising path instead.  0.37 -> ~0.1 ms per find_closest_neighbours call at the ML-100K shape."""
+    hwer_query_mix_f64rows -> hwer_knn_search_f64rows (MFMA screen on the float32 rounding, fused select on the float64 rows) ->
+    hwer_knn_exact_device_f64rows -> ids / scores / flag D2H, captured ONCE as a hipGraph per (node type, k, score mode) - the float32 flavour's
+    launch chain (round 5 captured the 12-launch candidate scheme here).  A replay that comes back uncertified beyond the on-device pass (flag 0)
+    is answered by the general, synchronising path instead."""
 
-    def __init__(self, ix, node_type, k):
+    def __init__(self, ix, node_type, k, mode=0):
         import threading
         torch = _torch()
-        dev = ix.device
-        self.k = int(k)
+        lib, dev = ix.lib, ix.device
+        self.k, self.mode = int(k), int(mode)
         self.lock = threading.Lock()
         tt = ix.tables[node_type]
         self.h_anchor = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -185,27 +185,39 @@ class _OneAnchorSearchF64:
         self.d_anchor = torch.zeros(1, dtype=torch.int32, device=dev)
         self.Q64 = torch.empty((1, ix.d), dtype=torch.float64, device=dev)
         self.Q32 = torch.empty((1, ix.ldx), dtype=torch.float32, device=dev)
-        self.idx = torch.empty((1, k), dtype=torch.int64, device=dev)
-        self.score = torch.empty((1, k), dtype=torch.float64, device=dev)
-        self.flags = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.buf = torch.zeros(2 * k + 1, dtype=torch.int64, device=dev)
-        self.h_buf = torch.zeros(2 * k + 1, dtype=torch.int64).pin_memory()
+        nw = 2 * k + 1 + (k if mode == 2 else 0)
+        self.buf = torch.zeros(nw, dtype=torch.int64, device=dev)
+        self.h_buf = torch.zeros(nw, dtype=torch.int64).pin_memory()
         self.h_np = self.h_buf.numpy()
-        self.workspaces = {}
+        idx = self.buf[:k].view(1, k)
+        score = self.buf[k:2 * k].view(torch.float64).view(1, k)
+        flags = self.buf[2 * k:2 * k + 1].view(torch.int32)[:1]
+        d2 = self.buf[2 * k + 1:].view(torch.float64).view(1, k) if mode == 2 else None
+        x16, x16_exp = ix._x16(tt, 1)
+        opt = (ix.KNN_F16_SCREEN if (ix.f16_screen and x16 is not None) else 0) | ix._path_options()
+        wsb = lib.hwer_knn_workspace_bytes_opts(1, tt.n, ix.d, k, opt)
+        if wsb == 0:
+            raise native.HwerNativeError("knn: unsupported shape (n=%d, d=%d, k=%d)" % (tt.n, ix.d, k))
+        self.ws = torch.empty(int(wsb), dtype=torch.uint8, device=dev)
+        self.wse = torch.empty(int(lib.hwer_knn_exact_device_workspace_bytes(tt.n, k)), dtype=torch.uint8, device=dev)
         P = native.ptr
+        A64 = P(ix.V64) if mode != 2 else None
 
         def launch():
             st = native.stream_ptr(dev)
             self.d_anchor.copy_(self.h_anchor, non_blocking=True)
-            native.check(ix.lib.hwer_query_mix_f64rows(P(ix.V64), ix.N, ix.d, ix.d, P(self.d_anchor), None, None, None, None, 1, P(self.Q64), P(self.Q32),
-                                                        ix.ldx, st), "query_mix_f64rows")
-            ix._search_candidates(tt, self.Q64, self.Q32, k, self.d_anchor, 0, True, True, None, self.idx, self.score, None, self.flags, no_sync=True,
-                                  workspaces=self.workspaces)
-            self.buf[:k] = self.idx[0]
-            self.buf[k:2 * k] = self.score[0].view(torch.int64)
-            self.buf[2 * k:] = self.flags.to(torch.int64)
+            native.check(lib.hwer_query_mix_f64rows(P(ix.V64), ix.N, ix.d, ix.ld64, P(self.d_anchor), None, None, None, None, 1, P(self.Q64), P(self.Q32),
+                                                    ix.ldx, st), "query_mix_f64rows")
+            native.check(lib.hwer_knn_search_f64rows(
+                P(tt.X), P(tt.hnorm), tt.n, ix.d, ix.ldx, P(self.Q32), P(self.Q64), P(ix.V64), ix.ld64, P(tt.rows_dev), A64, ix.ld64, P(self.d_anchor), 1, k,
+                mode, 1, P(tt.rows_dev), 0, tt.hnorm_max, P(idx), P(score), P(d2), P(flags), P(self.ws), self.ws.numel(), opt, P(x16), x16_exp, st),
+                "knn_search_f64rows")
+            native.check(lib.hwer_knn_exact_device_f64rows(
+                P(ix.V64), ix.ld64, P(tt.rows_dev), tt.n, ix.d, P(self.Q64), A64, ix.ld64, P(self.d_anchor), k, mode, 1, P(tt.rows_dev), 0, P(idx), P(score),
+                P(d2), P(flags), P(self.ws), None, P(self.wse), self.wse.numel(), st), "knn_exact_device_f64rows")
             self.h_buf.copy_(self.buf, non_blocking=True)
         with native.device_guard(dev):
+            native.check(lib.hwer_knn_workspace_init(P(self.ws), self.ws.numel(), native.stream_ptr(dev)), "knn_workspace_init")
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
@@ -217,13 +229,13 @@ class _OneAnchorSearchF64:
             with torch.cuda.graph(g):
                 launch()
             self.graph = g
-        self._keep = (tt, ix.V64, ix.V)
+        self._keep = (tt, x16, ix.V64, ix.V)
         self.dev, self.dev_index = dev, dev.index
         self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-        self._sync = ix.lib.hwer_stream_synchronize
+        self._sync = lib.hwer_stream_synchronize
 
     def run(self, anchor: int):
-        """-> (ids (k,) int64, scores (k,) float64, flag) as fresh numpy arrays; thread-safe like _OneAnchorSearch.run"""
+        """-> (ids (k,) int64, scores (k,) float64, flag, squared distances (k,) float64 or None) as fresh numpy arrays; thread-safe like _OneAnchorSearch.run"""
         with self.lock:
             self.h_anchor_np[0] = anchor
             self.graph.replay()
@@ -235,7 +247,8 @@ class _OneAnchorSearchF64:
             else:
                 _torch().cuda.current_stream(self.dev).synchronize()
             k, h = self.k, self.h_np
-            return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k])
+            d2 = h[2 * k + 1:].view(np.float64).copy() if self.mode == 2 else None
+            return h[:k].copy(), h[k:2 * k].view(np.float64).copy(), int(h[2 * k] & 0xFFFFFFFF), d2
 
 
 class DeviceIndex:
@@ -262,6 +275,7 @@ class DeviceIndex:
     def _init(self, vectors, type_rows, arith, audit):
         torch = _torch()
         self.V64 = None
+        self.ld64 = 0
         if isinstance(vectors, np.ndarray):
             if arith is None:
                 arith = 0 if vectors.dtype == np.float64 else 1
@@ -272,7 +286,14 @@ class DeviceIndex:
             # (hwer/recommendation_base.py:74,79,109,135-144).  The float64 table stays resident beside its float32 rounding: the MFMA
             # screen runs on the rounding (a superset is all it has to keep), values come from the float64 rows (_search_candidates).
             if vectors.dtype == np.float64 and self.keep_f64 and not np.array_equal(host.astype(np.float64), vectors, equal_nan=True):
-                self.V64 = torch.from_numpy(np.ascontiguousarray(vectors)).to(self.device)
+                # rows padded with zeros to a multiple of 8 columns: every 8-column chunk of a row is one aligned 64-byte segment (what the
+                # fused float64-row select gathers, hwer_knn_search_f64rows)
+                self.ld64 = roundup(d, 8)
+                if self.ld64 == d:
+                    self.V64 = torch.from_numpy(np.ascontiguousarray(vectors)).to(self.device)
+                else:
+                    self.V64 = torch.zeros((N, self.ld64), dtype=torch.float64, device=self.device)
+                    self.V64[:, :d] = torch.from_numpy(np.ascontiguousarray(vectors)).to(self.device)
         else:
             if arith is None:
                 arith = 1
@@ -343,7 +364,7 @@ class DeviceIndex:
         P = s.numel()
         if arith == 0 and self.V64 is not None:     # float64 rows: the reference's float64 products
             out = torch.empty(P, dtype=torch.float64, device=self.device)
-            native.check(self.lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(s), native.ptr(t), P,
+            native.check(self.lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.ld64, native.ptr(s), native.ptr(t), P,
                                                           native.ptr(out), native.stream_ptr(self.device)), "pair_score_f64rows")
             return out.cpu().numpy()
         if arith == 0:
@@ -392,7 +413,7 @@ class DeviceIndex:
         Q64 = torch.empty((B, self.d), dtype=torch.float64, device=self.device)
         Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=self.device)
         if self.V64 is not None and self.arith == 0:
-            native.check(self.lib.hwer_query_mix_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(a), native.ptr(pp), native.ptr(pi),
+            native.check(self.lib.hwer_query_mix_f64rows(native.ptr(self.V64), self.N, self.d, self.ld64, native.ptr(a), native.ptr(pp), native.ptr(pi),
                                                          native.ptr(np_), native.ptr(ni), B, native.ptr(Q64), native.ptr(Q32), self.ldx,
                                                          native.stream_ptr(self.device)), "query_mix_f64rows")
             return Q64, Q32, a
@@ -486,6 +507,12 @@ class DeviceIndex:
             # anchor row of query b defaults to row b of the table - materialised ONCE, so that every chunk and every
             # fallback tier scores query b against V[b] (a NULL a_idx means "chunk-local index" inside the library)
             anchors_dev = torch.arange(B, dtype=torch.int32, device=self.device)
+        if self.V64 is not None and not self.wide and k <= self.lib.hwer_knn_max_k() and score_mode in (0, 2) and not os.environ.get("HWER_F64ROWS_CANDIDATES"):
+            # genuine float64 rows inside the fused search's limits (round 6): the float32 flavour's launches, values from the float64 rows
+            fh = self._search_f32(tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags, f64rows=True)
+            if _flags_host_out is not None:
+                _flags_host_out.append(fh)
+            return idx, score, dist2, flags
         if self.V64 is not None or k > self.lib.hwer_knn_max_k() or self.wide:
             if os.environ.get("HWER_FORCE_EXHAUSTIVE") and self.V64 is None:     # tests: the certified fallback on its own
                 self._search_exhaustive(tt, Q64, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags)
@@ -497,11 +524,19 @@ class DeviceIndex:
             _flags_host_out.append(fh)      # the host copy of `flags` the small-batch path already fetched (None otherwise)
         return idx, score, dist2, flags
 
-    def _search_f32(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags, no_sync=False, workspaces=None):
-        """the HIP search on the float32 table (d <= 256, k <= 392): MFMA screen -> float64 re-rank -> certificate, then the
+    def _search_f32(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, want_dist, idx, score, dist2, flags, no_sync=False, workspaces=None,
+                    f64rows=False):
+        """the fused HIP search (d <= 256, k <= 392): MFMA screen -> float64 re-rank -> certificate, then the
         exhaustive tiers for uncertified queries; fills idx / score / dist2 / flags.  -> the host copy of the final flags when the
-        small-batch branch fetched one and nothing changed them afterwards (else None)."""
+        small-batch branch fetched one and nothing changed them afterwards (else None).
+        f64rows (round 6): GENUINE float64 rows - the screen runs on their float32 rounding (tt.X / tt.X16), the select stage and every
+        exhaustive tier read the float64 rows of V64 (hwer_knn_search_f64rows, hwer_knn_exact_device_f64rows, hwer_knn_exact_f64rows):
+        the same launches as the float32 flavour; score_mode 0 or 2."""
         torch = _torch()
+        P = native.ptr
+        if f64rows:
+            assert self.V64 is not None and score_mode in (0, 2)
+            A64 = P(self.V64) if score_mode != 2 else None
         B = Q64.shape[0]
         path_opt = self._path_options()
         st = native.stream_ptr(self.device)       # one stream lookup per call (torch.cuda.current_stream costs ~4 us)
@@ -529,6 +564,18 @@ class DeviceIndex:
             else:
                 ws = self._workspace(wsb)
             a_sub = anchors_dev[b0:b1] if anchors_dev is not None else None
+            wse = workspaces["wse"] if workspaces is not None else self._exact_workspace(wseb)
+            if f64rows:
+                native.check(self.lib.hwer_knn_search_f64rows(
+                    P(tt.X), P(tt.hnorm), tt.n, self.d, self.ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(self.V64), self.ld64, P(tt.rows_dev), A64, self.ld64,
+                    P(a_sub), nb, k, score_mode, 1 if sort_by_score else 0, P(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
+                    tt.hnorm_max, P(idx[b0:b1]), P(score[b0:b1]), P(dist2[b0:b1]) if want_dist else None, P(flags[b0:b1]), P(ws), ws.numel(), opt,
+                    P(x16), x16_exp, st), "knn_search_f64rows")
+                native.check(self.lib.hwer_knn_exact_device_f64rows(
+                    P(self.V64), self.ld64, P(tt.rows_dev), tt.n, self.d, P(Q64[b0:b1]), A64, self.ld64, P(a_sub), k, score_mode, 1 if sort_by_score else 0,
+                    P(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), P(idx[b0:b1]), P(score[b0:b1]),
+                    P(dist2[b0:b1]) if want_dist else None, P(flags[b0:b1]), P(ws), None, P(wse), wse.numel(), st), "knn_exact_device_f64rows")
+                continue
             native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(Q32[b0:b1]), native.ptr(Q64[b0:b1]),
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub), nb, k, score_mode,
@@ -537,7 +584,6 @@ class DeviceIndex:
                 native.ptr(flags[b0:b1]), native.ptr(ws), ws.numel(), opt, native.ptr(x16), x16_exp, st), "knn_search")
             # queries the screen could not certify (rare) are recomputed exhaustively on the device, stream-ordered, up
             # to 8 per call; anything beyond that is picked up by the host-driven pass below
-            wse = workspaces["wse"] if workspaces is not None else self._exact_workspace(wseb)
             native.check(self.lib.hwer_knn_exact_device(
                 native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64[b0:b1]), native.ptr(self.V) if score_mode != 2 else None,
                 self.ldv, native.ptr(a_sub), k, score_mode, 1 if sort_by_score else 0,
@@ -562,11 +608,11 @@ class DeviceIndex:
                 # many uncertified queries = the sampled thresholds were defeated (e.g. a catalogue sorted by cluster): run
                 # them again with exact thresholds before falling back to the exhaustive pass query by query
                 self._retry_exact_thresholds(tt, bad, Q64, Q32, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base,
-                                             idx, score, dist2, flags)
+                                             idx, score, dist2, flags, f64rows=f64rows)
                 bad = torch.nonzero(flags == 0).flatten()
             if bad.numel():
                 self._exact_fallback(tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
-                                     dist2, flags)
+                                     dist2, flags, f64rows=f64rows)
         return flags_host
 
     #: extra candidates asked of the screen by _search_candidates (the certificate needs a gap between the k-th exact distance and
@@ -621,7 +667,7 @@ class DeviceIndex:
             dst = rows.to(torch.int32).contiguous().view(-1)
             if score_mode == 0 and self.V64 is not None:
                 out = torch.empty(nb * k, dtype=torch.float64, device=dev)
-                native.check(lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.d, native.ptr(src), native.ptr(dst), nb * k,
+                native.check(lib.hwer_pair_score_f64rows(native.ptr(self.V64), self.N, self.d, self.ld64, native.ptr(src), native.ptr(dst), nb * k,
                                                          native.ptr(out), stream), "pair_score_f64rows")
             else:
                 out = torch.empty(nb * k, dtype=torch.float64 if score_mode == 0 else torch.float32, device=dev)
@@ -658,7 +704,7 @@ class DeviceIndex:
         stream = native.stream_ptr(dev)
         kc = min(n, k + self.CAND_MARGIN)
         use_hip = self.V64 is not None and not self.wide and kc <= lib.hwer_knn_max_k()
-        table, is64, ld = (self.V64, 1, self.d) if self.V64 is not None else (self.V, 0, self.ldv)
+        table, is64, ld = (self.V64, 1, self.ld64) if self.V64 is not None else (self.V, 0, self.ldv)
         xmax = float(np.sqrt(2.0 * max(tt.hnorm_max, 0.0))) * (1.0 + 1e-6)
         n_pad = tt.X.shape[0]
         per = max(1, min(B, 65535, (1 << 28) // max(n_pad if not use_hip else kc, 1)))       # <= 1 GiB of float32 keys at a time
@@ -744,8 +790,9 @@ class DeviceIndex:
     RETRY_MIN = 16
 
     def _retry_exact_thresholds(self, tt, bad, Q64, Q32, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base,
-                                idx, score, dist2, flags):
+                                idx, score, dist2, flags, f64rows=False):
         torch = _torch()
+        P = native.ptr
         nb = int(bad.numel())
         q64, q32 = Q64.index_select(0, bad).contiguous(), Q32.index_select(0, bad).contiguous()
         a_sub = anchors_dev.index_select(0, bad).contiguous() if anchors_dev is not None else None
@@ -758,6 +805,14 @@ class DeviceIndex:
             b1 = min(nb, b0 + self.QUERY_CHUNK)
             wsb = self.lib.hwer_knn_workspace_bytes_opts(b1 - b0, tt.n, self.d, k, opt)
             ws = self._workspace(wsb)
+            if f64rows:
+                native.check(self.lib.hwer_knn_search_f64rows(
+                    P(tt.X), P(tt.hnorm), tt.n, self.d, self.ldx, P(q32[b0:b1]), P(q64[b0:b1]), P(self.V64), self.ld64, P(tt.rows_dev),
+                    P(self.V64) if score_mode != 2 else None, self.ld64, P(a_sub[b0:b1]) if a_sub is not None else None, b1 - b0, k, score_mode,
+                    1 if sort_by_score else 0, P(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), tt.hnorm_max, P(r_idx[b0:b1]),
+                    P(r_score[b0:b1]), P(r_dist2[b0:b1]) if r_dist2 is not None else None, P(r_flags[b0:b1]), P(ws), ws.numel(), opt, None, 0,
+                    native.stream_ptr(self.device)), "knn_search_f64rows(exact thresholds)")
+                continue
             native.check(self.lib.hwer_knn_search_opts_f32(
                 native.ptr(tt.X), native.ptr(tt.hnorm), tt.n, self.d, self.ldx, native.ptr(q32[b0:b1]), native.ptr(q64[b0:b1]),
                 native.ptr(self.V) if score_mode != 2 else None, self.ldv, native.ptr(a_sub[b0:b1]) if a_sub is not None else None,
@@ -774,12 +829,20 @@ class DeviceIndex:
         flags.index_copy_(0, rows, r_flags.index_select(0, good))
 
     def _exact_fallback(self, tt, bad, Q64, anchors_dev, k, score_mode, sort_by_score, use_rows, id_base, idx, score,
-                        dist2, flags):
+                        dist2, flags, f64rows=False):
         """Queries whose certificate failed (near-ties at the K'-cut, e.g. many duplicate rows): exhaustive float64
         pass on the device."""
         qsel = np.ascontiguousarray(bad.cpu().numpy(), dtype=np.int32)
         wsb = self.lib.hwer_knn_exact_workspace_bytes(tt.n, k)
         ws = self._workspace(wsb)
+        if f64rows:
+            P = native.ptr
+            native.check(self.lib.hwer_knn_exact_f64rows(
+                P(self.V64), self.ld64, P(tt.rows_dev), tt.n, self.d, P(Q64), P(self.V64) if score_mode != 2 else None, self.ld64, P(anchors_dev),
+                qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), k, score_mode, 1 if sort_by_score else 0, P(tt.rows_dev) if use_rows else None,
+                0 if use_rows else int(id_base), P(idx), P(score), P(dist2) if dist2 is not None else None, P(flags), P(ws), ws.numel(),
+                native.stream_ptr(self.device)), "knn_exact_f64rows")
+            return
         native.check(self.lib.hwer_knn_exact_f64(
             native.ptr(tt.X), tt.n, self.d, self.ldx, native.ptr(Q64), native.ptr(self.V) if score_mode != 2 else None,
             self.ldv, native.ptr(anchors_dev), qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), k, score_mode,
@@ -799,12 +862,12 @@ class DeviceIndex:
         if lock is None:
             lock = self.__dict__.setdefault("_one_anchor_lock", threading.Lock())
         tt = self.tables[node_type]
-        key = (node_type, int(k), mode if isinstance(mode, str) else int(mode), bool(self.f16_screen), bool(self.use_f16_storage), self._path_options(), id(tt.X16))
+        key = (node_type, int(k), mode if isinstance(mode, tuple) else int(mode), bool(self.f16_screen), bool(self.use_f16_storage), self._path_options(), id(tt.X16))
         with lock:      # (construction captures a hipGraph: one thread at a time)
             cache = self.__dict__.setdefault("_one_anchor", {})
             one = cache.pop(key, None)
             if one is None:
-                one = _OneAnchorSearchF64(self, node_type, k) if mode == "f64rows" else _OneAnchorSearch(self, node_type, k, mode)
+                one = _OneAnchorSearchF64(self, node_type, k, mode[1]) if isinstance(mode, tuple) else _OneAnchorSearch(self, node_type, k, mode)
                 key = key[:-1] + (id(tt.X16),)       # (the constructor may have built the float16 copy)
             cache[key] = one                         # most recently used last
             while len(cache) > self.ONE_ANCHOR_CACHE:
@@ -831,16 +894,16 @@ class DeviceIndex:
                     # not depend on the number of anchors)
                     return ids.reshape(1, k), sc.reshape(1, k), (np.sqrt(d2).reshape(1, k) if d2 is not None else None), np.asarray([flag], dtype=np.int32)
                 # (uncertified beyond the on-device exhaustive pass: the general path below runs the host-driven tiers)
-        if (self.one_anchor_graphs and np.size(anchors) == 1 and sort_by_score and not want_dist and mode == 0 and self.arith == 0 and self.V64 is not None and not self.wide
-                and k + self.CAND_MARGIN <= self._max_k and k + self.CAND_MARGIN <= self.tables[node_type].n and not self._has_lists(positive)
-                and not self._has_lists(negative) and not os.environ.get("HWER_FORCE_EXHAUSTIVE")):
-            # the same call on genuine float64 rows (ContentRecommendation.fit since round 5): a cached hipGraph of the candidate scheme
+        if (self.one_anchor_graphs and np.size(anchors) == 1 and sort_by_score and not want_dist and mode in (0, 2) and self.arith == 0 and self.V64 is not None
+                and not self.wide and k <= self._max_k and k <= self.tables[node_type].n and not self._has_lists(positive)
+                and not self._has_lists(negative) and not os.environ.get("HWER_FORCE_EXHAUSTIVE") and not os.environ.get("HWER_F64ROWS_CANDIDATES")):
+            # the same call on genuine float64 rows (ContentRecommendation.fit since round 5): a cached hipGraph of the fused float64-row search
             a0 = int(np.asarray(anchors).reshape(-1)[0])
             if 0 <= a0 < self.N:
-                one = self._one_anchor_search(node_type, k, "f64rows")
-                ids, sc, flag = one.run(a0)
+                one = self._one_anchor_search(node_type, k, ("f64rows", mode))
+                ids, sc, flag, d2 = one.run(a0)
                 if flag > 0:
-                    return ids.reshape(1, k), sc.reshape(1, k), None, np.asarray([flag], dtype=np.int32)
+                    return ids.reshape(1, k), sc.reshape(1, k), (np.sqrt(d2).reshape(1, k) if d2 is not None else None), np.asarray([flag], dtype=np.int32)
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
         fh = []
         idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist, _flags_host_out=fh)

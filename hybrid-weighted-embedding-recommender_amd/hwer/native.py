@@ -58,6 +58,17 @@ PROTOTYPES = {
     "hwer_knn_screen_f32": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, c_int64, c_int, _P, c_size_t, ctypes.c_uint32, _P, c_int, _P]),
     "hwer_knn_select_f32": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, c_int64, c_float,
                                     _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, _P]),
+    # X, hnorm, n, d, ldx, Q32, Q64, X64, ld64, x64_rows, A64, lda64, a_idx, B, k, mode, sort, row_ids, id_base, hnorm_max, idx, score, dist2, flags, ws, ws_bytes, opts, X16, x16_exp, stream
+    "hwer_knn_search_f64rows": (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, c_int64,
+                                        c_float, _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, c_int, _P]),
+    "hwer_knn_select_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, c_int64,
+                                        c_float, _P, _P, _P, _P, _P, c_size_t, ctypes.c_uint32, _P, _P]),
+    # X64, ld64, x64_rows, n, d, Q64, A64, lda64, a_idx, k, mode, sort, row_ids, id_base, idx, score, dist2, flags, knn_ws, missed, ws, ws_bytes, stream
+    "hwer_knn_exact_device_f64rows": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_int64, _P, c_int, c_int, c_int, _P, c_int64, _P, _P, _P, _P, _P, _P,
+                                              _P, c_size_t, _P]),
+    "hwer_knn_exact_f64rows": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, _P, c_int64, _P, _P, c_int64, c_int, c_int, c_int, _P, c_int64, _P, _P, _P, _P,
+                                       _P, c_size_t, _P]),
+    "hwer_pack_rows_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int, c_float, _P, _P, _P]),
     "hwer_query_mix_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "hwer_pair_score_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),
     "hwer_knn_cand_dist2": (c_int, [_P, c_int, c_int64, c_int, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P]),

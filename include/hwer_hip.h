@@ -353,8 +353,8 @@ int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, 
  *   hwer_pair_score_f64rows : hwer_pair_score_f64 over a float64 table
  *   hwer_knn_cand_dist2     : out[b][c] = ||Q64[b] - table[cand[b][c]]||^2 in scikit-learn's summation order for listed candidate
  *                             rows of a float32 (table_is_f64 = 0) or float64 table; cand < 0 -> +inf.  The exact re-rank behind a
- *                             candidate set: the float32 search asked for k + 32 (float64 flavour), or a library GEMM screen for
- *                             tables wider than hwer_knn_max_dim() / k above hwer_knn_max_k() (hwer/device_index.py).  B <= 65535.
+ *                             candidate set: hwer_knn_keys_f32 + hwer_knn_topk_rows_f32 for tables wider than hwer_knn_max_dim() / k above
+ *                             hwer_knn_max_k() (hwer/device_index.py; float64 rows inside those limits: hwer_knn_search_f64rows).  B <= 65535.
  * ------------------------------------------------------------------------------------------------- */
 int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
                            const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
@@ -363,6 +363,52 @@ int hwer_pair_score_f64rows(const double* V64, int64_t N, int d, int64_t ldv, co
                             double* out, void* stream);
 int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int d, int64_t ld, const int64_t* cand, int64_t ld_cand,
                         int64_t B, int64_t kc, const double* Q64, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * F64S   the FUSED search on genuine float64 rows (round 6) - replaces MultiKNN.query (KDTree over float64 `vectors`,
+ *        hwer/recommendation_base.py:74,78-83) and the re-score / sort at :171-173 (predict on float64 rows, :141-143) for the rows
+ *        ContentRecommendation.fit returns (hwer/content_recommender.py:96).  Same two stages as hwer_knn_search_opts_f32: the MFMA screen runs
+ *        on the float32 (or float16) ROUNDING of the rows - X / hnorm / X16 from hwer_pack_rows_f64rows (or hwer_pack_rows_f32 over a rounded copy) -
+ *        and the select stage reads the float64 rows themselves: candidate rows gathered in 64-byte segments (8 columns), squared distances in
+ *        scikit-learn's sequential order, scores in numpy's pairwise order from float64 products, certificate widened by the rounding of the
+ *        rows (|key32 - key| <= (2 d + 19) 2^-24 (||q|| ||x||max + hnorm_max) (+ the float16 term)), (distance, id) / score order, flags, the
+ *        uncertified list in the workspace header - ONE select launch; rounds 3-5 composed ~12 launches (hwer_knn_cand_dist2,
+ *        hwer_knn_order_rows_f64, hwer_pair_score_f64rows, ...) for the same result.  Results are bit-identical to the reference on float64 rows.
+ *   X64      : (rows, ld64) float64, 64-byte aligned, ld64 % 8 == 0, ld64 >= d, columns >= d ZERO (whole 64-byte segments are loaded)
+ *   x64_rows : (n_items) nullable: row of X64 that holds local item i (else i) - pass the whole `vectors` table as X64 and the type's row list
+ *   A64      : anchor rows for score_mode 0 (row of query b = A64[(a_idx ? a_idx[b] : b) * lda64]; normally the same table); NULL with score_mode 2
+ *   score_mode 0 (float64 scores, numpy order) or 2 (GcnNCF: (2 - dist) / 2); everything else as hwer_knn_search_opts_f32 (same workspace:
+ *   hwer_knn_workspace_bytes_opts, same options, same flags / uncertified-list semantics).
+ *   hwer_knn_select_f64rows            : the select stage alone, behind hwer_knn_screen_f32 on the same workspace (X only identifies the plan)
+ *   hwer_knn_exact_device_f64rows      : hwer_knn_exact_device reading the float64 rows (on-device exhaustive pass of the listed queries)
+ *   hwer_knn_exact_f64rows             : hwer_knn_exact_f64 reading the float64 rows (host-listed queries)
+ *   hwer_pack_rows_f64rows             : X[i] = float32(V64[row_ids[i]]) zero-padded to ldx, hnorm[i] = 0.5 ||X[i]||^2 (pad rows: zeros, +inf), optional
+ *                                        float16 copy scaled by 2^x_exp, and the unit-norm audit of the FLOAT64 rows (hwer/recommendation_base.py:
+ *                                        106-107): audit_counts[0..2] += rows with norm > 1 + eps / < 1 - eps / NaN, audit_absdev_sum += |norm - 1|
+ *                                        (both nullable, caller-zeroed accumulators).  X / hnorm / X16 hold hwer_knn_padded_rows(n_rows) rows.
+ * ------------------------------------------------------------------------------------------------- */
+int hwer_knn_search_f64rows(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32, const double* Q64,
+                            const double* X64, int64_t ld64, const int64_t* x64_rows /*nullable*/, const double* A64, int64_t lda64,
+                            const int32_t* a_idx, int64_t B, int k, int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base,
+                            float hnorm_max, int64_t* out_idx, double* out_score, double* out_dist2, int32_t* out_flags, void* workspace,
+                            size_t workspace_bytes, uint32_t options, const void* X16 /*nullable*/, int x16_exp, void* stream);
+int hwer_knn_select_f64rows(const float* X, int64_t n_items, int d, int64_t ldx, const double* Q64, const double* X64, int64_t ld64,
+                            const int64_t* x64_rows /*nullable*/, const double* A64, int64_t lda64, const int32_t* a_idx, int64_t B, int k,
+                            int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base, float hnorm_max, int64_t* out_idx,
+                            double* out_score, double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes, uint32_t options,
+                            const void* X16 /*nullable: only whether the screen had one*/, void* stream);
+int hwer_knn_exact_device_f64rows(const double* X64, int64_t ld64, const int64_t* x64_rows /*nullable*/, int64_t n_items, int d, const double* Q64,
+                                  const double* A64, int64_t lda64, const int32_t* a_idx, int k, int score_mode, int sort_by_score,
+                                  const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score, double* out_dist2,
+                                  int32_t* out_flags, void* knn_workspace, int32_t* missed_accum, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int hwer_knn_exact_f64rows(const double* X64, int64_t ld64, const int64_t* x64_rows /*nullable*/, int64_t n_items, int d, const double* Q64,
+                           const double* A64, int64_t lda64, const int32_t* a_idx, const int32_t* qsel_host /*host*/, int64_t nq, int k,
+                           int score_mode, int sort_by_score, const int64_t* row_ids, int64_t id_base, int64_t* out_idx, double* out_score,
+                           double* out_dist2, int32_t* out_flags, void* workspace, size_t workspace_bytes, void* stream);
+int hwer_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, const int64_t* row_ids /*nullable*/, int64_t n_rows, float* X,
+                           int64_t ldx, float* hnorm, void* X16 /*nullable*/, int x_exp, float eps, uint64_t* audit_counts /*nullable*/,
+                           double* audit_absdev_sum /*nullable*/, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * W1-W4  exact k-NN for the shapes the fused search does not take (round 4) - tables wider than hwer_knn_max_dim(), k above

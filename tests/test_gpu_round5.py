@@ -317,7 +317,7 @@ def test_one_anchor_graph_on_float64_rows_equals_the_general_path(hw, U, N, d, k
     assert ix.V64 is not None
     Vd = ix.V64.cpu().numpy()
     per_anchor = {u: m.find_closest_neighbours("item", u, k=k) for u in users}
-    assert any(key[:3] == ("item", k, "f64rows") for key in ix.__dict__.get("_one_anchor", {}))       # the graph path was taken
+    assert any(key[:3] == ("item", k, ("f64rows", 0)) for key in ix.__dict__.get("_one_anchor", {}))       # the graph path was taken
     again = m.find_closest_neighbours("item", users[1], k=k)                                           # the graph is reused
     assert again == per_anchor[users[1]]
     ix.one_anchor_graphs = False

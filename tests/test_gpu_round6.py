@@ -1,0 +1,159 @@
+"""GPU parity tests added in round 6: the FUSED search on genuine float64 rows (hwer_knn_search_f64rows / hwer_knn_select_f64rows /
+hwer_knn_exact_device_f64rows / hwer_knn_exact_f64rows, csrc/knn_select_f64.hip) - what ContentRecommendation serves since round 5's float64
+blend stage (reference: hwer/recommendation_base.py:74,78-83,141-143,171-173 on the float64 `vectors` of hwer/content_recommender.py:96).
+Every path the float32 flavour has (dense one-query-per-workgroup and wave-per-query selects, small-batch list select, streaming select,
+on-device and host-driven exhaustive tiers) against the numpy oracle on the float64 rows, and against rounds 3-5's candidate scheme on every
+query.  Bit-exact unless an assert states a tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import hwer_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hw():
+    import hwer
+    from hwer import native
+    native.lib()
+    return hwer
+
+
+def _rows64(seed, n, d, scale_spread=False):
+    x = np.random.default_rng(seed).standard_normal((n, d))
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    if scale_spread:      # row norms within the unit audit's 1e-4
+        x *= (1.0 + 8e-5 * np.random.default_rng(seed + 1).uniform(-1, 1, (n, 1)))
+    return x
+
+
+def _plant(X, B):
+    """float32-colliding rows and exact duplicates next to each other: only the float64 distances / the id order separate them"""
+    X[B + 11] = X[B + 10] * (1.0 + 3e-9)
+    X[B + 12] = X[B + 10] * (1.0 - 2e-9)
+    X[B + 13] = X[B + 10]
+    return X
+
+
+# (B, N, d, k): dense COOP select / dense wave-per-query / small-batch list select (COOP) / streaming select, d = 128 and 256, odd widths
+SHAPES = [(40, 1682, 64, 200), (3000, 3706, 128, 200), (64, 20000, 96, 200), (1, 20000, 128, 50), (2, 9000, 66, 10), (2500, 20000, 128, 200),
+          (1500, 12000, 256, 100), (300, 2000, 12, 392), (5, 300, 7, 300), (1100, 8193, 66, 64)]
+
+
+@pytest.mark.parametrize("B,N,d,k", SHAPES)
+@pytest.mark.parametrize("scoring", ["base", "gcn"])
+def test_fused_float64_row_search_vs_oracle_and_candidate_scheme(hw, B, N, d, k, scoring):
+    from hwer.device_index import DeviceIndex
+    if scoring == "gcn" and (B, N) not in ((40, 1682), (64, 20000), (2500, 20000), (5, 300)):
+        pytest.skip("the GcnNCF score flavour on one shape per path")
+    X = _plant(_rows64(600 + d + B, B + N, d, scale_spread=True), B)
+    ix = DeviceIndex(X, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    assert ix.V64 is not None and ix.ld64 % 8 == 0
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k, scoring=scoring)
+    assert (flags > 0).all()
+    # the lazy-distance variant of the same search (what find_closest_neighbours_batch asks for)
+    idx_l, score_l, dist_l, flags_l = ix.search("item", np.arange(B), k=k, scoring=scoring, want_dist=False)
+    assert np.array_equal(idx, idx_l) and np.array_equal(score, score_l) and (flags_l > 0).all()
+    rows = np.arange(B, B + N)
+    for u in sorted(set(list(range(0, B, max(1, B // 10))) + [B - 1])):
+        o_idx, o_score, o_dist = orc.find_closest(X, rows, u, k=k, scoring=scoring)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist), u
+    # every query against the candidate scheme of rounds 3-5 (an independent composition of other kernels)
+    os.environ["HWER_F64ROWS_CANDIDATES"] = "1"
+    try:
+        idx_c, score_c, dist_c, flags_c = ix.search("item", np.arange(B), k=k, scoring=scoring)
+    finally:
+        del os.environ["HWER_F64ROWS_CANDIDATES"]
+    assert np.array_equal(idx, idx_c) and np.array_equal(score, score_c) and np.array_equal(dist, dist_c)
+
+
+def test_fused_float64_rows_query_at_the_planted_ties(hw):
+    """anchors that ARE the planted rows' neighbours: the float32 screen cannot separate rows 10 .. 13 (equal after rounding), the float64
+    re-rank must, in (distance, id) order, on the dense, list and streaming selects"""
+    from hwer.device_index import DeviceIndex
+    for B, N, d, k in [(8, 3000, 64, 4), (8, 20000, 64, 4), (1500, 20000, 64, 3)]:
+        X = _rows64(77, B + N, d)
+        X[0] = X[B + 10]                       # anchor 0 sits on the planted group
+        X = _plant(X, B)
+        ix = DeviceIndex(X, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+        idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+        o_idx, o_score, o_dist = orc.find_closest(X, np.arange(B, B + N), 0, k=k)
+        assert np.array_equal(idx[0], o_idx) and np.array_equal(score[0], o_score) and np.array_equal(dist[0], o_dist), (B, N)
+        assert set(idx[0].tolist()) >= {B + 10, B + 13} and flags[0] > 0
+
+
+def test_float64_row_exhaustive_tiers(hw):
+    """many exact duplicates at the cut: the certificate fails (flag 0) and the on-device / host-driven exhaustive passes - reading the
+    float64 rows - answer; > 16 uncertified queries also go through the exact-threshold retry tier"""
+    from hwer.device_index import DeviceIndex
+    B, N, d, k = 40, 12000, 32, 20
+    X = _rows64(5, B + N, d)
+    X[B + 100:B + 700] = X[B + 50]            # 600 copies of one row: more near-ties than the re-rank set holds
+    for b in range(B):
+        X[b] = X[B + 50] * (1 - 1e-7 * (b + 1)) + 1e-4 * X[B + 1000 + b]
+        X[b] /= np.linalg.norm(X[b])
+    ix = DeviceIndex(X, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k)
+    assert (flags > 0).all() and (flags == 2).any()
+    for u in (0, 7, B - 1):
+        o_idx, o_score, o_dist = orc.find_closest(X, np.arange(B, B + N), u, k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist), u
+
+
+def test_fused_float64_rows_positive_negative_lists(hw):
+    """queries that are NOT rows (hwer/recommendation_base.py:164-170: mean of anchor / positive / negative unit vectors, not re-normalised):
+    candidates by distance to q, scores against the anchor row - on float64 rows"""
+    from hwer.device_index import DeviceIndex
+    B, N, d, k = 24, 5000, 48, 30
+    X = _rows64(31, B + N, d)
+    rng = np.random.default_rng(2)
+    pos = [list(rng.integers(0, B + N, rng.integers(0, 4))) for _ in range(B)]
+    neg = [list(rng.integers(-1, B + N, rng.integers(0, 3))) for _ in range(B)]
+    ix = DeviceIndex(X, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)})
+    idx, score, dist, flags = ix.search("item", np.arange(B), k=k, positive=pos, negative=neg)
+    assert (flags > 0).all()
+    for u in range(B):
+        o_idx, o_score, o_dist = orc.find_closest(X, np.arange(B, B + N), u, positive=pos[u], negative=neg[u], k=k)
+        assert np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_score) and np.array_equal(dist[u], o_dist), u
+
+
+def test_pack_rows_f64rows_kernel(hw):
+    """hwer_pack_rows_f64rows: the float32 rounding of listed float64 rows, half norms, float16 copy, pad rows, and the unit audit of the
+    float64 rows (hwer/recommendation_base.py:106-107)"""
+    import torch
+    from hwer import native
+    lib = native.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(8)
+    for N, d, n_rows in [(500, 66, 301), (310, 128, 300), (100, 7, 64)]:
+        ld64 = (d + 7) // 8 * 8
+        V = np.zeros((N, ld64))
+        V[:, :d] = _rows64(9 + d, N, d)
+        V[3, :d] *= 1.001
+        V[4, :d] *= 0.998
+        V[5, 0] = np.nan
+        rows = np.concatenate([[3, 4, 5], 6 + np.sort(rng.choice(N - 6, n_rows - 3, replace=False))]).astype(np.int64)
+        ldx = lib.hwer_knn_padded_dim(d)
+        n_pad = lib.hwer_knn_padded_rows(n_rows)
+        Vd, rd = torch.from_numpy(V).to(dev), torch.from_numpy(rows).to(dev)
+        X = torch.full((n_pad, ldx), 7.0, dtype=torch.float32, device=dev)
+        hn = torch.empty(n_pad, dtype=torch.float32, device=dev)
+        X16 = torch.empty((n_pad, ldx), dtype=torch.float16, device=dev)
+        counts = torch.zeros(4, dtype=torch.int64, device=dev)
+        dev_sum = torch.zeros(1, dtype=torch.float64, device=dev)
+        x_exp = int(lib.hwer_knn_f16_scale_exp(0.51))
+        native.check(lib.hwer_pack_rows_f64rows(native.ptr(Vd), N, d, ld64, native.ptr(rd), n_rows, native.ptr(X), ldx, native.ptr(hn), native.ptr(X16),
+                                                x_exp, 1e-4, native.ptr(counts), native.ptr(dev_sum), native.stream_ptr(dev)), "pack_rows_f64rows")
+        Xh, hh, X16h = X.cpu().numpy(), hn.cpu().numpy(), X16.cpu().numpy()
+        want = np.zeros((n_pad, ldx), np.float32)
+        want[:n_rows, :d] = V[rows, :d].astype(np.float32)
+        assert np.array_equal(Xh, want, equal_nan=True)
+        hw_ = (0.5 * (want[:n_rows].astype(np.float64) ** 2).sum(1))
+        ok = ~np.isnan(hw_)
+        assert np.allclose(hh[:n_rows][ok], hw_[ok], rtol=2e-7, atol=0) and np.isinf(hh[n_rows:]).all()
+        assert np.array_equal(X16h[:n_rows][ok], np.ldexp(want[:n_rows][ok], x_exp).astype(np.float16))
+        c = counts.cpu().numpy()
+        assert (c[0], c[1], c[2]) == (1, 1, 1)
