@@ -50,6 +50,10 @@ CONFIGS = {
     "c5": dict(U=131072, B=4096, I=1250000, d=256, T=4, per_row=True,
                name="multi-alpha hybrid shard (3 content + 1 collaborative, per-row alpha, d=256; 131072 user + 1.25M item rows blended, 4096 queries)"),
     "c4full": dict(U=4096, I=10000000, d=128, T=2, per_row=False, name="10M-item catalogue (4096 queries x 10M items, d=128)"),
+    # the reference's float64 flavour (ContentRecommendation: float64 tables -> float64 `vectors`, hwer/content_recommender.py:85,96): the SAME step in
+    # float64 - hwer.pipeline.BlendSearchStepF64: float64 blend, fused search whose distances / scores come from the float64 rows (round 6)
+    "c1_f64rows": dict(U=943, I=1682, d=64, T=2, per_row=False, f64rows=True, name="ML-100K-shaped synthetic, float64 tables and rows (943x1682, d=64, alpha=0.5)"),
+    "c3_f64rows": dict(U=138493, I=26744, d=128, T=2, per_row=False, f64rows=True, name="ML-20M-shaped synthetic, float64 tables and rows (138493x26744, d=128)"),
 }
 K = 200
 PROFILE_EVERY = 5
@@ -631,6 +635,119 @@ def run_config(torch, lib, name, dev, steps, warmup, args, cpu_budget_s=0.0, api
     return res
 
 
+def gen_unit_rows_f64(torch, seed, n, d, dev):
+    """genuine float64 unit rows (not float32-representable): N(0, 1) in float64, row-normalised in float64"""
+    out = torch.empty((n, d), dtype=torch.float64, device=dev)
+    gen = torch.Generator(device=dev)
+    for lo in range(0, n, GEN_BLOCK):
+        gen.manual_seed(seed * 1000003 + lo // GEN_BLOCK)
+        x = torch.randn((min(GEN_BLOCK, n - lo), d), generator=gen, device=dev, dtype=torch.float64)
+        out[lo:lo + x.shape[0]] = x / x.norm(dim=1, keepdim=True)
+    return out
+
+
+def run_config_f64rows(torch, lib, name, dev, steps, warmup, args):
+    """One configuration in the reference's float64 flavour (hwer.pipeline.BlendSearchStepF64): float64 tables -> hwer_blend_normalize_f64 ->
+    float64 `vectors` -> audit + float32 / float16 rounding of the item rows (screen only) -> queries from the float64 rows -> fused search on the
+    float64 rows.  Same timed-region contract as run_config; parity: the blended rows against the numpy expression (array_equal) and sampled queries
+    against the numpy oracle ON THE FLOAT64 ROWS (ids, scores: bit for bit)."""
+    import gc
+    from hwer.pipeline import BlendSearchStepF64
+    from oracle import hwer_oracle as orc
+    cfg = CONFIGS[name]
+    U, I, d, T = cfg["U"], cfg["I"], cfg["d"], cfg["T"]
+    N = U + I
+    tables = [gen_unit_rows_f64(torch, 3100 + 20 * t, N, d, dev) for t in range(T)]
+    alpha = torch.full((T,), 1.0 / T, dtype=torch.float64, device=dev)
+    w = BlendSearchStepF64(tables, alpha, search_row0=U, n_search=I, anchors=torch.arange(0, U, dtype=torch.int32, device=dev), k=K)
+    graph = None
+    if I <= 8192 and not args.no_graph:
+        w.capture()
+        graph = w._graph
+    run_step = graph.replay if graph is not None else w.step
+
+    def region(n_steps, n_warm):
+        gc.collect()
+        gc.disable()
+        try:
+            for _ in range(n_warm):
+                run_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                run_step()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        finally:
+            gc.enable()
+    elapsed = region(steps, warmup)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    evs[0].record()
+    for i in range(steps):
+        run_step()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    series = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+    steady = region(500, max(warmup, 100)) / 500 * 1e3 if (graph is not None and steps < 500) else None
+    # the two parts of a step in real (eager) steps, and the search's kernels bracketed by HIP events on the launch stream
+    n_split = max(5, min(steps, 10))
+    marks = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_split)]
+    lib.hwer_profile_enable(1)
+    for e0, e1, e2 in marks:
+        e0.record()
+        w.step(mark=e1)
+        e2.record()
+    torch.cuda.synchronize()
+    lib.hwer_profile_enable(0)
+    screen_ms, select_ms, _ = read_profile(lib)
+    searches_per_step = (U + w.CH - 1) // w.CH
+    pro, sea = float(np.median([a.elapsed_time(b) for a, b, _ in marks])), float(np.median([b.elapsed_time(c) for _, b, c in marks]))
+    stages = {"blend_normalize_f64": cuda_time(torch, w.stage_blend, 10), "audit+pack_rows_f64rows": cuda_time(torch, w.stage_pack, 10),
+              "query_mix_f64rows": cuda_time(torch, w.stage_queries, 10)}
+    run_step()
+    torch.cuda.synchronize()
+    o = w.sets[0]
+    n_exhaustive = w.checks(o)
+    ms_per_step = elapsed / steps * 1e3
+    value = float(U) * float(I) / (elapsed / steps)
+    # ---- parity: blend stage == numpy on sampled rows; sampled queries == the numpy oracle on the float64 rows ------------------------------
+    idx_h, score_h = o["idx"].cpu().numpy(), o["score"].cpu().numpy()
+    Vh = w.V64[:, :d].cpu().numpy()
+    rows_chk = np.unique(np.linspace(0, N - 1, 64).astype(np.int64))
+    acc = np.zeros((len(rows_chk), d))
+    for t in range(T):
+        acc = acc + (1.0 / T) * tables[t][torch.from_numpy(rows_chk).to(dev)].cpu().numpy()
+    ref_rows = acc / np.expand_dims(np.linalg.norm(acc, axis=1), 1)
+    assert np.array_equal(Vh[rows_chk], ref_rows), "float64 blend differs from the numpy expression (%s)" % name
+    sel = np.unique(np.linspace(0, U - 1, 16).astype(np.int64))
+    for u in sel:
+        o_idx, o_sc, _ = orc.find_closest(Vh, np.arange(U, N), int(u), k=K)
+        assert np.array_equal(idx_h[u], o_idx), "GPU indices differ from the oracle on float64 rows (%s, query %d)" % (name, u)
+        assert np.array_equal(score_h[u], o_sc), "GPU scores differ from the oracle on float64 rows (%s, query %d)" % (name, u)
+    flops = 2.0 * U * I * d
+    sc_ms, se_ms = screen_ms * searches_per_step, select_ms * searches_per_step
+    stage_tf = flops / ((sc_ms + se_ms) * 1e-3) / 1e12 if sc_ms + se_ms > 0 else 0.0
+    gather_bytes = float(U) * (K + 16) * 8.0 * w.ld64
+    table_bytes = float(N) * w.ld64 * 8
+    level, gather_peak = ("l2", 17800.0) if table_bytes <= 4.0e6 else (("infinity_cache", 8600.0) if table_bytes <= 2.56e8 else ("hbm_random_rows", 5600.0))
+    res = {"workload": cfg["name"], "users": U, "items": I, "d": d, "k": K, "tables": T, "alpha": "scalar", "f16_screen": w.f16_screen, "dtype": "f64",
+           "dtype_note": "float64 tables, float64 blend, float64 rows: distances and scores from the float64 rows; the MFMA screen runs on their %s rounding (superset only)" % ("float16" if w.f16_screen else "float32"),
+           "steps": steps, "warmup": warmup, "hip_graph": graph is not None, "value": value, "unit": "pairs/s", "ms_per_step": ms_per_step,
+           "ms_median": float(np.median(series)), "ms_min": float(series.min()), "ms_max": float(series.max()), "ms_mean_events": float(series.mean()),
+           "timed_region": {"attempts": 1, "reported": "first", "remeasured_ms_per_step": None, "steady_ms_per_step": None if steady is None else round(steady, 5)},
+           "stages_in_step_ms": {"prologue": pro, "search": sea}, "stage_sum_ms": pro + sea, "stages_ms": stages,
+           "knn_screen_ms": sc_ms, "knn_select_f64rows_ms": se_ms,
+           "roofline": {"kernel": "cosine_topk = knn_screen + knn_select_f64rows (SURVEY 8d unit)", "bound": "mfma", "achieved": stage_tf, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": stage_tf / MFMA_F32_PEAK_TFLOPS, "traffic": None, "traffic_source": "not collected for this configuration"},
+           "select_gather": {"bound": "gather:" + level, "achieved": gather_bytes / (se_ms * 1e-3) / 1e9 if se_ms > 0 else 0.0, "peak": gather_peak, "unit": "GB/s",
+                             "algorithmic_bytes": gather_bytes, "note": "(k + 16) float64 rows of 8 ld64 bytes per query"},
+           "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive, "parity_checked_queries": int(len(sel)),
+           "parity_note": "ids and scores == the numpy oracle on the float64 rows; blended rows == numpy (array_equal, %d rows)" % len(rows_chk)}
+    del w, tables
+    torch.cuda.empty_cache()
+    return res
+
+
 def cpu_baseline(w, Vh, idx_h, budget_s, cores, cores_note):
     from oracle import c_oracle
     from oracle import hwer_oracle as orc
@@ -856,6 +973,8 @@ def run_single(args):
     base = {"metric": METRIC, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "data": "synthetic"}
     cpu = (lambda s_: 0.0 if args.no_cpu_baseline else s_)
+    if args.config and CONFIGS[args.config].get("f64rows"):
+        return finish_line(base, run_config_f64rows(torch, lib, args.config, dev, args.steps, args.warmup, args))
     if args.config:      # one configuration only (profiling runs)
         r = run_config(torch, lib, args.config, dev, args.steps, args.warmup, args, cpu_budget_s=cpu(8.0),
                        latencies=() if args.sweep_only else ((1,) if args.config != "c4" else (1, 64, 4096)), f32_beside=not args.sweep_only)
@@ -871,6 +990,9 @@ def run_single(args):
     configs["c4"] = run_config(torch, lib, "c4", dev, max(20, min(args.steps, 40)), max(5, min(args.warmup, 10)), args, latencies=(1, 64, 4096), stage_reps=10, f32_beside=True)
     configs["c5"] = run_config(torch, lib, "c5", dev, max(20, min(args.steps, 40)), max(5, min(args.warmup, 10)), args, stage_reps=10, f32_beside=True)
     configs["c4full"] = run_config(torch, lib, "c4full", dev, max(10, min(args.steps, 20)), max(5, min(args.warmup, 5)), args, stage_reps=3)
+    # the reference's float64 flavour of the headline shape and of the roofline shape (round 6: fused float64-row search)
+    configs["c1_f64rows"] = run_config_f64rows(torch, lib, "c1_f64rows", dev, args.steps, args.warmup, args)
+    configs["c3_f64rows"] = run_config_f64rows(torch, lib, "c3_f64rows", dev, max(10, min(args.steps, 20)), max(3, min(args.warmup, 5)), args)
     configs["c4full"]["note"] = ("the whole 10M-item catalogue on ONE GPU: the 1-GPU value of the workload that `bench.py --gpus N` (N > 1) strong-scales; "
                                  "use this value as the N = 1 point of the scaling curve")
     out = finish_line(base, top)
@@ -890,7 +1012,7 @@ def finish_line(base, r):
     for k_ in ("ms_median", "ms_min", "ms_max", "ms_mean_events", "timed_region", "ms_series", "ms_series_note", "roofline", "dominant_kernel", "stage_frac", "stage_frac_note",
                "kernels", "stages_ms", "stage_sum_ms", "stage_sum_note", "stages_in_step_ms", "stage_sum_separate_ms", "certified_queries", "exhaustive_fallback_queries",
                "parity_checked_queries", "hip_graph", "f32_screen", "query_latency_ms", "pair_score", "cpu_baseline", "speedup_vs_cpu",
-               "speedup_vs_reference_shaped_loop", "api_latency_ms"):
+               "speedup_vs_reference_shaped_loop", "api_latency_ms", "knn_screen_ms", "knn_select_f64rows_ms", "select_gather", "dtype_note", "parity_note"):
         if k_ in r:
             out[k_] = r[k_]
     if "api_latency_ms" in r and "model_get_topk" in r["api_latency_ms"]:
@@ -938,7 +1060,9 @@ def compact_line(full, detail_path):
         out["recall_latency_ms"] = _r(full["recall_latency_ms"], 4)
     al = full.get("api_latency_ms") or {}
     if "find_closest_neighbours" in al:      # one call of the reference's per-anchor API, and its loop over every anchor, beside the batched sweep
-        out["api_latency_ms"] = {"find_closest_neighbours": _r(al["find_closest_neighbours"], 4), "per_anchor_loop_all": _r(al.get("model_get_topk_knn_per_anchor"), 4)}
+        out["api_latency_ms"] = {"find_closest_neighbours": _r(al["find_closest_neighbours"], 4), "per_anchor_loop_all": _r(al.get("model_get_topk_knn_per_anchor"), 4),
+                                 "find_closest_neighbours_f64rows": _r(al.get("find_closest_neighbours_f64rows"), 4),
+                                 "batch_all_anchors": _r(al.get("find_closest_neighbours_batch"), 4), "batch_all_anchors_f64rows": _r(al.get("find_closest_neighbours_batch_f64rows"), 4)}
     tr = full.get("timed_region")
     if tr:      # always in the line: which region is reported, and whether a second one was taken
         out["timed_region"] = {"attempts": tr["attempts"], "reported": tr.get("reported"), "remeasured_ms_per_step": tr.get("remeasured_ms_per_step")}

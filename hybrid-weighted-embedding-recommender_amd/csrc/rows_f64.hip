@@ -340,6 +340,8 @@ struct Pack64Args {
 __global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args a) {
     const int sub = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int x2 = int(a.ldx / 2), d2 = (a.d + 1) / 2;
+    unsigned int n_pos = 0, n_neg = 0, n_nan = 0;   // this 16-lane group's audit tallies (lane 0), combined per block below: one atomic per block and counter
+    double dev_sum = 0.0;
     for (int64_t r = int64_t(blockIdx.x) * 16 + sub; r < a.n_out; r += int64_t(gridDim.x) * 16) {   // (uniform per 16-lane group)
         const bool live = r < a.n_rows;
         const double* src = a.V64 + (live ? (a.row_ids ? a.row_ids[r] : r) : 0) * a.ld64;
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args
             const float2 w = make_float2(float(v.x), float(v.y));
             ss64 += v.x * v.x + v.y * v.y;
             ss32 += double(w.x) * double(w.x) + double(w.y) * double(w.y);
-            *reinterpret_cast<float2*>(a.X + r * a.ldx + 2 * c) = w;
+            if (a.X) *reinterpret_cast<float2*>(a.X + r * a.ldx + 2 * c) = w;
             if (a.X16) {
                 typedef _Float16 half2_rt __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<half2_rt*>(a.X16 + r * a.ldx + 2 * c) = half2_rt{(_Float16)ldexpf(w.x, a.x_exp), (_Float16)ldexpf(w.y, a.x_exp)};
@@ -365,14 +367,29 @@ __global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args
             ss64 += shfl_xor_t(ss64, m);
         }
         if (l == 0) {
-            a.hnorm[r] = live ? float(0.5 * ss32) : INFINITY;
-            if (live && a.counts) {
+            if (a.hnorm) a.hnorm[r] = live ? float(0.5 * ss32) : INFINITY;
+            if (live) {
                 const double n = sqrt(ss64);
-                if (n > 1.0 + a.eps) atomicAdd(&a.counts[0], 1ull);
-                if (n < 1.0 - a.eps) atomicAdd(&a.counts[1], 1ull);
-                if (n != n) atomicAdd(&a.counts[2], 1ull);
-                if (a.absdev) atomicAdd(a.absdev, fabs(n - 1.0));
+                n_pos += n > 1.0 + a.eps;
+                n_neg += n < 1.0 - a.eps;
+                n_nan += n != n;
+                dev_sum += fabs(n - 1.0);
             }
+        }
+    }
+    if (a.counts) {   // (kernel-uniform)
+        __shared__ unsigned int s_c[3][16];
+        __shared__ double s_d[16];
+        if (l == 0) { s_c[0][sub] = n_pos; s_c[1][sub] = n_neg; s_c[2][sub] = n_nan; s_d[sub] = dev_sum; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            unsigned int t = 0;
+            for (int i = 0; i < 16; ++i) t += s_c[threadIdx.x][i];
+            if (t) atomicAdd(&a.counts[threadIdx.x], (unsigned long long)t);
+        } else if (threadIdx.x == 3 && a.absdev) {
+            double t = 0.0;
+            for (int i = 0; i < 16; ++i) t += s_d[i];
+            atomicAdd(a.absdev, t);
         }
     }
 }
@@ -454,11 +471,14 @@ int hwer_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, co
                            float* hnorm, void* X16, int x_exp, float eps, uint64_t* audit_counts, double* audit_absdev_sum, void* stream) {
     int rc;
     if ((rc = check_table64("pack_rows_f64rows(V64)", V64, ld64, d))) return rc;
-    if (!X || !hnorm) return fail(HWER_EINVAL, "pack_rows_f64rows: null X / hnorm");
+    const bool audit_only = !X && !hnorm && !X16;   // (only the unit-norm audit of the listed rows)
+    if (audit_only && !audit_counts) return fail(HWER_EINVAL, "pack_rows_f64rows: nothing to do (no X / hnorm and no audit accumulators)");
+    if (!audit_only && (!X || !hnorm)) return fail(HWER_EINVAL, "pack_rows_f64rows: null X / hnorm");
+    if (audit_only) ldx = 2 * ((d + 1) / 2);
     if (ldx < d || ldx % 2 != 0 || (reinterpret_cast<uintptr_t>(X) & 7) || (X16 && (reinterpret_cast<uintptr_t>(X16) & 3)))
         return fail(HWER_EINVAL, "pack_rows_f64rows: ldx must be even and >= d, X 8-byte aligned");
     if (n_rows < 0 || (!row_ids && n_rows > N)) return fail(HWER_EINVAL, "pack_rows_f64rows: n_rows > N without row_ids");
-    Pack64Args a{V64, ld64, d, row_ids, n_rows, hwer_knn_padded_rows(n_rows), X, ldx, hnorm, static_cast<_Float16*>(X16), x_exp, double(eps),
+    Pack64Args a{V64, ld64, d, row_ids, n_rows, audit_only ? n_rows : hwer_knn_padded_rows(n_rows), X, ldx, hnorm, static_cast<_Float16*>(X16), x_exp, double(eps),
                  reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum};
     if (a.n_out == 0) return HWER_OK;
     const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_out, 16), kMaxStreamBlocks * 4)));

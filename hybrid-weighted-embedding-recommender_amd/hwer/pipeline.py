@@ -392,3 +392,163 @@ class BlendSearchStep:
             sc = sc.astype(np.float32)      # exact: the kernel widened float32 values
         out = (o["idx"].cpu().numpy(), sc)
         return out + (np.sqrt(o["dist2"].cpu().numpy()),) if o["dist2"] is not None else out
+
+
+class BlendSearchStepF64:
+    """The same resident step in the reference's own float64 arithmetic (round 6): T FLOAT64 tables -> hwer_blend_normalize_f64 (the bits of
+    hwer/content_recommender.py:85,96 / hwer/utils.py:43-44) -> float64 `vectors` V64 -> unit-norm audit of the float64 rows + the float32 / float16
+    rounding of the searched type's rows for the MFMA screen (hwer_pack_rows_f64rows; hwer/recommendation_base.py:105-110, :64-76) -> anchor queries
+    from the float64 rows (hwer_query_mix_f64rows; :153-155,164-170) -> hwer_knn_search_f64rows + hwer_knn_exact_device_f64rows: exact top-k whose
+    distances and scores are computed from the float64 rows (:74,78-83,141-143,171-173) - what ContentRecommendation serves, as one
+    allocation-free, capturable step.  tables: (N, d) float64 device tensors with row stride ld (even, >= d); alpha (T,) or (N, T) float64.
+    Rows [search_row0, + n_search) are the searched type, ids reported = id_base + local row (default: the row id)."""
+
+    def __init__(self, tables: Sequence, alpha, search_row0: int, n_search: int, anchors, k: int = 200, id_base: Optional[int] = None,
+                 want_dist: bool = False, sort_by_score: bool = True, f16_screen: Optional[bool] = None, eps: float = 1e-4, score_mode: int = 0):
+        import torch
+        lib = self.lib = native.lib()
+        self.torch = torch
+        self.tables = list(tables)
+        T = self.T = len(self.tables)
+        dev = self.dev = self.tables[0].device
+        N, d = self.tables[0].shape
+        self.N, self.d = int(N), int(d)
+        self.ld_in = int(self.tables[0].stride(0))
+        for t in self.tables:
+            assert t.dtype == torch.float64 and tuple(t.shape) == (N, d) and t.stride(1) == 1 and t.stride(0) == self.ld_in and self.ld_in % 2 == 0
+        self.ldx = lib.hwer_knn_padded_dim(d)
+        if self.ldx < 0:
+            raise native.HwerNativeError("BlendSearchStepF64: d=%d unsupported (1..%d)" % (d, lib.hwer_knn_max_dim()))
+        self.alpha, self.per_row = alpha, alpha.dim() == 2
+        assert alpha.dtype == torch.float64 and alpha.is_contiguous() and tuple(alpha.shape) in ((T,), (N, T))
+        self.I, self.search_row0 = int(n_search), int(search_row0)
+        assert self.I >= 1 and self.search_row0 + self.I <= N
+        I, K = self.I, int(k)
+        self.k, self.anchors = K, anchors
+        B = self.B = int(anchors.numel())
+        assert anchors.dtype == torch.int32 and B >= 1
+        self.eps, self.score_mode = float(eps), int(score_mode)
+        with native.device_guard(dev):
+            self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
+            self.ld64 = roundup(d, 8)
+            self.V64 = torch.zeros((N, self.ld64), dtype=torch.float64, device=dev)      # (pad columns stay zero: the blend writes d of them)
+            self.item_rows = torch.arange(self.search_row0, self.search_row0 + I, dtype=torch.int64, device=dev)
+            self.other_ranges = [(0, self.search_row0), (self.search_row0 + I, N)]
+            I_pad = self.I_pad = lib.hwer_knn_padded_rows(I)
+            self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
+            self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
+            if f16_screen is None:
+                f16_screen = bool(lib.hwer_knn_f16_screen_pays(min(B, QUERY_CHUNK), I, d))
+            self.f16_screen = bool(f16_screen and self.ldx >= 64)
+            self.X16 = torch.empty((I_pad, self.ldx), dtype=torch.float16, device=dev) if self.f16_screen else None
+            self.audit_buf = torch.zeros(6, dtype=torch.int64, device=dev)
+            self.audit_counts, self.audit_dev = self.audit_buf[:4], self.audit_buf[4:5].view(torch.float64)
+            self.Q64 = torch.empty((B, d), dtype=torch.float64, device=dev)
+            self.Q32 = torch.empty((B, self.ldx), dtype=torch.float32, device=dev)
+            if not sort_by_score or score_mode == 2:
+                want_dist = True
+            self.want_dist, self.sort_by_score = want_dist, 1 if sort_by_score else 0
+            self.sets = [dict(idx=torch.empty((B, K), dtype=torch.int64, device=dev), score=torch.empty((B, K), dtype=torch.float64, device=dev),
+                              dist2=torch.empty((B, K), dtype=torch.float64, device=dev) if want_dist else None, flags=torch.empty(B, dtype=torch.int32, device=dev))]
+            self.CH = QUERY_CHUNK
+            self.opts = KNN_F16_SCREEN if self.f16_screen else 0
+            ws_bytes = lib.hwer_knn_workspace_bytes_opts(min(B, self.CH), I, d, K, self.opts)
+            if ws_bytes == 0:
+                raise native.HwerNativeError("BlendSearchStepF64: unsupported shape (B=%d, n=%d, d=%d, k=%d; k <= %d)" % (B, I, d, K, lib.hwer_knn_max_k()))
+            self.ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws), self.ws.numel(), self.S()), "knn_workspace_init")
+            self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
+            self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.hnorm_max = 0.5 * (1.0 + self.eps) ** 2
+        self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
+        self.id_base = self.search_row0 if id_base is None else int(id_base)
+        self._graph = None
+
+    def S(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def stage_blend(self):
+        P, lib = native.ptr, self.lib
+        native.check(lib.hwer_blend_normalize_f64(P(self.tab_ptrs), self.ld_in, None, P(self.alpha), 1 if self.per_row else 0, self.T, self.N, self.d,
+                                                  P(self.V64), self.ld64, None, self.S()), "blend_normalize_f64")
+
+    def stage_pack(self):
+        """unit-norm audit of every float64 row + the screen's float32 / float16 rounding of the searched type's rows"""
+        P, lib = native.ptr, self.lib
+        self.audit_buf.zero_()
+        for lo, hi in self.other_ranges:
+            if hi > lo:
+                native.check(lib.hwer_pack_rows_f64rows(P(self.V64[lo:hi]), hi - lo, self.d, self.ld64, None, hi - lo, None, 0, None, None, 0, self.eps,
+                                                        P(self.audit_counts), P(self.audit_dev), self.S()), "audit_f64rows")
+        native.check(lib.hwer_pack_rows_f64rows(P(self.V64), self.N, self.d, self.ld64, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
+                                                P(self.X16), self.x16_exp, self.eps, P(self.audit_counts), P(self.audit_dev), self.S()), "pack_rows_f64rows")
+
+    def stage_queries(self):
+        P, lib = native.ptr, self.lib
+        native.check(lib.hwer_query_mix_f64rows(P(self.V64), self.N, self.d, self.ld64, P(self.anchors), None, None, None, None, self.B, P(self.Q64), P(self.Q32),
+                                                self.ldx, self.S()), "query_mix_f64rows")
+
+    def stage_search(self, o=None):
+        P, lib, K = native.ptr, self.lib, self.k
+        o = self.sets[0] if o is None else o
+        oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
+        A64 = P(self.V64) if self.score_mode != 2 else None
+        for b0 in range(0, self.B, self.CH):
+            b1 = min(self.B, b0 + self.CH)
+            native.check(lib.hwer_knn_search_f64rows(
+                P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.V64), self.ld64, P(self.item_rows), A64,
+                self.ld64, P(self.anchors[b0:b1]), b1 - b0, K, self.score_mode, self.sort_by_score, None, self.id_base, self.hnorm_max, P(oi[b0:b1]),
+                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(), self.opts, P(self.X16), self.x16_exp,
+                self.S()), "knn_search_f64rows")
+            native.check(lib.hwer_knn_exact_device_f64rows(
+                P(self.V64), self.ld64, P(self.item_rows), self.I, self.d, P(self.Q64[b0:b1]), A64, self.ld64, P(self.anchors[b0:b1]), K, self.score_mode,
+                self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws),
+                P(self.missed), P(self.ws_exact), self.ws_exact.numel(), self.S()), "knn_exact_device_f64rows")
+
+    def step(self, o=None, mark=None):
+        self.stage_blend()
+        self.stage_pack()
+        self.stage_queries()
+        if mark is not None:
+            mark.record()
+        self.stage_search(o)
+        return self.sets[0] if o is None else o
+
+    def run(self, o=None):
+        with native.device_guard(self.dev):
+            if self._graph is not None and o is None:
+                self._graph.replay()
+                return self.sets[0]
+            return self.step(o)
+
+    def capture(self, warm_steps: int = 2):
+        torch = self.torch
+        with native.device_guard(self.dev):
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(warm_steps):
+                    self.step()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step()
+            self._graph = g
+        return self
+
+    def checks(self, o=None):
+        o = self.sets[0] if o is None else o
+        pos, neg, nan = self.audit_counts.tolist()[:3]
+        assert pos + neg + nan == 0, "unit-norm audit failed: %s" % ((pos, neg, nan),)
+        n_uncert = int((o["flags"] == 0).sum().item())
+        assert n_uncert == 0, "%d queries left without an exact result" % n_uncert
+        assert int(self.missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(self.missed.item())
+        return int((o["flags"] == 2).sum().item())
+
+    def results(self, o=None):
+        import numpy as np
+        o = self.sets[0] if o is None else o
+        self.checks(o)
+        out = (o["idx"].cpu().numpy(), o["score"].cpu().numpy())
+        return out + (np.sqrt(o["dist2"].cpu().numpy()),) if o["dist2"] is not None else out

@@ -386,6 +386,7 @@ int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int
  *                                        float16 copy scaled by 2^x_exp, and the unit-norm audit of the FLOAT64 rows (hwer/recommendation_base.py:
  *                                        106-107): audit_counts[0..2] += rows with norm > 1 + eps / < 1 - eps / NaN, audit_absdev_sum += |norm - 1|
  *                                        (both nullable, caller-zeroed accumulators).  X / hnorm / X16 hold hwer_knn_padded_rows(n_rows) rows.
+ *                                        X = hnorm = X16 = NULL: only the audit of the listed rows (the rows of the other node types).
  * ------------------------------------------------------------------------------------------------- */
 int hwer_knn_search_f64rows(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32, const double* Q64,
                             const double* X64, int64_t ld64, const int64_t* x64_rows /*nullable*/, const double* A64, int64_t lda64,

@@ -1,8 +1,6 @@
 set -e
-python tools/probe_f64rows_latency.py
-python tools/probe_f64rows_batch.py 943 1682 64
-python tools/probe_f64rows_batch.py 4096 26744 128
-HWER_F64ROWS_CANDIDATES=1 python tools/probe_f64rows_batch.py 943 1682 64
-HWER_F64ROWS_CANDIDATES=1 python tools/probe_f64rows_batch.py 4096 26744 128
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_f64b -- python3 $GRAFT_REPO_ROOT/tools/probe_f64rows_batch.py 4096 26744 128 > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT && find gpurun_out/prof_f64b -name "*kernel_stats.csv" | head -1 | xargs -I{} sh -c 'head -14 {} | cut -c1-200'
+python bench.py --config c3_f64rows --steps 10 --warmup 3 --detail-out gpurun_out/r6_c3f64_detail.json > gpurun_out/r6_c3f64.json 2> gpurun_out/r6_c3f64.err
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_c3f64 -o c3f64 --output-format csv -- python3 bench.py --config c3_f64rows --steps 5 --warmup 2 > /dev/null 2> gpurun_out/prof_c3f64.err
+python3 tools/prof_summary.py stats gpurun_out/prof_c3f64 > gpurun_out/r6_stats_c3f64.txt
+rm -f gpurun_out/prof_c3f64/*/*kernel_trace.csv
