@@ -50,6 +50,8 @@ CONFIGS = {
     "c5": dict(U=131072, B=4096, I=1250000, d=256, T=4, per_row=True,
                name="multi-alpha hybrid shard (3 content + 1 collaborative, per-row alpha, d=256; 131072 user + 1.25M item rows blended, 4096 queries)"),
     "c4full": dict(U=4096, I=10000000, d=128, T=2, per_row=False, name="10M-item catalogue (4096 queries x 10M items, d=128)"),
+    "c5full": dict(U=131072, B=4096, I=10000000, d=256, T=4, per_row=True,
+                   name="multi-alpha hybrid, whole catalogue (3 content + 1 collaborative, per-row alpha, d=256; 131072 user + 10M item rows blended, 4096 queries)"),
     # the reference's float64 flavour (ContentRecommendation: float64 tables -> float64 `vectors`, hwer/content_recommender.py:85,96): the SAME step in
     # float64 - hwer.pipeline.BlendSearchStepF64: float64 blend, fused search whose distances / scores come from the float64 rows (round 6)
     "c1_f64rows": dict(U=943, I=1682, d=64, T=2, per_row=False, f64rows=True, name="ML-100K-shaped synthetic, float64 tables and rows (943x1682, d=64, alpha=0.5)"),
@@ -1138,6 +1140,7 @@ def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_
         e[i + 1].record()
     torch.cuda.synchronize()
     single_ms = float(np.median([e[i].elapsed_time(e[i + 1]) for i in range(steps)]))
+    n_repaired_single = w1.repair(w1.sets[0])     # (the reference result of the comparison: queries beyond the on-device pass's 8 per search, if any)
     n_exh_single = w1.checks(w1.sets[0])
     one = {k_: w1.sets[0][k_].clone() for k_ in ("idx", "score", "dist2")}
     items_h = w1.V[U:, :d].cpu().numpy() if n_oracle else None
@@ -1193,7 +1196,7 @@ def emulate_shards(torch, lib, cfg, dev, G, steps=3, warmup=2, n_oracle=32, f32_
         n_par = int(len(sel))
     return {"shards": G, "queries": B, "items_total": I_total, "single_table_ms": single_ms, "shard_ms": shard_ms, "shard_ms_max": max(shard_ms),
             "merge_ms": merge_ms, "speedup_before_exchange": single_ms / (max(shard_ms) + merge_ms), "merged_equals_single_table": True,
-            "queries_compared": B, "oracle_checked_queries": n_par, "exhaustive_fallback_queries": {"single": n_exh_single, "shards": n_exh},
+            "queries_compared": B, "oracle_checked_queries": n_par, "exhaustive_fallback_queries": {"single": n_exh_single, "shards": n_exh, "single_host_repaired": n_repaired_single},
             "local_list_len": k_in, "lists_ran_out_first_pass": 0, "exchange_bytes_per_rank": 24 * B * k_in,
             "recv_layout": "(G, 3, B, k_in) int64 = all_gather_into_tensor's receive buffer; merged in place by hwer_merge_topk_lists (list stride 3*B*k_in)"}
 

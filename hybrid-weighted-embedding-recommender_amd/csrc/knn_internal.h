@@ -73,6 +73,7 @@ struct ScreenPlan {
 };
 
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options = 0);
+int kprime_for(int k, int64_t n_items, int ldx, bool f16_screen);   // candidate keys kept per query (knn_screen.hip)
 
 // Header at the start of the k-NN workspace: the queries the last search could not certify (flag 0), appended by the
 // select kernels, consumed by the on-device exhaustive pass (hwer_knn_exact_device) without a host round trip.

@@ -1283,10 +1283,33 @@ int repack_queries(const float* Q32, int64_t B, int64_t B_padded, int ldx, float
 #define HWER_SEED_MAX_TILES 8192
 #endif
 constexpr int64_t SEED_MAX_TILES = HWER_SEED_MAX_TILES;   // largest sample: 262 144 rows
+// K' = candidate keys kept per query.  The certificate needs some kept key below t_k - 2 E (E = the screen's key error bound, t_k ~ the k-th
+// largest key, bracketed to within 12 ranks): the slack K' - k has to cover the ~12 keys of the bracket plus the keys that lie within 2 E of the
+// k-th.  Under a float32 screen E is ~1e-5 of the key range and SLACK = 56 is ample; under the FLOAT16 screen E ~ 2^-10 ||q|| ||x|| is a fixed
+// absolute width while the key spacing at the k-th key shrinks like 1 / (N pdf): on a 10 M x 256 catalogue ~28 keys sit inside 2 E and 0.3 % of
+// the queries came back uncertified (round 6: c5full on ONE GPU, 12 of 4 096 - more than the on-device exhaustive pass takes).  Rule: with
+// m = the expected number of keys within 2 E of the k-th key - unit rows with iid components, cosines ~ N(0, 1 / d): m = N phi(z_k) sqrt(d) 2 E,
+// z_k = the upper k / N quantile - K' grows by 64 until K' - k - 12 - m >= 3.7 sqrt(m) (~1e-4 uncertified queries per query).  A PERFORMANCE
+// heuristic only: a catalogue that does not look like the model gets more (or fewer) exhaustive passes, never a wrong answer.
+int kprime_for(int k, int64_t n_items, int ldx, bool f16_screen) {
+    int kp = ((k + SLACK + 63) / 64) * 64;
+    if (!f16_screen || n_items <= DENSE_MAX_ITEMS || k >= n_items) return kp;
+    const double p_k = double(k) / double(n_items);
+    double lo = 0.0, hi = 12.0;
+    for (int it = 0; it < 60; ++it) {
+        const double mid = 0.5 * (lo + hi);
+        if (0.5 * erfc(mid * 0.7071067811865476) > p_k) lo = mid; else hi = mid;
+    }
+    const double z = 0.5 * (lo + hi);
+    const double m = double(n_items) * exp(-0.5 * z * z) * 0.3989422804014327 * sqrt(double(ldx)) * 2.0 * 1.02 * 0.0009765625;
+    while (kp + 64 <= KPRIME_MAX && double(kp - k) - 12.0 - m < 3.7 * sqrt(m)) kp += 64;
+    return kp;
+}
+
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options) {
     ScreenPlan p{};
     p.ng = ldx / 8;
-    p.kprime = ((k + SLACK + 63) / 64) * 64;
+    p.kprime = kprime_for(k, n_items, ldx, (options & HWER_KNN_F16_SCREEN) != 0 && ldx >= 64);
     // queries per wave: TQ = 2 subtiles (64 queries, 256 per workgroup) while the B fragments fit the register budget
     // (NG * TQ float4 <= 32 float4) AND the query blocks alone fill the 512 workgroup slots.  Below that (B <= 65 536) the
     // launch is split over the items anyway, and TQ = 1 is the better trade: twice the query blocks -> half the item splits

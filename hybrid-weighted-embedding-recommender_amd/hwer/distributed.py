@@ -43,7 +43,7 @@ def local_list_len(k: int, world_size: int) -> int:
     return k if k_in >= k else k_in
 
 
-def all_gather_results(idx, score, dist2, group=None):
+def all_gather_results(idx, score, dist2, group=None, send=None, recv=None):
     """ONE all_gather_into_tensor of the three (B, k) result arrays -> three (G, B, k) views of the receive buffer.
     Every rank packs (idx | score bits | dist2 bits) into one (3, B, k) int64 buffer (device tensors: one hwer_pack_exchange
     launch), the collective writes rank g's buffer to recv[g], and the returned tensors are STRIDED VIEWS of recv (list
@@ -56,14 +56,20 @@ def all_gather_results(idx, score, dist2, group=None):
     B, k = idx.shape
     if B == 0:
         return idx.new_empty((G, 0, k)), score.new_empty((G, 0, k)), dist2.new_empty((G, 0, k))
-    send = pack_send_buffer(idx, score, dist2, 1)[0]                      # (3, B, k) int64
+    # send / recv (optional): preallocated (1, 3, B, k) / (G, 3, B, k) int64 buffers - a pipelined caller issues this on a side stream and must not
+    # allocate there (ShardedStepPipeline owns one pair per result set)
+    send = pack_send_buffer(idx, score, dist2, 1, out=send)[0]            # (3, B, k) int64
     if send.is_cuda and dist.get_backend(group) != "nccl":
         # test harness only (e.g. two ranks sharing one GPU over gloo): stage the payload through host memory
         host = torch.empty((G,) + tuple(send.shape), dtype=torch.int64)
         dist.all_gather_into_tensor(host.view(-1), send.cpu().view(-1), group=group)
-        recv = host.to(send.device)
+        if recv is None:
+            recv = host.to(send.device)
+        else:
+            recv.copy_(host)
     else:
-        recv = torch.empty((G,) + tuple(send.shape), dtype=torch.int64, device=send.device)
+        if recv is None:
+            recv = torch.empty((G,) + tuple(send.shape), dtype=torch.int64, device=send.device)
         dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=group)
     return recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64)
 
@@ -73,14 +79,15 @@ def query_slice(n_queries: int, world_size: int, rank: int) -> Tuple[int, int]:
     return shard_bounds(n_queries, world_size, rank)
 
 
-def pack_send_buffer(idx, score, dist2, G: int):
+def pack_send_buffer(idx, score, dist2, G: int, out=None):
     """(G, 3, Bs, k) int64 send buffer of the user-partitioned exchange, Bs = ceil(B / G): send[g] = (idx, score bits,
     dist2 bits) of the queries of rank g's slice; rows past the batch are padding (id -1, score 0, dist2 +inf: they lose
     every merge).  Device tensors: one hwer_pack_exchange launch."""
     import torch
     B, k = idx.shape
     Bs = (B + G - 1) // G
-    send = torch.empty((G, 3, Bs, k), dtype=torch.int64, device=idx.device)
+    send = torch.empty((G, 3, Bs, k), dtype=torch.int64, device=idx.device) if out is None else out
+    assert tuple(send.shape) == (G, 3, Bs, k) and send.dtype == torch.int64 and send.is_contiguous()
     if idx.is_cuda:
         from . import native
         idx, score, dist2 = idx.contiguous(), score.contiguous(), dist2.contiguous()
@@ -105,7 +112,7 @@ def pack_send_buffer(idx, score, dist2, G: int):
     return send
 
 
-def exchange_by_query(idx, score, dist2, group=None):
+def exchange_by_query(idx, score, dist2, group=None, send=None, recv=None):
     """User-partitioned exchange (SURVEY.md §8e variant): rank r receives, from every rank g, g's local results for the
     queries of r's slice -> three (G, Bs, k) tensors, Bs = ceil(B/G) (rows beyond the slice are padding: ids -1,
     dist2 +inf).  Per link this moves 1/G of what the all-gather moves: xGMI is point-to-point, so the exchange is G
@@ -119,11 +126,14 @@ def exchange_by_query(idx, score, dist2, group=None):
     if B == 0:
         return idx.new_empty((G, 0, k)), score.new_empty((G, 0, k)), dist2.new_empty((G, 0, k))
     Bs = (B + G - 1) // G
-    send = pack_send_buffer(idx, score, dist2, G)
+    send = pack_send_buffer(idx, score, dist2, G, out=send)
     staged = send.is_cuda and dist.get_backend(group) != "nccl"        # test harness only: ranks sharing a GPU over gloo
+    recv_dev = recv
     if staged:
         send = send.cpu()
-    recv = torch.empty_like(send)
+        recv = None
+    if recv is None:
+        recv = torch.empty_like(send)
     if dist.get_backend(group) == "nccl":
         dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)   # equal splits: slice g <-> rank g
     else:
@@ -138,12 +148,16 @@ def exchange_by_query(idx, score, dist2, group=None):
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
     if staged:
-        recv = recv.to(idx.device)
+        if recv_dev is None:
+            recv = recv.to(idx.device)
+        else:
+            recv_dev.copy_(recv)
+            recv = recv_dev
     # strided views of the receive buffer (list stride 3 Bs k): merge_on_device reads them in place
     return recv[:, 0], recv[:, 1].view(torch.float64), recv[:, 2].view(torch.float64)
 
 
-def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True, k=None, want_exhausted=False):
+def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True, k=None, want_exhausted=False, out=None):
     """hwer_merge_topk_lists over gathered (G, B, k_in) tensors -> (idx, score, dist2) (B, k) tensors, k >= k_in (default k_in);
     with want_exhausted a fourth (B,) int32 tensor: 1 where some list gave all its k_in entries to the winners (k_in < k only:
     that query has to be repeated with full lists)."""
@@ -156,10 +170,15 @@ def merge_on_device(g_idx, g_score, g_dist2, sort_by_score=True, k=None, want_ex
     if len(strides) != 1 or g_idx.stride()[1:] != (k_in, 1) or (G > 1 and g_idx.stride(0) < B * k_in):
         g_idx, g_score, g_dist2 = g_idx.contiguous(), g_score.contiguous(), g_dist2.contiguous()
     list_stride = g_idx.stride(0) if G > 1 else B * k_in
-    o_idx = torch.empty((B, k), dtype=torch.int64, device=g_idx.device)
-    o_score = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
-    o_dist2 = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
-    o_ex = torch.zeros((B,), dtype=torch.int32, device=g_idx.device) if want_exhausted else None
+    if out is not None:      # preallocated (idx, score, dist2, exhausted) of at least B rows (a pipelined caller: no allocation on its side stream)
+        o_idx, o_score, o_dist2 = out[0][:B], out[1][:B], out[2][:B]
+        o_ex = out[3][:B] if want_exhausted else None
+        assert o_idx.shape == (B, k) and o_idx.is_contiguous() and o_score.is_contiguous() and o_dist2.is_contiguous()
+    else:
+        o_idx = torch.empty((B, k), dtype=torch.int64, device=g_idx.device)
+        o_score = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
+        o_dist2 = torch.empty((B, k), dtype=torch.float64, device=g_idx.device)
+        o_ex = torch.zeros((B,), dtype=torch.int32, device=g_idx.device) if want_exhausted else None
     with native.device_guard(g_idx.device):
         native.check(lib.hwer_merge_topk_lists(native.ptr(g_idx), native.ptr(g_score), native.ptr(g_dist2), list_stride, G, B, k_in, k,
                                                1 if sort_by_score else 0, native.ptr(o_idx), native.ptr(o_score),
@@ -258,6 +277,11 @@ class ShardedSearch:
             ev.record(torch.cuda.current_stream(count.device))
         else:
             host, ev = count.view(1).clone(), None
+        if deferred:
+            # the repeat runs one search later: a pipelined caller has refilled its resident query buffers by then - keep the queries of THIS
+            # search (a device-side copy, no host synchronisation; advisor finding of round 5)
+            Q64 = Q64.clone()
+            Q32 = Q32.clone() if Q32 is not None else None
         self._pending = (ev, host, exhausted, Q64, Q32, k, sort_by_score, (m_idx, m_score, m_dist2))
         if not deferred:
             self.settle()
@@ -295,7 +319,8 @@ class ShardedStepPipeline:
 
         step = BlendSearchStep(tables, alpha, ..., k=k_in, want_dist=True, sort_by_score=False, n_sets=2)
         pipe = ShardedStepPipeline(step, k=200, exchange="all_gather")
-        for _ in range(n): merged = pipe.run()          # (idx, score, dist2) of the step just issued; final after pipe.wait()
+        for _ in range(n): merged = pipe.run()          # (idx, score, dist2) of the step just issued; final after pipe.wait(),
+                                                        # overwritten by the run() after next (the pipeline owns two sets of buffers)
         pipe.wait(); assert pipe.exhausted_queries() == 0
     """
 
@@ -310,9 +335,24 @@ class ShardedStepPipeline:
         self.comm = torch.cuda.Stream(device=dev)
         self.ev_searched = [torch.cuda.Event() for _ in range(2)]
         self.ev_merged = [torch.cuda.Event() for _ in range(2)]
-        self.merged = [None, None]
         self.n_steps = 0
         self.ex_accum = torch.zeros((step.B,), dtype=torch.int32, device=dev)
+        # Every buffer the side stream touches is allocated HERE, once per result set (round 6; round 5 allocated the receive buffer and the merge
+        # outputs inside run() under `torch.cuda.stream(comm)` and handed them to the caller's stream without record_stream: the caching allocator
+        # could have given such a block back to the side stream while the caller still read it).  Lifetime rule instead of allocator bookkeeping:
+        # the tensors run() returns for step i are overwritten by step i + 2 - stream-ordered behind everything the caller enqueued on its stream
+        # before that run() call (the side stream waits for ev_searched of step i + 2, recorded on the caller's stream).
+        import torch.distributed as dist
+        G = dist.get_world_size(group)
+        B, k_in, K = step.B, self.k_in, self.k
+        Bs = (B + G - 1) // G
+        Bm = Bs if exchange == "by_query" else B          # rows of the merged result a rank ends with
+        n_send = G if exchange == "by_query" else 1
+        self.send = [torch.empty((n_send, 3, Bs if exchange == "by_query" else B, k_in), dtype=torch.int64, device=dev) for _ in range(2)]
+        self.recv = [torch.empty((G, 3, Bs if exchange == "by_query" else B, k_in), dtype=torch.int64, device=dev) for _ in range(2)]
+        self.out = [(torch.empty((Bm, K), dtype=torch.int64, device=dev), torch.empty((Bm, K), dtype=torch.float64, device=dev),
+                     torch.empty((Bm, K), dtype=torch.float64, device=dev), torch.zeros((Bm,), dtype=torch.int32, device=dev)) for _ in range(2)]
+        self.merged = [tuple(o[:3]) for o in self.out]
         self.time_events = bool(time_events)
         self.event_log = []        # time_events: (exchange start, collective done, merge done) events of every step
 
@@ -331,15 +371,16 @@ class ShardedStepPipeline:
             self.comm.wait_event(self.ev_searched[s])
             if te:
                 te[0].record(self.comm)
-            g = (exchange_by_query if self.exchange == "by_query" else all_gather_results)(o["idx"], o["score"], o["dist2"], self.group)
+            g = (exchange_by_query if self.exchange == "by_query" else all_gather_results)(o["idx"], o["score"], o["dist2"], self.group,
+                                                                                           send=self.send[s], recv=self.recv[s])
             if te:
                 te[1].record(self.comm)
             if self.k_in < self.k:
-                *m3, ex = merge_on_device(*g, self.sort_by_score, k=self.k, want_exhausted=True)
-                self.merged[s] = tuple(m3)
-                self.ex_accum[:ex.numel()] |= ex
+                *m3, ex = merge_on_device(*g, self.sort_by_score, k=self.k, want_exhausted=True, out=self.out[s])
+                self.ex_accum[:ex.numel()].bitwise_or_(ex)
             else:
-                self.merged[s] = merge_on_device(*g, self.sort_by_score)
+                m3 = merge_on_device(*g, self.sort_by_score, out=self.out[s])
+            self.merged[s] = tuple(m3[:3])
             if te:
                 te[2].record(self.comm)
                 self.event_log.append(tuple(te))

@@ -382,6 +382,28 @@ class BlendSearchStep:
         assert int(self.missed.item()) == 0, "the on-device exhaustive pass left %d queries to the host path" % int(self.missed.item())
         return int((o["flags"] == 2).sum().item())
 
+    def repair(self, o=None):
+        """Host-driven last tier (synchronises; NOT part of the resident step): queries a step left uncertified beyond what its on-device
+        exhaustive pass takes (8 per search call) are recomputed exhaustively in float64 - hwer_knn_exact_f64, the tier DeviceIndex runs
+        behind every search.  -> the number of repaired queries (0: nothing to do)."""
+        import numpy as np
+        torch, lib, P = self.torch, self.lib, native.ptr
+        o = self.sets[0] if o is None else o
+        with native.device_guard(self.dev):
+            bad = torch.nonzero(o["flags"] == 0).flatten()
+            if bad.numel() == 0:
+                return 0
+            qsel = np.ascontiguousarray(bad.cpu().numpy(), dtype=np.int32)
+            ws = torch.empty(lib.hwer_knn_exact_workspace_bytes(self.I, self.k), dtype=torch.uint8, device=self.dev)
+            od = o["dist2"]
+            native.check(lib.hwer_knn_exact_f64(P(self.X), self.I, self.d, self.ldx, P(self.Q64), P(self.V), self.ldv, P(self.anchors),
+                                                qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), self.k, self.arith, self.sort_by_score, P(self.search_ids),
+                                                self.id_base, P(o["idx"]), P(o["score"]), P(od) if od is not None else None, P(o["flags"]), P(ws), ws.numel(),
+                                                self.S()), "knn_exact")
+            self.missed.zero_()
+            torch.cuda.synchronize(self.dev)
+        return int(len(qsel))
+
     def results(self, o=None):
         """-> numpy (idx (B, k) int64 ids, score (B, k) in the reference's dtype [, dist (B, k) float64]) after checks()"""
         import numpy as np

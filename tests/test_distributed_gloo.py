@@ -83,6 +83,16 @@ def _worker(rank, world, port, n_items, k, out_dir, list_len=None):
         assert sh.settle() == rep_first == int(open(os.path.join(out_dir, "rep%d" % rank)).read())   # the same batch again: the same repeats
         assert sh.settle() == 0                                                                       # nothing pending any more
         assert torch.equal(second[0], idx) and torch.equal(second[1], score) and torch.equal(second[2], dist2)
+        # a pipelined caller REFILLS its resident query buffers between steps (advisor finding, round 5): the deferred repeat of search 1 runs one
+        # search later and must still use search 1's queries (search() snapshots them) - with the buffers' new content it would patch wrong rows
+        Qbuf, Q32buf = torch.from_numpy(Q.copy()), torch.from_numpy(Q.astype(np.float32))
+        first = sh.search(Qbuf, Q32buf, k, deferred=True)
+        perm = np.roll(np.arange(B), 1)
+        Qbuf.copy_(torch.from_numpy(Q[perm]))
+        Q32buf.copy_(torch.from_numpy(Q[perm].astype(np.float32)))
+        sh.search(Qbuf, Q32buf, k, deferred=True)            # settles `first` - after the buffers changed
+        sh.settle()
+        assert torch.equal(first[0], idx) and torch.equal(first[1], score) and torch.equal(first[2], dist2)
     # user-partitioned exchange: this rank ends with the merged rows of its own query slice only
     from hwer.distributed import query_slice
     B = 6

@@ -33,20 +33,22 @@ def bench_mod():
 
 
 # ------------------------------------------------------------------------------------------------- 8 shards on one GPU
-@pytest.mark.parametrize("name,items,G", [("c4full", 10000000, 8), ("c4full", 1000003, 3)])
-def test_emulated_shards_equal_single_table(hw, bench_mod, name, items, G):
+@pytest.mark.parametrize("name,items,G,n_oracle", [("c4full", 10000000, 8, 256), ("c4full", 1000003, 3, 256), ("c5full", 10000000, 8, 64)])
+def test_emulated_shards_equal_single_table(hw, bench_mod, name, items, G, n_oracle):
     """SURVEY.md 8e at BASELINE.json configs[3]'s full size: the 10 M x 128 catalogue cut into the 8 `shard_bounds` ranges, every
     shard searched like rank g of the 8-GPU job (own blend, own table, ids = id_base + local row, (distance, id) order), packed
     by hwer_pack_exchange into slice g of a (8, 3, B, k) buffer laid out like the all-gather's receive buffer, merged in place by
     hwer_merge_topk_strided: ids, scores and squared distances must EQUAL the single-table result for all 4 096 queries and the
-    oracle's brute force over the whole catalogue on 256 of them (round 4; 32 before).  (A ragged 3-shard cut of 1 000 003 rows as well.)"""
+    oracle's brute force over the whole catalogue on 256 of them (round 4; 32 before).  (A ragged 3-shard cut of 1 000 003 rows as well.)
+    Round 6: the same for configs[4] at ITS full size - c5full: 4 tables, per-row alpha, d = 256, 131 072 user + 10 M item rows blended,
+    8 shards of 1.25 M rows, oracle on 64 queries."""
     import torch
     from hwer import native
     cfg = dict(bench_mod.CONFIGS[name])
     cfg["I"] = items
     dev = torch.device("cuda", 0)
-    r = bench_mod.emulate_shards(torch, native.lib(), cfg, dev, G, steps=1, warmup=1, n_oracle=256)
-    assert r["merged_equals_single_table"] and r["queries_compared"] == 4096 and r["oracle_checked_queries"] == 256
+    r = bench_mod.emulate_shards(torch, native.lib(), cfg, dev, G, steps=1, warmup=1, n_oracle=n_oracle)
+    assert r["merged_equals_single_table"] and r["queries_compared"] == 4096 and r["oracle_checked_queries"] == n_oracle
     assert len(r["shard_ms"]) == G
     # round 3: the shards sent shortened lists (72 of 200 entries for 8 shards, 136 for 3) and no list ran out
     from hwer.distributed import local_list_len

@@ -157,3 +157,33 @@ def test_pack_rows_f64rows_kernel(hw):
         assert np.array_equal(X16h[:n_rows][ok], np.ldexp(want[:n_rows][ok], x_exp).astype(np.float16))
         c = counts.cpu().numpy()
         assert (c[0], c[1], c[2]) == (1, 1, 1)
+
+
+# ------------------------------------------------------------------------------------------------- the N > 1 pipeline under allocator churn
+def _run_pipe_workers(backend, world, tmp_path, exchange, steps):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29700 + (os.getpid() * 13 + world + len(exchange)) % 2500
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "pipe_stress_worker.py"), backend, str(r), str(world), str(port), str(tmp_path), exchange,
+                               str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
+        assert (tmp_path / ("ok%d" % r)).exists()
+
+
+@pytest.mark.parametrize("backend,world,exchange", [("nccl", 1, "both"), ("gloo", 2, "both")])
+def test_sharded_step_pipeline_under_allocator_churn(hw, tmp_path, backend, world, exchange):
+    """hwer.distributed.ShardedStepPipeline (what `bench.py --gpus N` runs) owns every buffer its side stream touches (round 6: allocated once
+    per result set in __init__; round 5 allocated the receive buffer and the merge outputs on the side stream inside run() without
+    record_stream).  200 steps (50 over gloo) with the returned tensors dropped at once and allocator churn on the compute stream: every step's merged result
+    == the single table's.  RCCL at world size 1 and two ranks over gloo sharing the GPU, both exchanges."""
+    _run_pipe_workers(backend, world, tmp_path, exchange, 200 if backend == "nccl" else 50)      # (gloo stages every exchange through the host: fewer steps)
