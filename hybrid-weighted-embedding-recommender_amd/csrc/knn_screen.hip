@@ -1306,7 +1306,26 @@ int kprime_for(int k, int64_t n_items, int ldx, bool f16_screen) {
     return kp;
 }
 
+static ScreenPlan make_screen_plan_uncached(int64_t B, int64_t n_items, int ldx, int k, uint32_t options);
+// The plan is a pure function of its arguments (production builds: no environment switches) and a search asks for it several times (workspace
+// size, query padding, screen, select) - its seed-rank loops evaluate lgamma / exp tails, up to O(groups^2) terms: the last plan is kept per thread
+// (advisor finding, round 5).
 ScreenPlan make_screen_plan(int64_t B, int64_t n_items, int ldx, int k, uint32_t options) {
+#if defined(HWER_DIAG_STAMPS) || defined(HWER_DIAG_ABLATE)
+    return make_screen_plan_uncached(B, n_items, ldx, k, options);      // (diagnostic builds read tuning overrides from the environment on every call)
+#else
+    struct Key { int64_t B, n; int ldx, k; uint32_t opt; };
+    thread_local Key last{-1, -1, 0, 0, 0};
+    thread_local ScreenPlan plan{};
+    if (last.B != B || last.n != n_items || last.ldx != ldx || last.k != k || last.opt != options) {
+        plan = make_screen_plan_uncached(B, n_items, ldx, k, options);
+        last = Key{B, n_items, ldx, k, options};
+    }
+    return plan;
+#endif
+}
+
+static ScreenPlan make_screen_plan_uncached(int64_t B, int64_t n_items, int ldx, int k, uint32_t options) {
     ScreenPlan p{};
     p.ng = ldx / 8;
     p.kprime = kprime_for(k, n_items, ldx, (options & HWER_KNN_F16_SCREEN) != 0 && ldx >= 64);

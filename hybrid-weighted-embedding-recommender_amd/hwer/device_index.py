@@ -753,7 +753,7 @@ class DeviceIndex:
             return
         bad = torch.nonzero(flags[:B] == 0).flatten()
         if bad.numel():     # all rows of the type, a few queries at a time (ties keep the row (= id) order); flag 2 like every exhaustive result
-            step = max(1, (1 << 26) // n)
+            step = max(1, min(65535, (1 << 26) // n))      # (hwer_knn_cand_dist2 takes at most 65 535 queries per call: the batch is its grid.y)
             for c0 in range(0, int(bad.numel()), step):
                 sel = bad[c0:c0 + step]
                 ns = int(sel.numel())
