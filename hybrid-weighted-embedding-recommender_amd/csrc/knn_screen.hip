@@ -788,6 +788,13 @@ __global__ __launch_bounds__(256, 2) void screen_kernel(const ScreenArgs a) {
 #define HWER_PP_SPARSE_MAX 0.6   // expected passing keys per 32-row subtile and wave below which the ping-pong kernel takes the max-tree filter (4.0 measured: c4 +-0)
 #endif
 #ifndef HWER_PP_WIDE_PARK
+#ifndef HWER_PP_MOVREL_POP
+#define HWER_PP_MOVREL_POP 0   // round 6, MEASURED AND NOT KEPT (1 = on): few passing keys per subtile (shard regime) - a passing key read out of its ACCUMULATOR
+#endif                         // REGISTER by a wave-uniform register index (the compiler emits s_set_gpr_idx_on / off around a v_mov) instead of parking the subtile's
+                               // 16 TQ accumulators in LDS and reading one back.  No scratch, 227 VGPRs - and the shard's screen runs 8 % SLOWER (c4, same box,
+                               // interleaved: 1.444 - 1.466 -> 1.573 - 1.576 ms, step 2.07 - 2.10 -> 2.19 - 2.24; profiles/r6_ab_movrel_pop.txt): the index-mode
+                               // switches and the ballot -> readlane -> index chain of a round are dependent scalar / vector hand-overs that nothing hides, where the
+                               // park's ds_writes issue back to back and the pops' LDS reads overlap with the partner wave's burst.
 #define HWER_PP_WIDE_PARK 0   // 1: d = 256 under the ping-pong kernel filters by the expected-hits rule (its LDS has room for the key park)
 #endif
 #ifndef HWER_PP_TOKEN
@@ -1131,9 +1138,10 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                     // (only the query subtiles that have a passing key are parked: on a 1.25 M-row shard a subtile of a wave has a hit 57 % of the time -
                     // c4 screen -1.5 %.  Measured with it and left out: the second subtile's accumulator set-up inside the first subtile's burst (second
                     // accumulator set) +-0; the fragments' swizzled offsets kept in registers: +-0, c4full +0.7 % - both sit in the MFMAs' shadow already)
+                    const bool use_park = !HWER_PP_MOVREL_POP || a.many_hits;      // (wave-uniform)
 #pragma unroll
                     for (int b = 0; b < TQ; ++b) {
-                        if (TQ == 1 || a.many_hits || __any(((mask >> (16 * b)) & 0xFFFFu) != 0u)) {
+                        if (use_park && (TQ == 1 || a.many_hits || __any(((mask >> (16 * b)) & 0xFFFFu) != 0u))) {
 #pragma unroll
                             for (int q = 0; q < 16; ++q) park[(16 * b + q) * 64] = acc[b][q];
                         }
@@ -1168,6 +1176,27 @@ __global__ __launch_bounds__(512, 2) void screen16_pp_kernel(const ScreenArgs a)
                                     else cnt[0] += 1;
                                 }
                             }
+                        }
+                    } else if (HWER_PP_MOVREL_POP) {
+                        // One round per DISTINCT set bit of the wave (1.7 passing keys per subtile and wave on a 1.25 M-row shard: one or two rounds): the bit of the
+                        // first lane that still has one is broadcast (v_readlane), the accumulator it names is selected by a wave-uniform register index, and
+                        // every lane that has this bit set appends - no LDS park (16 - 32 ds_write per subtile with a hit), no LDS round trip per pop.
+                        uint64_t act = __ballot(mask != 0u);
+                        while (act != 0ull) {
+                            const int src = __builtin_ctzll(act);
+                            const int bit = __builtin_amdgcn_readlane(__builtin_ctz(mask | 0x80000000u), src);      // (wave-uniform)
+                            const int q = 15 - (bit & 15);
+                            const bool second = TQ == 2 && (bit & 16) != 0;
+                            const float accv = second ? acc[TQ - 1][q] : acc[0][q];
+                            const bool mine = ((mask >> bit) & 1u) != 0u;
+                            mask &= ~(1u << bit);
+                            if (mine) {
+                                const float kval = ldexpf((fold ? (second ? tau_f[TQ - 1] : tau_f[0]) : 0.f) - accv, -(second ? e_tot[TQ - 1] : e_tot[0]));
+                                const uint64_t key = pack_key(kval, item0 + (q & 3) + 8 * (q >> 2));
+                                if (second) append(TQ - 1, key);
+                                else append(0, key);
+                            }
+                            act = __ballot(mask != 0u);
                         }
                     } else
                     while (__any(mask != 0u)) {
