@@ -344,7 +344,7 @@ def load_traffic(config):
     that file carries the digest of the library that is running (`library_digest`; tools/pmc_summary.py writes it) - counters of
     another build of the kernels are not this run's traffic: then `traffic` is null and `traffic_source` says why."""
     dig = library_digest()
-    for fn in ("r5_pmc_traffic.json", "r4_pmc_traffic.json"):
+    for fn in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", fn)) as fh:
                 doc = json.load(fh)
@@ -745,6 +745,13 @@ def run_config_f64rows(torch, lib, name, dev, steps, warmup, args):
                              "algorithmic_bytes": gather_bytes, "note": "(k + 16) float64 rows of 8 ld64 bytes per query"},
            "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive, "parity_checked_queries": int(len(sel)),
            "parity_note": "ids and scores == the numpy oracle on the float64 rows; blended rows == numpy (array_equal, %d rows)" % len(rows_chk)}
+    if se_ms > sc_ms and I > 8192:
+        # streaming shapes: the dominant kernel is the fused float64-row select, bound by the gather of (k + boundary) float64 rows per query from the
+        # level the float64 table lives in (MI355X_MICROARCH.md "Indexed rows: gather") - priced like knn_select_rerank of the float32 flavour
+        g = res["select_gather"]
+        res["roofline"] = {"kernel": "knn_select_f64rows (gather of the candidates' float64 rows + float64 re-rank + certificate + sort)", "bound": g["bound"],
+                           "achieved": g["achieved"], "peak": g["peak"], "unit": "GB/s", "frac": g["achieved"] / g["peak"], "traffic": None,
+                           "traffic_source": "not collected for this configuration", "share_of_step": se_ms / ms_per_step}
     del w, tables
     torch.cuda.empty_cache()
     return res
