@@ -745,6 +745,21 @@ def run_config_f64rows(torch, lib, name, dev, steps, warmup, args):
                              "algorithmic_bytes": gather_bytes, "note": "(k + 16) float64 rows of 8 ld64 bytes per query"},
            "certified_queries": U - n_exhaustive, "exhaustive_fallback_queries": n_exhaustive, "parity_checked_queries": int(len(sel)),
            "parity_note": "ids and scores == the numpy oracle on the float64 rows; blended rows == numpy (array_equal, %d rows)" % len(rows_chk)}
+    blend_bytes, pack_bytes = N * 8.0 * d * (T + 1), N * 8.0 * d + I * (4.0 * w.ldx + (2.0 * w.ldx if w.f16_screen else 0.0) + 4.0)
+    qmix_bytes = U * (8.0 * d + 8.0 * d + 4.0 * w.ldx + 4.0)
+    res["kernels"] = [
+        {"kernel": "blend_normalize_f64", "ms_per_step": stages["blend_normalize_f64"], "share": stages["blend_normalize_f64"] / ms_per_step, "bound": "hbm",
+         "achieved": blend_bytes / stages["blend_normalize_f64"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": blend_bytes / stages["blend_normalize_f64"] / 1e6 / HBM_PEAK_GBS},
+        {"kernel": "audit + pack_rows_f64rows", "ms_per_step": stages["audit+pack_rows_f64rows"], "share": stages["audit+pack_rows_f64rows"] / ms_per_step, "bound": "hbm",
+         "achieved": pack_bytes / stages["audit+pack_rows_f64rows"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pack_bytes / stages["audit+pack_rows_f64rows"] / 1e6 / HBM_PEAK_GBS},
+        {"kernel": "query_mix_f64rows", "ms_per_step": stages["query_mix_f64rows"], "share": stages["query_mix_f64rows"] / ms_per_step, "bound": "hbm",
+         "achieved": qmix_bytes / stages["query_mix_f64rows"] / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": qmix_bytes / stages["query_mix_f64rows"] / 1e6 / HBM_PEAK_GBS},
+        {"kernel": "knn_screen (on the %s rounding of the float64 rows)" % ("float16" if w.f16_screen else "float32"), "ms_per_step": sc_ms, "share": sc_ms / ms_per_step, "bound": "mfma",
+         "achieved": flops / (sc_ms * 1e-3) / 1e12 if sc_ms > 0 else 0.0, "peak": MFMA_F16_PEAK_TFLOPS if w.f16_screen else MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": (flops / (sc_ms * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS if w.f16_screen else MFMA_F32_PEAK_TFLOPS)) if sc_ms > 0 else 0.0},
+        {"kernel": "knn_select_f64rows", "ms_per_step": se_ms, "share": se_ms / ms_per_step, "bound": res["select_gather"]["bound"], "achieved": res["select_gather"]["achieved"],
+         "peak": gather_peak, "unit": "GB/s", "frac": res["select_gather"]["achieved"] / gather_peak},
+    ]
     if se_ms > sc_ms and I > 8192:
         # streaming shapes: the dominant kernel is the fused float64-row select, bound by the gather of (k + boundary) float64 rows per query from the
         # level the float64 table lives in (MI355X_MICROARCH.md "Indexed rows: gather") - priced like knn_select_rerank of the float32 flavour
