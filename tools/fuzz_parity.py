@@ -4,6 +4,8 @@
 with and without distances, against the oracle's C restatement on every query.
 
     python tools/fuzz_parity.py [--cases 60] [--seed 0]
+    python tools/fuzz_parity.py --f64rows [--cases 40]      # (round 6) GENUINE float64 rows: the fused float64-row search against the numpy oracle on the
+                                                            # float64 rows (sampled queries) and against the candidate scheme of rounds 3-5 (every query)
 """
 import argparse
 import os
@@ -23,11 +25,62 @@ def unit_rows(rng, n, d):
     return x.astype(np.float32)
 
 
+def fuzz_f64rows(args):
+    from hwer.device_index import DeviceIndex
+    from oracle import hwer_oracle as orc
+    rng = np.random.default_rng(args.seed + 64)
+    Bs = [1, 2, 31, 33, 64, 65, 128, 257, 1000, 1024, 1025, 2049, 3000]
+    Ns = [1, 5, 32, 33, 1000, 4095, 8192, 8193, 12000, 20000, 40000]
+    ds = [1, 3, 7, 8, 9, 17, 32, 33, 64, 66, 100, 128, 129, 200, 256]
+    ks = [1, 2, 10, 64, 100, 200, 256, 392]
+    bad = 0
+    for case in range(args.cases):
+        while True:
+            B, N, d = int(rng.choice(Bs)), int(rng.choice(Ns)), int(rng.choice(ds))
+            k = int(rng.choice([x for x in ks if x <= N]))
+            if float(B) * N * d <= 2e9:
+                break
+        X = rng.standard_normal((B + N, d))
+        X /= np.linalg.norm(X, axis=1, keepdims=True)
+        if d > 1 and rng.random() < 0.3:
+            X[B:] *= rng.uniform(0.5, 3.0, size=(N, 1))
+        if N > 20 and rng.random() < 0.5:      # float32-colliding rows and an exact duplicate
+            X[B + 11] = X[B + 10] * (1.0 + 3e-9)
+            X[B + 12] = X[B + 10]
+        ix = DeviceIndex(X, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}, audit=False)
+        if ix.V64 is None:      # (d = 1: unit rows are +-1, float32-representable - the index keeps float32 rows; covered by the other mode)
+            print("case %3d  B=%5d N=%6d d=%3d: rows are float32-representable, skipped" % (case, B, N, d), flush=True)
+            continue
+        scoring = "gcn" if rng.random() < 0.25 else "base"
+        want = bool(rng.integers(0, 2)) or scoring == "gcn"
+        idx, score, dist, flags = ix.search("item", np.arange(B), k=k, scoring=scoring, want_dist=want)
+        ok = bool((flags > 0).all())
+        for u in rng.choice(B, size=min(B, 4), replace=False).tolist():
+            o_idx, o_sc, o_dist = orc.find_closest(X, np.arange(B, B + N), int(u), k=k, scoring=scoring)
+            ok = ok and np.array_equal(idx[u], o_idx) and np.array_equal(score[u], o_sc) and (not want or np.array_equal(dist[u], o_dist))
+        os.environ["HWER_F64ROWS_CANDIDATES"] = "1"
+        try:
+            c_idx, c_score, c_dist, _ = ix.search("item", np.arange(B), k=k, scoring=scoring, want_dist=True)
+        finally:
+            del os.environ["HWER_F64ROWS_CANDIDATES"]
+        ok = ok and np.array_equal(idx, c_idx) and np.array_equal(score, c_score) and (not want or np.array_equal(dist, c_dist))
+        print("case %3d  B=%5d N=%6d d=%3d k=%3d float64 rows %-4s dist=%d  exhaustive=%d  %s" % (case, B, N, d, k, scoring, want, int((flags == 2).sum()),
+                                                                                                "OK" if ok else "MISMATCH"), flush=True)
+        bad += 0 if ok else 1
+        del ix
+    if bad:
+        raise SystemExit("%d case(s) differ" % bad)
+    print("all %d float64-row cases agree with the numpy oracle (sampled queries) and the candidate scheme (every query)" % args.cases)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--f64rows", action="store_true")
     args = ap.parse_args()
+    if args.f64rows:
+        return fuzz_f64rows(args)
     from hwer.device_index import DeviceIndex
     from oracle import c_oracle
     rng = np.random.default_rng(args.seed)
