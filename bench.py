@@ -1269,9 +1269,10 @@ def run_sharded(args, rank, local_rank, world):
     dev = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # a rank that never arrives (crashed before the rendezvous, wrong port) must not hold the others for torch's default 10-30 minutes:
-    # the rendezvous and every collective give up after HWER_BENCH_DIST_TIMEOUT_S (default 300 s) and the rank exits non-zero
+    # the rendezvous and every collective give up after HWER_BENCH_DIST_TIMEOUT_S (default 600 s: ranks 1 .. N-1 wait in the closing barrier while rank 0 runs
+    # the CPU baseline, the oracle check and the one-GPU anchor - tens of seconds on a busy host; advisor, round 5) and the rank exits non-zero
     # (self_launch / torchrun then end the job)
-    tmo = datetime.timedelta(seconds=float(os.environ.get("HWER_BENCH_DIST_TIMEOUT_S", "300")))
+    tmo = datetime.timedelta(seconds=float(os.environ.get("HWER_BENCH_DIST_TIMEOUT_S", "600")))
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=tmo)
     else:
@@ -1499,7 +1500,11 @@ def main():
         # backend (nccl = RCCL) at world size 1: what a one-GPU box can execute of it; tests/test_gpu_round5.py)
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29577")
+            if "MASTER_PORT" not in os.environ:      # a free port (two such rehearsals may share a host)
+                import socket
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         run_sharded(args, int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), world)
         return
     full = run_emulated_shards(args) if args.emulate_shards else run_single(args)

@@ -111,12 +111,16 @@ def segment_mean(E, indptr, indices, device=None):
 
 @native.on_device_kw
 def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, device=None, return_device=False,
-                 return_norm=False):
+                 return_norm=False, dtype=None):
     """out[r] = unit(sum_t alpha[r, t] * tables[t][row_idx[t][r]]) — the weighted blend of content and
     collaborative tables (north_star; reference special case hwer/content_recommender.py:85 with alpha=(.5,.5)).
     alpha: (T,) shared weights or (R, T) per-row weights.  row_idx[t]: None (row r) or an int array (R,).
     float64 tables (all of them) run hwer_blend_normalize_f64: float64 weights, products and sums in the order of
-    `acc = acc + alpha_t * T_t`, numpy's norm - float64 rows out, identical to that numpy expression."""
+    `acc = acc + alpha_t * T_t`, numpy's norm - float64 rows out, identical to that numpy expression.
+    dtype ("float32" | "float64" | None): the arithmetic, explicitly (tables of the other dtype are converted); None infers it from the
+    tables - float64 only when EVERY table is float64; a mix of float32 and float64 tables runs the float32 arithmetic and warns
+    (round 6, advisor).  float64 rows are answered by the index from the float64 table (DeviceIndex: the fused float64-row search) -
+    same speed class as float32 rows since round 6, twice the gathered bytes."""
     import torch
     from .device_index import _require_gpu, roundup
     lib = native.lib()
@@ -124,7 +128,17 @@ def blend_tables(tables: Sequence, alpha, row_idx: Optional[Sequence] = None, de
     T = len(tables)
     D = tables[0].shape[1]
     ld = roundup(D, 4)
-    f64 = all(_is_f64(t) for t in tables)
+    kinds = {bool(_is_f64(t)) for t in tables}
+    if dtype is not None:
+        f64 = np.dtype(dtype) == np.float64
+        if not f64 and np.dtype(dtype) != np.float32:
+            raise ValueError("blend_tables: dtype must be float32 or float64")
+    else:
+        f64 = kinds == {True}
+        if len(kinds) > 1:
+            import warnings
+            warnings.warn("blend_tables: float32 and float64 tables mixed - running the float32 arithmetic; pass dtype='float64' (or 'float32') to choose",
+                          RuntimeWarning, stacklevel=3)
     if f64:
         return _blend_tables_f64(tables, alpha, row_idx, dev, ld, return_device, return_norm)
     tabs = [_dev_table(t, dev, ld) for t in tables]
@@ -210,7 +224,10 @@ class ContentRecommendation(RecommendationBase):
 
     #: arithmetic of the blend stage behind fit(): "float64" = the reference's own (its table is float64 from the PCA on:
     #: hwer/content_recommender.py:68-96), rows come back as genuine float64 values and the index answers from them; "float32" = rounds
-    #: 1-4's flavour (float32 rows widened: within 1e-6 of the reference, half the bytes, the fused float32 search)
+    #: 1-4's flavour (float32 rows widened: within 1e-6 of the reference, half the bytes).  Cost of the default: the index keeps the float64 table
+    #: beside its float32 rounding and the search gathers float64 rows - since round 6 inside the same fused kernels (hwer_knn_search_f64rows): one
+    #: find_closest_neighbours call 0.068 ms against 0.065, all 943 anchors of the ML-100K shape 0.26 ms against 0.28, a 138 493 x 26 744 sweep 1.5x the
+    #: float32 flavour's time (twice the gathered bytes); rounds 3-5: ~10x per query.  Set it per instance (`model.blend_dtype = "float32"`) before fit().
     blend_dtype = "float64"
 
     def __build_feature_table__(self, nodes: List[Node], node_data, n_dims):
