@@ -187,3 +187,25 @@ def test_sharded_step_pipeline_under_allocator_churn(hw, tmp_path, backend, worl
     record_stream).  200 steps (50 over gloo) with the returned tensors dropped at once and allocator churn on the compute stream: every step's merged result
     == the single table's.  RCCL at world size 1 and two ranks over gloo sharing the GPU, both exchanges."""
     _run_pipe_workers(backend, world, tmp_path, exchange, 200 if backend == "nccl" else 50)      # (gloo stages every exchange through the host: fewer steps)
+
+
+def test_blend_tables_explicit_dtype_and_mixed_warning(hw):
+    """blend_tables(dtype=...): the arithmetic is the caller's choice (advisor, round 5); float32 and float64 tables mixed without it run the
+    float32 kernel and say so"""
+    from hwer.content_recommender import blend_tables
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((300, 24))
+    b = rng.standard_normal((300, 24)).astype(np.float32)
+    al = np.array([0.25, 0.75])
+    with pytest.warns(RuntimeWarning, match="mixed"):
+        mixed = blend_tables([a, b], al)
+    assert mixed.dtype == np.float32
+    out64 = blend_tables([a, b], al, dtype="float64")
+    acc = np.zeros_like(a)
+    for w_, t in zip(al, (a, b.astype(np.float64))):
+        acc = acc + w_ * t
+    assert out64.dtype == np.float64 and np.array_equal(out64, acc / np.expand_dims(np.linalg.norm(acc, axis=1), 1))
+    out32 = blend_tables([a, a], al, dtype="float32")
+    assert out32.dtype == np.float32
+    with pytest.raises(ValueError):
+        blend_tables([a, a], al, dtype="float16")
