@@ -3,8 +3,10 @@
 The reference keeps its index only in memory (a dict of scikit-learn KD-trees rebuilt by every `fit`).  This build's
 index is three flat arrays, so the on-disk format is a single uncompressed `.npz`:
 
-    format        "hwer-index/1"
-    vectors       (N, d) float32   the `vectors` table, rows in registry order (exactly what the kernels read)
+    format        "hwer-index/1" | "hwer-index/2" (round 6: /2 = /1 + `vectors64`)
+    vectors       (N, d) float32   the `vectors` table, rows in registry order (what the screen kernels read)
+    vectors64     (N, d) float64   ONLY for GENUINE float64 `vectors` (what ContentRecommendation.fit returns: hwer/content_recommender.py:96): the rows
+                                   every value is computed from (distances, scores, predict) - `vectors` is then their float32 rounding
     arith         int              0: the reference's float64 score arithmetic, 1: float32 (GcnNCF flavour)
     scoring       str              "base" | "gcn"
     type_names    (T,) str         node types with a retrieval table
@@ -13,7 +15,8 @@ index is three flat arrays, so the on-disk format is a single uncompressed `.npz
     node_ids      (N,) str         }
 
 `save_index` / `load_index` are host-side only (numpy); `restore_model` rebuilds a fitted `VectorIndex` on the GPU.
-float32 storage is exact: the device table IS float32 (a float64 `vectors` input is rounded once, at upload).
+float32 storage is exact for float32 tables and for float64 tables whose values are float32-representable; a table of genuine float64 rows is
+stored in full beside its rounding (format /2; rounds 3-5 stored the rounding only and a restored ContentRecommendation answered from it).
 """
 from __future__ import annotations
 
@@ -22,18 +25,24 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 
 FORMAT = "hwer-index/1"
+FORMAT64 = "hwer-index/2"
 
 
 def save_index(path: str, vectors: np.ndarray, type_rows: Dict[str, np.ndarray], arith: int, scoring: str = "base",
                nodes: Optional[Sequence] = None) -> None:
-    """vectors: (N, d) float32 (or float64: stored as its float32 rounding, like the device table).
-    nodes: optional registry in row order (objects with .node_type / .node_external_id, e.g. hwer.Node)."""
+    """vectors: (N, d) float32, or float64 - stored as its float32 rounding and, when the values are not float32-representable, in full as well
+    (`vectors64`, format /2).  nodes: optional registry in row order (objects with .node_type / .node_external_id, e.g. hwer.Node)."""
     v = np.ascontiguousarray(vectors, dtype=np.float32)
     if v.ndim != 2:
         raise ValueError("vectors must be (N, d)")
+    v64 = None
+    if np.asarray(vectors).dtype == np.float64 and not np.array_equal(v.astype(np.float64), vectors, equal_nan=True):
+        v64 = np.ascontiguousarray(vectors, dtype=np.float64)
     names = sorted(type_rows)
-    payload = {"format": np.array(FORMAT), "vectors": v, "arith": np.array(int(arith)), "scoring": np.array(str(scoring)),
+    payload = {"format": np.array(FORMAT if v64 is None else FORMAT64), "vectors": v, "arith": np.array(int(arith)), "scoring": np.array(str(scoring)),
                "type_names": np.array(names, dtype=str)}
+    if v64 is not None:
+        payload["vectors64"] = v64
     for i, t in enumerate(names):
         rows = np.ascontiguousarray(type_rows[t], dtype=np.int64)
         if rows.size and (rows.min() < 0 or rows.max() >= len(v) or (np.diff(rows) <= 0).any()):
@@ -49,12 +58,12 @@ def save_index(path: str, vectors: np.ndarray, type_rows: Dict[str, np.ndarray],
 
 
 def load_index(path: str) -> dict:
-    """-> {"vectors", "type_rows", "arith", "scoring", "node_types" | None, "node_ids" | None} (numpy, host)."""
+    """-> {"vectors", "vectors64" | None, "type_rows", "arith", "scoring", "node_types" | None, "node_ids" | None} (numpy, host)."""
     with np.load(path, allow_pickle=False) as z:
-        if str(z["format"]) != FORMAT:
+        if str(z["format"]) not in (FORMAT, FORMAT64):
             raise ValueError("not a %s file: %r" % (FORMAT, str(z["format"])))
         names = [str(t) for t in z["type_names"]]
-        out = {"vectors": z["vectors"], "arith": int(z["arith"]), "scoring": str(z["scoring"]),
+        out = {"vectors": z["vectors"], "vectors64": z["vectors64"] if "vectors64" in z.files else None, "arith": int(z["arith"]), "scoring": str(z["scoring"]),
                "type_rows": {t: z["type_rows_%d" % i] for i, t in enumerate(names)},
                "node_types": z["node_types"] if "node_types" in z.files else None,
                "node_ids": z["node_ids"] if "node_ids" in z.files else None}
@@ -66,7 +75,7 @@ def save_model(path: str, model) -> None:
     assert model.fit_done
     ix = model.knn.index
     table = model.knn.idx_to_node()
-    v = ix.V[:, :ix.d].cpu().numpy()
+    v = ix.V64[:, :ix.d].cpu().numpy() if ix.V64 is not None else ix.V[:, :ix.d].cpu().numpy()      # (genuine float64 rows are persisted as they are)
     save_index(path, v, {t: tt.rows for t, tt in ix.tables.items()}, ix.arith, model.scoring, table)
 
 
@@ -80,7 +89,7 @@ def restore_model(path: str, device=None):
     nodes = [Node(t, i) for t, i in zip(z["node_types"].tolist(), z["node_ids"].tolist())]
     cls = GcnScoredIndex if z["scoring"] == "gcn" else VectorIndex
     m = cls(node_types=set(z["type_rows"]), n_dims=int(z["vectors"].shape[1]))
-    v = z["vectors"] if z["arith"] == 1 else z["vectors"].astype(np.float64)
+    v = z["vectors64"] if z["vectors64"] is not None else (z["vectors"] if z["arith"] == 1 else z["vectors"].astype(np.float64))
     if cls is GcnScoredIndex:   # rows are already unit length: skip prepare_for_knn
         VectorIndex.fit(m, nodes, v)
     else:

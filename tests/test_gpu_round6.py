@@ -209,3 +209,31 @@ def test_blend_tables_explicit_dtype_and_mixed_warning(hw):
     assert out32.dtype == np.float32
     with pytest.raises(ValueError):
         blend_tables([a, a], al, dtype="float16")
+
+
+def test_persisted_model_keeps_genuine_float64_rows(hw, tmp_path):
+    """hwer.persist: a model that serves genuine float64 rows - what ContentRecommendation.fit returns - comes back from disk
+    with those rows (format hwer-index/2), not with their float32 rounding (rounds 3-5): same neighbours, scores and predict values bit for bit,
+    float32-colliding rows at an anchor's cut included."""
+    from hwer import Node, VectorIndex, persist
+    U, I, d = 30, 2500, 40
+    X = _rows64(91, U + I, d)
+    X[0] = X[U + 10]
+    X = _plant(X, U)
+    nodes = [Node("user", i) for i in range(U)] + [Node("item", "i%d" % i) for i in range(I)]
+    m = VectorIndex(node_types={"user", "item"}, n_dims=d)
+    m.fit(nodes, X)
+    assert m.knn.index.V64 is not None
+    path = str(tmp_path / "m64.npz")
+    persist.save_model(path, m)
+    assert persist.load_index(path)["vectors64"] is not None
+    m2 = persist.restore_model(path)
+    assert m2.knn.index.V64 is not None and np.array_equal(m2.knn.index.V64[:, :d].cpu().numpy(), X)
+    for u in (0, 7, 29):
+        a = m.find_closest_neighbours("item", nodes[u], k=60)
+        b = m2.find_closest_neighbours("item", nodes[u], k=60)
+        assert [n for n, _ in a] == [n for n, _ in b] and [s_ for _, s_ in a] == [s_ for _, s_ in b]
+        o_idx, o_sc, _ = orc.find_closest(X, np.arange(U, U + I), u, k=60)
+        assert [m2.nodes_to_idx[n] for n, _ in b] == o_idx.tolist() and [s_ for _, s_ in b] == o_sc.tolist()
+    pairs = [(nodes[1], nodes[50]), (nodes[2], nodes[99])]
+    assert np.array_equal(m.predict(pairs), m2.predict(pairs))

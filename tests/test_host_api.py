@@ -112,6 +112,10 @@ def test_persisted_index_format_roundtrip(tmp_path):
     persist.save_index(path, v, rows, arith=0, scoring="base", nodes=nodes)
     z = persist.load_index(path)
     assert z["vectors"].dtype == np.float32 and np.array_equal(z["vectors"], v.astype(np.float32))
+    # round 6: genuine float64 rows are persisted in full beside their rounding (format /2); float32-representable ones as float32 only (/1)
+    assert z["vectors64"] is not None and z["vectors64"].dtype == np.float64 and np.array_equal(z["vectors64"], v)
+    persist.save_index(path, v.astype(np.float32).astype(np.float64), rows, arith=0, scoring="base", nodes=nodes)
+    assert persist.load_index(path)["vectors64"] is None
     assert z["arith"] == 0 and z["scoring"] == "base" and set(z["type_rows"]) == {"user", "item"}
     assert all(np.array_equal(z["type_rows"][t], rows[t]) for t in rows)
     assert z["node_types"].tolist() == [n.node_type for n in nodes] and z["node_ids"].tolist() == [str(i) for i in range(30)]
