@@ -237,3 +237,16 @@ def test_persisted_model_keeps_genuine_float64_rows(hw, tmp_path):
         assert [m2.nodes_to_idx[n] for n, _ in b] == o_idx.tolist() and [s_ for _, s_ in b] == o_sc.tolist()
     pairs = [(nodes[1], nodes[50]), (nodes[2], nodes[99])]
     assert np.array_equal(m.predict(pairs), m2.predict(pairs))
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_sharded_search_on_genuine_float64_rows(hw, tmp_path, backend, world):
+    """the N > 1 search over GENUINE float64 rows: every rank's local lists come from the fused float64-row search on its shard (ids = id_base + local
+    row, the whole float64 table addressed through the shard's row list), one exchange, hwer_merge_topk_lists - ids, scores, distances == the numpy oracle
+    on the float64 rows over the whole catalogue; all-gather, user-partitioned exchange and shortened lists (tests/dist_worker.py, "f64rows")"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from test_gpu_round2 import _run_workers
+    _run_workers(backend, world, tmp_path, (6007, 48, 33, 100, "f64rows"))
+    assert "float64 rows" in (tmp_path / "ok0").read_text()
