@@ -250,3 +250,28 @@ def test_sharded_search_on_genuine_float64_rows(hw, tmp_path, backend, world):
     from test_gpu_round2 import _run_workers
     _run_workers(backend, world, tmp_path, (6007, 48, 33, 100, "f64rows"))
     assert "float64 rows" in (tmp_path / "ok0").read_text()
+
+
+@pytest.mark.parametrize("env", ["HWER_NO_DENSE", "HWER_NO_SMALL", "HWER_NO_PINGPONG", "HWER_F16_OFF"])
+def test_fused_float64_rows_on_every_forced_path(hw, env, monkeypatch):
+    """the path-forcing switches of the float32 flavour (results are identical on every path) applied to the fused float64-row search: a dense-size
+    catalogue through the streaming screen, a small batch through the streaming screen instead of the list path, the two-workgroup float16 screen, and
+    the float32 screen instead of the float16 one - ids, scores, distances == the default path's and the oracle's"""
+    from hwer.device_index import DeviceIndex
+    cases = {"HWER_NO_DENSE": (300, 3000, 64, 50), "HWER_NO_SMALL": (64, 20000, 96, 100), "HWER_NO_PINGPONG": (2100, 20000, 128, 200), "HWER_F16_OFF": (2100, 20000, 128, 200)}
+    B, N, d, k = cases[env]
+    X = _plant(_rows64(40 + d, B + N, d), B)
+    rows = {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}
+    ref = DeviceIndex(X, rows).search("item", np.arange(B), k=k)
+    ix = DeviceIndex(X, rows)
+    if env == "HWER_F16_OFF":
+        ix.f16_screen = False
+        ix.use_f16_storage = False
+    else:
+        monkeypatch.setenv(env, "1")
+    got = ix.search("item", np.arange(B), k=k)
+    assert (got[3] > 0).all()
+    for a, b in zip(ref[:3], got[:3]):
+        assert np.array_equal(a, b)
+    o_idx, o_score, o_dist = orc.find_closest(X, np.arange(B, B + N), B - 1, k=k)
+    assert np.array_equal(got[0][B - 1], o_idx) and np.array_equal(got[1][B - 1], o_score) and np.array_equal(got[2][B - 1], o_dist)
