@@ -682,7 +682,10 @@ class DeviceIndex:
             dist2[pos] = d2
 
     def _search_candidates(self, tt, Q64, Q32, k, anchors_dev, score_mode, sort_by_score, use_rows, id_base, idx, score, dist2, flags, no_sync=False, workspaces=None):
-        """Exact k-NN as "screen a superset, re-rank it exactly, certify" for the shapes the fused HIP search does not take:
+        """Exact k-NN as "screen a superset, re-rank it exactly, certify" for the shapes the fused HIP search does not take (since round 6 genuine
+        float64 rows with d <= 256 and k <= 392 take the FUSED float64-row search, _search_f32(f64rows=True); this composition stays for their
+        float32-arithmetic score flavour, as the independent implementation the tests hold the fused path to - HWER_F64ROWS_CANDIDATES=1 - and for
+        wide tables / large k):
           * genuine float64 `vectors` (V64): the HIP search on the float32 rounding of the table returns the k + 32 nearest ROUNDED rows
             (exact for the rounded table); rounding moves a squared distance by at most eps(D) = 2 sqrt(D) delta + delta^2, delta =
             2^-24 ||x||max, so every row outside the candidates has a true squared distance >= T - eps(T), T = the largest candidate's
