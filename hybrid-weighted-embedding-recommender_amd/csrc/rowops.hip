@@ -769,8 +769,8 @@ __device__ __forceinline__ T np_pairwise_sq_t(const T* p, int n, int k) {
         return a + b;
     }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void anchor_query_kernel(const float* __restrict__ V, int64_t ldv, int d, int d4, const int32_t* __restrict__ anchor, int64_t B,
+template <typename T, typename TV = float>      // TV = double (round 6): the rows of a float64 table (hwer_query_mix_f64rows), two 16-byte loads per 4-column chunk
+__global__ __launch_bounds__(256) void anchor_query_kernel(const TV* __restrict__ V, int64_t ldv, int d, int d4, const int32_t* __restrict__ anchor, int64_t B,
                                                            double* __restrict__ Q64, float* __restrict__ Q32, int64_t ldq32, int stride, int pb_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -789,9 +789,16 @@ __global__ __launch_bounds__(256) void anchor_query_kernel(const float* __restri
             const int32_t an = anchor[b];
             const bool unknown = an < 0;
             for (int c = c0; c < d4; c += L) {
-                const float4 v = load_row4(V, ldv, an, c);
                 T* w = slab + slot * stride + 4 * c;
+                if constexpr (std::is_same<TV, double>::value) {
+                    const double* p = V + int64_t(unknown ? 0 : an) * ldv + 4 * c;
+                    const double2 lo = *reinterpret_cast<const double2*>(p), hi = *reinterpret_cast<const double2*>(p + 2);
+                    w[0] = unknown ? clip_unknown<T>(T(lo.x)) : T(lo.x); w[1] = unknown ? clip_unknown<T>(T(lo.y)) : T(lo.y);
+                    w[2] = unknown ? clip_unknown<T>(T(hi.x)) : T(hi.x); w[3] = unknown ? clip_unknown<T>(T(hi.y)) : T(hi.y);
+                } else {
+                const float4 v = load_row4(V, ldv, an, c);
                 w[0] = widen<T>(v.x, unknown); w[1] = widen<T>(v.y, unknown); w[2] = widen<T>(v.z, unknown); w[3] = widen<T>(v.w, unknown);
+                }
             }
         }
         wave_lds_sync();
@@ -1566,6 +1573,21 @@ int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, con
     if (!V64 || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "query_mix_f64rows: null pointer");
     if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix_f64rows: bad shape");
     if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix_f64rows: ptr without idx");
+    // anchor-only queries in bulk (round 6): the row-streaming kernel of hwer_query_mix on float64 rows - same values as the general kernel below
+    if (!pos_ptr && !neg_ptr && B >= 4096 && ldv % 4 == 0 && ldq32 % 4 == 0 && (reinterpret_cast<uintptr_t>(V64) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(Q32) & 15) == 0 && !diag_env("HWER_NO_ANCHOR_QUERY_KERNEL")) {
+        const int d4 = (d + 3) / 4;
+        int stride = 4 * d4;
+        while (stride % 32 != 8) stride += 2;
+        int pb_n = 8;
+        while (pb_n > 2 && size_t(pb_n) * stride * sizeof(double) > size_t(4800)) pb_n >>= 1;
+        const size_t lds = size_t(4) * (size_t(pb_n) * stride + 8) * sizeof(double);
+        if (lds <= size_t(64) * 1024) {
+            const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(cdiv64(B, pb_n), 4), kMaxStreamBlocks * 2)));
+            hipLaunchKernelGGL((anchor_query_kernel<double, double>), dim3(grid), dim3(256), lds, as_stream(stream), V64, ldv, d, d4, anchor, B, Q64, Q32, ldq32, stride, pb_n);
+            return check_launch("query_mix_f64rows(anchors)");
+        }
+    }
     int gq = 8;
     while (gq > 1 && size_t(gq) * 3 * d * sizeof(double) > size_t(128) * 1024) gq >>= 1;
     const size_t per_wave = size_t(gq) * 3 * d * sizeof(double);

@@ -336,15 +336,30 @@ struct Pack64Args {
     double eps;
     unsigned long long* counts;
     double* absdev;
+    // audit_all (hwer_audit_pack_rows_f64rows): group g < n_table works on table row g - audited always, rounded into X[g - pack_row0] when it lies in the
+    // searched range [pack_row0, pack_row0 + n_rows); groups n_table .. n_table + (n_out - n_rows) write the pad rows of X
+    int audit_all;
+    int64_t n_table, pack_row0;
 };
 __global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args a) {
     const int sub = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int x2 = int(a.ldx / 2), d2 = (a.d + 1) / 2;
     unsigned int n_pos = 0, n_neg = 0, n_nan = 0;   // this 16-lane group's audit tallies (lane 0), combined per block below: one atomic per block and counter
     double dev_sum = 0.0;
-    for (int64_t r = int64_t(blockIdx.x) * 16 + sub; r < a.n_out; r += int64_t(gridDim.x) * 16) {   // (uniform per 16-lane group)
-        const bool live = r < a.n_rows;
-        const double* src = a.V64 + (live ? (a.row_ids ? a.row_ids[r] : r) : 0) * a.ld64;
+    const int64_t n_groups = a.audit_all ? a.n_table + (a.n_out - a.n_rows) : a.n_out;
+    for (int64_t g = int64_t(blockIdx.x) * 16 + sub; g < n_groups; g += int64_t(gridDim.x) * 16) {   // (uniform per 16-lane group)
+        // r: row of X this group writes (-1: none, audit only); live: the group reads a table row
+        int64_t r = g;
+        bool live = g < a.n_rows;
+        const double* src = a.V64;
+        if (a.audit_all) {
+            live = g < a.n_table;
+            r = live ? ((g >= a.pack_row0 && g < a.pack_row0 + a.n_rows) ? g - a.pack_row0 : -1) : a.n_rows + (g - a.n_table);
+            src = a.V64 + (live ? g : 0) * a.ld64;
+        } else {
+            src = a.V64 + (live ? (a.row_ids ? a.row_ids[g] : g) : 0) * a.ld64;
+        }
+        const bool store = r >= 0;
         double ss32 = 0.0, ss64 = 0.0;
         for (int c = l; c < x2; c += 16) {
             double2 v = make_double2(0.0, 0.0);
@@ -355,8 +370,8 @@ __global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args
             const float2 w = make_float2(float(v.x), float(v.y));
             ss64 += v.x * v.x + v.y * v.y;
             ss32 += double(w.x) * double(w.x) + double(w.y) * double(w.y);
-            if (a.X) *reinterpret_cast<float2*>(a.X + r * a.ldx + 2 * c) = w;
-            if (a.X16) {
+            if (a.X && store) *reinterpret_cast<float2*>(a.X + r * a.ldx + 2 * c) = w;
+            if (a.X16 && store) {
                 typedef _Float16 half2_rt __attribute__((ext_vector_type(2)));
                 *reinterpret_cast<half2_rt*>(a.X16 + r * a.ldx + 2 * c) = half2_rt{(_Float16)ldexpf(w.x, a.x_exp), (_Float16)ldexpf(w.y, a.x_exp)};
             }
@@ -367,7 +382,7 @@ __global__ __launch_bounds__(256) void pack_rows_f64rows_kernel(const Pack64Args
             ss64 += shfl_xor_t(ss64, m);
         }
         if (l == 0) {
-            if (a.hnorm) a.hnorm[r] = live ? float(0.5 * ss32) : INFINITY;
+            if (a.hnorm && store) a.hnorm[r] = live ? float(0.5 * ss32) : INFINITY;
             if (live) {
                 const double n = sqrt(ss64);
                 n_pos += n > 1.0 + a.eps;
@@ -479,11 +494,27 @@ int hwer_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, co
         return fail(HWER_EINVAL, "pack_rows_f64rows: ldx must be even and >= d, X 8-byte aligned");
     if (n_rows < 0 || (!row_ids && n_rows > N)) return fail(HWER_EINVAL, "pack_rows_f64rows: n_rows > N without row_ids");
     Pack64Args a{V64, ld64, d, row_ids, n_rows, audit_only ? n_rows : hwer_knn_padded_rows(n_rows), X, ldx, hnorm, static_cast<_Float16*>(X16), x_exp, double(eps),
-                 reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum};
+                 reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, 0, 0, 0};
     if (a.n_out == 0) return HWER_OK;
     const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(a.n_out, 16), kMaxStreamBlocks * 4)));
     hipLaunchKernelGGL(pack_rows_f64rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
     return check_launch("pack_rows_f64rows");
+}
+
+int hwer_audit_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, int64_t pack_row0, int64_t n_rows, float* X, int64_t ldx, float* hnorm,
+                                 void* X16, int x_exp, float eps, uint64_t* audit_counts, double* audit_absdev_sum, void* stream) {
+    int rc;
+    if ((rc = check_table64("audit_pack_rows_f64rows(V64)", V64, ld64, d))) return rc;
+    if (!X || !hnorm || !audit_counts) return fail(HWER_EINVAL, "audit_pack_rows_f64rows: null X / hnorm / audit_counts");
+    if (ldx < d || ldx % 2 != 0 || (reinterpret_cast<uintptr_t>(X) & 7) || (X16 && (reinterpret_cast<uintptr_t>(X16) & 3)))
+        return fail(HWER_EINVAL, "audit_pack_rows_f64rows: ldx must be even and >= d, X 8-byte aligned");
+    if (N < 1 || n_rows < 1 || pack_row0 < 0 || pack_row0 + n_rows > N) return fail(HWER_EINVAL, "audit_pack_rows_f64rows: the searched rows must be a range of the table");
+    Pack64Args a{V64, ld64, d, nullptr, n_rows, hwer_knn_padded_rows(n_rows), X, ldx, hnorm, static_cast<_Float16*>(X16), x_exp, double(eps),
+                 reinterpret_cast<unsigned long long*>(audit_counts), audit_absdev_sum, 1, N, pack_row0};
+    const int64_t n_groups = N + (a.n_out - n_rows);
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(n_groups, 16), kMaxStreamBlocks * 4)));
+    hipLaunchKernelGGL(pack_rows_f64rows_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    return check_launch("audit_pack_rows_f64rows");
 }
 
 int hwer_pair_score_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst, int64_t P, double* out,

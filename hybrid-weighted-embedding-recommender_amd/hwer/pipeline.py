@@ -498,12 +498,9 @@ class BlendSearchStepF64:
         """unit-norm audit of every float64 row + the screen's float32 / float16 rounding of the searched type's rows"""
         P, lib = native.ptr, self.lib
         self.audit_buf.zero_()
-        for lo, hi in self.other_ranges:
-            if hi > lo:
-                native.check(lib.hwer_pack_rows_f64rows(P(self.V64[lo:hi]), hi - lo, self.d, self.ld64, None, hi - lo, None, 0, None, None, 0, self.eps,
-                                                        P(self.audit_counts), P(self.audit_dev), self.S()), "audit_f64rows")
-        native.check(lib.hwer_pack_rows_f64rows(P(self.V64), self.N, self.d, self.ld64, P(self.item_rows), self.I, P(self.X), self.ldx, P(self.hnorm),
-                                                P(self.X16), self.x16_exp, self.eps, P(self.audit_counts), P(self.audit_dev), self.S()), "pack_rows_f64rows")
+        # ONE launch: every row audited, the searched range also rounded into X / hnorm / X16 (hwer_audit_pack_rows_f64rows)
+        native.check(lib.hwer_audit_pack_rows_f64rows(P(self.V64), self.N, self.d, self.ld64, self.search_row0, self.I, P(self.X), self.ldx, P(self.hnorm),
+                                                      P(self.X16), self.x16_exp, self.eps, P(self.audit_counts), P(self.audit_dev), self.S()), "audit_pack_rows_f64rows")
 
     def stage_queries(self):
         P, lib = native.ptr, self.lib

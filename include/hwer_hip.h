@@ -387,6 +387,8 @@ int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int
  *                                        106-107): audit_counts[0..2] += rows with norm > 1 + eps / < 1 - eps / NaN, audit_absdev_sum += |norm - 1|
  *                                        (both nullable, caller-zeroed accumulators).  X / hnorm / X16 hold hwer_knn_padded_rows(n_rows) rows.
  *                                        X = hnorm = X16 = NULL: only the audit of the listed rows (the rows of the other node types).
+ *   hwer_audit_pack_rows_f64rows       : both in ONE launch when the searched type's rows are a range of the table: every row of V64 is audited, rows
+ *                                        [pack_row0, pack_row0 + n_rows) are also rounded into X / hnorm / X16 (what hwer.pipeline.BlendSearchStepF64 runs).
  * ------------------------------------------------------------------------------------------------- */
 int hwer_knn_search_f64rows(const float* X, const float* hnorm, int64_t n_items, int d, int64_t ldx, const float* Q32, const double* Q64,
                             const double* X64, int64_t ld64, const int64_t* x64_rows /*nullable*/, const double* A64, int64_t lda64,
@@ -410,6 +412,9 @@ int hwer_knn_exact_f64rows(const double* X64, int64_t ld64, const int64_t* x64_r
 int hwer_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, const int64_t* row_ids /*nullable*/, int64_t n_rows, float* X,
                            int64_t ldx, float* hnorm, void* X16 /*nullable*/, int x_exp, float eps, uint64_t* audit_counts /*nullable*/,
                            double* audit_absdev_sum /*nullable*/, void* stream);
+int hwer_audit_pack_rows_f64rows(const double* V64, int64_t N, int d, int64_t ld64, int64_t pack_row0, int64_t n_rows, float* X, int64_t ldx,
+                                 float* hnorm, void* X16 /*nullable*/, int x_exp, float eps, uint64_t* audit_counts, double* audit_absdev_sum /*nullable*/,
+                                 void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * W1-W4  exact k-NN for the shapes the fused search does not take (round 4) - tables wider than hwer_knn_max_dim(), k above

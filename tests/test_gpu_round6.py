@@ -275,3 +275,75 @@ def test_fused_float64_rows_on_every_forced_path(hw, env, monkeypatch):
         assert np.array_equal(a, b)
     o_idx, o_score, o_dist = orc.find_closest(X, np.arange(B, B + N), B - 1, k=k)
     assert np.array_equal(got[0][B - 1], o_idx) and np.array_equal(got[1][B - 1], o_score) and np.array_equal(got[2][B - 1], o_dist)
+
+
+@pytest.mark.parametrize("d", [64, 66, 7, 128])
+def test_anchor_query_kernel_on_float64_rows(hw, d):
+    """hwer_query_mix_f64rows with >= 4 096 plain anchors takes the row-streaming kernel (anchor_query_kernel<double, double>): Q64 == numpy's
+    unit(row) (hwer/recommendation_base.py:153-155,164-170 with only the anchor), Q32 == its float32 rounding zero-padded, unknown anchors (-1) == the
+    clipped row 0 - and == the general kernel's output on a batch small enough to take that one"""
+    import torch
+    from hwer import native
+    lib, P = native.lib(), native.ptr
+    dev = torch.device("cuda:0")
+    N, B = 3000, 5000
+    ld64 = (d + 7) // 8 * 8
+    V = np.zeros((N, ld64))
+    V[:, :d] = _rows64(300 + d, N, d) * (1.0 + 5e-5 * np.random.default_rng(d).uniform(-1, 1, (N, 1)))
+    an = np.random.default_rng(1).integers(-1, N, B).astype(np.int32)
+    ldx = lib.hwer_knn_padded_dim(d)
+    Vd, ad = torch.from_numpy(V).to(dev), torch.from_numpy(an).to(dev)
+
+    def run(n):
+        Q64 = torch.full((n, d), 7.0, dtype=torch.float64, device=dev)
+        Q32 = torch.full((n, ldx), 7.0, dtype=torch.float32, device=dev)
+        native.check(lib.hwer_query_mix_f64rows(P(Vd), N, d, ld64, P(ad), None, None, None, None, n, P(Q64), P(Q32), ldx, native.stream_ptr(dev)), "query_mix_f64rows")
+        return Q64.cpu().numpy(), Q32.cpu().numpy()
+    q64, q32 = run(B)              # the streaming kernel
+    g64, g32 = run(1000)           # the general kernel (fewer than 4 096 anchors)
+    assert np.array_equal(q64[:1000], g64) and np.array_equal(q32[:1000], g32)
+    for b in list(range(0, B, 397)) + [B - 1]:
+        row = V[an[b], :d] if an[b] >= 0 else np.clip(V[0, :d], 1e-6, 1e-5)
+        want = (row / np.linalg.norm(row, axis=0)) / 1.0        # (axis given: numpy reduces pairwise, as utils.unit_length does - without it a 1-D norm is a BLAS dot)
+        assert np.array_equal(q64[b], want), b
+    want32 = np.zeros((B, ldx), np.float32)
+    want32[:, :d] = q64.astype(np.float32)
+    assert np.array_equal(q32, want32)
+
+
+def test_audit_pack_rows_f64rows_one_launch(hw):
+    """hwer_audit_pack_rows_f64rows == the two hwer_pack_rows_f64rows calls it replaces (audit of the other rows + audit and rounding of the searched range)"""
+    import torch
+    from hwer import native
+    lib, P = native.lib(), native.ptr
+    dev = torch.device("cuda:0")
+    for N, d, row0, n in [(700, 66, 200, 301), (400, 128, 0, 400), (90, 7, 26, 64)]:
+        ld64 = (d + 7) // 8 * 8
+        V = np.zeros((N, ld64))
+        V[:, :d] = _rows64(11 + d, N, d)
+        V[3, :d] *= 1.001
+        V[row0 + 1, :d] *= 0.998
+        V[N - 1, 0] = np.nan
+        Vd = torch.from_numpy(V).to(dev)
+        ldx, n_pad = lib.hwer_knn_padded_dim(d), lib.hwer_knn_padded_rows(n)
+        x_exp = int(lib.hwer_knn_f16_scale_exp(0.51))
+        outs = []
+        for fused in (False, True):
+            X = torch.full((n_pad, ldx), 7.0, dtype=torch.float32, device=dev)
+            hn = torch.full((n_pad,), 7.0, dtype=torch.float32, device=dev)
+            X16 = torch.full((n_pad, ldx), 7.0, dtype=torch.float16, device=dev)
+            cnt = torch.zeros(4, dtype=torch.int64, device=dev)
+            dv = torch.zeros(1, dtype=torch.float64, device=dev)
+            st = native.stream_ptr(dev)
+            if fused:
+                native.check(lib.hwer_audit_pack_rows_f64rows(P(Vd), N, d, ld64, row0, n, P(X), ldx, P(hn), P(X16), x_exp, 1e-4, P(cnt), P(dv), st), "audit_pack")
+            else:
+                for lo, hi in ((0, row0), (row0 + n, N)):
+                    if hi > lo:
+                        native.check(lib.hwer_pack_rows_f64rows(P(Vd[lo:hi]), hi - lo, d, ld64, None, hi - lo, None, 0, None, None, 0, 1e-4, P(cnt), P(dv), st), "audit")
+                rows = torch.arange(row0, row0 + n, dtype=torch.int64, device=dev)
+                native.check(lib.hwer_pack_rows_f64rows(P(Vd), N, d, ld64, P(rows), n, P(X), ldx, P(hn), P(X16), x_exp, 1e-4, P(cnt), P(dv), st), "pack")
+            outs.append((X.cpu().numpy(), hn.cpu().numpy(), X16.cpu().numpy(), cnt.cpu().numpy()))
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b, equal_nan=True)
+        assert tuple(outs[1][3][:3]) == (1, 1, 1)
