@@ -1566,15 +1566,38 @@ int hwer_query_mix(const float* V, int64_t N, int d, int64_t ldv, const int32_t*
     return check_launch("query_mix");
 }
 
+static int query_mix_f64rows_impl(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                                  const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
+                                  int64_t ldq32, void* knn_workspace, int64_t bq, void* stream);
 int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
                            const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
                            int64_t ldq32, void* stream) {
+    return query_mix_f64rows_impl(V64, N, d, ldv, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0, stream);
+}
+// ... and, like hwer_prepare_search_f32 for float32 rows, the MFMA query fragments of the search that follows written straight into its workspace
+// (float32 fragments for bq > 0, float16 fragments + exponents for bq < 0: |bq| = hwer_knn_query_padding(...)); search with HWER_KNN_QUERIES_READY
+int hwer_query_mix_frag_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                                const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
+                                int64_t ldq32, void* knn_workspace, int64_t bq, void* stream) {
+    if (!knn_workspace || bq == 0) return fail(HWER_EINVAL, "query_mix_frag_f64rows: workspace and bq required (hwer_query_mix_f64rows writes no fragments)");
+    return query_mix_f64rows_impl(V64, N, d, ldv, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, knn_workspace, bq, stream);
+}
+static int query_mix_f64rows_impl(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                                  const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
+                                  int64_t ldq32, void* knn_workspace, int64_t bq, void* stream) {
     if (B == 0) return HWER_OK;
+    const int frag16 = bq < 0 ? 1 : 0;
+    if (frag16) bq = -bq;
+    if (knn_workspace) {
+        if ((reinterpret_cast<uintptr_t>(knn_workspace) & 255) != 0 || bq < B || bq % 32 != 0)
+            return fail(HWER_EINVAL, "query_mix_frag_f64rows: workspace must be 256-byte aligned and |bq| = hwer_knn_query_padding(...) >= B");
+        if (ldq32 % 8 != 0 || (frag16 && ldq32 % 16 != 0) || d > 256) return fail(HWER_EINVAL, "query_mix_frag_f64rows: ldq32 must be the search's padded width (d <= 256)");
+    }
     if (!V64 || !anchor || !Q64 || !Q32) return fail(HWER_EINVAL, "query_mix_f64rows: null pointer");
     if (N < 1 || d < 1 || d > 1024 || ldv < d || ldq32 < d) return fail(HWER_EINVAL, "query_mix_f64rows: bad shape");
     if ((pos_ptr && !pos_idx) || (neg_ptr && !neg_idx)) return fail(HWER_EINVAL, "query_mix_f64rows: ptr without idx");
     // anchor-only queries in bulk (round 6): the row-streaming kernel of hwer_query_mix on float64 rows - same values as the general kernel below
-    if (!pos_ptr && !neg_ptr && B >= 4096 && ldv % 4 == 0 && ldq32 % 4 == 0 && (reinterpret_cast<uintptr_t>(V64) & 15) == 0 &&
+    if (!knn_workspace && !pos_ptr && !neg_ptr && B >= 4096 && ldv % 4 == 0 && ldq32 % 4 == 0 && (reinterpret_cast<uintptr_t>(V64) & 15) == 0 &&
         (reinterpret_cast<uintptr_t>(Q32) & 15) == 0 && !diag_env("HWER_NO_ANCHOR_QUERY_KERNEL")) {
         const int d4 = (d + 3) / 4;
         int stride = 4 * d4;
@@ -1592,8 +1615,10 @@ int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, con
     while (gq > 1 && size_t(gq) * 3 * d * sizeof(double) > size_t(128) * 1024) gq >>= 1;
     const size_t per_wave = size_t(gq) * 3 * d * sizeof(double);
     const int wpb = per_wave * 4 <= 64 * 1024 ? 4 : 1;
-    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(B, gq * wpb), kMaxStreamBlocks * 4)));
-    const QueryMixArgs qa{nullptr, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, nullptr, 0, V64, gq == 8 ? 0 : gq};
+    const int64_t q_rows = knn_workspace ? std::max(B, bq) : B;      // (fragment rows past the batch are written as zeros)
+    const int grid = int(std::max<int64_t>(1, std::min<int64_t>(cdiv64(q_rows, gq * wpb), kMaxStreamBlocks * 4)));
+    float* qf = knn_workspace ? reinterpret_cast<float*>(static_cast<unsigned char*>(knn_workspace) + WS_HEADER_BYTES) : nullptr;
+    const QueryMixArgs qa{nullptr, ldv, d, anchor, pos_ptr, pos_idx, neg_ptr, neg_idx, B, Q64, Q32, ldq32, qf, knn_workspace ? bq : 0, V64, gq == 8 ? 0 : gq, frag16};
     hipLaunchKernelGGL(query_mix_kernel<double>, dim3(grid), dim3(64 * wpb), per_wave * wpb, as_stream(stream), qa);
     return check_launch("query_mix_f64rows");
 }

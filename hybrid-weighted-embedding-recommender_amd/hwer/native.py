@@ -71,6 +71,7 @@ PROTOTYPES = {
     "hwer_pack_rows_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, c_int64, _P, c_int64, _P, _P, c_int, c_float, _P, _P, _P]),
     "hwer_audit_pack_rows_f64rows": (c_int, [_P, c_int64, c_int, c_int64, c_int64, c_int64, _P, c_int64, _P, _P, c_int, c_float, _P, _P, _P]),
     "hwer_query_mix_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P]),
+    "hwer_query_mix_frag_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P]),
     "hwer_pair_score_f64rows": (c_int, [_P, c_int64, c_int, c_int64, _P, _P, c_int64, _P, _P]),
     "hwer_knn_cand_dist2": (c_int, [_P, c_int, c_int64, c_int, c_int64, _P, c_int64, c_int64, c_int64, _P, _P, _P]),
     "hwer_knn_f16_scale_exp": (c_int, [c_float]),

@@ -484,6 +484,9 @@ class BlendSearchStepF64:
         self.hnorm_max = 0.5 * (1.0 + self.eps) ** 2
         self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
         self.id_base = self.search_row0 if id_base is None else int(id_base)
+        # one search call per step: its query fragments come out of the query launch (hwer_query_mix_frag_f64rows + HWER_KNN_QUERIES_READY)
+        self.fused_fragments = B <= self.CH and not os.environ.get("HWER_NO_FUSED_FRAGMENTS")
+        self.bq_frag = int(lib.hwer_knn_query_padding(B, I, d, K, self.opts)) * (-1 if self.f16_screen else 1) if self.fused_fragments else 0
         self._graph = None
 
     def S(self):
@@ -504,6 +507,10 @@ class BlendSearchStepF64:
 
     def stage_queries(self):
         P, lib = native.ptr, self.lib
+        if self.fused_fragments:
+            native.check(lib.hwer_query_mix_frag_f64rows(P(self.V64), self.N, self.d, self.ld64, P(self.anchors), None, None, None, None, self.B, P(self.Q64), P(self.Q32),
+                                                         self.ldx, P(self.ws), self.bq_frag, self.S()), "query_mix_frag_f64rows")
+            return
         native.check(lib.hwer_query_mix_f64rows(P(self.V64), self.N, self.d, self.ld64, P(self.anchors), None, None, None, None, self.B, P(self.Q64), P(self.Q32),
                                                 self.ldx, self.S()), "query_mix_f64rows")
 
@@ -517,8 +524,8 @@ class BlendSearchStepF64:
             native.check(lib.hwer_knn_search_f64rows(
                 P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.V64), self.ld64, P(self.item_rows), A64,
                 self.ld64, P(self.anchors[b0:b1]), b1 - b0, K, self.score_mode, self.sort_by_score, None, self.id_base, self.hnorm_max, P(oi[b0:b1]),
-                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(), self.opts, P(self.X16), self.x16_exp,
-                self.S()), "knn_search_f64rows")
+                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(),
+                self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0), P(self.X16), self.x16_exp, self.S()), "knn_search_f64rows")
             native.check(lib.hwer_knn_exact_device_f64rows(
                 P(self.V64), self.ld64, P(self.item_rows), self.I, self.d, P(self.Q64[b0:b1]), A64, self.ld64, P(self.anchors[b0:b1]), K, self.score_mode,
                 self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws),

@@ -359,6 +359,12 @@ int hwer_knn_all_dist2_f64(const float* X, int64_t n_items, int d, int64_t ldx, 
 int hwer_query_mix_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
                            const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
                            int64_t ldq32, void* stream);
+/* hwer_query_mix_f64rows + the MFMA query fragments of the search that follows, written straight into that search's workspace (what hwer_prepare_search_f32
+ * does for float32 rows): bq = hwer_knn_query_padding(...) for the float32 fragments, -bq for the float16 fragments + per-query exponents of an
+ * HWER_KNN_F16_SCREEN search; then search with HWER_KNN_QUERIES_READY (it skips its own repacking launch).  d <= 256, ldq32 = hwer_knn_padded_dim(d). */
+int hwer_query_mix_frag_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* anchor, const int64_t* pos_ptr,
+                                const int32_t* pos_idx, const int64_t* neg_ptr, const int32_t* neg_idx, int64_t B, double* Q64, float* Q32,
+                                int64_t ldq32, void* knn_workspace, int64_t bq, void* stream);
 int hwer_pair_score_f64rows(const double* V64, int64_t N, int d, int64_t ldv, const int32_t* src, const int32_t* dst, int64_t P,
                             double* out, void* stream);
 int hwer_knn_cand_dist2(const void* table, int table_is_f64, int64_t n_rows, int d, int64_t ld, const int64_t* cand, int64_t ld_cand,

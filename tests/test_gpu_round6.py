@@ -347,3 +347,45 @@ def test_audit_pack_rows_f64rows_one_launch(hw):
         for a, b in zip(*outs):
             assert np.array_equal(a, b, equal_nan=True)
         assert tuple(outs[1][3][:3]) == (1, 1, 1)
+
+
+@pytest.mark.parametrize("U,I,d,T,graph", [(300, 3000, 64, 2, True), (2100, 20000, 128, 2, False), (40, 9000, 66, 3, False)])
+def test_blend_search_step_f64(hw, U, I, d, T, graph, monkeypatch):
+    """hwer.pipeline.BlendSearchStepF64 - the resident step in the reference's float64 flavour (what bench.py's c1_f64rows / c3_f64rows time): float64 tables
+    -> blended float64 rows == the numpy expression -> audit -> fused float64-row search == the numpy oracle on those rows; the query launch that also writes
+    the search's MFMA fragments (hwer_query_mix_frag_f64rows + HWER_KNN_QUERIES_READY; float32 fragments on the dense path, float16 ones under the float16
+    screen, the small-batch path ignores them) gives the same results as the search's own repacking; a captured hipGraph replays the same step"""
+    import torch
+    from hwer.pipeline import BlendSearchStepF64
+    dev = torch.device("cuda:0")
+    N = U + I
+    ld = (d + 1) // 2 * 2
+    tabs_h = [np.zeros((N, ld)) for _ in range(T)]
+    for t in range(T):
+        tabs_h[t][:, :d] = _rows64(700 + 10 * t + d, N, d)
+    al_h = np.random.default_rng(9).dirichlet(np.ones(T))
+    tabs = [torch.from_numpy(x).to(dev)[:, :d] if ld != d else torch.from_numpy(x).to(dev) for x in tabs_h]
+    alpha = torch.from_numpy(al_h).to(dev)
+    anchors = torch.arange(U, dtype=torch.int32, device=dev)
+    res = {}
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setenv("HWER_NO_FUSED_FRAGMENTS", "1")
+        step = BlendSearchStepF64(tabs, alpha, search_row0=U, n_search=I, anchors=anchors, k=50, want_dist=True)
+        assert step.fused_fragments == fused
+        if graph and fused:
+            step.capture()
+        step.run()
+        res[fused] = step.results()
+        if fused:
+            V = step.V64[:, :d].cpu().numpy()
+            acc = np.zeros((N, d))
+            for w_, x in zip(al_h, tabs_h):
+                acc = acc + w_ * x[:, :d]
+            assert np.array_equal(V, acc / np.expand_dims(np.linalg.norm(acc, axis=1), 1))
+            assert step.audit_counts.tolist()[:3] == [0, 0, 0]
+            for u in (0, U // 2, U - 1):
+                o_idx, o_sc, o_dist = orc.find_closest(V, np.arange(U, N), u, k=50)
+                assert np.array_equal(res[True][0][u], o_idx) and np.array_equal(res[True][1][u], o_sc) and np.array_equal(res[True][2][u], o_dist)
+    for a, b in zip(res[True], res[False]):
+        assert np.array_equal(a, b)
