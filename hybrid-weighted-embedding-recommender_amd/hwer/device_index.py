@@ -57,7 +57,7 @@ def _on_device(fn):
 
 
 class _TypeTable:
-    __slots__ = ("rows", "rows_dev", "X", "hnorm", "hnorm_max", "n", "id_base", "X16", "x16_exp")
+    __slots__ = ("rows", "rows_dev", "X", "hnorm", "hnorm_max", "n", "id_base", "X16", "x16_exp", "row0")
 
     def __init__(self):
         self.rows = None
@@ -69,6 +69,7 @@ class _TypeTable:
         self.id_base = 0
         self.X16 = None      # float16 storage of X for the HBM-bound small-batch screen (built on first use)
         self.x16_exp = 0
+        self.row0 = -1       # >= 0: the type's rows are the RANGE [row0, row0 + n) of the vector table (float64 rows: addressed without the row map)
 
 
 class _OneAnchorSearch:
@@ -202,6 +203,7 @@ class _OneAnchorSearchF64:
         self.wse = torch.empty(int(lib.hwer_knn_exact_device_workspace_bytes(tt.n, k)), dtype=torch.uint8, device=dev)
         P = native.ptr
         A64 = P(ix.V64) if mode != 2 else None
+        X64p, xmap = ix._x64(tt)
 
         def launch():
             st = native.stream_ptr(dev)
@@ -209,11 +211,11 @@ class _OneAnchorSearchF64:
             native.check(lib.hwer_query_mix_f64rows(P(ix.V64), ix.N, ix.d, ix.ld64, P(self.d_anchor), None, None, None, None, 1, P(self.Q64), P(self.Q32),
                                                     ix.ldx, st), "query_mix_f64rows")
             native.check(lib.hwer_knn_search_f64rows(
-                P(tt.X), P(tt.hnorm), tt.n, ix.d, ix.ldx, P(self.Q32), P(self.Q64), P(ix.V64), ix.ld64, P(tt.rows_dev), A64, ix.ld64, P(self.d_anchor), 1, k,
+                P(tt.X), P(tt.hnorm), tt.n, ix.d, ix.ldx, P(self.Q32), P(self.Q64), X64p, ix.ld64, xmap, A64, ix.ld64, P(self.d_anchor), 1, k,
                 mode, 1, P(tt.rows_dev), 0, tt.hnorm_max, P(idx), P(score), P(d2), P(flags), P(self.ws), self.ws.numel(), opt, P(x16), x16_exp, st),
                 "knn_search_f64rows")
             native.check(lib.hwer_knn_exact_device_f64rows(
-                P(ix.V64), ix.ld64, P(tt.rows_dev), tt.n, ix.d, P(self.Q64), A64, ix.ld64, P(self.d_anchor), k, mode, 1, P(tt.rows_dev), 0, P(idx), P(score),
+                X64p, ix.ld64, xmap, tt.n, ix.d, P(self.Q64), A64, ix.ld64, P(self.d_anchor), k, mode, 1, P(tt.rows_dev), 0, P(idx), P(score),
                 P(d2), P(flags), P(self.ws), None, P(self.wse), self.wse.numel(), st), "knn_exact_device_f64rows")
             self.h_buf.copy_(self.buf, non_blocking=True)
         with native.device_guard(dev):
@@ -338,6 +340,8 @@ class DeviceIndex:
         tt.rows = np.ascontiguousarray(rows, dtype=np.int64)
         tt.n = len(tt.rows)
         tt.rows_dev = torch.from_numpy(tt.rows).to(self.device)
+        if tt.n and int(tt.rows[-1]) - int(tt.rows[0]) == tt.n - 1 and bool((np.diff(tt.rows) == 1).all()):
+            tt.row0 = int(tt.rows[0])
         n_pad = self.lib.hwer_knn_padded_rows(tt.n)   # whole 32-row tiles: pad rows are zero with a +inf half norm
         tt.X = torch.empty((n_pad, self.ldx), dtype=torch.float32, device=self.device)
         tt.hnorm = torch.empty(n_pad, dtype=torch.float32, device=self.device)
@@ -461,6 +465,13 @@ class DeviceIndex:
                                                      native.stream_ptr(self.device)), "pack_rows_f16")
         return tt.X16, tt.x16_exp
 
+    def _x64(self, tt):
+        """(float64 table pointer, row map pointer) the float64-row kernels address `tt`'s rows with: the table sliced at the type's first row and NO map when
+        the rows are a range of the table (one dependent load per gathered row less), else the whole table + the type's row list"""
+        if tt.row0 >= 0:
+            return native.ptr(self.V64[tt.row0:tt.row0 + tt.n]), None
+        return native.ptr(self.V64), native.ptr(tt.rows_dev)
+
     def _workspace(self, nbytes):
         torch = _torch()
         if self._ws is None or self._ws.numel() < nbytes:
@@ -537,6 +548,7 @@ class DeviceIndex:
         if f64rows:
             assert self.V64 is not None and score_mode in (0, 2)
             A64 = P(self.V64) if score_mode != 2 else None
+            X64p, xmap = self._x64(tt)
         B = Q64.shape[0]
         path_opt = self._path_options()
         st = native.stream_ptr(self.device)       # one stream lookup per call (torch.cuda.current_stream costs ~4 us)
@@ -567,12 +579,12 @@ class DeviceIndex:
             wse = workspaces["wse"] if workspaces is not None else self._exact_workspace(wseb)
             if f64rows:
                 native.check(self.lib.hwer_knn_search_f64rows(
-                    P(tt.X), P(tt.hnorm), tt.n, self.d, self.ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), P(self.V64), self.ld64, P(tt.rows_dev), A64, self.ld64,
+                    P(tt.X), P(tt.hnorm), tt.n, self.d, self.ldx, P(Q32[b0:b1]), P(Q64[b0:b1]), X64p, self.ld64, xmap, A64, self.ld64,
                     P(a_sub), nb, k, score_mode, 1 if sort_by_score else 0, P(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base),
                     tt.hnorm_max, P(idx[b0:b1]), P(score[b0:b1]), P(dist2[b0:b1]) if want_dist else None, P(flags[b0:b1]), P(ws), ws.numel(), opt,
                     P(x16), x16_exp, st), "knn_search_f64rows")
                 native.check(self.lib.hwer_knn_exact_device_f64rows(
-                    P(self.V64), self.ld64, P(tt.rows_dev), tt.n, self.d, P(Q64[b0:b1]), A64, self.ld64, P(a_sub), k, score_mode, 1 if sort_by_score else 0,
+                    X64p, self.ld64, xmap, tt.n, self.d, P(Q64[b0:b1]), A64, self.ld64, P(a_sub), k, score_mode, 1 if sort_by_score else 0,
                     P(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), P(idx[b0:b1]), P(score[b0:b1]),
                     P(dist2[b0:b1]) if want_dist else None, P(flags[b0:b1]), P(ws), None, P(wse), wse.numel(), st), "knn_exact_device_f64rows")
                 continue
@@ -810,7 +822,7 @@ class DeviceIndex:
             ws = self._workspace(wsb)
             if f64rows:
                 native.check(self.lib.hwer_knn_search_f64rows(
-                    P(tt.X), P(tt.hnorm), tt.n, self.d, self.ldx, P(q32[b0:b1]), P(q64[b0:b1]), P(self.V64), self.ld64, P(tt.rows_dev),
+                    P(tt.X), P(tt.hnorm), tt.n, self.d, self.ldx, P(q32[b0:b1]), P(q64[b0:b1]), self._x64(tt)[0], self.ld64, self._x64(tt)[1],
                     P(self.V64) if score_mode != 2 else None, self.ld64, P(a_sub[b0:b1]) if a_sub is not None else None, b1 - b0, k, score_mode,
                     1 if sort_by_score else 0, P(tt.rows_dev) if use_rows else None, 0 if use_rows else int(id_base), tt.hnorm_max, P(r_idx[b0:b1]),
                     P(r_score[b0:b1]), P(r_dist2[b0:b1]) if r_dist2 is not None else None, P(r_flags[b0:b1]), P(ws), ws.numel(), opt, None, 0,
@@ -841,7 +853,7 @@ class DeviceIndex:
         if f64rows:
             P = native.ptr
             native.check(self.lib.hwer_knn_exact_f64rows(
-                P(self.V64), self.ld64, P(tt.rows_dev), tt.n, self.d, P(Q64), P(self.V64) if score_mode != 2 else None, self.ld64, P(anchors_dev),
+                self._x64(tt)[0], self.ld64, self._x64(tt)[1], tt.n, self.d, P(Q64), P(self.V64) if score_mode != 2 else None, self.ld64, P(anchors_dev),
                 qsel.ctypes.data_as(ctypes.c_void_p), len(qsel), k, score_mode, 1 if sort_by_score else 0, P(tt.rows_dev) if use_rows else None,
                 0 if use_rows else int(id_base), P(idx), P(score), P(dist2) if dist2 is not None else None, P(flags), P(ws), ws.numel(),
                 native.stream_ptr(self.device)), "knn_exact_f64rows")

@@ -454,8 +454,9 @@ class BlendSearchStepF64:
             self.tab_ptrs = torch.tensor([t.data_ptr() for t in self.tables], dtype=torch.int64, device=dev)
             self.ld64 = roundup(d, 8)
             self.V64 = torch.zeros((N, self.ld64), dtype=torch.float64, device=dev)      # (pad columns stay zero: the blend writes d of them)
-            self.item_rows = torch.arange(self.search_row0, self.search_row0 + I, dtype=torch.int64, device=dev)
-            self.other_ranges = [(0, self.search_row0), (self.search_row0 + I, N)]
+            # the searched type's rows are a RANGE of the float64 table: the search addresses them as X64 = V64 + search_row0 * ld64 with no row map
+            # (a row map costs one dependent load per gathered candidate row)
+            self.X64 = self.V64[self.search_row0:self.search_row0 + I]
             I_pad = self.I_pad = lib.hwer_knn_padded_rows(I)
             self.X = torch.empty((I_pad, self.ldx), dtype=torch.float32, device=dev)
             self.hnorm = torch.empty(I_pad, dtype=torch.float32, device=dev)
@@ -522,12 +523,12 @@ class BlendSearchStepF64:
         for b0 in range(0, self.B, self.CH):
             b1 = min(self.B, b0 + self.CH)
             native.check(lib.hwer_knn_search_f64rows(
-                P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.V64), self.ld64, P(self.item_rows), A64,
+                P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.X64), self.ld64, None, A64,
                 self.ld64, P(self.anchors[b0:b1]), b1 - b0, K, self.score_mode, self.sort_by_score, None, self.id_base, self.hnorm_max, P(oi[b0:b1]),
                 P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(),
                 self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0), P(self.X16), self.x16_exp, self.S()), "knn_search_f64rows")
             native.check(lib.hwer_knn_exact_device_f64rows(
-                P(self.V64), self.ld64, P(self.item_rows), self.I, self.d, P(self.Q64[b0:b1]), A64, self.ld64, P(self.anchors[b0:b1]), K, self.score_mode,
+                P(self.X64), self.ld64, None, self.I, self.d, P(self.Q64[b0:b1]), A64, self.ld64, P(self.anchors[b0:b1]), K, self.score_mode,
                 self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws),
                 P(self.missed), P(self.ws_exact), self.ws_exact.numel(), self.S()), "knn_exact_device_f64rows")
 
