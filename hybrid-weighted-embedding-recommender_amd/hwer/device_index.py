@@ -889,6 +889,46 @@ class DeviceIndex:
                 cache.pop(next(iter(cache)))
         return one
 
+    #: batches up to this many queries come back in ONE device-to-host copy (ids | score bits | distance bits | flags in one buffer): the batched API's
+    #: latency at MovieLens sizes is its copies and synchronisations, not its kernels (943 anchors: 45 us of kernels in a 0.27 ms call -> 0.235 ms); larger
+    #: batches keep the tiered path (an uncertified query - likelier among more - would cost this path a second search)
+    ONE_COPY_MAX_QUERIES = 16384
+
+    def _search_one_copy(self, node_type, Q64, Q32, a, k, mode, sort_by_score, want_dist):
+        """The fused search (float32 rows, or genuine float64 rows) for a small batch with every output in ONE int64 device buffer and ONE synchronising copy to the
+        host instead of three (flags, ids, scores).  -> the numpy result tuple of `search`, or None when the shape is not the fused search's or some query came back
+        uncertified beyond the on-device exhaustive pass (rare: the caller then takes the tiered path)."""
+        torch = _torch()
+        tt = self.tables[node_type]
+        B = int(Q64.shape[0])
+        f64rows = self.V64 is not None
+        if not (2 <= B <= self.ONE_COPY_MAX_QUERIES and sort_by_score and not self.wide and k <= self._max_k and k <= tt.n) or os.environ.get("HWER_FORCE_EXHAUSTIVE"):
+            return None
+        if f64rows and (mode not in (0, 2) or os.environ.get("HWER_F64ROWS_CANDIDATES")):
+            return None
+        if mode == 2:
+            want_dist = True
+        nk = B * k
+        n_words = 2 * nk + (nk if want_dist else 0) + (B + 1) // 2
+        buf = torch.empty(n_words, dtype=torch.int64, device=self.device)
+        idx, score = buf[:nk].view(B, k), buf[nk:2 * nk].view(torch.float64).view(B, k)
+        off = 2 * nk
+        dist2 = None
+        if want_dist:
+            dist2 = buf[off:off + nk].view(torch.float64).view(B, k)
+            off += nk
+        flags = buf[off:].view(torch.int32)[:B]
+        self._search_f32(tt, Q64, Q32, k, a, mode, True, True, None, want_dist, idx, score, dist2, flags, no_sync=True, f64rows=f64rows)
+        host = buf.cpu().numpy()                      # the one synchronisation of the call
+        flags_h = host[off:].view(np.int32)[:B]
+        if (flags_h == 0).any():
+            return None
+        sc = host[nk:2 * nk].view(np.float64).reshape(B, k)
+        if mode == 1:
+            sc = sc.astype(np.float32)                # exact: the kernel widened float32 values
+        dist = np.sqrt(host[2 * nk:3 * nk].view(np.float64).reshape(B, k)) if want_dist else None
+        return host[:nk].reshape(B, k), sc, dist, flags_h
+
     @_on_device
     def search(self, node_type: str, anchors: np.ndarray, k: int = 200, positive=None, negative=None,
                scoring: str = "base", sort_by_score: bool = True, want_dist: bool = True):
@@ -920,6 +960,9 @@ class DeviceIndex:
                 if flag > 0:
                     return ids.reshape(1, k), sc.reshape(1, k), (np.sqrt(d2).reshape(1, k) if d2 is not None else None), np.asarray([flag], dtype=np.int32)
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
+        one = self._search_one_copy(node_type, Q64, Q32, a, k, mode, sort_by_score, want_dist)
+        if one is not None:
+            return one
         fh = []
         idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist, _flags_host_out=fh)
         sc = score.cpu().numpy()
