@@ -889,10 +889,13 @@ class DeviceIndex:
                 cache.pop(next(iter(cache)))
         return one
 
-    #: batches up to this many queries come back in ONE device-to-host copy (ids | score bits | distance bits | flags in one buffer): the batched API's
-    #: latency at MovieLens sizes is its copies and synchronisations, not its kernels (943 anchors: 45 us of kernels in a 0.27 ms call -> 0.235 ms); larger
-    #: batches keep the tiered path (an uncertified query - likelier among more - would cost this path a second search)
+    #: batches up to this many queries AND up to ONE_COPY_MAX_ENTRIES result entries come back in ONE device-to-host copy (ids | score bits | distance bits |
+    #: flags in one buffer): the batched API's latency at MovieLens sizes is its copies and synchronisations, not its kernels (943 anchors: 45 us of kernels in
+    #: a 0.27 ms call -> 0.23 ms; float64 rows 0.21 -> 0.18).  Larger results keep the tiered path: an uncertified query - likelier among more - would cost this
+    #: path a second search, and one 13 MB host array (4 096 x 200) measured BIMODAL here (0.6 or 1.8 - 2.2 ms per call for dozens of calls: the host
+    #: allocator's page faults on a fresh mapping of that size) where two 6.5 MB arrays are stable
     ONE_COPY_MAX_QUERIES = 16384
+    ONE_COPY_MAX_ENTRIES = 262144
 
     def _search_one_copy(self, node_type, Q64, Q32, a, k, mode, sort_by_score, want_dist):
         """The fused search (float32 rows, or genuine float64 rows) for a small batch with every output in ONE int64 device buffer and ONE synchronising copy to the
@@ -909,6 +912,8 @@ class DeviceIndex:
         if mode == 2:
             want_dist = True
         nk = B * k
+        if nk > self.ONE_COPY_MAX_ENTRIES:
+            return None
         n_words = 2 * nk + (nk if want_dist else 0) + (B + 1) // 2
         buf = torch.empty(n_words, dtype=torch.int64, device=self.device)
         idx, score = buf[:nk].view(B, k), buf[nk:2 * nk].view(torch.float64).view(B, k)
