@@ -889,51 +889,6 @@ class DeviceIndex:
                 cache.pop(next(iter(cache)))
         return one
 
-    #: batches up to this many queries AND up to ONE_COPY_MAX_ENTRIES result entries come back in ONE device-to-host copy (ids | score bits | distance bits |
-    #: flags in one buffer): the batched API's latency at MovieLens sizes is its copies and synchronisations, not its kernels (943 anchors: 45 us of kernels in
-    #: a 0.27 ms call -> 0.23 ms; float64 rows 0.21 -> 0.18).  Larger results keep the tiered path: an uncertified query - likelier among more - would cost this
-    #: path a second search, and one 13 MB host array (4 096 x 200) measured BIMODAL here (0.6 or 1.8 - 2.2 ms per call for dozens of calls: the host
-    #: allocator's page faults on a fresh mapping of that size) where two 6.5 MB arrays are stable
-    ONE_COPY_MAX_QUERIES = 16384
-    ONE_COPY_MAX_ENTRIES = 262144
-
-    def _search_one_copy(self, node_type, Q64, Q32, a, k, mode, sort_by_score, want_dist):
-        """The fused search (float32 rows, or genuine float64 rows) for a small batch with every output in ONE int64 device buffer and ONE synchronising copy to the
-        host instead of three (flags, ids, scores).  -> the numpy result tuple of `search`, or None when the shape is not the fused search's or some query came back
-        uncertified beyond the on-device exhaustive pass (rare: the caller then takes the tiered path)."""
-        torch = _torch()
-        tt = self.tables[node_type]
-        B = int(Q64.shape[0])
-        f64rows = self.V64 is not None
-        if not (2 <= B <= self.ONE_COPY_MAX_QUERIES and sort_by_score and not self.wide and k <= self._max_k and k <= tt.n) or os.environ.get("HWER_FORCE_EXHAUSTIVE"):
-            return None
-        if f64rows and (mode not in (0, 2) or os.environ.get("HWER_F64ROWS_CANDIDATES")):
-            return None
-        if mode == 2:
-            want_dist = True
-        nk = B * k
-        if nk > self.ONE_COPY_MAX_ENTRIES:
-            return None
-        n_words = 2 * nk + (nk if want_dist else 0) + (B + 1) // 2
-        buf = torch.empty(n_words, dtype=torch.int64, device=self.device)
-        idx, score = buf[:nk].view(B, k), buf[nk:2 * nk].view(torch.float64).view(B, k)
-        off = 2 * nk
-        dist2 = None
-        if want_dist:
-            dist2 = buf[off:off + nk].view(torch.float64).view(B, k)
-            off += nk
-        flags = buf[off:].view(torch.int32)[:B]
-        self._search_f32(tt, Q64, Q32, k, a, mode, True, True, None, want_dist, idx, score, dist2, flags, no_sync=True, f64rows=f64rows)
-        host = buf.cpu().numpy()                      # the one synchronisation of the call
-        flags_h = host[off:].view(np.int32)[:B]
-        if (flags_h == 0).any():
-            return None
-        sc = host[nk:2 * nk].view(np.float64).reshape(B, k)
-        if mode == 1:
-            sc = sc.astype(np.float32)                # exact: the kernel widened float32 values
-        dist = np.sqrt(host[2 * nk:3 * nk].view(np.float64).reshape(B, k)) if want_dist else None
-        return host[:nk].reshape(B, k), sc, dist, flags_h
-
     @_on_device
     def search(self, node_type: str, anchors: np.ndarray, k: int = 200, positive=None, negative=None,
                scoring: str = "base", sort_by_score: bool = True, want_dist: bool = True):
@@ -965,9 +920,9 @@ class DeviceIndex:
                 if flag > 0:
                     return ids.reshape(1, k), sc.reshape(1, k), (np.sqrt(d2).reshape(1, k) if d2 is not None else None), np.asarray([flag], dtype=np.int32)
         Q64, Q32, a = self.build_queries(anchors, positive, negative)
-        one = self._search_one_copy(node_type, Q64, Q32, a, k, mode, sort_by_score, want_dist)
-        if one is not None:
-            return one
+        # (round 6, measured and not kept: every output of a small batch in ONE device buffer and one device-to-host copy instead of three - 943 anchors 0.208 ->
+        # 0.176 ms in a long-lived process, but 0.3 - 0.7 ms for the first dozens of calls of a fresh one: a single fresh 3 MB host array per call sits on the host
+        # allocator's mmap / page-fault path until its thresholds adapt, two 1.5 MB arrays do not; profiles/r6_probe_one_copy.txt)
         fh = []
         idx, score, dist2, flags = self.search_queries(node_type, Q64, Q32, k, a, mode, sort_by_score, want_dist=want_dist, _flags_host_out=fh)
         sc = score.cpu().numpy()

@@ -390,31 +390,3 @@ def test_blend_search_step_f64(hw, U, I, d, T, graph, monkeypatch):
     for a, b in zip(res[True], res[False]):
         assert np.array_equal(a, b)
 
-
-def test_one_copy_batch_path_equals_the_tiered_path(hw):
-    """DeviceIndex.search for 2 .. 16 384 anchors returns every output through ONE device buffer and one device-to-host copy (_search_one_copy): the same arrays as
-    the tiered path (search_queries + separate copies), float32 and float64 rows, with / without distances, GcnNCF scoring; a batch with uncertified queries
-    (600 copies of one row at the cut) falls back to the tiers and still returns the exact result"""
-    from hwer.device_index import DeviceIndex
-    B, N, d, k = 700, 5000, 48, 60
-    X = _plant(_rows64(17, B + N, d), B)
-    rows = {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}
-    for V in (X, X.astype(np.float32)):
-        ix = DeviceIndex(V, rows)
-        for scoring, want in (("base", False), ("base", True), ("gcn", False)):
-            fast = ix.search("item", np.arange(B), k=k, scoring=scoring, want_dist=want)
-            ix.ONE_COPY_MAX_QUERIES = 0
-            slow = ix.search("item", np.arange(B), k=k, scoring=scoring, want_dist=want)
-            del ix.ONE_COPY_MAX_QUERIES
-            for a, b in zip(fast, slow):
-                assert (a is None and b is None) or (a.dtype == b.dtype and np.array_equal(a, b))
-    Y = _rows64(5, 40 + 12000, 32)
-    Y[40 + 100:40 + 700] = Y[40 + 50]
-    for b in range(40):
-        Y[b] = Y[40 + 50] * (1 - 1e-7 * (b + 1)) + 1e-4 * Y[40 + 1000 + b]
-        Y[b] /= np.linalg.norm(Y[b])
-    iy = DeviceIndex(Y, {"user": np.arange(40, dtype=np.int64), "item": np.arange(40, 40 + 12000, dtype=np.int64)})
-    idx, score, dist, flags = iy.search("item", np.arange(40), k=20)
-    assert (flags > 0).all() and (flags == 2).any()
-    o_idx, o_score, o_dist = orc.find_closest(Y, np.arange(40, 40 + 12000), 7, k=20)
-    assert np.array_equal(idx[7], o_idx) and np.array_equal(score[7], o_score) and np.array_equal(dist[7], o_dist)
