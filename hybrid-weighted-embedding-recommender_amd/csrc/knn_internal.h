@@ -141,6 +141,24 @@ __device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_byte_addr) : "memory");
 }
+// the same with a 64-bit per-lane source address (row gathers from tables beyond 4 GB)
+__device__ __forceinline__ void lds_dma16_v(const void* vptr, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vptr), "s"(lds_byte_addr) : "memory");
+}
+// four of them in one statement: pieces p0 .. p3 land at lds_byte_addr + {0, 1, 2, 3} * STRIDE (one save / restore of M0 for the four)
+template <int STRIDE>
+__device__ __forceinline__ void lds_dma16_v4(const void* p0, const void* p1, const void* p2, const void* p3, uint32_t lds_byte_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off\n\t"
+                 "s_add_u32 m0, m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, off\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "s"(lds_byte_addr), "i"(STRIDE) : "memory", "scc");
+}
 __device__ __forceinline__ void lds_dma4(const void* sbase, uint32_t voff, uint32_t lds_byte_addr) {
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"

@@ -913,8 +913,8 @@ static int knn_search_stages(int stages, const float* X, const float* hnorm, int
     if (B == 0) return HWER_OK;
     const bool do_screen = (stages & 1) != 0, do_select = (stages & 2) != 0;
     if (f64 && do_select) {   // genuine float64 rows: values from X64 / A64 (knn_select_f64.hip), the screen on their float32 rounding X
-        if (!f64->X64 || f64->ld64 % 8 != 0 || f64->ld64 < d || (reinterpret_cast<uintptr_t>(f64->X64) & 63))
-            return fail(HWER_EINVAL, "knn_search_f64rows: X64 must be 64-byte aligned with a row stride that is a multiple of 8 and >= d (zero padded)");
+        if (!f64->X64 || f64->ld64 % 8 != 0 || f64->ld64 < d || f64->ld64 > (int64_t(1) << 24) || (reinterpret_cast<uintptr_t>(f64->X64) & 63))
+            return fail(HWER_EINVAL, "knn_search_f64rows: X64 must be 64-byte aligned with a row stride that is a multiple of 8, >= d (zero padded) and <= 2^24");
         if (score_mode != 0 && score_mode != 2) return fail(HWER_EINVAL, "knn_search_f64rows: score_mode must be 0 (float64 scores) or 2 (from the distance)");
         if (score_mode == 0 && (!f64->A64 || f64->lda64 < d)) return fail(HWER_EINVAL, "knn_search_f64rows: A64 (row stride >= d) required for score_mode 0");
     }

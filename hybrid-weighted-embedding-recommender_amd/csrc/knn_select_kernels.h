@@ -188,8 +188,15 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     const cfloat_p a32 = (cfloat_p)(a.A32 ? a.A32 + arow * a.lda : a.X);   // mode 2 never reads it
     const cdouble_p a64 = (cdouble_p)((F64 && a.A64) ? a.A64 + arow * a.lda64 : a.Q64);   // (F64, mode 0)
     // row of the float64 table that holds local item `item` (F64)
-    auto xrow64 = [&](uint32_t item) -> const double* { return a.X64 + (a.x64_rows ? a.x64_rows[item] : int64_t(item)) * a.ld64; };
-    (void)a32; (void)a64; (void)xrow64;
+    // (row strides are < 2^32 bytes - ldx <= 256 floats, ld64 checked by the launchers - and item ids are 32-bit: one v_mad_u64_u32 per row address
+    // where the int64 stride took two and two moves; round 6)
+    const uint32_t ld64_bytes = uint32_t(a.ld64) * 8u, ldx_bytes = uint32_t(a.ldx) * 4u;
+    auto xrow64 = [&](uint32_t item) -> const double* {
+        return a.x64_rows ? a.X64 + a.x64_rows[item] * a.ld64
+                          : reinterpret_cast<const double*>(reinterpret_cast<const char*>(a.X64) + uint64_t(item) * uint64_t(ld64_bytes));
+    };
+    auto xrow32 = [&](uint32_t item) -> const float* { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.X) + uint64_t(item) * uint64_t(ldx_bytes)); };
+    (void)a32; (void)a64; (void)xrow64; (void)xrow32;
     // numpy pairwise structure for this d (d <= 256: at most two leaves)
     const bool two = d > 128;
     int n2 = d / 2;
@@ -271,14 +278,18 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             if constexpr (mode == 0) {
                 const int g8 = c;   // one 8-group of numpy's pairwise leaf per chunk
                 if (g8 < n_groups8) {   // uniform
-                    const bool first = g8 == 0 || g8 == gA;
                     const int jj = 8 * g8;
                     const double p0 = __dmul_rn(a64[jj + 0], xv[0]), p1 = __dmul_rn(a64[jj + 1], xv[1]), p2 = __dmul_rn(a64[jj + 2], xv[2]), p3 = __dmul_rn(a64[jj + 3], xv[3]);
                     const double p4 = __dmul_rn(a64[jj + 4], xv[4]), p5 = __dmul_rn(a64[jj + 5], xv[5]), p6 = __dmul_rn(a64[jj + 6], xv[6]), p7 = __dmul_rn(a64[jj + 7], xv[7]);
-                    if (first) { r0 = p0; r1 = p1; r2 = p2; r3 = p3; r4 = p4; r5 = p5; r6 = p6; r7 = p7; }
-                    else { r0 = __dadd_rn(r0, p0); r1 = __dadd_rn(r1, p1); r2 = __dadd_rn(r2, p2); r3 = __dadd_rn(r3, p3);
-                           r4 = __dadd_rn(r4, p4); r5 = __dadd_rn(r5, p5); r6 = __dadd_rn(r6, p6); r7 = __dadd_rn(r7, p7); }
-                    if (g8 == gA - 1) sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                    // (the chains start from zero: 0 + p = p up to the sign of a zero, which (res + 1) / 2 cannot see; the leaf hand-over is a real branch -
+                    // see the float32-row block below)
+                    r0 = __dadd_rn(r0, p0); r1 = __dadd_rn(r1, p1); r2 = __dadd_rn(r2, p2); r3 = __dadd_rn(r3, p3);
+                    r4 = __dadd_rn(r4, p4); r5 = __dadd_rn(r5, p5); r6 = __dadd_rn(r6, p6); r7 = __dadd_rn(r7, p7);
+                    if (g8 == gA - 1) {
+                        asm volatile("" ::: "memory");
+                        sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                        r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = 0.0;
+                    }
                 }
             }
         }
@@ -288,10 +299,10 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         // transposed through wave-private LDS (row stride 80 B: conflict-free ds_read_b128).
         // (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop in scratch)
         const int srow = lane >> 2, scol = 4 * (lane & 3);
-        const float* src0 = a.X + int64_t(min(cand[min(g0 + 0 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
-        const float* src1 = a.X + int64_t(min(cand[min(g0 + 16 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
-        const float* src2 = a.X + int64_t(min(cand[min(g0 + 32 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
-        const float* src3 = a.X + int64_t(min(cand[min(g0 + 48 + srow, n_r - 1)], a.item_max)) * a.ldx + scol;
+        const float* src0 = xrow32(min(cand[min(g0 + 0 + srow, n_r - 1)], a.item_max)) + scol;
+        const float* src1 = xrow32(min(cand[min(g0 + 16 + srow, n_r - 1)], a.item_max)) + scol;
+        const float* src2 = xrow32(min(cand[min(g0 + 32 + srow, n_r - 1)], a.item_max)) + scol;
+        const float* src3 = xrow32(min(cand[min(g0 + 48 + srow, n_r - 1)], a.item_max)) + scol;
         float* dst = stage + srow * RR_RS + scol;
         // software pipeline: the gathers of chunk c + 1 are in flight while chunk c is reduced in float64
         // (round 3: a second chunk of look-ahead - +16 VGPRs, 128 with a few spilled - measured slower: c2 search 0.155 -> 0.160 ms, c3 4.80 -> 4.99)
@@ -322,30 +333,42 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
             }
             if (!abl_stage) wave_lds_sync();
-            const int j0 = RR_CW * c;
-            if (!need_d2) {
-            } else if (j0 + RR_CW <= d) {   // whole chunk (always, when d is a multiple of 16): straight-line code
+            // Per 8-column group (one 8-group of numpy's pairwise leaf): the candidate's elements are widened ONCE and serve both the distance
+            // chain and the score chains (round 6: the distance and the score blocks each converted them - 16 v_cvt per chunk of a boundary round).
+            // The score chains start from zero and always accumulate: fma(a, x, 0) is the exact product (the only difference from numpy's
+            // r = a * b is the sign of a zero, which (res + 1) / 2 cannot see), so a group has no `first` branch, and the leaf hand-over
+            // (d > 128: two leaves) is a REAL branch - as a select it cost the 7-add reduction tree + 2 v_cndmask per 8-group, 18 of the 70 vector
+            // instructions of a chunk, for a value that is only wanted once per round (round 6, found in the ISA).
 #pragma unroll
-                for (int t = 0; t < RR_CW; ++t) {
-                    const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
-                    acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+            for (int gg = 0; gg < RR_CW / 8; ++gg) {
+                const int g8 = (RR_CW / 8) * c + gg;
+                const int jj = 8 * g8;
+                double xd[8];
+                if constexpr (mode == 0) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) xd[t] = double(xv[8 * gg + t]);
                 }
-            } else {
+                if (need_d2) {   // wave-uniform
+                    if (jj + 8 <= d) {   // whole group (always, when d is a multiple of 8): straight-line code
 #pragma unroll
-                for (int t = 0; t < RR_CW; ++t) {
-                    if (j0 + t < d) {   // uniform
-                        const double tmp = __dsub_rn(q64[j0 + t], double(xv[t]));
-                        acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                        for (int t = 0; t < 8; ++t) {
+                            double xt;
+                            if constexpr (mode == 0) xt = xd[t]; else xt = double(xv[8 * gg + t]);
+                            const double tmp = __dsub_rn(q64[jj + t], xt);
+                            acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) {
+                            if (jj + t < d) {   // uniform (never reads the query beyond its d elements)
+                                const double tmp = __dsub_rn(q64[jj + t], double(xv[8 * gg + t]));
+                                acc = __dadd_rn(acc, __dmul_rn(tmp, tmp));
+                            }
+                        }
                     }
                 }
-            }
-            if constexpr (mode != 2) {
-#pragma unroll
-                for (int gg = 0; gg < RR_CW / 8; ++gg) {
-                    const int g8 = (RR_CW / 8) * c + gg;
+                if constexpr (mode != 2) {
                     if (g8 < n_groups8 && !abl_score) {   // uniform
-                        const bool first = g8 == 0 || g8 == gA;
-                        const int jj = 8 * g8;
                         if constexpr (mode == 0) {
                             // a and x are float32 values, so a * x is EXACT in float64 (48 significant bits): fma(a, x, r) rounds
                             // r + a x once, exactly like numpy's add of the (unrounded-because-exact) product - one instruction less
@@ -358,22 +381,26 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                             // of the next gathers: c2 select 121 -> 125 us, c3 2.12 -> 2.16 ms, profiles/r5_ab_select_scalar_hoist.txt)
                             const double a0 = double(a32[jj + 0]), a1 = double(a32[jj + 1]), a2 = double(a32[jj + 2]), a3 = double(a32[jj + 3]);
                             const double a4 = double(a32[jj + 4]), a5 = double(a32[jj + 5]), a6 = double(a32[jj + 6]), a7 = double(a32[jj + 7]);
-                            const double x0 = double(xv[8 * gg + 0]), x1 = double(xv[8 * gg + 1]), x2 = double(xv[8 * gg + 2]), x3 = double(xv[8 * gg + 3]);
-                            const double x4 = double(xv[8 * gg + 4]), x5 = double(xv[8 * gg + 5]), x6 = double(xv[8 * gg + 6]), x7 = double(xv[8 * gg + 7]);
-                            if (first) { r0 = __dmul_rn(a0, x0); r1 = __dmul_rn(a1, x1); r2 = __dmul_rn(a2, x2); r3 = __dmul_rn(a3, x3);
-                                         r4 = __dmul_rn(a4, x4); r5 = __dmul_rn(a5, x5); r6 = __dmul_rn(a6, x6); r7 = __dmul_rn(a7, x7); }
-                            else { r0 = __fma_rn(a0, x0, r0); r1 = __fma_rn(a1, x1, r1); r2 = __fma_rn(a2, x2, r2); r3 = __fma_rn(a3, x3, r3);
-                                   r4 = __fma_rn(a4, x4, r4); r5 = __fma_rn(a5, x5, r5); r6 = __fma_rn(a6, x6, r6); r7 = __fma_rn(a7, x7, r7); }
-                            if (g8 == gA - 1) sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                            r0 = __fma_rn(a0, xd[0], r0); r1 = __fma_rn(a1, xd[1], r1); r2 = __fma_rn(a2, xd[2], r2); r3 = __fma_rn(a3, xd[3], r3);
+                            r4 = __fma_rn(a4, xd[4], r4); r5 = __fma_rn(a5, xd[5], r5); r6 = __fma_rn(a6, xd[6], r6); r7 = __fma_rn(a7, xd[7], r7);
+                            if (g8 == gA - 1) {   // end of the first leaf (d > 128 only): its sum, and the chains start over
+                                asm volatile("" ::: "memory");   // keeps this a branch: as a select the tree below runs after every group
+                                sA = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                                r0 = r1 = r2 = r3 = r4 = r5 = r6 = r7 = 0.0;
+                            }
                         } else {
                             const float p0 = __fmul_rn((a32[jj + 0]), xv[8 * gg + 0]), p1 = __fmul_rn((a32[jj + 1]), xv[8 * gg + 1]);
                             const float p2 = __fmul_rn((a32[jj + 2]), xv[8 * gg + 2]), p3 = __fmul_rn((a32[jj + 3]), xv[8 * gg + 3]);
                             const float p4 = __fmul_rn((a32[jj + 4]), xv[8 * gg + 4]), p5 = __fmul_rn((a32[jj + 5]), xv[8 * gg + 5]);
                             const float p6 = __fmul_rn((a32[jj + 6]), xv[8 * gg + 6]), p7 = __fmul_rn((a32[jj + 7]), xv[8 * gg + 7]);
-                            if (first) { f0 = p0; f1 = p1; f2 = p2; f3 = p3; f4 = p4; f5 = p5; f6 = p6; f7 = p7; }
-                            else { f0 = __fadd_rn(f0, p0); f1 = __fadd_rn(f1, p1); f2 = __fadd_rn(f2, p2); f3 = __fadd_rn(f3, p3);
-                                   f4 = __fadd_rn(f4, p4); f5 = __fadd_rn(f5, p5); f6 = __fadd_rn(f6, p6); f7 = __fadd_rn(f7, p7); }
-                            if (g8 == gA - 1) fA = ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7));
+                            // (0 + p = p: the chains start from zero, see above)
+                            f0 = __fadd_rn(f0, p0); f1 = __fadd_rn(f1, p1); f2 = __fadd_rn(f2, p2); f3 = __fadd_rn(f3, p3);
+                            f4 = __fadd_rn(f4, p4); f5 = __fadd_rn(f5, p5); f6 = __fadd_rn(f6, p6); f7 = __fadd_rn(f7, p7);
+                            if (g8 == gA - 1) {
+                                asm volatile("" ::: "memory");
+                                fA = ((f0 + f1) + (f2 + f3)) + ((f4 + f5) + (f6 + f7));
+                                f0 = f1 = f2 = f3 = f4 = f5 = f6 = f7 = 0.f;
+                            }
                         }
                     }
                 }
@@ -382,7 +409,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         }   // !F64
         if (COOP && g0 == 0) SEL_STAMP(9);
         double sco;
-        const float* xr = a.X + int64_t(it) * a.ldx;
+        const float* xr = xrow32(it);
         (void)xr;
         if constexpr (mode == 0 && F64) {
             double res = n_groups8 > 0 ? ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) : 0.0;
@@ -478,7 +505,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                     d2 = __dadd_rn(d2, __dmul_rn(tmp, tmp));
                 }
             } else {
-                const float* xr = a.X + int64_t(min(cand[slot], a.item_max)) * a.ldx;
+                const float* xr = xrow32(min(cand[slot], a.item_max));
                 for (int j = 0; j < d; ++j) {
                     const double tmp = __dsub_rn(q64[j], double(xr[j]));
                     d2 = __dadd_rn(d2, __dmul_rn(tmp, tmp));
