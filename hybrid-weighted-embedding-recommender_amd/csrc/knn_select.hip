@@ -641,7 +641,7 @@ static unsigned long long* sel_stamps_buffer(int64_t B) {
             int64_t nr = 0;
             for (int64_t q = 0; q < buf_B; ++q) {
                 const unsigned long long* t = &h[size_t(q) * 16];
-                if (!(t[12] && t[13] && t[14] && t[15]) || t[6] <= t[0]) continue;
+                if (!(t[12] && t[13] && t[14] && t[15]) || t[6] <= t[0] || (t[15] >> 62)) continue;
                 if (t[7] && t[8] && t[9]) { rr[0] += double(t[7] - t[3]); rr[1] += double(t[8] - t[7]); rr[2] += double(t[9] - t[8]); rr[3] += double(t[12] - t[9]); }
                 r[0] += double(t[12] - t[3]); r[1] += double(t[13] - t[12]); r[2] += double(t[14] - t[13]); r[3] += double(t[15] - t[14]); r[4] += double(t[4] - t[15]);
                 ++nr;
@@ -650,6 +650,18 @@ static unsigned long long* sel_stamps_buffer(int64_t B) {
                             (long long)nr, r[0] / nr, r[1] / nr, r[2] / nr, r[3] / nr, r[4] / nr);
             if (nr && rr[1] > 0) fprintf(stderr, "[select stamps]   inside wave 0's rounds: set-up + first gathers issued=%.0f until the first chunk is staged=%.0f rest of the chunk loop=%.0f score + table writes=%.0f\n",
                                          rr[0] / nr, rr[1] / nr, rr[2] / nr, rr[3] / nr);
+        }
+        {   // wave-per-query forms: the chunk loop of the re-rank rounds by part (accumulated per query)
+            double ck[5] = {0, 0, 0, 0, 0};
+            int64_t nq = 0;
+            for (int64_t q = 0; q < buf_B; ++q) {
+                const unsigned long long* t = &h[size_t(q) * 16];
+                if (!(t[15] >> 62)) continue;
+                ck[0] += double(t[12]); ck[1] += double(t[13]); ck[2] += double(t[14]); ck[3] += double(t[15] & 0xFF); ck[4] += double((t[15] & ~(3ull << 62)) >> 8);
+                ++nq;
+            }
+            if (nq) fprintf(stderr, "[select stamps]   chunk loop of %lld queries (%.1f chunks each), cycles per query: wait for the chunk's pieces=%.0f LDS reads=%.0f widen + chains (scalar operand loads included)=%.0f round set-up=%.0f\n",
+                            (long long)nq, ck[3] / nq, ck[0] / nq, ck[1] / nq, ck[2] / nq, ck[4] / nq);
         }
         if (nt) fprintf(stderr, "[select stamps]   tail of %lld lazy queries: boundary-rank=%.0f keys=%.0f sort=%.0f fixup=%.0f\n", (long long)nt, tail[0] / nt, tail[1] / nt, tail[2] / nt, tail[3] / nt);
         if (n) fprintf(stderr, "[select stamps] queries=%lld cycles/query: load+minmax=%.0f rank-search=%.0f collect=%.0f rerank-rounds=%.0f sorts=%.0f emit=%.0f total=%.0f\n",

@@ -110,6 +110,7 @@ struct EmitArgs {
 #ifdef HWER_DIAG_STAMPS
 #define SEL_STAMP(slot) do { if (a_stamps && (threadIdx.x & 63) == 0) { unsigned long long t_; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); __builtin_amdgcn_sched_barrier(0); a_stamps[(slot)] = t_; \
     if ((slot) == 0) a_stamps[10] = __builtin_amdgcn_s_memrealtime(); if ((slot) == 6) a_stamps[11] = __builtin_amdgcn_s_memrealtime(); } } while (0)   /* 10 / 11: start / end in 10-ns ticks (one clock for the whole chip) */
+#define CK_NOW(x) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SEL_STAMP(slot) do { } while (0)
 #endif
@@ -122,13 +123,43 @@ struct EmitArgs {
 // ---------------------------------------------------------------------------------------------------
 constexpr int RR_CW = 16;            // columns per re-rank step
 constexpr int RR_RS = RR_CW + 4;     // LDS row stride of the staging area in floats (5 x 16 B: odd -> conflict-free ds_read_b128)
+// Round 6: the staging area is filled by LDS-DMA (global_load_lds_dwordx4: no register destination, no ds_write_b128 - that store costs ~13 LDS
+// cycles per wave-instruction against 4 for the ds_read_b128 that takes the transposed rows back out, MI355X_MICROARCH.md, LDS).  A DMA
+// instruction writes its 64 x 16 bytes lane-linearly (1 KiB, no padding), so the conflict-free image comes from WHICH row a lane fetches:
+// piece b (b = 0 .. 3, at byte b * RR_PIECE) holds 16 rows x 64 B; the candidate that reader lane l takes out sits in piece m >> 2 at row
+// 4 g + (m & 3), where g is l's ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, the same + 32) and m its position in the
+// group: the 16 lanes of a group then read 16-byte slots (b + 4 (m & 3) + t) mod 16 - all different - of the 256-byte bank row.
+#ifndef HWER_SELECT_GLDS
+#define HWER_SELECT_GLDS 1
+#endif
+constexpr int RR_PIECE = 1024 + 16;  // byte distance of the four 1-KiB DMA pieces (one 16-byte slot of skew per piece)
+constexpr int RR_BUF = 4160;         // one chunk's four pieces (3 * RR_PIECE + 1024 = 4144, rounded to 64 bytes)
+static_assert(3 * RR_PIECE + 1024 <= RR_BUF && RR_BUF <= 64 * RR_RS * 4, "the four DMA pieces fit the staging area");
+// Chunk buffers per wave of the COOP form (one query per workgroup, few workgroups: LDS is plentiful).  Two - the DMA two chunks ahead of the
+// arithmetic - were built and measured: c1's chunk loop 6 463 -> 6 446 cycles per query, step 0.0481 -> 0.0490 ms; a chunk's time is not its
+// gather (the in-loop stamps: 11 % waiting for the pieces, 79 % in the arithmetic part with its scalar operand loads; profiles/r6_ab_select_rounds.txt).
+constexpr int RR_COOP_NBUF = 1;
+constexpr int RR_COOP_STAGE = (HWER_SELECT_GLDS && RR_COOP_NBUF > 1) ? RR_COOP_NBUF * RR_BUF : 64 * RR_RS * 4;   // staging bytes per wave of the COOP form
+// reader lane l -> (group g, member m)
+__device__ __forceinline__ void rr_reader_gm(int l, int& g, int& m) {
+    const int x = l & 31;
+    const bool odd = (x >= 4 && x < 12) || (x >= 16 && x < 20) || x >= 28;
+    g = 2 * (l >> 5) + (odd ? 1 : 0);
+    m = odd ? (x < 12 ? x - 4 : (x < 20 ? x - 8 : x - 16)) : (x < 4 ? x : (x < 16 ? x - 8 : x - 12));
+}
+// (group g, member m) -> reader lane
+__device__ __forceinline__ int rr_reader_lane(int g, int m) {
+    const int base = 32 * (g >> 1);
+    if (g & 1) return base + (m < 8 ? m + 4 : (m < 12 ? m + 8 : m + 16));
+    return base + (m < 4 ? m : (m < 8 ? m + 8 : m + 12));
+}
 __host__ __device__ inline size_t wave_lds_bytes(int d, int kp) {
     (void)d;
     return size_t(kp) * (8 + 8 + 4) + size_t(64) * RR_RS * 4;
 }
 // COOP variant: ONE query per 256-thread workgroup - the four waves share the query's tables and split the re-rank rounds
 // (one staging area per wave); for launches with so few queries that a wave per query leaves most of the chip idle
-__host__ __device__ inline size_t coop_lds_bytes(int d, int kp) { return wave_lds_bytes(d, kp) + size_t(3) * 64 * RR_RS * 4; }
+__host__ __device__ inline size_t coop_lds_bytes(int d, int kp) { (void)d; return size_t(kp) * (8 + 8 + 4) + size_t(4) * RR_COOP_STAGE; }
 
 // F64ROWS: the keys were computed on the float32 ROUNDING of float64 rows, the values come from the float64 rows: rounding moves q.x by at most
 // ||q|| 2^-24 ||x|| and 0.5 ||x||^2 by at most 2^-24 ||x||^2 (1 + 2^-25), i.e. the true key by <= 2^-24 (||q|| ||x||max + 2 hnorm_max) (1 + tiny)
@@ -172,7 +203,8 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     double* t_d2 = reinterpret_cast<double*>(lds);
     double* t_sc = t_d2 + kp;
     uint32_t* cand = reinterpret_cast<uint32_t*>(t_sc + kp);
-    float* stage = reinterpret_cast<float*>(cand + kp) + coop_wave * (64 * RR_RS);
+    constexpr int NBUF = COOP ? RR_COOP_NBUF : 1;   // chunk buffers of this wave's staging area
+    float* stage = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(cand + kp) + coop_wave * (COOP ? RR_COOP_STAGE : 64 * RR_RS * 4));
 
     // The query and the anchor row are wave-uniform: they are read with SCALAR loads straight from global memory and
     // enter the float64 arithmetic as SGPR operands.  (Broadcasting them from LDS costs a full 1-KiB LDS return per
@@ -208,7 +240,20 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
     constexpr int CW = F64 ? 8 : RR_CW;   // columns per step: one 64-byte segment of a row
     const int n_chunks = (d + CW - 1) / CW;
     const bool lazy = a.out_dist2 == nullptr && a.sort_by_score && mode != 2 && n_b < n_r;
+#if HWER_SELECT_GLDS
+    // LDS-DMA staging maps (see RR_PIECE): what this lane fetches for the four pieces, and where it reads its own candidate's row
+    const int fq = lane & 3;
+    const int fl0 = rr_reader_lane(lane >> 4, 0 + ((lane >> 2) & 3)), fl1 = rr_reader_lane(lane >> 4, 4 + ((lane >> 2) & 3));
+    const int fl2 = rr_reader_lane(lane >> 4, 8 + ((lane >> 2) & 3)), fl3 = rr_reader_lane(lane >> 4, 12 + ((lane >> 2) & 3));
+    int rd_g, rd_m;
+    rr_reader_gm(lane, rd_g, rd_m);
+    const unsigned char* const rd = reinterpret_cast<const unsigned char*>(stage) + (rd_m >> 2) * RR_PIECE + 64 * (4 * rd_g + (rd_m & 3));
+    const uint32_t stage_lds = uint32_t(__builtin_amdgcn_readfirstlane(int(lds_addr(stage))));
+#endif
 
+#ifdef HWER_DIAG_STAMPS
+    unsigned long long ck_vm = 0, ck_lds = 0, ck_cmp = 0, ck_n = 0, ck_pro = 0;   // chunk-loop time by part (wave-per-query forms: stamp slots 12 - 15)
+#endif
 #pragma unroll 1
     for (int g0 = 64 * coop_wave; g0 < ((a.debug_skip & 1) ? 0 : n_r); g0 += COOP ? 256 : 64) {   // wave-uniform rounds of 64 candidates
 #ifdef HWER_DIAG_STAMPS   // ablation of the round's ingredients (HWER_SELECT_SKIP bits 8 no distances, 16 no score arithmetic, 32 no row gathers, 64 no LDS staging)
@@ -217,6 +262,10 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
 #else
         const bool need_d2 = !lazy || g0 < n_b;   // wave-uniform
         constexpr bool abl_score = false, abl_gather = false, abl_stage = false;
+#endif
+#ifdef HWER_DIAG_STAMPS
+        unsigned long long ckr0, ckr1;
+        CK_NOW(ckr0);
 #endif
         const int ci = g0 + lane;
         const bool live = ci < n_r;
@@ -227,6 +276,31 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         if constexpr (F64) {
         // the same staging map for 8-byte elements: 4 lanes x 16 B (two doubles) per row = the 64-byte segment of an 8-column chunk, 16 rows per
         // instruction, 4 instructions per chunk, transposed through the same wave-private LDS area (row stride 80 B = 10 doubles)
+#if HWER_SELECT_GLDS
+        const double* src0 = xrow64(min(cand[min(g0 + fl0, n_r - 1)], a.item_max)) + 2 * fq;
+        const double* src1 = xrow64(min(cand[min(g0 + fl1, n_r - 1)], a.item_max)) + 2 * fq;
+        const double* src2 = xrow64(min(cand[min(g0 + fl2, n_r - 1)], a.item_max)) + 2 * fq;
+        const double* src3 = xrow64(min(cand[min(g0 + fl3, n_r - 1)], a.item_max)) + 2 * fq;
+        lds_dma16_v4<RR_PIECE>(src0, src1, src2, src3, stage_lds);
+        if (NBUF == 2 && n_chunks > 1) lds_dma16_v4<RR_PIECE>(src0 + CW, src1 + CW, src2 + CW, src3 + CW, stage_lds + RR_BUF);
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            // the chunk's four pieces have landed (the DMA is invisible to hipcc's counters; loads retire in order: 4 = the next chunk's pieces)
+            if (NBUF == 2 && c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned char* const rdc = rd + (NBUF == 2 ? (c & 1) * RR_BUF : 0);
+            double xv[CW];
+#pragma unroll
+            for (int t = 0; t < CW / 2; ++t) {
+                const double2 v = *reinterpret_cast<const double2*>(rdc + 16 * t);
+                xv[2 * t] = v.x; xv[2 * t + 1] = v.y;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are in registers: the next pieces may overwrite them
+            if (c + NBUF < n_chunks) {   // (ld64 is a multiple of 8: the last chunk's loads stay inside the row's zero padding)
+                const int o = CW * (c + NBUF);
+                lds_dma16_v4<RR_PIECE>(src0 + o, src1 + o, src2 + o, src3 + o, stage_lds + (NBUF == 2 ? (c & 1) * RR_BUF : 0));
+            }
+#else
         constexpr int RS64 = RR_RS / 2;
         const int srow = lane >> 2, scol = 2 * (lane & 3);
         const double* src0 = xrow64(min(cand[min(g0 + 0 + srow, n_r - 1)], a.item_max)) + scol;
@@ -258,6 +332,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 xv[2 * t] = v.x; xv[2 * t + 1] = v.y;
             }
             wave_lds_sync();
+#endif
             const int j0 = CW * c;
             if (!need_d2) {
             } else if (j0 + CW <= d) {   // whole chunk: straight-line code
@@ -298,6 +373,50 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
         // would use a quarter of each access), 16 rows per instruction, 4 instructions per 16-column chunk; the rows are
         // transposed through wave-private LDS (row stride 80 B: conflict-free ds_read_b128).
         // (named scalars, not arrays: hipcc leaves small arrays touched inside a rolled loop in scratch)
+#if HWER_SELECT_GLDS
+        // (diagnostic mask 32: the rows of the candidate SLOTS instead of the candidates' - 256 rows that stay in L2, distinct per slot so that no
+        // ties appear: what the select costs when its gathers never leave the L2)
+        const float* src0 = xrow32(min(abl_gather ? uint32_t(g0 + fl0) : cand[min(g0 + fl0, n_r - 1)], a.item_max)) + 4 * fq;
+        const float* src1 = xrow32(min(abl_gather ? uint32_t(g0 + fl1) : cand[min(g0 + fl1, n_r - 1)], a.item_max)) + 4 * fq;
+        const float* src2 = xrow32(min(abl_gather ? uint32_t(g0 + fl2) : cand[min(g0 + fl2, n_r - 1)], a.item_max)) + 4 * fq;
+        const float* src3 = xrow32(min(abl_gather ? uint32_t(g0 + fl3) : cand[min(g0 + fl3, n_r - 1)], a.item_max)) + 4 * fq;
+        // software pipeline: the DMA of chunk c + 1 is in flight while chunk c is reduced in float64
+        lds_dma16_v4<RR_PIECE>(src0, src1, src2, src3, stage_lds);
+        if (NBUF == 2 && n_chunks > 1) lds_dma16_v4<RR_PIECE>(src0 + RR_CW, src1 + RR_CW, src2 + RR_CW, src3 + RR_CW, stage_lds + RR_BUF);
+        if (COOP && g0 == 0) SEL_STAMP(7);
+#ifdef HWER_DIAG_STAMPS
+        CK_NOW(ckr1);
+        ck_pro += ckr1 - ckr0;
+#endif
+#pragma unroll 1
+        for (int c = 0; c < n_chunks; ++c) {
+            // the chunk's four pieces have landed (the DMA is invisible to hipcc's counters; loads retire in order: 4 = the next chunk's pieces)
+#ifdef HWER_DIAG_STAMPS
+            unsigned long long ck0, ck1, ck2, ck3;
+            CK_NOW(ck0);
+#endif
+            if (NBUF == 2 && c + 1 < n_chunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef HWER_DIAG_STAMPS
+            CK_NOW(ck1);
+#endif
+            if (COOP && g0 == 0 && c == 0) SEL_STAMP(8);
+            const unsigned char* const rdc = rd + (NBUF == 2 ? (c & 1) * RR_BUF : 0);
+            float xv[RR_CW];
+#pragma unroll
+            for (int t = 0; t < RR_CW / 4; ++t) {
+                const float4 v = *reinterpret_cast<const float4*>(rdc + 16 * t);
+                xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the rows are in registers: the next pieces may overwrite them
+#ifdef HWER_DIAG_STAMPS
+            CK_NOW(ck2);
+#endif
+            if (c + NBUF < n_chunks) {
+                const int o = RR_CW * (c + NBUF);
+                lds_dma16_v4<RR_PIECE>(src0 + o, src1 + o, src2 + o, src3 + o, stage_lds + (NBUF == 2 ? (c & 1) * RR_BUF : 0));
+            }
+#else
         const int srow = lane >> 2, scol = 4 * (lane & 3);
         const float* src0 = xrow32(min(cand[min(g0 + 0 + srow, n_r - 1)], a.item_max)) + scol;
         const float* src1 = xrow32(min(cand[min(g0 + 16 + srow, n_r - 1)], a.item_max)) + scol;
@@ -333,6 +452,7 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                 xv[4 * t] = v.x; xv[4 * t + 1] = v.y; xv[4 * t + 2] = v.z; xv[4 * t + 3] = v.w;
             }
             if (!abl_stage) wave_lds_sync();
+#endif
             // Per 8-column group (one 8-group of numpy's pairwise leaf): the candidate's elements are widened ONCE and serve both the distance
             // chain and the score chains (round 6: the distance and the score blocks each converted them - 16 v_cvt per chunk of a boundary round).
             // The score chains start from zero and always accumulate: fma(a, x, 0) is the exact product (the only difference from numpy's
@@ -379,8 +499,14 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                             // (also measured and not kept: the chunk's 16 anchor floats requested at the top of the step, in front of the wait for the
                             // gathered rows, so that their scalar-cache latency hides under it - 105 more spilled SGPRs and a full lgkmcnt drain in front
                             // of the next gathers: c2 select 121 -> 125 us, c3 2.12 -> 2.16 ms, profiles/r5_ab_select_scalar_hoist.txt)
+#ifdef HWER_ABL_NO_A32   // timing experiment only (wrong scores): no scalar loads of the anchor row
+                            const double a0 = xd[1], a1 = xd[2], a2 = xd[3], a3 = xd[4], a4 = xd[5], a5 = xd[6], a6 = xd[7], a7 = xd[0];
+#else
+                            // (round 6, measured and NOT kept: the anchor row staged behind the chunk buffer and read back as four broadcast ds_read_b128 beside
+                            // the candidate rows - no scalar loads in the chunk: c3 select -2 %, c2 +2 %, c1 +7 %; profiles/r6_ab_select_rounds.txt)
                             const double a0 = double(a32[jj + 0]), a1 = double(a32[jj + 1]), a2 = double(a32[jj + 2]), a3 = double(a32[jj + 3]);
                             const double a4 = double(a32[jj + 4]), a5 = double(a32[jj + 5]), a6 = double(a32[jj + 6]), a7 = double(a32[jj + 7]);
+#endif
                             r0 = __fma_rn(a0, xd[0], r0); r1 = __fma_rn(a1, xd[1], r1); r2 = __fma_rn(a2, xd[2], r2); r3 = __fma_rn(a3, xd[3], r3);
                             r4 = __fma_rn(a4, xd[4], r4); r5 = __fma_rn(a5, xd[5], r5); r6 = __fma_rn(a6, xd[6], r6); r7 = __fma_rn(a7, xd[7], r7);
                             if (g8 == gA - 1) {   // end of the first leaf (d > 128 only): its sum, and the chains start over
@@ -405,6 +531,10 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
                     }
                 }
             }
+#ifdef HWER_DIAG_STAMPS
+            CK_NOW(ck3);
+            ck_vm += ck1 - ck0; ck_lds += ck2 - ck1; ck_cmp += ck3 - ck2; ++ck_n;
+#endif
         }
         }   // !F64
         if (COOP && g0 == 0) SEL_STAMP(9);
@@ -435,6 +565,11 @@ __device__ __forceinline__ void wave_rerank_emit_t(const EmitArgs& a, int64_t b,
             t_sc[ci] = sco;
         }
     }
+#ifdef HWER_DIAG_STAMPS
+    if (!COOP && a_stamps && lane == 0 && ck_n) {   // (slot 15's top bit tells these from the one-workgroup-per-query stamps)
+        a_stamps[12] = ck_vm; a_stamps[13] = ck_lds; a_stamps[14] = ck_cmp; a_stamps[15] = (1ull << 62) | (ck_pro << 8) | ck_n;
+    }
+#endif
     // COOP, usual (lazy, one-round boundary, <= 256 candidates) case: the whole workgroup puts the candidates in score order - one
     // candidate per thread, position = number of keys below its own, counted over the 256 keys in LDS (independent broadcast
     // reads instead of the 36 dependent exchange stages of a register sort by one wave: 12.4 K -> ~4 K cycles) - and wave 0 only
@@ -830,6 +965,7 @@ __global__ __launch_bounds__(256, MAXV <= 16 ? 4 : 2) void select_dense_kernel(c
     uint32_t* cand_item = reinterpret_cast<uint32_t*>(lds_emit + size_t(kp) * 16);
     const float4* row = reinterpret_cast<const float4*>(a.keys + b * a.ld);
     const int n4 = int(a.ld / 4);
+
     // COOP: wave w owns slices w, w + 4, ...: MV = MAXV / 4 per lane; s_x = the workgroup's exchange words
     constexpr int MV = COOP ? (MAXV + 3) / 4 : MAXV;
     __shared__ float s_mm[COOP ? 8 : 1];

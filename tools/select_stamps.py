@@ -12,6 +12,6 @@ try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", c, "--no-cpu-baseline", "--no-graph", "--sweep-only", "--steps", "6", "--warmup", "2",
                             "--detail-out", os.path.join(ROOT, "gpurun_out", "stamps_%s.json" % c)], env=env, capture_output=True, text=True, timeout=600)
         lines = [l for l in r.stderr.splitlines() if l.startswith("[select stamps]")]
-        print(c, "\n".join(lines[-4:]) if lines else "no stamps: " + r.stderr[-300:], flush=True)
+        print(c, "\n".join(lines[-6:]) if lines else "no stamps: " + r.stderr[-300:], flush=True)
 finally:
     shutil.copy(keep, os.path.join(L, "libhwer_hip.so"))
