@@ -44,7 +44,7 @@ class BlendSearchStep:
     def __init__(self, tables: Sequence, alpha, search_row0: int, n_search: int, other_row0: int, n_other: int, anchors, k: int = 200,
                  id_base: Optional[int] = None, arith: int = 0, want_dist: bool = False, sort_by_score: bool = True,
                  f16_screen: Optional[bool] = None, f16_dense: bool = False, n_sets: int = 1, extra_options: int = 0,
-                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = False, eps: float = 1e-4,
+                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: Optional[bool] = None, eps: float = 1e-4,
                  search_ids=None, other_ids=None, pipeline: Optional[bool] = None, tail_under_select: Optional[bool] = None):
         import torch
         lib = self.lib = native.lib()
@@ -110,7 +110,7 @@ class BlendSearchStep:
             self.sets = [dict(idx=torch.empty((B, K), dtype=torch.int64, device=dev), score=torch.empty((B, K), dtype=torch.float64, device=dev),
                               dist2=torch.empty((B, K), dtype=torch.float64, device=dev) if want_dist else None,
                               flags=torch.empty(B, dtype=torch.int32, device=dev)) for _ in range(n_sets)]
-            self.CH = QUERY_CHUNK
+            self.CH = int(os.environ.get("HWER_QUERY_CHUNK", QUERY_CHUNK))     # (the override is for chunk-size experiments)
             self.opts = (KNN_F16_SCREEN if self.f16_screen else 0) | int(extra_options)
             ws_bytes = max(lib.hwer_knn_workspace_bytes_opts(min(B, self.CH), I, d, K, self.opts),
                            lib.hwer_knn_workspace_bytes_opts(1, I, d, K, 0), lib.hwer_knn_workspace_bytes_opts(min(B, 64), I, d, K, 0))
@@ -126,12 +126,18 @@ class BlendSearchStep:
             # sitting on a SIMD keeps the second one out - a workgroup that starts late still needs its full 2.1 ms, so the step was
             # bimodal (rocprofv3: the main screen 2.19 ... 3.97 ms; steps of 4.96 or 6.2 ms, with or without stream priorities).
             # One search after the other: 5.05 ms, every step.
+            # Round 6: ON again by default (tail_stream=None) - with the ping-pong screen of rounds 4-5 (one 512-thread workgroup per CU) and the rebuilt
+            # select the side-by-side step is 3 - 4 % faster than one search after the other and no longer bimodal: c3 over 300 steps, same box,
+            # 4.29 - 4.35 ms (max 4.48 - 4.52) against 4.48 (max 4.68); smaller main chunks (98 304 / 69 632 + a longer tail) are slower, 4.79 / 5.06
+            # (profiles/r6_ab_c3_tail_stream.txt).
             # Round 5 experiment, OFF by default: tail_under_select=True makes the side stream wait for the main chunk's screen launch
             # (hwer_knn_screen_f32 / hwer_knn_select_f32: the search as two stream-ordered calls) and runs the short last search beside
             # the main SELECT, whose workgroups are small (256 threads, 128 VGPRs).  Measured at c3 (profiles/r5_ab_c3.txt, rocprofv3
             # timeline): the tail's 512-thread / 169-VGPR screen workgroups are not dispatched while the select's 34 000 workgroups keep
             # every SIMD's register file full - the 158 us launch stretches to the select's whole 1.96 ms whatever the stream priorities -
             # and its list merge and select still run behind the main select: 4.81 -> 4.76 ms, inside the noise.
+            if tail_stream is None:
+                tail_stream = B > self.CH and B % self.CH != 0 and not tail_under_select and not pipeline
             self.tail_under_select = bool(tail_under_select) and B > self.CH and B % self.CH != 0 and not tail_stream and not pipeline
             self.tail = B % self.CH if (B > self.CH and (tail_stream or self.tail_under_select)) else 0
             self.overlap_tail = True
@@ -150,6 +156,7 @@ class BlendSearchStep:
                 self.side = torch.cuda.Stream(device=dev, priority=0)
                 self.main_hi = torch.cuda.Stream(device=dev, priority=-1)
                 self.ws_tail = torch.empty(lib.hwer_knn_workspace_bytes_opts(self.tail, I, d, K, self.opts), dtype=torch.uint8, device=dev)
+                native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws_tail), self.ws_tail.numel(), self.S()), "knn_workspace_init")
                 self.ws_exact_tail = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
         # rows pass the eps unit-norm audit (checked by `check()` after the step) => 0.5||x||^2 <= 0.5 (1 + eps)^2
         self.hnorm_max = 0.5 * (1.0 + self.eps) ** 2
@@ -482,6 +489,15 @@ class BlendSearchStepF64:
             native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws), self.ws.numel(), self.S()), "knn_workspace_init")
             self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
             self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
+            # more anchors than one search takes (ML-20M shape: 131 072 + 7 421): the short last search runs on a second stream, beside the main
+            # one, with its own workspaces (BlendSearchStep's tail_stream, on by default since round 6)
+            self.tail = B % self.CH if (B > self.CH and B % self.CH != 0 and not os.environ.get("HWER_NO_TAIL_STREAM")) else 0
+            if self.tail:
+                self.side = torch.cuda.Stream(device=dev, priority=0)
+                self.main_hi = torch.cuda.Stream(device=dev, priority=-1)
+                self.ws_tail = torch.empty(lib.hwer_knn_workspace_bytes_opts(self.tail, I, d, K, self.opts), dtype=torch.uint8, device=dev)
+                native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws_tail), self.ws_tail.numel(), self.S()), "knn_workspace_init")
+                self.ws_exact_tail = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
         self.hnorm_max = 0.5 * (1.0 + self.eps) ** 2
         self.x16_exp = int(lib.hwer_knn_f16_scale_exp(self.hnorm_max)) if self.f16_screen else 0
         self.id_base = self.search_row0 if id_base is None else int(id_base)
@@ -520,17 +536,33 @@ class BlendSearchStepF64:
         o = self.sets[0] if o is None else o
         oi, osc, od, of = o["idx"], o["score"], o["dist2"], o["flags"]
         A64 = P(self.V64) if self.score_mode != 2 else None
-        for b0 in range(0, self.B, self.CH):
-            b1 = min(self.B, b0 + self.CH)
+
+        def search(b0, b1, ws, ws_exact):   # on the CURRENT torch stream
             native.check(lib.hwer_knn_search_f64rows(
                 P(self.X), P(self.hnorm), self.I, self.d, self.ldx, P(self.Q32[b0:b1]), P(self.Q64[b0:b1]), P(self.X64), self.ld64, None, A64,
                 self.ld64, P(self.anchors[b0:b1]), b1 - b0, K, self.score_mode, self.sort_by_score, None, self.id_base, self.hnorm_max, P(oi[b0:b1]),
-                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws), self.ws.numel(),
+                P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(ws), ws.numel(),
                 self.opts | (KNN_QUERIES_READY if self.fused_fragments else 0), P(self.X16), self.x16_exp, self.S()), "knn_search_f64rows")
             native.check(lib.hwer_knn_exact_device_f64rows(
                 P(self.X64), self.ld64, None, self.I, self.d, P(self.Q64[b0:b1]), A64, self.ld64, P(self.anchors[b0:b1]), K, self.score_mode,
-                self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(self.ws),
-                P(self.missed), P(self.ws_exact), self.ws_exact.numel(), self.S()), "knn_exact_device_f64rows")
+                self.sort_by_score, None, self.id_base, P(oi[b0:b1]), P(osc[b0:b1]), P(od[b0:b1]) if od is not None else None, P(of[b0:b1]), P(ws),
+                P(self.missed), P(ws_exact), ws_exact.numel(), self.S()), "knn_exact_device_f64rows")
+
+        if self.tail:   # the short last search on the second stream, the main chunks beside it on the high-priority one
+            torch = self.torch
+            cur = torch.cuda.current_stream(self.dev)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                search(self.B - self.tail, self.B, self.ws_tail, self.ws_exact_tail)
+            self.main_hi.wait_stream(cur)
+            with torch.cuda.stream(self.main_hi):
+                for b0 in range(0, self.B - self.tail, self.CH):
+                    search(b0, min(self.B - self.tail, b0 + self.CH), self.ws, self.ws_exact)
+            cur.wait_stream(self.main_hi)
+            cur.wait_stream(self.side)
+            return
+        for b0 in range(0, self.B, self.CH):
+            search(b0, min(self.B, b0 + self.CH), self.ws, self.ws_exact)
 
     def step(self, o=None, mark=None):
         self.stage_blend()
