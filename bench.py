@@ -248,7 +248,7 @@ def make_workload_class():
                              want_dist=want_dist, sort_by_score=not local_order, f16_screen=False if f32_screen else None, f16_dense=f16_dense,
                              n_sets=n_sets, extra_options=int(env("HWER_BENCH_OPTS", "0")),     # A/B runs: e.g. 16 = HWER_KNN_NO_SEED
                              fused_blend=True if env("HWER_BENCH_FORCE_FUSED_BLEND") else (False if env("HWER_BENCH_NO_FUSED_BLEND") else None),
-                             fused_prologue=False if env("HWER_BENCH_NO_FUSED_PROLOGUE") else None, tail_stream=(env("HWER_BENCH_TAIL_STREAM") != "0") if env("HWER_BENCH_TAIL_STREAM") else None,
+                             fused_prologue=False if env("HWER_BENCH_NO_FUSED_PROLOGUE") else None, tail_stream=bool(env("HWER_BENCH_TAIL_STREAM")) and env("HWER_BENCH_TAIL_STREAM") != "0",
                              tail_under_select=bool(env("HWER_BENCH_TAIL_UNDER_SELECT")),
                              pipeline=bool(env("HWER_BENCH_PIPELINE")))
 

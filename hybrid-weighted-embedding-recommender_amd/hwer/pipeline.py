@@ -44,7 +44,7 @@ class BlendSearchStep:
     def __init__(self, tables: Sequence, alpha, search_row0: int, n_search: int, other_row0: int, n_other: int, anchors, k: int = 200,
                  id_base: Optional[int] = None, arith: int = 0, want_dist: bool = False, sort_by_score: bool = True,
                  f16_screen: Optional[bool] = None, f16_dense: bool = False, n_sets: int = 1, extra_options: int = 0,
-                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: Optional[bool] = None, eps: float = 1e-4,
+                 fused_blend: Optional[bool] = None, fused_prologue: Optional[bool] = None, tail_stream: bool = False, eps: float = 1e-4,
                  search_ids=None, other_ids=None, pipeline: Optional[bool] = None, tail_under_select: Optional[bool] = None):
         import torch
         lib = self.lib = native.lib()
@@ -126,18 +126,17 @@ class BlendSearchStep:
             # sitting on a SIMD keeps the second one out - a workgroup that starts late still needs its full 2.1 ms, so the step was
             # bimodal (rocprofv3: the main screen 2.19 ... 3.97 ms; steps of 4.96 or 6.2 ms, with or without stream priorities).
             # One search after the other: 5.05 ms, every step.
-            # Round 6: ON again by default (tail_stream=None) - with the ping-pong screen of rounds 4-5 (one 512-thread workgroup per CU) and the rebuilt
-            # select the side-by-side step is 3 - 4 % faster than one search after the other and no longer bimodal: c3 over 300 steps, same box,
-            # 4.29 - 4.35 ms (max 4.48 - 4.52) against 4.48 (max 4.68); smaller main chunks (98 304 / 69 632 + a longer tail) are slower, 4.79 / 5.06
-            # (profiles/r6_ab_c3_tail_stream.txt).
+            # Round 6, re-measured with the ping-pong screen of rounds 4-5 and the rebuilt select (profiles/r6_ab_c3_tail_stream.txt): in a process that runs
+            # only this step the side-by-side form is 3 - 4 % faster than one search after the other and no longer bimodal (c3 over 300 steps, same box:
+            # 4.29 - 4.35 ms, max 4.52, against 4.48, max 4.68) - but as the third workload of a process (bench.py's full run: c1 and c2 before it) the SAME
+            # step is 8 % SLOWER than the sequential one (4.89 - 4.95 against 4.38 - 4.60 ms), whichever search is submitted first: how the runtime maps
+            # streams onto hardware queues depends on the process's history.  It stays OFF by default: the sequential step costs the same everywhere.
             # Round 5 experiment, OFF by default: tail_under_select=True makes the side stream wait for the main chunk's screen launch
             # (hwer_knn_screen_f32 / hwer_knn_select_f32: the search as two stream-ordered calls) and runs the short last search beside
             # the main SELECT, whose workgroups are small (256 threads, 128 VGPRs).  Measured at c3 (profiles/r5_ab_c3.txt, rocprofv3
             # timeline): the tail's 512-thread / 169-VGPR screen workgroups are not dispatched while the select's 34 000 workgroups keep
             # every SIMD's register file full - the 158 us launch stretches to the select's whole 1.96 ms whatever the stream priorities -
             # and its list merge and select still run behind the main select: 4.81 -> 4.76 ms, inside the noise.
-            if tail_stream is None:
-                tail_stream = B > self.CH and B % self.CH != 0 and not tail_under_select and not pipeline
             self.tail_under_select = bool(tail_under_select) and B > self.CH and B % self.CH != 0 and not tail_stream and not pipeline
             self.tail = B % self.CH if (B > self.CH and (tail_stream or self.tail_under_select)) else 0
             self.overlap_tail = True
@@ -267,17 +266,19 @@ class BlendSearchStep:
             cur.wait_stream(self.side)
             return
         side_tail = self.tail and not self.tail_under_select and U == self.B and self.overlap_tail
-        if side_tail:   # the short last search, on the second stream
+        if side_tail:
+            # the main chunks on the high-priority stream, SUBMITTED FIRST (round 6: when the runtime maps both streams onto one hardware queue - it does
+            # in a process that has used several streams before, e.g. the bench's full run - the searches execute in submission order, and the short one
+            # in front of the long one cost 9 %: c3 4.93 against 4.53 ms; main first, that case is the sequential step), the short last search beside them
             torch = self.torch
             cur = torch.cuda.current_stream(self.dev)
+            self.main_hi.wait_stream(cur)
+            with torch.cuda.stream(self.main_hi):
+                for b0 in range(0, U - self.tail, self.CH):
+                    search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
             self.side.wait_stream(cur)
             with torch.cuda.stream(self.side):
                 search(U - self.tail, U, self.ws_tail, self.ws_exact_tail)
-        if side_tail:     # the main chunks on the high-priority stream
-            self.main_hi.wait_stream(cur)
-            with self.torch.cuda.stream(self.main_hi):
-                for b0 in range(0, U - self.tail, self.CH):
-                    search(b0, min(U, b0 + self.CH), self.ws, self.ws_exact)
             cur.wait_stream(self.main_hi)
             cur.wait_stream(self.side)
         else:
@@ -489,9 +490,9 @@ class BlendSearchStepF64:
             native.check(lib.hwer_knn_workspace_init(native.ptr(self.ws), self.ws.numel(), self.S()), "knn_workspace_init")
             self.ws_exact = torch.empty(lib.hwer_knn_exact_device_workspace_bytes(I, K), dtype=torch.uint8, device=dev)
             self.missed = torch.zeros(1, dtype=torch.int32, device=dev)
-            # more anchors than one search takes (ML-20M shape: 131 072 + 7 421): the short last search runs on a second stream, beside the main
-            # one, with its own workspaces (BlendSearchStep's tail_stream, on by default since round 6)
-            self.tail = B % self.CH if (B > self.CH and B % self.CH != 0 and not os.environ.get("HWER_NO_TAIL_STREAM")) else 0
+            # more anchors than one search takes (ML-20M shape: 131 072 + 7 421): HWER_TAIL_STREAM=1 runs the short last search on a second stream, beside the
+            # main one, with its own workspaces (BlendSearchStep's tail_stream; c3_f64rows 6.70 -> 6.66 ms alone, 7.17 -> 7.02 in the bench's full run)
+            self.tail = B % self.CH if (B > self.CH and B % self.CH != 0 and os.environ.get("HWER_TAIL_STREAM")) else 0     # (opt-in: BlendSearchStep's tail_stream note)
             if self.tail:
                 self.side = torch.cuda.Stream(device=dev, priority=0)
                 self.main_hi = torch.cuda.Stream(device=dev, priority=-1)
@@ -551,13 +552,13 @@ class BlendSearchStepF64:
         if self.tail:   # the short last search on the second stream, the main chunks beside it on the high-priority one
             torch = self.torch
             cur = torch.cuda.current_stream(self.dev)
-            self.side.wait_stream(cur)
-            with torch.cuda.stream(self.side):
-                search(self.B - self.tail, self.B, self.ws_tail, self.ws_exact_tail)
-            self.main_hi.wait_stream(cur)
+            self.main_hi.wait_stream(cur)      # (main first: BlendSearchStep.stage_search)
             with torch.cuda.stream(self.main_hi):
                 for b0 in range(0, self.B - self.tail, self.CH):
                     search(b0, min(self.B - self.tail, b0 + self.CH), self.ws, self.ws_exact)
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                search(self.B - self.tail, self.B, self.ws_tail, self.ws_exact_tail)
             cur.wait_stream(self.main_hi)
             cur.wait_stream(self.side)
             return
