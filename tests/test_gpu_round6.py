@@ -390,3 +390,34 @@ def test_blend_search_step_f64(hw, U, I, d, T, graph, monkeypatch):
     for a, b in zip(res[True], res[False]):
         assert np.array_equal(a, b)
 
+
+
+# Round 6 (second half): the re-rank rounds stage the candidates' rows by LDS-DMA into a lane-permuted image (csrc/knn_select_kernels.h: rr_reader_lane /
+# rr_reader_gm) and their instruction stream was rebuilt (leaf hand-over as a branch, chains from zero, shared widening).  Shapes that walk the edges of that
+# code: candidate counts around the 64-slot rounds (k = 50 ... 392), widths that are not a multiple of the 16-column chunk or end inside an 8-group (d = 7,
+# 17, 100), two pairwise leaves (d = 200, 256), the one-query-per-workgroup, wave-per-query, list and streaming selects - EVERY query against the C oracle.
+@pytest.mark.parametrize("B,N,d,k,arith", [(97, 1500, 64, 50, 0), (33, 1200, 17, 120, 0), (2100, 5000, 100, 200, 0), (3000, 9000, 7, 64, 0),
+                                           (5, 20000, 200, 392, 0), (1500, 40000, 256, 200, 0), (70, 300, 128, 256, 0), (600, 2500, 66, 129, 1)])
+def test_rebuilt_rerank_rounds_every_query_vs_c_oracle(hw, B, N, d, k, arith):
+    from hwer.device_index import DeviceIndex
+    from oracle import c_oracle
+    rng = np.random.default_rng(B * 7 + d)
+    V32 = rng.standard_normal((B + N, d), dtype=np.float32).astype(np.float64)
+    V32 = (V32 / np.linalg.norm(V32, axis=1, keepdims=True)).astype(np.float32)
+    V32[B + 5] = V32[B + 4]                      # an exact duplicate: ordered by id
+    V = V32.astype(np.float64) if arith == 0 else V32
+    ix = DeviceIndex(V, {"user": np.arange(B, dtype=np.int64), "item": np.arange(B, B + N, dtype=np.int64)}, arith=arith, audit=False)
+    for want in (False, True):                   # lazy distances (scores only) and the full re-rank
+        idx, score, dist, flags = ix.search("item", np.arange(B), k=k, want_dist=want)
+        assert (flags > 0).all()
+        Q64, _, _ = ix.build_queries(np.arange(B))
+        o_idx, o_sc, o_d2 = c_oracle.find_closest_f64(V32[B:], Q64.cpu().numpy(), V32[:B].astype(np.float64), k, threads=c_oracle.effective_cpus())
+        if arith == 0:
+            assert np.array_equal(idx, o_idx + B) and np.array_equal(score, o_sc)
+            if want:
+                assert np.array_equal(dist, np.sqrt(o_d2))
+        else:                                    # float32 flavour: the order follows the float32 scores - same neighbour SETS, exact order on samples
+            assert np.array_equal(np.sort(idx, axis=1), np.sort(o_idx + B, axis=1))
+            for u in (0, B // 2, B - 1):
+                n_idx, n_sc, _ = orc.find_closest(V, np.arange(B, B + N), u, k=k)
+                assert np.array_equal(idx[u], n_idx) and np.array_equal(score[u], n_sc)
